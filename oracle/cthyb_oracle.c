@@ -1,0 +1,1020 @@
+/* TEST INFRASTRUCTURE ONLY (oracle) - see cthyb_oracle.h.
+ *
+ * CPU restatement of the reference CT-HYB hot path for density-density local problems with diagonal
+ * hybridisation.  References are to files under /root/reference/src/ctqmc_fortran unless stated otherwise.
+ * The reference keeps operators in doubly linked lists and reallocates matrices; here the configuration is one
+ * time-sorted array and M blocks are dense row-major arrays (row = creator rank, column = annihilator rank in
+ * time order inside the flavour, as `MInv%Mat(creator, annihilator)`, CTQMC.F90:2303-2304).
+ *
+ * Index conventions:
+ *   flavour f = 2*(orb-1) + (spin-1)             (array order (Nd,2) of every result array)
+ *   Fock bit of flavour: (orb-1) + Nd*(spin-1)   (States.F90:198-199, 328-334)
+ *   global-move flavour number i = orb + Nd*(spin-1)   (Trace.F90:2148-2151)
+ *   ca: 1 = creator, 2 = annihilator              (Trace.F90:35-38)
+ *   superstate index = Fock state integer (one state per block; States.F90:149-184 with "Nt Szt Azt")
+ */
+#include "cthyb_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MAXFLAV 16
+
+typedef struct {
+    double tau;
+    int flav; /* 0-based flavour */
+    int ca;   /* 1 creator, 2 annihilator */
+} op_t;
+
+typedef struct { double log, sign; } logval;
+
+struct ora_walker {
+    ora_params p;
+    ora_rng *rng;
+    int nflav, nstates;
+    double *ftab;   /* [nflav][nftau] diagonal F(tau) */
+    double *E;      /* [nstates] <n|H_loc|n> */
+    double Egs;
+    /* configuration */
+    op_t *ops; int nops, cap;
+    double *M[MAXFLAV]; int k[MAXFLAV];
+    int outer_sst;
+    logval det, tr;
+    double cfgsign;
+    /* window (Trace.F90:1608-1751) */
+    double taudiff_max, wmin, wmax; int num_windows, wpos;
+    int nslide;
+    /* counters */
+    double try_add, acc_add, accqn_add, try_rem, acc_rem, accqn_rem, try_glob, acc_glob, accqn_glob;
+    double try_shift, acc_shift, cnt_sampling, cnt_meas;
+    int64_t *accpair;
+    /* accumulators */
+    double *gleg, *gtau, *giw, *histo, *dm, *outer_histo;
+    double meas_sign; int64_t cnt_sign;
+    double mean_sign;
+    int aborted;
+};
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* pure pieces                                                                                               */
+/* ------------------------------------------------------------------------------------------------------- */
+
+/* Trace.F90:1014-1033 get_HybrF: linear interpolation, antiperiodic continuation for negative arguments */
+double ora_hybr(const double *ftab, int nftau, double beta, double dtau)
+{
+    double sig = 1.0;
+    if (dtau < 0.0) { dtau += beta; sig = -1.0; }
+    double n = dtau / beta * (double)(nftau - 1);
+    int i = (int)n;
+    return sig * (ftab[i] + (n - (double)i) * (ftab[i + 1] - ftab[i]));
+}
+
+/* MatrixUpdate.F90:392-407: S - sum_ij R_i N_ij Q_j, same accumulation order */
+double ora_detrat_add(const double *M, int k, const double *Q, const double *R, double S)
+{
+    double r = S;
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j)
+            r = r - R[i] * M[i * k + j] * Q[j];
+    return r;
+}
+
+/* MatrixUpdate.F90:410-442: new (k+1)x(k+1) inverse after inserting row pos_c / column pos_a (0-based here) */
+void ora_mat_add(const double *M, int k, const double *Q, const double *R, double S, int pc, int pa, double *out)
+{
+    int n = k + 1;
+    out[pc * n + pa] = 1.0 / S;
+    for (int i = 0; i < k; ++i) {              /* new column: -N.Q/S */
+        double s = 0.0;
+        for (int j = 0; j < k; ++j) s += M[i * k + j] * Q[j];
+        int in = i < pc ? i : i + 1;
+        out[in * n + pa] = -s / S;
+    }
+    for (int j = 0; j < k; ++j) {              /* new row: -R.N/S */
+        double s = 0.0;
+        for (int i = 0; i < k; ++i) s += R[i] * M[i * k + j];
+        int jn = j < pa ? j : j + 1;
+        out[pc * n + jn] = -s / S;
+    }
+    for (int i = 0; i < k; ++i) {
+        int in = i < pc ? i : i + 1;
+        for (int j = 0; j < k; ++j) {
+            int jn = j < pa ? j : j + 1;
+            out[in * n + jn] = M[i * k + j] + S * out[in * n + pa] * out[pc * n + jn];
+        }
+    }
+}
+
+/* MatrixUpdate.F90:455-482 */
+void ora_mat_rem(const double *M, int k, int pc, int pa, double *out)
+{
+    int n = k - 1;
+    for (int i = 0; i < n; ++i) {
+        int io = i < pc ? i : i + 1;
+        for (int j = 0; j < n; ++j) {
+            int jo = j < pa ? j : j + 1;
+            out[i * n + j] = M[io * k + jo] - M[io * k + pa] * M[pc * k + jo] / M[pc * k + pa];
+        }
+    }
+}
+
+/* What get_MatLogDetFull (MatrixUpdate.F90:41-99) gets from dgetrf/dgetri: inverse, log|det| and sign(det).
+ * Own Gauss-Jordan with partial pivoting (LAPACK itself is third-party; any conforming result agrees to rounding). */
+int ora_inverse_logdet(double *A, int k, double *logdet, double *sign)
+{
+    *logdet = 0.0; *sign = 1.0;
+    if (k == 0) return 0;
+    double *inv = (double *)calloc((size_t)k * k, sizeof(double));
+    for (int i = 0; i < k; ++i) inv[i * k + i] = 1.0;
+    for (int c = 0; c < k; ++c) {
+        int piv = c; double best = fabs(A[c * k + c]);
+        for (int r = c + 1; r < k; ++r)
+            if (fabs(A[r * k + c]) > best) { best = fabs(A[r * k + c]); piv = r; }
+        if (best == 0.0) { free(inv); *logdet = -HUGE_VAL; *sign = 0.0; return 1; }
+        if (piv != c) {
+            for (int j = 0; j < k; ++j) {
+                double t = A[c * k + j]; A[c * k + j] = A[piv * k + j]; A[piv * k + j] = t;
+                t = inv[c * k + j]; inv[c * k + j] = inv[piv * k + j]; inv[piv * k + j] = t;
+            }
+            *sign = -*sign;
+        }
+        double d = A[c * k + c];
+        *logdet += log(fabs(d));
+        if (d < 0) *sign = -*sign;
+        double id = 1.0 / d;
+        for (int j = 0; j < k; ++j) { A[c * k + j] *= id; inv[c * k + j] *= id; }
+        for (int r = 0; r < k; ++r) {
+            if (r == c) continue;
+            double f = A[r * k + c];
+            if (f == 0.0) continue;
+            for (int j = 0; j < k; ++j) { A[r * k + j] -= f * A[c * k + j]; inv[r * k + j] -= f * inv[c * k + j]; }
+        }
+    }
+    memcpy(A, inv, (size_t)k * k * sizeof(double));
+    free(inv);
+    return 0;
+}
+
+/* CTQMC.F90:2285-2424 (MeasGtauRem, MInv branch) for one flavour, plus Nfft_z.F90:376-414 (naive get_giw).
+ * M(ic, ia); loops: annihilators outer, creators inner as in the reference. */
+void ora_meas_flavour(const double *M, int k, const double *tau_c, const double *tau_a, double beta, double cfgsign,
+                      int nleg, double *gleg, int ntau, double *gtau, int niw2, double *giw)
+{
+    for (int ia = 0; ia < k; ++ia) {
+        for (int ic = 0; ic < k; ++ic) {
+            double m = M[ic * k + ia];
+            double d = tau_a[ia] - tau_c[ic];
+            int idt; double x;
+            if (d > 0.0) {
+                idt = (int)(d / beta * (double)ntau) + 1;
+                x = 2.0 / beta * d - 1.0;
+            } else {
+                idt = (int)((beta + tau_a[ia] - tau_c[ic]) / beta * (double)ntau) + 1;
+                x = 2.0 / beta * (beta + tau_a[ia] - tau_c[ic]) - 1.0;
+                m = -m;
+            }
+            m = m * cfgsign;
+            if (gleg) {
+                double plx = 0.0, plm1 = 0.0, plp1 = 0.0;
+                for (int il = 0; il < nleg; ++il) {
+                    if (x == -1.0 || x == 1.0) plp1 = pow(x, il);
+                    if (il == 0) plp1 = 1.0;
+                    else if (il == 1) plp1 = x;
+                    else {
+                        int l = il - 1;
+                        plp1 = (2.0 * (double)l + 1.0) / (double)(l + 1) * x * plx - (double)l / (double)(l + 1) * plm1;
+                    }
+                    gleg[il] += m * plp1;
+                    plm1 = plx; plx = plp1;
+                }
+            }
+            if (gtau) {
+                if (idt > ntau) idt = ntau;
+                gtau[idt - 1] += m;
+            }
+        }
+    }
+    if (giw) {
+        /* no configuration sign here (CTQMC.F90:1039-1043) */
+        for (int ifr = 1; ifr <= niw2; ++ifr) {
+            double freq = M_PI / beta * (double)(2 * ifr - niw2 - 1);
+            double re = 0.0, im = 0.0;
+            for (int ic = 0; ic < k; ++ic) {
+                double cr = cos(-freq * tau_c[ic]), ci = sin(-freq * tau_c[ic]);
+                for (int ia = 0; ia < k; ++ia) {
+                    double ar = cos(freq * tau_a[ia]), ai = sin(freq * tau_a[ia]);
+                    double m = M[ic * k + ia];
+                    double pr = m * cr, pi = m * ci;            /* (m*exp_c)*exp_a, left to right */
+                    re += pr * ar - pi * ai;
+                    im += pr * ai + pi * ar;
+                }
+            }
+            giw[2 * (ifr - 1)] += re;
+            giw[2 * (ifr - 1) + 1] += im;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* local problem                                                                                             */
+/* ------------------------------------------------------------------------------------------------------- */
+
+static inline int flav_bit(const ora_walker *w, int f) { return (f >> 1) + w->p.nd * (f & 1); }
+
+/* Connect(orb,spin,ca) of Operator.F90:145-197 for single-state blocks: new Fock state or -1 */
+static inline int connect(const ora_walker *w, int state, int f, int ca)
+{
+    int bit = 1 << flav_bit(w, f);
+    if (ca == 1) return (state & bit) ? -1 : (state | bit);
+    return (state & bit) ? (state & ~bit) : -1;
+}
+
+/* fermionic sign of c/c+ acting on `state` (Operator.F90:158-171): (-1)^(occupied bits below the flavour's bit) */
+static inline double fsign(const ora_walker *w, int state, int f)
+{
+    int b = flav_bit(w, f);
+    int below = state & ((1 << b) - 1);
+    return (__builtin_popcount((unsigned)below) & 1) ? -1.0 : 1.0;
+}
+
+/* diagonal of H_loc = sum muimp c+c + 1/2 sum U_1234 c+1 c+2 c4 c3  (Operator.F90:482-542, 1042-1107) */
+static int build_energies(ora_walker *w, const double *U, const double *mu_full)
+{
+    int nf = w->nflav, nd = w->p.nd;
+    /* refuse anything that is not density-density: every U element that can connect different Fock states */
+    for (int a = 0; a < nf; ++a) for (int b = 0; b < nf; ++b) for (int c = 0; c < nf; ++c) for (int d = 0; d < nf; ++d) {
+        double u = U[((a * nf + b) * nf + c) * nf + d];
+        if (u == 0.0) continue;
+        int diag = (a == c && b == d) || (a == d && b == c);
+        if (!diag && a != b && c != d) return 1;
+    }
+    for (int b1 = 0; b1 < nd; ++b1) for (int s1 = 0; s1 < 2; ++s1) for (int b2 = 0; b2 < nd; ++b2) for (int s2 = 0; s2 < 2; ++s2)
+        if ((b1 != b2 || s1 != s2) && mu_full[((b1 * 2 + s1) * nd + b2) * 2 + s2] != 0.0) return 1;
+    for (int st = 0; st < w->nstates; ++st) {
+        double e = 0.0;
+        for (int f = 0; f < nf; ++f) {
+            if (!(st >> flav_bit(w, f) & 1)) continue;
+            int b = f >> 1, s = f & 1;
+            e += mu_full[((b * 2 + s) * nd + b) * 2 + s];
+            for (int g = 0; g < nf; ++g) {
+                if (g == f || !(st >> flav_bit(w, g) & 1)) continue;
+                e += 0.5 * (U[((f * nf + g) * nf + f) * nf + g] - U[((f * nf + g) * nf + g) * nf + f]);
+            }
+        }
+        w->E[st] = e;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* configuration helpers                                                                                     */
+/* ------------------------------------------------------------------------------------------------------- */
+
+static void ensure_cap(ora_walker *w, int n)
+{
+    if (n <= w->cap) return;
+    w->cap = n * 2 + 16;
+    w->ops = (op_t *)realloc(w->ops, (size_t)w->cap * sizeof(op_t));
+}
+
+/* insert keeping time order; returns index */
+static int list_insert(ora_walker *w, op_t o)
+{
+    ensure_cap(w, w->nops + 1);
+    int i = w->nops;
+    while (i > 0 && w->ops[i - 1].tau > o.tau) { w->ops[i] = w->ops[i - 1]; --i; }
+    w->ops[i] = o; w->nops++;
+    return i;
+}
+
+static void list_remove(ora_walker *w, int idx)
+{
+    for (int i = idx; i + 1 < w->nops; ++i) w->ops[i] = w->ops[i + 1];
+    w->nops--;
+}
+
+/* rank (0-based) of op idx among operators of the same flavour and type */
+static int frank(const ora_walker *w, int idx)
+{
+    int r = 0;
+    for (int i = 0; i < idx; ++i)
+        if (w->ops[i].flav == w->ops[idx].flav && w->ops[i].ca == w->ops[idx].ca) ++r;
+    return r;
+}
+
+/* quantum-number check of the whole sequence for outer superstate `outer` (equivalent, for a configuration that
+ * was valid before the local change, to check_sst_sequence on the changed span, Trace.F90:1243-1302) */
+static int sequence_valid(const ora_walker *w, int outer)
+{
+    int s = outer;
+    for (int i = 0; i < w->nops; ++i) {
+        s = connect(w, s, w->ops[i].flav, w->ops[i].ca);
+        if (s < 0) return 0;
+    }
+    return s == outer;
+}
+
+/* scalar local trace from scratch: Trace.F90:5556-5727 with FullR/FullL */
+static logval full_trace(const ora_walker *w, int outer)
+{
+    logval t = { 0.0, 1.0 };
+    int s = outer; double tprev = 0.0;
+    for (int i = 0; i < w->nops; ++i) {
+        t.log += -(w->E[s] - w->Egs) * (w->ops[i].tau - tprev);
+        t.sign *= fsign(w, s, w->ops[i].flav);
+        s = connect(w, s, w->ops[i].flav, w->ops[i].ca);
+        if (s < 0) { t.log = -HUGE_VAL; t.sign = 0.0; return t; }
+        tprev = w->ops[i].tau;
+    }
+    if (s != outer) { t.log = -HUGE_VAL; t.sign = 0.0; return t; }
+    t.log += -(w->E[s] - w->Egs) * (w->p.beta - tprev);
+    return t;
+}
+
+/* Trace.F90:3594-3618 */
+static double block_sign(const ora_walker *w)
+{
+    int nd = w->p.nd; long perm = 0;
+    int tn[MAXFLAV];
+    for (int f = 0; f < w->nflav; ++f) tn[f] = 2 * w->k[f];
+    for (int i = 0; i < w->nops; ++i) {
+        int f = w->ops[i].flav, orb = f >> 1, spin = f & 1;  /* orb 0-based, spin 0 -> Fortran 1 */
+        tn[f] -= 1;
+        if (spin == 1) { for (int o = 0; o <= orb; ++o) perm += tn[2 * o + 0]; }
+        else { for (int o = 0; o < orb; ++o) perm += tn[2 * o + 1]; }
+        for (int o = 0; o < orb; ++o) perm += tn[2 * o + spin];
+    }
+    (void)nd;
+    return (perm & 1) ? -1.0 : 1.0;
+}
+
+/* Trace.F90:3554-3588 */
+static double permaltca(const ora_walker *w)
+{
+    long perm = 0; int tn[MAXFLAV];
+    for (int f = 0; f < w->nflav; ++f) tn[f] = 2 * w->k[f];
+    for (int i = 0; i < w->nops; ++i) {
+        int f = w->ops[i].flav;
+        tn[f] -= 1;
+        perm += tn[f] % (3 - w->ops[i].ca);
+    }
+    if (((w->nops / 2) % 2) == 1) perm += 1;
+    return (perm & 1) ? -1.0 : 1.0;
+}
+
+/* Trace.F90:3479-3498 (diagonal hybridisation, no worm) */
+static double get_sign(const ora_walker *w)
+{
+    return w->tr.sign * w->det.sign * block_sign(w) * permaltca(w);
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* window and NPairs                                                                                         */
+/* ------------------------------------------------------------------------------------------------------- */
+
+static void set_window(ora_walker *w) /* Trace.F90:1691-1751 (only the bounds matter here) */
+{
+    if (w->num_windows > 1) {
+        w->wmin = ((double)w->wpos / (double)(w->num_windows + 1)) * w->p.beta;
+        w->wmax = ((double)(w->wpos + 2) / (double)(w->num_windows + 1)) * w->p.beta;
+    }
+}
+
+static void init_window(ora_walker *w, double tdm) /* Trace.F90:1608-1648 */
+{
+    w->wpos = 0;
+    if (tdm > 0.0) {
+        w->taudiff_max = tdm;
+        int nw = (int)floor(w->p.beta / tdm) - 1;
+        w->num_windows = nw > 1 ? nw : 1;
+        w->wmin = ((double)w->wpos / (double)(w->num_windows + 1)) * w->p.beta;
+        w->wmax = ((double)(w->wpos + 2) / (double)(w->num_windows + 1)) * w->p.beta;
+    } else {
+        w->taudiff_max = w->p.beta; w->num_windows = 1; w->wmin = 0.0; w->wmax = w->p.beta;
+    }
+    set_window(w);
+}
+
+static void shift_window(ora_walker *w) /* Trace.F90:1652-1678 */
+{
+    if (w->num_windows > 1) {
+        w->wpos += 1;
+        if (w->wpos == w->num_windows) w->wpos = 0;
+        set_window(w);
+    } else w->wpos = 0;
+}
+
+/* Trace.F90:1770-1815: pairs (El earlier, mEl later) of one creator and one annihilator of equal flavour, both in
+ * [wmin, wmax], distance <= taudiff_max.  If pick > 0 returns through (*i1,*i2) the pick-th pair in the reference's
+ * enumeration order (gen_OperRemove, Trace.F90:4879-4917). */
+static int count_pairs(const ora_walker *w, int pick, int *i1, int *i2)
+{
+    int n = 0;
+    for (int i = 0; i < w->nops; ++i) {
+        const op_t *a = &w->ops[i];
+        if (a->tau < w->wmin) continue;
+        if (pick == 0 && a->tau > w->wmax) break;
+        for (int j = i + 1; j < w->nops; ++j) {
+            const op_t *b = &w->ops[j];
+            if (b->flav != a->flav) continue;
+            if (b->tau > w->wmax) break;
+            if (b->tau > a->tau + w->taudiff_max) break;
+            if (b->ca != a->ca) {
+                ++n;
+                if (pick > 0 && n == pick) { *i1 = i; *i2 = j; return n; }
+            }
+        }
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* moves                                                                                                     */
+/* ------------------------------------------------------------------------------------------------------- */
+
+static inline double U01(ora_walker *w) { return w->rng->uniform(w->rng->state); }
+static inline int RINT(ora_walker *w, int lo, int hi) { return w->rng->randint(w->rng->state, lo, hi); }
+
+static void accpair_add(ora_walker *w, int f, double dt)
+{
+    int n = w->p.ntau;
+    int bin = (int)floor(dt / w->p.beta * (double)n) + 1;
+    if (bin > n) bin = n;
+    w->accpair[(size_t)f * n + (bin - 1)] += 1;
+}
+
+/* CTQMC.F90:3353-3612 StepAdd (change_outer = false, diagonal hybridisation) */
+static void step_add(ora_walker *w)
+{
+    const double *ft;
+    w->try_add += 1;
+    /* pair_OperAdd, Trace.F90:3657-3698 */
+    double width1 = w->wmax - w->wmin;
+    double tau1 = w->wmin + width1 * U01(w);            /* i=1: CA = mod(1,2)+1 = 2 (annihilator) */
+    int orb = RINT(w, 1, w->p.nd);
+    int spin = RINT(w, 1, 2);
+    double tmin = fmax(tau1 - w->taudiff_max, w->wmin);
+    double width2 = fmin(tau1 + w->taudiff_max, w->wmax) - tmin;
+    double tau2 = tmin + width2 * U01(w);               /* i=2: CA = 1 (creator) */
+    double taudiff_factor = width1 * width2;
+    int f = 2 * (orb - 1) + (spin - 1);
+
+    /* process_OperAdd, Trace.F90:4275-4462: equal times are rejected and counted as QN rejections */
+    int equal = (tau1 == tau2);
+    for (int i = 0; i < w->nops && !equal; ++i)
+        if (w->ops[i].tau == tau1 || w->ops[i].tau == tau2) equal = 1;
+    if (equal) { w->accqn_add += 1; return; }
+
+    op_t oa = { tau1, f, 2 }, oc = { tau2, f, 1 };
+    int ia, ic;
+    if (tau1 < tau2) { ia = list_insert(w, oa); ic = list_insert(w, oc); }
+    else { ic = list_insert(w, oc); ia = list_insert(w, oa); if (ic >= ia) {} }
+    /* recompute indices after both insertions */
+    ia = ic = -1;
+    for (int i = 0; i < w->nops; ++i) {
+        if (w->ops[i].tau == tau1 && w->ops[i].flav == f && w->ops[i].ca == 2) ia = i;
+        if (w->ops[i].tau == tau2 && w->ops[i].flav == f && w->ops[i].ca == 1) ic = i;
+    }
+
+    if (!sequence_valid(w, w->outer_sst)) {
+        list_remove(w, ia > ic ? ia : ic); list_remove(w, ia > ic ? ic : ia);
+        w->accqn_add += 1;
+        return;
+    }
+
+    /* get_LogDetRatPairAdd, Trace.F90:2775-2832 */
+    int k = w->k[f];
+    ft = w->ftab + (size_t)f * w->p.nftau;
+    double *Q = (double *)malloc(sizeof(double) * (size_t)(k + 1)), *R = (double *)malloc(sizeof(double) * (size_t)(k + 1));
+    double S0 = ora_hybr(ft, w->p.nftau, w->p.beta, tau1 - tau2);
+    int iq = 0, ir = 0;
+    for (int i = 0; i < w->nops; ++i) {
+        const op_t *e = &w->ops[i];
+        if (e->flav != f || i == ia || i == ic) continue;
+        if (e->ca == 2) Q[iq++] = ora_hybr(ft, w->p.nftau, w->p.beta, e->tau - tau2);   /* annihilators vs new creator */
+        else R[ir++] = ora_hybr(ft, w->p.nftau, w->p.beta, tau1 - e->tau);              /* new annihilator vs creators */
+    }
+    double S = ora_detrat_add(w->M[f], k, Q, R, S0);
+    int pc = frank(w, ic), pa = frank(w, ia);
+    double sig = ((abs(pc - pa) % 2) == 0) ? 1.0 : -1.0;
+    logval detrat = { log(fabs(S)), (S < 0 ? -1.0 : 1.0) * sig };
+
+    logval trnew = full_trace(w, w->outer_sst);
+    double rnd = U01(w);
+    int npairs = count_pairs(w, 0, NULL, NULL);
+    double prob = fabs(taudiff_factor * (double)(2 * w->p.nd) / (double)npairs
+                       * exp((trnew.log - w->tr.log) + detrat.log));
+    if (rnd < prob) {
+        double *Mn = (double *)malloc(sizeof(double) * (size_t)(k + 1) * (k + 1));
+        ora_mat_add(w->M[f], k, Q, R, S, pc, pa, Mn);
+        free(w->M[f]); w->M[f] = Mn; w->k[f] = k + 1;
+        w->det.log += detrat.log; w->det.sign *= detrat.sign;
+        w->tr = trnew;
+        w->cfgsign = -get_sign(w);
+        w->acc_add += 1;
+        accpair_add(w, f, fabs(tau2 - tau1));
+    } else {
+        list_remove(w, ia > ic ? ia : ic); list_remove(w, ia > ic ? ic : ia);
+    }
+    free(Q); free(R);
+}
+
+/* CTQMC.F90:3892-4150 StepRem (change_outer = false) */
+static void step_rem(ora_walker *w)
+{
+    w->try_rem += 1;
+    /* gen_OperRemove, Trace.F90:4851-4950 */
+    int np = count_pairs(w, 0, NULL, NULL);
+    if (np <= 0) { w->accqn_rem += 1; return; }
+    int pick = RINT(w, 1, np);
+    int i1 = -1, i2 = -1;
+    count_pairs(w, pick, &i1, &i2);
+    op_t o1 = w->ops[i1], o2 = w->ops[i2];
+    int f = o1.flav;
+    int ic = (o1.ca == 1) ? i1 : i2, ia = (o1.ca == 2) ? i1 : i2;
+    int pc = frank(w, ic), pa = frank(w, ia);
+    double ta = w->ops[ia].tau;
+    double hybpairremfactor = (double)np / ((w->wmax - w->wmin)
+        * (fmin(ta + w->taudiff_max, w->wmax) - fmax(ta - w->taudiff_max, w->wmin)));
+
+    list_remove(w, i2); list_remove(w, i1);
+    if (!sequence_valid(w, w->outer_sst)) {
+        list_insert(w, o1); list_insert(w, o2);
+        w->accqn_rem += 1;
+        return;
+    }
+    int k = w->k[f];
+    /* get_LogDetRatPairRem, Trace.F90:2937-2963 */
+    double S = w->M[f][pc * k + pa];
+    double sig = ((abs(pc - pa) % 2) == 0) ? 1.0 : -1.0;
+    logval detrat = { log(fabs(S)), (S < 0 ? -1.0 : 1.0) * sig };
+    logval trnew = full_trace(w, w->outer_sst);
+    double prob = fabs(hybpairremfactor / (double)(2 * w->p.nd) * exp((trnew.log - w->tr.log) + detrat.log));
+    double rnd = U01(w);
+    if (rnd < prob) {
+        if (fabs(detrat.sign * exp(detrat.log)) < 1e-12) { fprintf(stderr, "DetRat too small in removal\n"); abort(); }
+        double *Mn = (double *)malloc(sizeof(double) * (size_t)((k - 1) * (k - 1) + 1));
+        ora_mat_rem(w->M[f], k, pc, pa, Mn);
+        free(w->M[f]); w->M[f] = Mn; w->k[f] = k - 1;
+        w->det.log += detrat.log; w->det.sign *= detrat.sign;
+        w->tr = trnew;
+        w->cfgsign = -get_sign(w);
+        accpair_add(w, f, o2.tau - o1.tau);
+        w->acc_rem += 1;
+    } else {
+        list_insert(w, o1); list_insert(w, o2);
+    }
+}
+
+/* Trace.F90:2279-2333 get_InvFullHybr: rebuild every M block as the inverse of F(tau_a_i - tau_c_j), det = prod */
+static void rebuild_minv(ora_walker *w, double **Mnew, int *knew, logval *det)
+{
+    det->log = 0.0; det->sign = 1.0;
+    for (int f = 0; f < w->nflav; ++f) {
+        int k = 0;
+        for (int i = 0; i < w->nops; ++i) if (w->ops[i].flav == f && w->ops[i].ca == 1) ++k;
+        knew[f] = k;
+        Mnew[f] = (double *)malloc(sizeof(double) * (size_t)(k * k + 1));
+        if (k == 0) continue;
+        const double *ft = w->ftab + (size_t)f * w->p.nftau;
+        double *tc = (double *)malloc(sizeof(double) * k), *ta = (double *)malloc(sizeof(double) * k);
+        int nc = 0, na = 0;
+        for (int i = 0; i < w->nops; ++i) {
+            if (w->ops[i].flav != f) continue;
+            if (w->ops[i].ca == 1) tc[nc++] = w->ops[i].tau; else ta[na++] = w->ops[i].tau;
+        }
+        /* Fortran Mat(pos_a, pos_c) column major == row-major [c][a]: after inversion this array read as
+         * row-major [c][a] is M(creator, annihilator) */
+        for (int c = 0; c < k; ++c)
+            for (int a = 0; a < k; ++a)
+                Mnew[f][c * k + a] = ora_hybr(ft, w->p.nftau, w->p.beta, ta[a] - tc[c]);
+        /* the array holds F^T in row-major terms; inverse of transpose = transpose of inverse, so inverting in
+         * place gives (F^-1)^T[c][a] = F^-1[a]... keep explicit: build F[a][c], invert, transpose */
+        double *F = (double *)malloc(sizeof(double) * (size_t)k * k);
+        for (int a = 0; a < k; ++a) for (int c = 0; c < k; ++c) F[a * k + c] = Mnew[f][c * k + a];
+        double ld, sg;
+        ora_inverse_logdet(F, k, &ld, &sg);          /* F^-1[c][a] */
+        for (int c = 0; c < k; ++c) for (int a = 0; a < k; ++a) Mnew[f][c * k + a] = F[c * k + a];
+        det->log += ld; det->sign *= sg;
+        free(F); free(tc); free(ta);
+    }
+}
+
+/* log-determinant of the current M blocks: Trace.F90:2665-2685 get_FullLogDet */
+static logval minv_logdet(const ora_walker *w)
+{
+    logval d = { 0.0, 1.0 };
+    for (int f = 0; f < w->nflav; ++f) {
+        int k = w->k[f];
+        if (k == 0) continue;
+        double *A = (double *)malloc(sizeof(double) * (size_t)k * k);
+        memcpy(A, w->M[f], sizeof(double) * (size_t)k * k);
+        double ld, sg;
+        ora_inverse_logdet(A, k, &ld, &sg);
+        d.log += ld; d.sign *= sg;
+        free(A);
+    }
+    return d;
+}
+
+/* Trace.F90:2126-2188 globalUpdate: gu[0] = flip c<->c+, gu[i] (1-based, spin-major flavour numbers) = new flavour */
+static void apply_global(ora_walker *w, const int *gu)
+{
+    int nd = w->p.nd;
+    for (int i = 0; i < w->nops; ++i) {
+        int f = w->ops[i].flav;
+        int num = (f >> 1) + nd * (f & 1) + 1;
+        int t = gu[num];
+        int orb = (t - 1) % nd, spin = (t - 1) / nd;
+        w->ops[i].flav = 2 * orb + spin;
+        if (gu[0] != 0) w->ops[i].ca = 3 - w->ops[i].ca;
+    }
+}
+
+/* Trace.F90:1402-1433 check_qn_all_ssts */
+static int check_all_ssts(const ora_walker *w, int *ssts)
+{
+    int n = w->nstates, possible = n;
+    for (int k = 0; k < n; ++k) ssts[k] = k;
+    for (int i = 0; i < w->nops; ++i) {
+        for (int k = 0; k < n; ++k) {
+            if (ssts[k] == -1) continue;
+            ssts[k] = connect(w, ssts[k], w->ops[i].flav, w->ops[i].ca);
+            if (ssts[k] == -1) --possible;
+        }
+        if (possible <= 0) return 0;
+    }
+    for (int k = 0; k < n; ++k) {
+        if (ssts[k] == -1) continue;
+        if (ssts[k] != k) { ssts[k] = -1; --possible; }
+    }
+    return possible;
+}
+
+/* CTQMC.F90:4433-4554 StepGlob (no user symmetry moves) */
+static void step_glob(ora_walker *w)
+{
+    int nf = w->nflav, nd = w->p.nd;
+    int gu[MAXFLAV + 1], inv[MAXFLAV + 1];
+    w->try_glob += 1;
+    if (w->nops == 0) return;
+    double r = U01(w);
+    int spinflip = 0;
+    if (r < 0.3) {                                   /* gen_SpinFlipUpdate, Trace.F90:1150-1166 */
+        spinflip = 1; gu[0] = 0;
+        for (int i = 1; i <= nd; ++i) gu[i] = i + nd;
+        for (int i = nd + 1; i <= 2 * nd; ++i) gu[i] = i - nd;
+    } else if (r < 0.6) {                            /* gen_CAFlip, Trace.F90:1186-1198 */
+        gu[0] = 1; for (int i = 1; i <= nf; ++i) gu[i] = i;
+    } else {                                         /* gen_GlobalUpdate_new + rand_perm, Trace.F90:1083-1123 */
+        for (int i = 1; i <= nf; ++i) gu[i] = i;
+        for (int j = 1; j <= nf; ++j) { int i = RINT(w, j, nf); int t = gu[j]; gu[j] = gu[i]; gu[i] = t; }
+        gu[0] = RINT(w, 0, 1);
+    }
+    int outer_old = w->outer_sst;
+    op_t *saved = (op_t *)malloc(sizeof(op_t) * (size_t)w->nops);
+    memcpy(saved, w->ops, sizeof(op_t) * (size_t)w->nops);
+    double sst_factor;
+    if (spinflip && w->p.has_szt) {                  /* perform_spinflip_check_qn, Trace.F90:1306-1339 */
+        int down = outer_old & ((1 << nd) - 1), up = (outer_old >> nd) & ((1 << nd) - 1);
+        w->outer_sst = up | (down << nd);
+        apply_global(w, gu);
+        sst_factor = sequence_valid(w, w->outer_sst) ? 1.0 : 0.0;
+    } else {                                         /* perform_global_check_qn, Trace.F90:1345-1394 */
+        int *so = (int *)malloc(sizeof(int) * (size_t)w->nstates), *sn = (int *)malloc(sizeof(int) * (size_t)w->nstates);
+        int pold = check_all_ssts(w, so);
+        if (pold <= 0) { fprintf(stderr, "impossible old configuration\n"); abort(); }
+        apply_global(w, gu);
+        int pnew = check_all_ssts(w, sn);
+        if (pnew <= 0) sst_factor = 0.0;
+        else {
+            sst_factor = (double)pnew / (double)pold;
+            int kk = RINT(w, 1, pnew);
+            for (int i = 0; i < w->nstates; ++i) if (sn[i] != -1) { if (--kk <= 0) { w->outer_sst = sn[i]; break; } }
+        }
+        free(so); free(sn);
+    }
+    (void)inv;
+    if (sst_factor == 0.0) {
+        w->outer_sst = outer_old; memcpy(w->ops, saved, sizeof(op_t) * (size_t)w->nops); free(saved);
+        w->accqn_glob += 1;
+        return;
+    }
+    double *Mn[MAXFLAV]; int kn[MAXFLAV]; logval detnew;
+    rebuild_minv(w, Mn, kn, &detnew);
+    logval dold = minv_logdet(w);
+    logval detrat = { detnew.log + dold.log, detnew.sign * dold.sign };
+    logval trnew = full_trace(w, w->outer_sst);
+    double rnd = U01(w);
+    if (rnd < fabs(exp((trnew.log - w->tr.log) + detrat.log) * sst_factor)) {
+        for (int f = 0; f < nf; ++f) { free(w->M[f]); w->M[f] = Mn[f]; w->k[f] = kn[f]; }
+        w->det = detnew; w->tr = trnew;
+        w->cfgsign = -get_sign(w);
+        w->acc_glob += 1;
+    } else {
+        for (int f = 0; f < nf; ++f) free(Mn[f]);
+        w->outer_sst = outer_old; memcpy(w->ops, saved, sizeof(op_t) * (size_t)w->nops);
+    }
+    free(saved);
+}
+
+/* CTQMC.F90:4570-4638 StepChangeOuter (no state sampling): draw the outer superstate of the empty configuration */
+static void step_change_outer(ora_walker *w)
+{
+    int n = w->nstates; double sum = 0.0;
+    double *v = (double *)malloc(sizeof(double) * (size_t)n);
+    for (int s = 0; s < n; ++s) { v[s] = exp(-(w->E[s] - w->Egs) * w->p.beta); sum += v[s]; }
+    for (int s = 0; s < n; ++s) v[s] /= sum;
+    double r = U01(w), acc = 0.0;
+    int sel = n - 1;
+    for (int s = 0; s < n; ++s) { acc += v[s]; sel = s; if (acc >= r && v[s] != 0.0) break; }
+    w->outer_sst = sel;
+    w->tr = full_trace(w, sel);
+    w->cfgsign = -get_sign(w);
+    free(v);
+}
+
+/* CTQMC.F90:4641-4835 StepShiftTau_proper + Trace.F90:2355-2457 */
+static void step_shift(ora_walker *w)
+{
+    if (w->nops == 0) { step_change_outer(w); return; }
+    double beta = w->p.beta;
+    double dt = U01(w) * beta;
+    if (dt == 0.0 || dt == beta) return;
+    w->try_shift += 1;
+    int n = w->nops, nf = w->nflav;
+    /* superstate in front of the first operator with tau >= dt (the new outer one); all wrap if none */
+    int first = 0; while (first < n && w->ops[first].tau < dt) ++first;
+    int outer_old = w->outer_sst, s = w->outer_sst;
+    if (first < n) for (int i = 0; i < first; ++i) s = connect(w, s, w->ops[i].flav, w->ops[i].ca);
+    int wrapped[MAXFLAV][3]; memset(wrapped, 0, sizeof(wrapped));
+    op_t *saved = (op_t *)malloc(sizeof(op_t) * (size_t)n), *tmp = (op_t *)malloc(sizeof(op_t) * (size_t)n);
+    memcpy(saved, w->ops, sizeof(op_t) * (size_t)n);
+    for (int i = 0; i < n; ++i) if (w->ops[i].tau < dt) wrapped[w->ops[i].flav][w->ops[i].ca] += 1;
+    int m = 0;
+    int cut = (first < n) ? first : 0;
+    for (int i = cut; i < n; ++i) { tmp[m] = saved[i]; tmp[m].tau = fmod(saved[i].tau - dt, beta); if (tmp[m].tau < 0) tmp[m].tau += beta; ++m; }
+    for (int i = 0; i < cut; ++i) { tmp[m] = saved[i]; tmp[m].tau = fmod(saved[i].tau - dt, beta); if (tmp[m].tau < 0) tmp[m].tau += beta; ++m; }
+    memcpy(w->ops, tmp, sizeof(op_t) * (size_t)n);
+    w->outer_sst = s;
+    int wpos_old = w->wpos; double wmin_old = w->wmin, wmax_old = w->wmax;
+    {   /* CTQMC.F90:4744-4746 */
+        int nw = w->num_windows;
+        int a = (int)floor((dt / beta) * (double)(nw + 1)); a = ((a % nw) + nw) % nw;
+        w->wpos = (((wpos_old - a) % nw) + nw) % nw;
+        set_window(w);
+    }
+    logval trnew = full_trace(w, w->outer_sst);
+    double rnd = U01(w);
+    if (rnd < fabs(trnew.sign * w->tr.sign * exp(trnew.log - w->tr.log))) {
+        w->tr = trnew;
+        double detrat = 1.0;
+        for (int f = 0; f < nf; ++f) {
+            int k = w->k[f], wc = wrapped[f][1], wa = wrapped[f][2];
+            if (!((wc == 0 && wa == 0) || (wc == k && wa == k))) {
+                double *Mn = (double *)malloc(sizeof(double) * (size_t)k * k);
+                for (int i = 0; i < k; ++i) for (int j = 0; j < k; ++j) {
+                    int io = (i + wc) % k, jo = (j + wa) % k;
+                    double sg = ((i >= k - wc) ? -1.0 : 1.0) * ((j >= k - wa) ? -1.0 : 1.0);
+                    Mn[i * k + j] = sg * w->M[f][io * k + jo];
+                }
+                free(w->M[f]); w->M[f] = Mn;
+            }
+            if ((k % 2) != 0 && ((wc + wa) % 2) != 0) detrat = -detrat;
+        }
+        w->det.sign *= detrat;
+        w->cfgsign = -get_sign(w);
+        w->acc_shift += 1;
+    } else {
+        memcpy(w->ops, saved, sizeof(op_t) * (size_t)n);
+        w->outer_sst = outer_old; w->wpos = wpos_old; w->wmin = wmin_old; w->wmax = wmax_old;
+    }
+    free(saved); free(tmp);
+}
+
+/* one iteration of the Z-space loop: CTQMC.F90:8213-8257 (warm-up) == 8434-8488 + 8530-8532 (sampling) */
+static void one_step(ora_walker *w)
+{
+    double r = U01(w);
+    double pg = w->p.p_glob, ps = w->p.p_shift;
+    if (r < (1.0 - ps - pg) / 2.0) {
+        (void)U01(w);       /* grnd() >= Percentage4OperatorMove (= 0): always the pair move */
+        (void)U01(w);       /* grnd() <  PercentageOuterMove     (= 0): never an outer move  */
+        step_add(w);
+    } else if (r <= 1.0 - ps - pg) {
+        (void)U01(w); (void)U01(w);
+        step_rem(w);
+    } else if (r <= 1.0 - ps) {
+        step_glob(w);
+    } else {
+        step_shift(w);
+    }
+    long tries = (long)(w->try_add + w->try_rem);
+    if (tries % w->nslide == 0) shift_window(w);
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* driver                                                                                                    */
+/* ------------------------------------------------------------------------------------------------------- */
+
+static void init_counters(ora_walker *w) /* CTQMC.F90:847-896 */
+{
+    w->try_add = w->acc_add = w->accqn_add = w->try_rem = w->acc_rem = w->accqn_rem = 0;
+    w->try_glob = w->acc_glob = w->accqn_glob = w->try_shift = w->acc_shift = 0;
+    w->cnt_sampling = w->cnt_meas = 0;
+    memset(w->accpair, 0, sizeof(int64_t) * (size_t)w->nflav * w->p.ntau);
+}
+
+ora_walker *ora_create(const ora_params *p, const double *U, const double *ftau_full, const double *mu_full, ora_rng *rng)
+{
+    ora_walker *w = (ora_walker *)calloc(1, sizeof(ora_walker));
+    w->p = *p; w->rng = rng;
+    w->nflav = 2 * p->nd; w->nstates = 1 << (2 * p->nd);
+    if (w->nflav > MAXFLAV) { free(w); return NULL; }
+    w->E = (double *)calloc((size_t)w->nstates, sizeof(double));
+    if (build_energies(w, U, mu_full)) { free(w->E); free(w); return NULL; }
+    w->Egs = w->E[0];
+    for (int s = 0; s < w->nstates; ++s) if (w->E[s] < w->Egs) w->Egs = w->E[s];   /* Trace.F90:576-583 */
+    int nd = p->nd, nft = p->nftau;
+    w->ftab = (double *)malloc(sizeof(double) * (size_t)w->nflav * nft);
+    for (int b = 0; b < nd; ++b) for (int s = 0; s < 2; ++s)                        /* CTQMC.F90:7950-7955 */
+        memcpy(w->ftab + (size_t)(2 * b + s) * nft,
+               ftau_full + ((((size_t)b * 2 + s) * nd + b) * 2 + s) * nft, sizeof(double) * (size_t)nft);
+    for (int f = 0; f < w->nflav; ++f) { w->M[f] = (double *)malloc(sizeof(double)); w->k[f] = 0; }
+    w->accpair = (int64_t *)calloc((size_t)w->nflav * p->ntau, sizeof(int64_t));
+    w->gleg = (double *)calloc((size_t)w->nflav * p->nlegmax, sizeof(double));
+    w->gtau = (double *)calloc((size_t)w->nflav * p->ntau, sizeof(double));
+    w->giw = (double *)calloc((size_t)w->nflav * 2 * p->niw * 2, sizeof(double));
+    w->histo = (double *)calloc((size_t)w->nflav * (p->maxhisto + 1), sizeof(double));
+    w->dm = (double *)calloc((size_t)w->nstates, sizeof(double));
+    w->outer_histo = (double *)calloc((size_t)w->nstates, sizeof(double));
+    w->det.log = 0.0; w->det.sign = 1.0;
+    w->cfgsign = -1.0;                                                              /* Trace.F90:129 */
+    init_window(w, p->taudiffmax);                                                  /* Trace.F90:605 */
+    /* initial outer superstate ~ empty-trace weight, Trace.F90:644-665 */
+    {
+        int n = w->nstates; double sum = 0.0;
+        double *v = (double *)malloc(sizeof(double) * (size_t)n);
+        for (int s = 0; s < n; ++s) { v[s] = exp(-(w->E[s] - w->Egs) * p->beta); sum += v[s]; }
+        for (int s = 0; s < n; ++s) v[s] /= sum;
+        double r = U01(w), acc = 0.0; int sel = n - 1;
+        for (int s = 0; s < n; ++s) { acc += v[s]; sel = s; if (acc >= r && v[s] != 0.0) break; }
+        w->outer_sst = sel;
+        free(v);
+    }
+    w->tr = full_trace(w, w->outer_sst);
+    {   /* CTQMC.F90:8069 */
+        int a = 2 * nd, b = (int)floor((double)p->ncorr / (double)w->num_windows);
+        w->nslide = a > b ? a : b;
+    }
+    init_counters(w);
+    return w;
+}
+
+void ora_destroy(ora_walker *w)
+{
+    if (!w) return;
+    for (int f = 0; f < w->nflav; ++f) free(w->M[f]);
+    free(w->ops); free(w->ftab); free(w->E); free(w->accpair); free(w->gleg); free(w->gtau); free(w->giw);
+    free(w->histo); free(w->dm); free(w->outer_histo); free(w);
+}
+
+void ora_set_taudiffmax(ora_walker *w, double x) { init_window(w, x); }
+
+void ora_warmup(ora_walker *w, int64_t n)
+{
+    init_counters(w);
+    for (int64_t i = 0; i < n; ++i) one_step(w);
+}
+
+void ora_measure_begin(ora_walker *w) { init_counters(w); }
+
+void ora_sweep(ora_walker *w, int64_t nsteps)
+{
+    for (int64_t i = 0; i < nsteps; ++i) { w->cnt_sampling += 1; one_step(w); }
+}
+
+void ora_measure_once(ora_walker *w)
+{
+    int nf = w->nflav;
+    w->cnt_meas += 1;
+    w->meas_sign += w->cfgsign; w->cnt_sign += 1;                       /* MeasSign, CTQMC.F90:3343-3350 */
+    w->outer_histo[w->outer_sst] += 1.0;                                /* MeasOuterHistograms, 3285-3339 */
+    for (int f = 0; f < nf; ++f) {                                      /* MeasExpOrder, 3264-3282 */
+        int k = w->k[f], last = w->p.maxhisto;
+        w->histo[(size_t)f * (last + 1) + (k < last ? k : last)] += 1.0;
+    }
+    {   /* MeasDensityMatrix_beta_half, CTQMC.F90:3088-3151 with Trace.F90:6213-6470 (scalar case): the state alive
+         * at beta/2, weight -cfgsign * sign(bra)sign(ket)/sign(trace) = -cfgsign */
+        int s = w->outer_sst;
+        for (int i = 0; i < w->nops && w->ops[i].tau <= w->p.beta / 2.0; ++i) s = connect(w, s, w->ops[i].flav, w->ops[i].ca);
+        w->dm[s] += -w->cfgsign;
+    }
+    for (int f = 0; f < nf; ++f) {                                      /* MeasGtauRem + measure_giw_nfft */
+        int k = w->k[f];
+        if (k == 0) continue;
+        double *tc = (double *)malloc(sizeof(double) * k), *ta = (double *)malloc(sizeof(double) * k);
+        int nc = 0, na = 0;
+        for (int i = 0; i < w->nops; ++i) {
+            if (w->ops[i].flav != f) continue;
+            if (w->ops[i].ca == 1) tc[nc++] = w->ops[i].tau; else ta[na++] = w->ops[i].tau;
+        }
+        ora_meas_flavour(w->M[f], k, tc, ta, w->p.beta, w->cfgsign, w->p.nlegmax, w->gleg + (size_t)f * w->p.nlegmax,
+                         w->p.ntau, w->gtau + (size_t)f * w->p.ntau, 2 * w->p.niw,
+                         w->p.meas_giw ? w->giw + (size_t)f * 4 * w->p.niw : NULL);
+        free(tc); free(ta);
+    }
+}
+
+void ora_measure_finish(ora_walker *w)
+{
+    int nf = w->nflav; double beta = w->p.beta;
+    if (w->cnt_meas == 0) { w->aborted = 2; return; }
+    w->mean_sign = w->meas_sign / (double)w->cnt_sign;                                  /* CTQMC.F90:8670 */
+    double zs = -1.0 / (w->cnt_meas * w->mean_sign);                                     /* 8697 */
+    for (int s = 0; s < w->nstates; ++s) w->dm[s] *= zs;                                /* 8706-8708 */
+    for (size_t i = 0; i < (size_t)nf * w->p.ntau; ++i)                                 /* 8726-8731 */
+        w->gtau[i] = -(w->gtau[i] / w->cnt_meas) / (-w->mean_sign) * (double)w->p.ntau / (beta * beta);
+    for (size_t i = 0; i < (size_t)nf * (w->p.maxhisto + 1); ++i) w->histo[i] /= w->cnt_meas;   /* 8755 */
+    for (int s = 0; s < w->nstates; ++s) w->outer_histo[s] /= w->cnt_meas;              /* 8760 */
+    for (int f = 0; f < nf; ++f)
+        for (int l = 0; l < w->p.nlegmax; ++l) {                                        /* 8766-8771 */
+            double *g = &w->gleg[(size_t)f * w->p.nlegmax + l];
+            *g = *g * sqrt((double)(2 * l) + 1.0) / beta;
+            *g = -*g * zs;
+        }
+    if (w->p.meas_giw)
+        for (size_t i = 0; i < (size_t)nf * 4 * w->p.niw; ++i) w->giw[i] = w->giw[i] * zs / beta;   /* 8815-8817 */
+}
+
+int ora_measure(ora_walker *w)
+{
+    ora_measure_begin(w);
+    for (int64_t m = 0; m < w->p.nmeas; ++m) {
+        ora_sweep(w, w->p.ncorr);
+        ora_measure_once(w);
+    }
+    ora_measure_finish(w);
+    return w->aborted;
+}
+
+/* ------------------------------------------------------------------------------------------------------- */
+/* accessors                                                                                                 */
+/* ------------------------------------------------------------------------------------------------------- */
+
+int ora_noper(const ora_walker *w) { return w->nops; }
+
+void ora_get_config(const ora_walker *w, double *taus, int *orbs, int *spins, int *cas, int *outer_sst)
+{
+    for (int i = 0; i < w->nops; ++i) {
+        taus[i] = w->ops[i].tau; orbs[i] = (w->ops[i].flav >> 1) + 1; spins[i] = (w->ops[i].flav & 1) + 1; cas[i] = w->ops[i].ca;
+    }
+    *outer_sst = w->outer_sst;
+}
+
+/* Trace.F90:6872-7000 set_mc_config_from_arrays */
+int ora_set_config(ora_walker *w, int n, const double *taus, const int *orbs, const int *spins, const int *cas, int outer_sst)
+{
+    ensure_cap(w, n);
+    w->nops = n;
+    for (int i = 0; i < n; ++i) { w->ops[i].tau = taus[i]; w->ops[i].flav = 2 * (orbs[i] - 1) + (spins[i] - 1); w->ops[i].ca = cas[i]; }
+    w->outer_sst = outer_sst;
+    w->wpos = 0; set_window(w);
+    w->tr = full_trace(w, outer_sst);
+    double *Mn[MAXFLAV]; int kn[MAXFLAV];
+    rebuild_minv(w, Mn, kn, &w->det);
+    for (int f = 0; f < w->nflav; ++f) { free(w->M[f]); w->M[f] = Mn[f]; w->k[f] = kn[f]; }
+    w->cfgsign = -get_sign(w);
+    return w->tr.sign == 0.0 ? 1 : 0;
+}
+
+int ora_get_minv(const ora_walker *w, int orb, int spin, double *out)
+{
+    int f = 2 * (orb - 1) + (spin - 1), k = w->k[f];
+    if (out) memcpy(out, w->M[f], sizeof(double) * (size_t)k * k);
+    return k;
+}
+
+void ora_get_state(const ora_walker *w, double *dl, double *ds, double *tl, double *ts, double *cs, int *wpos, int *np)
+{
+    *dl = w->det.log; *ds = w->det.sign; *tl = w->tr.log; *ts = w->tr.sign; *cs = w->cfgsign; *wpos = w->wpos;
+    *np = count_pairs(w, 0, NULL, NULL);
+}
+
+void ora_get_gleg(const ora_walker *w, double *o) { memcpy(o, w->gleg, sizeof(double) * (size_t)w->nflav * w->p.nlegmax); }
+void ora_get_gtau(const ora_walker *w, double *o) { memcpy(o, w->gtau, sizeof(double) * (size_t)w->nflav * w->p.ntau); }
+void ora_get_giw(const ora_walker *w, double *o) { memcpy(o, w->giw, sizeof(double) * (size_t)w->nflav * 4 * w->p.niw); }
+void ora_get_histo(const ora_walker *w, double *o) { memcpy(o, w->histo, sizeof(double) * (size_t)w->nflav * (w->p.maxhisto + 1)); }
+void ora_get_densitymatrix_diag(const ora_walker *w, double *o) { memcpy(o, w->dm, sizeof(double) * (size_t)w->nstates); }
+void ora_get_outer_histo(const ora_walker *w, double *o) { memcpy(o, w->outer_histo, sizeof(double) * (size_t)w->nstates); }
+void ora_get_accpair(const ora_walker *w, int64_t *o) { memcpy(o, w->accpair, sizeof(int64_t) * (size_t)w->nflav * w->p.ntau); }
+void ora_get_energies(const ora_walker *w, double *o) { memcpy(o, w->E, sizeof(double) * (size_t)w->nstates); }
+double ora_mean_sign(const ora_walker *w) { return w->mean_sign; }
+void ora_get_counters(const ora_walker *w, double *o)
+{
+    o[0] = w->try_add; o[1] = w->acc_add; o[2] = w->accqn_add; o[3] = w->try_rem; o[4] = w->acc_rem; o[5] = w->accqn_rem;
+    o[6] = w->try_glob; o[7] = w->acc_glob; o[8] = w->accqn_glob; o[9] = w->try_shift; o[10] = w->acc_shift;
+    o[11] = w->cnt_sampling; o[12] = w->cnt_meas;
+}

@@ -1,0 +1,104 @@
+/* TEST INFRASTRUCTURE ONLY (oracle): CPU restatement of the reference CT-HYB hot path.
+ *
+ * Single Markov chain, density-density local problem (every block of H_loc holds one Fock state: the
+ * reference's "scalar" trace path, Trace.F90:5556-5727), diagonal hybridisation.  Plain arrays instead of the
+ * reference's linked lists; the move logic, proposal volumes, acceptance ratios, random-number consumption
+ * order and estimator arithmetic follow the reference function by function (citations in cthyb_oracle.c).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this library.
+ */
+#ifndef CTHYB_ORACLE_H
+#define CTHYB_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Random source: the oracle never generates numbers itself, so that the same chain can be driven by
+ * std::mt19937 (to pin it against the reference) or by the product's counter-based generator (to check the GPU). */
+typedef struct ora_rng {
+    void *state;
+    double (*uniform)(void *state);               /* [0,1)      : Random.F90:49 grnd()     */
+    int (*randint)(void *state, int lo, int hi);  /* [lo,hi]    : Random.F90:54 randint()  */
+} ora_rng;
+
+typedef struct ora_params {
+    int nd;                 /* Nd */
+    double beta;
+    int nftau;              /* Nftau: points of F(tau) incl. both ends */
+    int ntau;               /* Ntau: G(tau) bins */
+    int nlegmax;            /* NLegMax */
+    int niw;                /* Niw (giw has 2*Niw frequencies) */
+    int meas_giw;           /* MeasGiw */
+    int ncorr;              /* NCorr */
+    int64_t nmeas;          /* Nmeas */
+    int maxhisto;           /* MaxHisto */
+    double p_glob;          /* PercentageGlobalMove */
+    double p_shift;         /* PercentageTauShiftMove */
+    double taudiffmax;      /* TaudiffMax from the parameter string (window at init_solver, NSlide) */
+    int has_szt;            /* "Szt" in QuantumNumbers (CTQMC.F90 glob_has_Szt) */
+} ora_params;
+
+typedef struct ora_walker ora_walker;
+
+/* init_solver (CTQMC.F90:7894-8085) for the density-density scalar case.
+ * umatrix (2Nd)^4, ftau_full (Nd,2,Nd,2,Nftau), muimp_full (Nd,2,Nd,2) [already negated], C order.
+ * Consumes one uniform() for the initial outer superstate (Trace.F90:657-663). Returns NULL when the local
+ * Hamiltonian is not diagonal in the occupation basis. */
+ora_walker *ora_create(const ora_params *p, const double *umatrix, const double *ftau_full,
+                       const double *muimp_full, ora_rng *rng);
+void ora_destroy(ora_walker *w);
+
+void ora_set_taudiffmax(ora_walker *w, double x);        /* CTQMC.F90:8180 */
+void ora_warmup(ora_walker *w, int64_t n);               /* CTQMC.F90:8188 */
+int ora_measure(ora_walker *w);                          /* CTQMC.F90:8355 sector Z; returns `aborted` */
+/* the two halves of ora_measure, for step-by-step checks */
+void ora_measure_begin(ora_walker *w);                   /* init_counters etc. */
+void ora_sweep(ora_walker *w, int64_t nsteps);           /* nsteps Monte Carlo steps of the Z-space loop */
+void ora_measure_once(ora_walker *w);                    /* one pass of all Z-space estimators */
+void ora_measure_finish(ora_walker *w);                  /* normalisation block, CTQMC.F90:8663-8817 */
+
+/* configuration access (CTQMC.F90:9358-9400; Trace.F90:6837-7000) */
+int ora_noper(const ora_walker *w);
+void ora_get_config(const ora_walker *w, double *taus, int *orbs, int *spins, int *cas, int *outer_sst);
+int ora_set_config(ora_walker *w, int n, const double *taus, const int *orbs, const int *spins, const int *cas,
+                   int outer_sst);
+/* M block of flavour (orb,spin) [1-based like the reference], time ordered, row=creator, col=annihilator;
+ * returns k and copies k*k doubles (row major) if out != NULL */
+int ora_get_minv(const ora_walker *w, int orb, int spin, double *out);
+void ora_get_state(const ora_walker *w, double *det_log, double *det_sign, double *tr_log, double *tr_sign,
+                   double *cfgsign, int *window_position, int *npairs);
+
+/* results (valid after ora_measure / ora_measure_finish); shapes as the reference's module arrays, C order */
+void ora_get_gleg(const ora_walker *w, double *out);      /* (Nd,2,NLegMax) */
+void ora_get_gtau(const ora_walker *w, double *out);      /* (Nd,2,Ntau) */
+void ora_get_giw(const ora_walker *w, double *out_reim);  /* (Nd,2,2Niw) complex interleaved */
+void ora_get_histo(const ora_walker *w, double *out);     /* (Nd,2,MaxHisto+1) */
+void ora_get_densitymatrix_diag(const ora_walker *w, double *out);  /* 4^Nd */
+void ora_get_outer_histo(const ora_walker *w, double *out);         /* 4^Nd */
+void ora_get_accpair(const ora_walker *w, int64_t *out);  /* (Nd,2,Ntau) */
+void ora_get_energies(const ora_walker *w, double *out);  /* 4^Nd eigenstate energies */
+double ora_mean_sign(const ora_walker *w);
+/* counters: [0]TryAdd [1]AccAdd [2]AccQNAdd [3]TryRem [4]AccRem [5]AccQNRem [6]TryGlob [7]AccGlob [8]AccQNGlob
+ * [9]TryShift [10]AccShift [11]CntSampling [12]CntMeas */
+void ora_get_counters(const ora_walker *w, double *out13);
+
+/* ---- pure pieces, exposed for kernel-level parity tests ---- */
+double ora_hybr(const double *ftab, int nftau, double beta, double dtau);          /* Trace.F90:1014-1033 */
+double ora_detrat_add(const double *M, int k, const double *Q, const double *R, double S);  /* MatrixUpdate.F90:392 */
+void ora_mat_add(const double *M, int k, const double *Q, const double *R, double S, int pos_c, int pos_a,
+                 double *out);                                                      /* MatrixUpdate.F90:410 */
+void ora_mat_rem(const double *M, int k, int pos_c, int pos_a, double *out);        /* MatrixUpdate.F90:455 */
+/* LU inverse + log-determinant, own restatement of what get_MatLogDetFull (MatrixUpdate.F90:41-99) obtains
+ * from LAPACK dgetrf/dgetri; A (k x k, row major) is overwritten by its inverse. returns 0 on success */
+int ora_inverse_logdet(double *A, int k, double *logdet, double *sign);
+/* one configuration's contribution to the Legendre / tau-bin / Matsubara estimators of one flavour
+ * (CTQMC.F90:2285-2424, Nfft_z.F90:376-414); accumulates into the outputs */
+void ora_meas_flavour(const double *M, int k, const double *tau_c, const double *tau_a, double beta, double cfgsign,
+                      int nleg, double *gleg, int ntau, double *gtau, int niw2, double *giw_reim);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,165 @@
+"""TEST INFRASTRUCTURE ONLY - ctypes binding of oracle/libcthyb_oracle.so (the CPU restatement).
+
+Used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class OraParams(C.Structure):
+    _fields_ = [("nd", C.c_int), ("beta", C.c_double), ("nftau", C.c_int), ("ntau", C.c_int), ("nlegmax", C.c_int),
+                ("niw", C.c_int), ("meas_giw", C.c_int), ("ncorr", C.c_int), ("nmeas", C.c_int64),
+                ("maxhisto", C.c_int), ("p_glob", C.c_double), ("p_shift", C.c_double), ("taudiffmax", C.c_double),
+                ("has_szt", C.c_int)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "libcthyb_oracle.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = os.path.join(_HERE, "libcthyb_oracle.so")
+    if not os.path.exists(path):
+        build()
+    L = C.CDLL(path)
+    dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+    ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+    lp = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+    vp = C.c_void_p
+    L.ora_rng_std.restype = vp; L.ora_rng_std.argtypes = [C.c_uint]
+    L.ora_rng_philox.restype = vp; L.ora_rng_philox.argtypes = [C.c_uint64, C.c_uint64]
+    L.ora_rng_philox_ndraw.restype = C.c_uint64; L.ora_rng_philox_ndraw.argtypes = [vp]
+    L.ora_rng_uniform.restype = C.c_double; L.ora_rng_uniform.argtypes = [vp]
+    L.ora_rng_randint.restype = C.c_int; L.ora_rng_randint.argtypes = [vp, C.c_int, C.c_int]
+    L.ora_create.restype = vp; L.ora_create.argtypes = [C.POINTER(OraParams), dp, dp, dp, vp]
+    L.ora_destroy.argtypes = [vp]
+    L.ora_set_taudiffmax.argtypes = [vp, C.c_double]
+    L.ora_warmup.argtypes = [vp, C.c_int64]
+    L.ora_measure.argtypes = [vp]; L.ora_measure.restype = C.c_int
+    L.ora_measure_begin.argtypes = [vp]
+    L.ora_sweep.argtypes = [vp, C.c_int64]
+    L.ora_measure_once.argtypes = [vp]
+    L.ora_measure_finish.argtypes = [vp]
+    L.ora_noper.argtypes = [vp]; L.ora_noper.restype = C.c_int
+    L.ora_get_config.argtypes = [vp, dp, ip, ip, ip, C.POINTER(C.c_int)]
+    L.ora_set_config.argtypes = [vp, C.c_int, dp, ip, ip, ip, C.c_int]; L.ora_set_config.restype = C.c_int
+    L.ora_get_minv.argtypes = [vp, C.c_int, C.c_int, C.c_void_p]; L.ora_get_minv.restype = C.c_int
+    L.ora_get_state.argtypes = [vp] + [C.POINTER(C.c_double)] * 5 + [C.POINTER(C.c_int)] * 2
+    for n in ("gleg", "gtau", "giw", "histo", "densitymatrix_diag", "outer_histo", "energies"):
+        getattr(L, "ora_get_" + n).argtypes = [vp, dp]
+    L.ora_get_accpair.argtypes = [vp, lp]
+    L.ora_get_counters.argtypes = [vp, dp]
+    L.ora_mean_sign.argtypes = [vp]; L.ora_mean_sign.restype = C.c_double
+    L.ora_hybr.argtypes = [dp, C.c_int, C.c_double, C.c_double]; L.ora_hybr.restype = C.c_double
+    L.ora_detrat_add.argtypes = [dp, C.c_int, dp, dp, C.c_double]; L.ora_detrat_add.restype = C.c_double
+    L.ora_mat_add.argtypes = [dp, C.c_int, dp, dp, C.c_double, C.c_int, C.c_int, dp]
+    L.ora_mat_rem.argtypes = [dp, C.c_int, C.c_int, C.c_int, dp]
+    L.ora_inverse_logdet.argtypes = [dp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.ora_inverse_logdet.restype = C.c_int
+    L.ora_meas_flavour.argtypes = [dp, C.c_int, dp, dp, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_int, C.c_void_p]
+    _LIB = L
+    return L
+
+
+def params_from_pstring(ps, nd, beta):
+    """Pick the keys the oracle needs out of a parsed parameter set (w2dynamics_amd.params.ParameterSet)."""
+    return OraParams(nd=nd, beta=beta, nftau=ps.get_int("Nftau"), ntau=ps.get_int("Ntau"),
+                     nlegmax=ps.get_int("NLegMax"), niw=ps.get_int("Niw"), meas_giw=ps.get_int("MeasGiw"),
+                     ncorr=ps.get_int("NCorr"), nmeas=ps.get_int("Nmeas"), maxhisto=ps.get_int("MaxHisto"),
+                     p_glob=ps.get_real("PercentageGlobalMove"), p_shift=ps.get_real("PercentageTauShiftMove"),
+                     taudiffmax=ps.get_real("TaudiffMax"), has_szt=int("Szt" in ps.get_str("QuantumNumbers")))
+
+
+class OracleWalker:
+    """One chain of the CPU restatement; rng = ("std", seed) or ("philox", seed, walker)."""
+
+    def __init__(self, problem, pset, rng=("std", 0)):
+        self.L = lib()
+        self.p = params_from_pstring(pset, problem.nd, problem.beta)
+        assert self.p.nftau == problem.nftau, "Nftau in the parameter string must match the F(tau) array"
+        if rng[0] == "std":
+            self.rng = self.L.ora_rng_std(int(rng[1]))
+        else:
+            self.rng = self.L.ora_rng_philox(int(rng[1]), int(rng[2]))
+        self.nd = problem.nd
+        self.h = self.L.ora_create(C.byref(self.p), problem.umatrix, problem.ftau, problem.muimp, self.rng)
+        if not self.h:
+            raise ValueError("oracle: local Hamiltonian is not density-density")
+
+    def set_taudiffmax(self, x): self.L.ora_set_taudiffmax(self.h, float(x))
+    def warmup(self, n): self.L.ora_warmup(self.h, int(n))
+    def measure(self): return self.L.ora_measure(self.h)
+    def measure_begin(self): self.L.ora_measure_begin(self.h)
+    def sweep(self, n): self.L.ora_sweep(self.h, int(n))
+    def measure_once(self): self.L.ora_measure_once(self.h)
+    def measure_finish(self): self.L.ora_measure_finish(self.h)
+
+    def get_config(self):
+        n = self.L.ora_noper(self.h)
+        taus = np.zeros(max(n, 1)); orbs = np.zeros(max(n, 1), np.int32); spins = orbs.copy(); cas = orbs.copy()
+        o = C.c_int()
+        self.L.ora_get_config(self.h, taus, orbs, spins, cas, C.byref(o))
+        return dict(taus=taus[:n].copy(), orbs=orbs[:n].copy(), spins=spins[:n].copy(), cas=cas[:n].copy(),
+                    hashybs=-np.ones(n, np.int32), outer_sst=o.value, outer_state=1)
+
+    def set_config(self, cfg):
+        n = len(cfg["taus"])
+        f = lambda a, t: np.ascontiguousarray(a if n else np.zeros(1), dtype=t)
+        return self.L.ora_set_config(self.h, n, f(cfg["taus"], np.float64), f(cfg["orbs"], np.int32),
+                                     f(cfg["spins"], np.int32), f(cfg["cas"], np.int32), int(cfg["outer_sst"]))
+
+    def minv(self, orb, spin):
+        k = self.L.ora_get_minv(self.h, orb, spin, None)
+        out = np.zeros((k, k))
+        if k:
+            self.L.ora_get_minv(self.h, orb, spin, out.ctypes.data)
+        return out
+
+    def state(self):
+        d = [C.c_double() for _ in range(5)]; i = [C.c_int(), C.c_int()]
+        self.L.ora_get_state(self.h, *[C.byref(x) for x in d], *[C.byref(x) for x in i])
+        return dict(det_log=d[0].value, det_sign=d[1].value, tr_log=d[2].value, tr_sign=d[3].value,
+                    cfgsign=d[4].value, window_position=i[0].value, npairs=i[1].value)
+
+    def results(self):
+        nd, p = self.nd, self.p
+        r = {}
+        a = np.zeros((nd, 2, p.nlegmax)); self.L.ora_get_gleg(self.h, a); r["gleg"] = a
+        a = np.zeros((nd, 2, p.ntau)); self.L.ora_get_gtau(self.h, a); r["gtau"] = a
+        a = np.zeros((nd, 2, 2 * p.niw, 2)); self.L.ora_get_giw(self.h, a); r["giw"] = a[..., 0] + 1j * a[..., 1]
+        a = np.zeros((nd, 2, p.maxhisto + 1)); self.L.ora_get_histo(self.h, a); r["histo"] = a
+        a = np.zeros(4 ** nd); self.L.ora_get_densitymatrix_diag(self.h, a); r["dm_diag"] = a
+        a = np.zeros(4 ** nd); self.L.ora_get_outer_histo(self.h, a); r["outersuperstatehisto"] = a
+        a = np.zeros(4 ** nd); self.L.ora_get_energies(self.h, a); r["eigenstatesenergies"] = a
+        a = np.zeros((nd, 2, p.ntau), np.int64); self.L.ora_get_accpair(self.h, a); r["accpair"] = a
+        a = np.zeros(13); self.L.ora_get_counters(self.h, a); r["counters"] = a
+        r["mean_sign"] = self.L.ora_mean_sign(self.h)
+        r["occ"] = occ_from_dm(r["dm_diag"], nd)
+        return r
+
+    def close(self):
+        if self.h:
+            self.L.ora_destroy(self.h); self.h = None
+
+
+def occ_from_dm(dm_diag, nd):
+    """occ(b1,s1,b2,s2) = sum_n rho_nn n_{b1s1} n_{b2s2}  (CTQMC.F90:2884-2942 for one-state blocks)."""
+    occ = np.zeros((nd, 2, nd, 2))
+    for st, wgt in enumerate(dm_diag):
+        if wgt == 0.0:
+            continue
+        n = np.array([[(st >> (b + nd * s)) & 1 for s in range(2)] for b in range(nd)], dtype=float)
+        occ += wgt * n[:, :, None, None] * n[None, None, :, :]
+    return occ

@@ -1,0 +1,99 @@
+"""Deterministic synthetic impurity problems: Bethe-lattice bath, density-density U.
+
+Conventions follow the reference's caller side:
+  * F(tau) > 0 on `Nftau` equidistant points including both ends, F(tau) = -Delta(beta - tau)
+    (`w2dyn/dmft/selfcons.py:477-492`), array layout (Nd, 2, Nd, 2, Nftau) as passed to `init_solver`
+    after the transpose of `w2dyn/dmft/impurity.py:526`;
+  * `muimp` is passed *negated* (`impurity.py:529`), i.e. init_solver receives -mu on the diagonal;
+  * U tensor indices [b1,s1,b2,s2,b3,s3,b4,s4] filled as in `w2dyn/dmft/interaction.py:182-189`
+    (Density) and reshaped to (2Nd)^4 with flavour index 2*band+spin (`impurity.py:530-532`).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def bethe_ftau(beta: float, nftau: int, D: float = 1.0, nquad: int = 4000) -> np.ndarray:
+    """F(tau) = int de (D/2)^2 rho(e) exp(-(beta-tau) e)/(1+exp(-beta e)), rho = semicircle of half width D.
+
+    Gauss-Chebyshev (second kind) quadrature, numerically stable for both signs of e."""
+    i = np.arange(1, nquad + 1)
+    theta = i * np.pi / (nquad + 1)
+    eps = D * np.cos(theta)
+    w = 2.0 / (nquad + 1) * np.sin(theta) ** 2
+    tau = np.linspace(0.0, beta, nftau)
+    e = eps[None, :]
+    t = tau[:, None]
+    pos = np.exp(-(beta - t) * np.abs(e)) / (1.0 + np.exp(-beta * np.abs(e)))   # e >= 0
+    neg = np.exp(-t * np.abs(e)) / (1.0 + np.exp(-beta * np.abs(e)))            # e < 0
+    kern = np.where(e >= 0, pos, neg)
+    return (D / 2.0) ** 2 * (kern * w[None, :]).sum(axis=1)
+
+
+def density_umatrix(nd: int, u: float, v: float = 0.0, j: float = 0.0) -> np.ndarray:
+    """Density-density U tensor (interaction.py:182-189) reshaped to (2Nd,)*4."""
+    U = np.zeros((nd, 2, nd, 2, nd, 2, nd, 2))
+    for b1 in range(nd):
+        for s in (0, 1):
+            U[b1, s, b1, 1 - s, b1, s, b1, 1 - s] = u
+        for b3 in range(nd):
+            if b3 == b1:
+                continue
+            for s in (0, 1):
+                for sp in (0, 1):
+                    U[b1, s, b3, sp, b1, s, b3, sp] = v
+                U[b1, s, b3, s, b3, s, b1, s] = j
+    return U.reshape((2 * nd,) * 4)
+
+
+class Problem:
+    """One impurity problem in the layout `init_solver` expects."""
+
+    def __init__(self, nd, beta, umatrix, ftau_full, muimp_full_negated, hamiltonian="Density",
+                 quantum_numbers="Nt Szt Azt"):
+        self.nd = nd
+        self.beta = float(beta)
+        self.umatrix = np.ascontiguousarray(umatrix, dtype=np.float64)
+        self.ftau = np.ascontiguousarray(ftau_full, dtype=np.float64)
+        self.muimp = np.ascontiguousarray(muimp_full_negated, dtype=np.float64)
+        self.screening = np.zeros_like(self.ftau)
+        self.hamiltonian = hamiltonian
+        self.quantum_numbers = quantum_numbers
+
+    @property
+    def nftau(self):
+        return self.ftau.shape[-1]
+
+
+def make_problem(nd: int, beta: float, u: float, j: float = 0.0, v: float | None = None, mu: float | None = None,
+                 D: float = 1.0, nftau: int = 5001, spin_split: float = 0.0) -> Problem:
+    """Half-filled (by default) density-density problem on a Bethe bath.
+
+    mu defaults to U/2 + (Nd-1)(V - J/2) (particle-hole symmetric point for this interaction).
+    `spin_split` adds +-h to the two spin species so that tests can break the symmetry."""
+    if v is None:
+        v = u - 2.0 * j
+    if mu is None:
+        mu = u / 2.0 + (nd - 1) * (v - j / 2.0)
+    f = bethe_ftau(beta, nftau, D)
+    ftau = np.zeros((nd, 2, nd, 2, nftau))
+    muimp = np.zeros((nd, 2, nd, 2))
+    for b in range(nd):
+        for s in (0, 1):
+            ftau[b, s, b, s, :] = f * (1.0 + 0.05 * b)    # mildly orbital dependent: catches flavour mix-ups
+            muimp[b, s, b, s] = -(mu + (0.5 - s) * 2.0 * spin_split)
+    return Problem(nd, beta, density_umatrix(nd, u, v, j), ftau, muimp)
+
+
+# the five BASELINE.json configurations (density-density ones are runnable by the HIP path this round)
+def config(name: str, nftau: int = 5001) -> Problem:
+    name = name.upper()
+    if name == "C1":
+        return make_problem(1, 10.0, 2.0, nftau=nftau)
+    if name == "C2":
+        return make_problem(1, 100.0, 2.0, nftau=nftau)
+    if name == "C3":
+        return make_problem(2, 50.0, 2.0, j=0.25, nftau=nftau)
+    if name == "C5Z":
+        return make_problem(5, 100.0, 2.0, j=0.25, nftau=nftau)
+    raise ValueError("unknown or not-yet-supported configuration %r" % name)
