@@ -1,0 +1,118 @@
+/* C ABI of libw2dyn_hip.so - the MI355X (gfx950) CT-HYB hot path.
+ *
+ * Every entry point replaces one call (or one group of module-variable reads) of the reference's f2py module
+ * `w2dyn.auxiliaries.CTQMC.mctqmc`, which is the only interface the reference's Python driver uses for this path
+ * (w2dyn/dmft/impurity.py:18, 387-388, 514-515, 578-598, 650-651).  Citations are to /root/reference.
+ *
+ * Conventions: plain pointers and sizes, C (row-major) order for every array with the axis order of the reference's
+ * Fortran arrays as numpy sees them, e.g. gleg(Nd,2,NLegMax).  All functions return 0 on success, a negative
+ * W2DYN_E* code otherwise; w2dyn_last_error() gives the message.  One solver context owns one GPU; it is not
+ * re-entrant (the reference module is a process-wide singleton, impurity.py:370-372).
+ *
+ * The reference runs ONE Markov chain per MPI rank.  Here one context runs `nwalkers` independent chains on its
+ * GPU; chain w draws from the stream (seed, first_walker + w) (reference: seed + rank, DMFT.py:259).  Nwarmups,
+ * Nmeas and NCorr keep their per-chain meaning.  Result arrays are means over all chains of the context.
+ */
+#ifndef W2DYN_HIP_H
+#define W2DYN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct w2dyn_solver w2dyn_solver;
+
+enum {
+    W2DYN_OK = 0,
+    W2DYN_EINVAL = -1,       /* bad argument / call order                                    */
+    W2DYN_EUNSUPPORTED = -2, /* a mode of the reference this build refuses loudly             */
+    W2DYN_EHIP = -3,         /* HIP runtime error                                            */
+    W2DYN_EOVERFLOW = -4,    /* a walker exceeded the configured expansion-order capacity    */
+    W2DYN_ENUMERIC = -5      /* reference would `stop` (e.g. "DetRat too small in removal")  */
+};
+
+/* lifetime -------------------------------------------------------------------------------------------------- */
+int w2dyn_create(w2dyn_solver **out, int device);            /* replaces importing the f2py module           */
+int w2dyn_destroy(w2dyn_solver *s);
+const char *w2dyn_last_error(const w2dyn_solver *s);
+
+/* chains per GPU, index of this context's first chain (for multi-GPU sharding), expansion-order capacity per
+ * flavour (0 = choose from beta), chains per accumulator bin.  Must precede init_solver. No reference counterpart:
+ * the reference has exactly one chain per process. */
+int w2dyn_set_layout(w2dyn_solver *s, int nwalkers, int64_t first_walker, int kmax, int walkers_per_bin);
+
+/* init_rnd(nseed)                                  CTQMC.F90:9404 */
+int w2dyn_init_rnd(w2dyn_solver *s, int64_t nseed);
+/* init_paras(parastr): "key = value #" lines      CTQMC.F90:9412, Parameters.F90:281-320 (prefix lookup 77-105) */
+int w2dyn_init_paras(w2dyn_solver *s, const char *parastr);
+/* dest_paras()                                     CTQMC.F90:9420 */
+int w2dyn_dest_paras(w2dyn_solver *s);
+/* module variable `fourpnt` (impurity.py:515)                       */
+int w2dyn_set_fourpnt(w2dyn_solver *s, int fourpnt);
+/* init_solver(u_matrix_in, ftau_full, muimp_full, screening_function, iter_no, nftau, nbands)
+ *                                                  CTQMC.F90:7894-8085
+ * u_matrix (2Nd)^4, ftau_full (Nd,2,Nd,2,Nftau), muimp_full (Nd,2,Nd,2) already negated (impurity.py:529),
+ * screening_function (Nd,2,Nd,2,Nftau) (must be zero: Phonon/Screening/Uw are refused). Host pointers. */
+int w2dyn_init_solver(w2dyn_solver *s, const double *u_matrix, const double *ftau_full, const double *muimp_full,
+                      const double *screening_function, int iter_no, int nftau, int nbands);
+/* set_taudiffmax(x)                                CTQMC.F90:8180 */
+int w2dyn_set_taudiffmax(w2dyn_solver *s, double taudiffmax);
+/* init_counters()                                  CTQMC.F90:847 */
+int w2dyn_init_counters(w2dyn_solver *s);
+/* ctqmc_warmup(n)                                  CTQMC.F90:8188 */
+int w2dyn_ctqmc_warmup(w2dyn_solver *s, int64_t nwarmups);
+/* ctqmc_measure(isector, icomponent)               CTQMC.F90:8355 (sector 1 = Z this round) */
+int w2dyn_ctqmc_measure(w2dyn_solver *s, int isector, int icomponent);
+/* dest_ctqmc()                                     CTQMC.F90:901 */
+int w2dyn_dest_ctqmc(w2dyn_solver *s);
+
+/* the pieces of ctqmc_measure, exposed so that a caller (bench, tests) can time / check them separately:
+ * nsteps Monte-Carlo steps for every chain (CTQMC.F90:8428-8533), one pass of the Z-space estimators over every
+ * chain (8541-8581), normalisation (8663-8817). */
+int w2dyn_measure_begin(w2dyn_solver *s);
+int w2dyn_sweep(w2dyn_solver *s, int64_t nsteps, int count_as_sampling);
+int w2dyn_measure_once(w2dyn_solver *s);
+int w2dyn_measure_finish(w2dyn_solver *s);
+int w2dyn_sync(w2dyn_solver *s);                    /* wait for the context's stream */
+
+/* configuration of one chain ---------------------------------------------------------------------------------- */
+/* get_mc_config_scalars() -> (n, outer_sst, outer_state)            CTQMC.F90:9358 */
+int w2dyn_get_mc_config_scalars(w2dyn_solver *s, int walker, int *n, int *outer_sst, int *outer_state);
+/* get_mc_config(n) -> taus, orbs, spins, cas, hashybs (time ordered; hashybs -1 = hybridising, Trace.F90:6861) */
+int w2dyn_get_mc_config(w2dyn_solver *s, int walker, int n, double *taus, int *orbs, int *spins, int *cas,
+                        int *hashybs, int *outer_sst, int *outer_state);
+/* set_mc_config(n, taus, ...) / set_empty_mc_config                 CTQMC.F90:9378, 9391; Trace.F90:6872-7000 */
+int w2dyn_set_mc_config(w2dyn_solver *s, int walker, int n, const double *taus, const int *orbs, const int *spins,
+                        const int *cas, const int *hashybs, int outer_sst, int outer_state);
+/* M block of one chain and flavour (orb, spin 1-based), brought to the reference's time order
+ * (row = creator, column = annihilator, CTQMC.F90:2303-2304); returns the order k in *k, copies k*k doubles if
+ * out != NULL.  No f2py counterpart (MInv is not exported); it is what recorded-configuration parity tests read. */
+int w2dyn_get_minv(w2dyn_solver *s, int walker, int orb, int spin, int *k, double *out, size_t out_doubles);
+/* per-chain scalars: [0] sign of det (time ordered), [1] log|det|, [2] window position, [3] NPairs (recounted),
+ * [4] number of random draws consumed, [5] cfgsign as the estimators see it */
+int w2dyn_get_walker_state(w2dyn_solver *s, int walker, double *out6);
+
+/* results = the module variables the driver reads after ctqmc_measure (impurity.py:1198-1283) ---------------- */
+/* name: "gtau" (Nd,2,Ntau) | "gleg" (Nd,2,NLegMax) | "giw" (Nd,2,2Niw) complex | "occ" (Nd,2,Nd,2) |
+ *       "histo" (Nd,2,MaxHisto+1) | "densitymatrix" (4^Nd,4^Nd) | "rho1" ((2Nd)^2) | "rho2" ((2Nd)^4) |
+ *       "outersuperstatehisto" | "outerstatehisto" | "signhistosuperstates" | "signhistostates" | "tracecontribsuperstates" |
+ *       "tracecontribstates" | "statessuperstates" (int32) | "eigenstatesenergies" | "occbasismapping" (4^Nd,Nd,2) int32 |
+ *       "accadd" (16) | "accrem" (16) | "accpair" (Nd,2,Ntau) int64 | "cntsampling" (16) int64 | "lhisto" | "rhisto" |
+ *       "gtau_full" | "gleg_full" | per-bin: "gleg_bins" (nbins,Nd,2,NLegMax), "gtau_bins", "occ_bins", "giw_bins"
+ * Writes min(bytes, size) bytes; *needed (if not NULL) receives the full size. */
+int w2dyn_get_result(w2dyn_solver *s, const char *name, void *out, size_t bytes, size_t *needed);
+/* scalars: "mean_sign" "aborted" "time_warmup" "time_sim" "time_sim_steps" "accglob" "accshift" "accadd4"
+ *          "accrem4" "accflavc" "nwalkers" "nbins" "kmax" "steps_done" "meas_done" */
+int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out);
+
+/* timing of the last w2dyn_sweep / w2dyn_measure_once launches, measured with HIP events on the context's own
+ * stream: average kernel duration in ms and number of launches since the last reset (bench.py roofline leg) */
+int w2dyn_kernel_time(w2dyn_solver *s, const char *kernel /* "sweep" | "meas_gleg" | "meas_misc" | "meas_giw" */,
+                      double *avg_ms, int64_t *launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

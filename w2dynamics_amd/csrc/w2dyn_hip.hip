@@ -1,0 +1,826 @@
+// Host side of libw2dyn_hip.so: the C ABI declared in include/w2dyn_hip.h.
+// Mirrors the call sequence of the reference's f2py module (CTQMC.F90:7894-9426) for the density-density /
+// diagonal-hybridisation Z-space path; refuses every other mode loudly.  No CPU fallback exists: all sampling and
+// all estimators run in the kernels of cthyb_kernels.hip.h.
+#include "../../include/w2dyn_hip.h"
+#include "cthyb_kernels.hip.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+using namespace w2dyn;
+
+namespace {
+
+struct Param { std::string key, value; };
+
+struct KTimer {
+    double total_ms = 0.0; int64_t launches = 0;
+};
+
+}  // namespace
+
+struct w2dyn_solver {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    // layout
+    int nwalkers = 1024, kmax_req = 0, walkers_per_bin = 8;
+    int64_t first_walker = 0;
+    int64_t seed = 0;
+    int fourpnt = 0;
+    std::vector<Param> paras;
+    bool have_paras = false, have_solver = false;
+    // parameters picked up at init_solver
+    int nd = 0, nflav = 0, nstates = 0, nftau = 0, ntau = 0, nleg = 0, niw = 0, meas_giw = 0, ncorr = 0, maxhisto = 0;
+    int64_t nmeas = 0;
+    double beta = 0, p_glob = 0, p_shift = 0, taudiffmax_param = 0;
+    int has_szt = 0;
+    std::vector<double> energies, udd, eps, outer_w, outer_cum, ftab;
+    double egs = 0;
+    DevConst C{};
+    std::vector<void *> allocs;
+    // accumulators bookkeeping
+    int64_t meas_done = 0, steps_done = 0;
+    int aborted = 0;
+    double mean_sign = 0, time_warmup = 0, time_sim = 0, time_sim_steps = 0;
+    std::map<std::string, std::vector<double>> res;      // normalised results (doubles / complex interleaved)
+    std::vector<long long> res_accpair;
+    std::vector<double> counters;                        // summed over walkers, C_NCOUNT
+    std::map<std::string, KTimer> timers;
+    bool timing = true;
+};
+
+namespace {
+
+int fail(w2dyn_solver *s, int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (s) s->err = buf;
+    return code;
+}
+
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(s, W2DYN_EHIP, "%s: %s", #call, hipGetErrorString(e_)); } while (0)
+
+// ---- parameter string (Parameters.F90:281-320; lookup by prefix of the stored identifier, 77-105) ----
+const Param *find_param(const w2dyn_solver *s, const char *id)
+{
+    size_t n = strlen(id);
+    for (const auto &p : s->paras) if (p.key.compare(0, n, id) == 0) return &p;
+    return nullptr;
+}
+bool get_int(w2dyn_solver *s, const char *id, long long &out)
+{
+    const Param *p = find_param(s, id);
+    if (!p) { fail(s, W2DYN_EINVAL, "%s not found in parameter list!", id); return false; }
+    if (p->value == "True") { out = 1; return true; }
+    if (p->value == "False" || p->value.empty()) { out = 0; return true; }
+    char *end = nullptr;
+    double v = strtod(p->value.c_str(), &end);
+    if (end == p->value.c_str()) { fail(s, W2DYN_EINVAL, "%s is not an integer", id); return false; }
+    out = (long long)v; return true;
+}
+bool get_real(w2dyn_solver *s, const char *id, double &out)
+{
+    const Param *p = find_param(s, id);
+    if (!p) { fail(s, W2DYN_EINVAL, "%s not found in parameter list!", id); return false; }
+    out = p->value.empty() ? 0.0 : strtod(p->value.c_str(), nullptr); return true;
+}
+bool get_str(w2dyn_solver *s, const char *id, std::string &out)
+{
+    const Param *p = find_param(s, id);
+    if (!p) { fail(s, W2DYN_EINVAL, "%s not found in parameter list!", id); return false; }
+    out = p->value; return true;
+}
+
+template <class T> int dev_alloc(w2dyn_solver *s, T *&ptr, size_t count)
+{
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    HIPCHK(hipMalloc(&p, bytes));
+    HIPCHK(hipMemsetAsync(p, 0, bytes, s->stream));
+    s->allocs.push_back(p);
+    ptr = (T *)p;
+    return 0;
+}
+template <class T> int dev_upload(w2dyn_solver *s, const T *&ptr, const std::vector<T> &v)
+{
+    T *p = nullptr;
+    int rc = dev_alloc(s, p, v.size());
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s->stream));
+    ptr = p;
+    return 0;
+}
+
+void free_device(w2dyn_solver *s)
+{
+    for (void *p : s->allocs) (void)hipFree(p);
+    s->allocs.clear();
+    s->have_solver = false;
+}
+
+inline int flav_bit_h(int f, int nd) { return (f >> 1) + nd * (f & 1); }
+
+// window parameters, Trace.F90:1608-1648
+void host_init_window(w2dyn_solver *s, double tdm, int &num_windows, double &taudiff_max)
+{
+    if (tdm > 0.0) {
+        taudiff_max = tdm;
+        int nw = (int)std::floor(s->beta / tdm) - 1;
+        num_windows = nw > 1 ? nw : 1;
+    } else { taudiff_max = s->beta; num_windows = 1; }
+}
+
+size_t lds_per_wave(int kmax) { return (size_t)(4 * kmax + WCAP + 2) * sizeof(double) + (size_t)2 * WCAP * sizeof(int); }
+
+struct Launch { dim3 grid, block; size_t lds; };
+Launch walker_launch(const w2dyn_solver *s)
+{
+    Launch l;
+    l.block = dim3(256);
+    l.grid = dim3((s->nwalkers + 3) / 4);
+    l.lds = 4 * s->C.lds_per_wave;
+    return l;
+}
+
+int time_begin(w2dyn_solver *s) { if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream)); return 0; }
+int time_end(w2dyn_solver *s, const char *name)
+{
+    if (!s->timing) return 0;
+    HIPCHK(hipEventRecord(s->ev1, s->stream));
+    HIPCHK(hipEventSynchronize(s->ev1));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    auto &t = s->timers[name]; t.total_ms += ms; t.launches += 1;
+    return 0;
+}
+
+int check_walker_errors(w2dyn_solver *s)
+{
+    std::vector<WalkerScalars> ws(s->nwalkers);
+    HIPCHK(hipMemcpyAsync(ws.data(), s->C.ws, ws.size() * sizeof(WalkerScalars), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    int e = 0;
+    for (auto &w : ws) e |= w.err;
+    if (e & ERR_KMAX) return fail(s, W2DYN_EOVERFLOW, "a chain reached the expansion-order capacity kmax=%d; raise it with w2dyn_set_layout", s->C.kmax);
+    if (e & ERR_WCAP) return fail(s, W2DYN_EOVERFLOW, "more than %d operators inside the sliding window; reduce TaudiffMax", WCAP);
+    if (e & ERR_DETRAT) return fail(s, W2DYN_ENUMERIC, "DetRat too small in removal");
+    if (e & ERR_SINGULAR) return fail(s, W2DYN_ENUMERIC, "singular hybridisation matrix in full rebuild");
+    return 0;
+}
+
+template <int T> void launch_gleg(w2dyn_solver *s)
+{
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_gleg<T>), dim3(s->C.nbins, s->nflav), dim3(64), 0, s->stream, s->C);
+}
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}  // namespace
+
+extern "C" {
+
+int w2dyn_create(w2dyn_solver **out, int device)
+{
+    if (!out) return W2DYN_EINVAL;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return W2DYN_EHIP;
+    w2dyn_solver *s = new w2dyn_solver();
+    s->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&s->stream) != hipSuccess ||
+        hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { delete s; return W2DYN_EHIP; }
+    *out = s;
+    return 0;
+}
+
+int w2dyn_destroy(w2dyn_solver *s)
+{
+    if (!s) return 0;
+    (void)hipSetDevice(s->device);
+    free_device(s);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+    return 0;
+}
+
+const char *w2dyn_last_error(const w2dyn_solver *s) { return s ? s->err.c_str() : "null solver"; }
+
+int w2dyn_set_layout(w2dyn_solver *s, int nwalkers, int64_t first_walker, int kmax, int walkers_per_bin)
+{
+    if (!s) return W2DYN_EINVAL;
+    if (s->have_solver) return fail(s, W2DYN_EINVAL, "set_layout must precede init_solver");
+    if (nwalkers <= 0 || first_walker < 0 || kmax < 0 || kmax > WCAP || walkers_per_bin <= 0)
+        return fail(s, W2DYN_EINVAL, "bad layout (nwalkers=%d kmax=%d walkers_per_bin=%d)", nwalkers, kmax, walkers_per_bin);
+    s->nwalkers = nwalkers; s->first_walker = first_walker; s->kmax_req = kmax; s->walkers_per_bin = walkers_per_bin;
+    return 0;
+}
+
+int w2dyn_init_rnd(w2dyn_solver *s, int64_t nseed) { if (!s) return W2DYN_EINVAL; s->seed = nseed; return 0; }
+
+int w2dyn_init_paras(w2dyn_solver *s, const char *parastr)
+{
+    if (!s || !parastr) return W2DYN_EINVAL;
+    s->paras.clear();
+    const char *p = parastr;
+    while (*p) {
+        const char *eol = strchr(p, '\n');
+        std::string line = eol ? std::string(p, eol) : std::string(p);
+        p = eol ? eol + 1 : p + line.size();
+        size_t eq = line.find('=');
+        if (eq == std::string::npos) continue;
+        std::string key = line.substr(0, eq), val = line.substr(eq + 1);
+        size_t hash = val.find('#'); if (hash != std::string::npos) val.resize(hash);
+        auto trim = [](std::string &t) { size_t a = t.find_first_not_of(" \t\r"), b = t.find_last_not_of(" \t\r"); t = (a == std::string::npos) ? "" : t.substr(a, b - a + 1); };
+        trim(key); trim(val);
+        if (key.empty() || key[0] == '#') continue;
+        s->paras.push_back({key, val});
+    }
+    s->have_paras = true;
+    return 0;
+}
+
+int w2dyn_dest_paras(w2dyn_solver *s) { if (!s) return W2DYN_EINVAL; s->paras.clear(); s->have_paras = false; return 0; }
+int w2dyn_set_fourpnt(w2dyn_solver *s, int fourpnt) { if (!s) return W2DYN_EINVAL; s->fourpnt = fourpnt; return 0; }
+
+int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full, const double *mu_full,
+                      const double *screening, int iter_no, int nftau, int nbands)
+{
+    (void)iter_no;
+    if (!s || !U || !ftau_full || !mu_full) return W2DYN_EINVAL;
+    if (!s->have_paras) return fail(s, W2DYN_EINVAL, "init_paras must precede init_solver");
+    HIPCHK(hipSetDevice(s->device));
+    free_device(s);
+    long long iv; double rv; std::string sv;
+    // ---- modes this build refuses ----
+    struct { const char *key; long long allowed; } zero_int[] = {
+        {"segment", 0}, {"offdiag", 0}, {"full_offdiag", 0}, {"statesampling", 0}, {"flavourchange_moves", 0}, {"Phonon", 0},
+        {"Screening", 0}, {"Uw", 0}, {"MeasGtauDetRat", 0}, {"MeasSusz", 0}, {"MeasG2iw", 0}, {"MeasG4iwPP", 0},
+        {"MeasExpResDensityMatrix", 0}, {"MeasSsquare", 0}, {"Gtau_mean_step", 0}, {"Gtau_mid_step", 0}, {"sign_step", 0},
+        {"NSymMove", 0}, {"MeasDensityMatrix", 1}, {"Eigenbasis", 1}, {"AccumGtau", 1}};
+    for (auto &z : zero_int) {
+        if (!get_int(s, z.key, iv)) return W2DYN_EINVAL;
+        if (iv != z.allowed) return fail(s, W2DYN_EUNSUPPORTED, "%s = %lld is not supported by the HIP solver (only %lld)", z.key, iv, z.allowed);
+    }
+    const char *zero_real[] = {"Percentage4OperatorMove", "PercentageOuterMove", "PercentageWormInsert", "PercentageWormReplace"};
+    for (auto key : zero_real) {
+        if (!get_real(s, key, rv)) return W2DYN_EINVAL;
+        if (rv != 0.0) return fail(s, W2DYN_EUNSUPPORTED, "%s = %g is not supported by the HIP solver (only 0)", key, rv);
+    }
+    if (!get_str(s, "EnableOuterTruncation", sv)) return W2DYN_EINVAL;
+    if (sv == "YES") return fail(s, W2DYN_EUNSUPPORTED, "EnableOuterTruncation = YES is not supported");
+    if (s->fourpnt != 0) return fail(s, W2DYN_EUNSUPPORTED, "FourPnt = %d is not supported yet", s->fourpnt);
+    if (screening) { /* must be zero; checked below once nd is known */ }
+
+    if (!get_int(s, "Nd", iv)) return W2DYN_EINVAL; s->nd = (int)iv;
+    if (nbands != s->nd) return fail(s, W2DYN_EINVAL, "nbands=%d differs from Nd=%d", nbands, s->nd);
+    if (s->nd < 1 || 2 * s->nd > MAXFLAV) return fail(s, W2DYN_EUNSUPPORTED, "Nd=%d out of range", s->nd);
+    s->nflav = 2 * s->nd; s->nstates = 1 << (2 * s->nd);
+    if (!get_real(s, "beta", s->beta)) return W2DYN_EINVAL;
+    if (!get_int(s, "Ntau", iv)) return W2DYN_EINVAL; s->ntau = (int)iv;
+    if (!get_int(s, "NLegMax", iv)) return W2DYN_EINVAL; s->nleg = (int)iv;
+    if (!get_int(s, "Niw", iv)) return W2DYN_EINVAL; s->niw = (int)iv;
+    if (!get_int(s, "MeasGiw", iv)) return W2DYN_EINVAL; s->meas_giw = (int)iv;
+    if (s->meas_giw) { if (!get_int(s, "NLookup_nfft", iv)) return W2DYN_EINVAL; if (iv != 0) return fail(s, W2DYN_EUNSUPPORTED, "MeasGiw needs NLookup_nfft = 0 (exact sums)"); }
+    if (!get_int(s, "NCorr", iv)) return W2DYN_EINVAL; s->ncorr = (int)iv;
+    if (!get_int(s, "Nmeas", iv)) return W2DYN_EINVAL; s->nmeas = iv;
+    if (!get_int(s, "MaxHisto", iv)) return W2DYN_EINVAL; s->maxhisto = (int)iv;
+    if (!get_real(s, "PercentageGlobalMove", s->p_glob)) return W2DYN_EINVAL;
+    if (!get_real(s, "PercentageTauShiftMove", s->p_shift)) return W2DYN_EINVAL;
+    if (!get_real(s, "TaudiffMax", s->taudiffmax_param)) return W2DYN_EINVAL;
+    if (!get_str(s, "QuantumNumbers", sv)) return W2DYN_EINVAL;
+    s->has_szt = sv.find("Szt") != std::string::npos;
+    if (sv.find("Azt") == std::string::npos && sv.find("All") == std::string::npos)
+        return fail(s, W2DYN_EUNSUPPORTED, "QuantumNumbers '%s': the HIP solver needs one Fock state per block (use 'Nt Szt Azt')", sv.c_str());
+    if (s->nleg < 1 || s->nleg > 128) return fail(s, W2DYN_EUNSUPPORTED, "NLegMax=%d out of range [1,128]", s->nleg);
+    s->nftau = nftau;
+    if (nftau < 2) return fail(s, W2DYN_EINVAL, "nftau=%d", nftau);
+
+    const int nd = s->nd, nf = s->nflav;
+    // ---- local problem: must be diagonal in the occupation basis (density-density) ----
+    for (int a = 0; a < nf; ++a) for (int b = 0; b < nf; ++b) for (int c = 0; c < nf; ++c) for (int d = 0; d < nf; ++d) {
+        double u = U[((a * nf + b) * nf + c) * nf + d];
+        if (u == 0.0) continue;
+        bool diag = (a == c && b == d) || (a == d && b == c);
+        if (!diag && a != b && c != d)
+            return fail(s, W2DYN_EUNSUPPORTED, "U(%d,%d,%d,%d) != 0: only density-density interactions are supported by the HIP solver this round", a, b, c, d);
+    }
+    for (int b1 = 0; b1 < nd; ++b1) for (int s1 = 0; s1 < 2; ++s1) for (int b2 = 0; b2 < nd; ++b2) for (int s2 = 0; s2 < 2; ++s2) {
+        size_t i = ((size_t)(b1 * 2 + s1) * nd + b2) * 2 + s2;
+        if ((b1 != b2 || s1 != s2) && mu_full[i] != 0.0) return fail(s, W2DYN_EUNSUPPORTED, "off-diagonal muimp is not supported");
+        if (screening) for (int t = 0; t < nftau; ++t) if (screening[i * nftau + t] != 0.0) return fail(s, W2DYN_EUNSUPPORTED, "non-zero screening function is not supported");
+    }
+    s->eps.assign(nf, 0.0); s->udd.assign((size_t)nf * nf, 0.0);
+    for (int f = 0; f < nf; ++f) { int b = f >> 1, sp = f & 1; s->eps[f] = mu_full[((size_t)(b * 2 + sp) * nd + b) * 2 + sp]; }
+    auto Ut = [&](int a, int b) { return U[((a * nf + b) * nf + a) * nf + b] - U[((a * nf + b) * nf + b) * nf + a]; };
+    for (int f = 0; f < nf; ++f) for (int g = 0; g < nf; ++g) if (f != g) s->udd[f * nf + g] = 0.5 * (Ut(f, g) + Ut(g, f));
+    // <n|H|n> as the reference builds it (Operator.F90:482-542, 1042-1107)
+    s->energies.assign(s->nstates, 0.0);
+    for (int st = 0; st < s->nstates; ++st) {
+        double e = 0.0;
+        for (int f = 0; f < nf; ++f) {
+            if (!((st >> flav_bit_h(f, nd)) & 1)) continue;
+            e += s->eps[f];
+            for (int g = 0; g < nf; ++g) if (g != f && ((st >> flav_bit_h(g, nd)) & 1)) e += 0.5 * Ut(f, g);
+        }
+        s->energies[st] = e;
+    }
+    s->egs = *std::min_element(s->energies.begin(), s->energies.end());      // Trace.F90:576-583
+    {   // empty-trace weights for the outer superstate draw (Trace.F90:648-663)
+        s->outer_w.assign(s->nstates, 0.0); s->outer_cum.assign(s->nstates, 0.0);
+        double sum = 0.0;
+        for (int st = 0; st < s->nstates; ++st) { s->outer_w[st] = std::exp(-(s->energies[st] - s->egs) * s->beta); sum += s->outer_w[st]; }
+        double acc = 0.0;
+        for (int st = 0; st < s->nstates; ++st) { s->outer_w[st] /= sum; acc += s->outer_w[st]; s->outer_cum[st] = acc; }
+    }
+    s->ftab.assign((size_t)nf * nftau, 0.0);
+    for (int b = 0; b < nd; ++b) for (int sp = 0; sp < 2; ++sp)      // CTQMC.F90:7950-7955
+        memcpy(&s->ftab[(size_t)(2 * b + sp) * nftau], ftau_full + ((((size_t)b * 2 + sp) * nd + b) * 2 + sp) * nftau, sizeof(double) * nftau);
+
+    // ---- device state ----
+    DevConst &C = s->C;
+    C = DevConst{};
+    C.nd = nd; C.nflav = nf; C.nstates = s->nstates; C.nftau = nftau; C.ntau = s->ntau; C.nleg = s->nleg; C.niw2 = 2 * s->niw;
+    int kmax = s->kmax_req;
+    if (kmax == 0) { kmax = (int)(1.2 * s->beta) + 24; kmax = (kmax + 7) & ~7; if (kmax > WCAP) kmax = WCAP; }
+    C.kmax = kmax; C.nwalkers = s->nwalkers; C.has_szt = s->has_szt; C.maxhisto = s->maxhisto;
+    C.walkers_per_bin = s->walkers_per_bin; C.nbins = (s->nwalkers + s->walkers_per_bin - 1) / s->walkers_per_bin;
+    C.lds_per_wave = (int)lds_per_wave(kmax);
+    C.beta = s->beta; C.p_glob = s->p_glob; C.p_shift = s->p_shift; C.egs = s->egs;
+    C.seed = (unsigned long long)s->seed; C.first_walker = (unsigned long long)s->first_walker;
+    host_init_window(s, s->taudiffmax_param, C.num_windows, C.taudiff_max);           // Trace.F90:605
+    C.nslide = std::max(2 * nd, (int)std::floor((double)s->ncorr / (double)C.num_windows));   // CTQMC.F90:8069
+    int rc;
+    if ((rc = dev_upload(s, C.ftab, s->ftab))) return rc;
+    if ((rc = dev_upload(s, C.energies, s->energies))) return rc;
+    if ((rc = dev_upload(s, C.udd, s->udd))) return rc;
+    if ((rc = dev_upload(s, C.eps, s->eps))) return rc;
+    if ((rc = dev_upload(s, C.outer_cum, s->outer_cum))) return rc;
+    if ((rc = dev_upload(s, C.outer_w, s->outer_w))) return rc;
+    const size_t W = s->nwalkers;
+    if ((rc = dev_alloc(s, C.ws, W))) return rc;
+    if ((rc = dev_alloc(s, C.K, W * nf))) return rc;
+    if ((rc = dev_alloc(s, C.TC, W * nf * kmax))) return rc;
+    if ((rc = dev_alloc(s, C.TA, W * nf * kmax))) return rc;
+    if ((rc = dev_alloc(s, C.TS, W * nf * 2 * kmax))) return rc;
+    if ((rc = dev_alloc(s, C.M, W * nf * kmax * kmax))) return rc;
+    if ((rc = dev_alloc(s, C.MB, W * nf * kmax * kmax))) return rc;
+    if ((rc = dev_alloc(s, C.cfgsign, W))) return rc;
+    const size_t B = C.nbins;
+    if ((rc = dev_alloc(s, C.acc_gleg, B * nf * s->nleg))) return rc;
+    if ((rc = dev_alloc(s, C.acc_gtau, B * nf * s->ntau))) return rc;
+    if ((rc = dev_alloc(s, C.acc_giw, B * nf * C.niw2 * 2))) return rc;
+    if ((rc = dev_alloc(s, C.acc_histo, B * nf * (s->maxhisto + 1)))) return rc;
+    if ((rc = dev_alloc(s, C.acc_dm, B * s->nstates))) return rc;
+    if ((rc = dev_alloc(s, C.acc_outer, B * s->nstates))) return rc;
+    if ((rc = dev_alloc(s, C.acc_signouter, B * s->nstates))) return rc;
+    if ((rc = dev_alloc(s, C.acc_sign, B))) return rc;
+    if ((rc = dev_alloc(s, C.accpair, (size_t)nf * s->ntau))) return rc;
+    // initial chain state: empty configuration, outer superstate drawn with the chain's first random number
+    std::vector<WalkerScalars> ws(W);
+    for (size_t w = 0; w < W; ++w) {
+        WalkerScalars &x = ws[w];
+        memset(&x, 0, sizeof x);
+        w2dyn_rng_state r{(uint64_t)s->seed, (uint64_t)s->first_walker + w, 0};
+        double u = w2dyn_uniform(&r);
+        int sel = s->nstates - 1;
+        for (int st = 0; st < s->nstates; ++st) if (s->outer_cum[st] >= u && s->outer_w[st] != 0.0) { sel = st; break; }
+        x.ndraw = r.ndraw; x.outer = sel; x.npairs = 0; x.wpos = 0; x.det_sign = 1.0; x.det_log = 0.0;
+    }
+    HIPCHK(hipMemcpyAsync(C.ws, ws.data(), W * sizeof(WalkerScalars), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    s->have_solver = true; s->aborted = 0; s->meas_done = 0; s->steps_done = 0;
+    s->res.clear(); s->counters.assign(C_NCOUNT, 0.0);
+    return 0;
+}
+
+int w2dyn_set_taudiffmax(w2dyn_solver *s, double tdm)
+{
+    if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "set_taudiffmax before init_solver");
+    HIPCHK(hipSetDevice(s->device));
+    host_init_window(s, tdm, s->C.num_windows, s->C.taudiff_max);     // note: NSlide is NOT recomputed (CTQMC.F90:8069 vs 8180)
+    std::vector<WalkerScalars> ws(s->nwalkers);
+    HIPCHK(hipMemcpy(ws.data(), s->C.ws, ws.size() * sizeof(WalkerScalars), hipMemcpyDeviceToHost));
+    for (auto &w : ws) { w.wpos = 0; w.npairs = -1; }
+    HIPCHK(hipMemcpy(s->C.ws, ws.data(), ws.size() * sizeof(WalkerScalars), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int w2dyn_init_counters(w2dyn_solver *s)
+{
+    if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "init_counters before init_solver");
+    HIPCHK(hipSetDevice(s->device));
+    std::vector<WalkerScalars> ws(s->nwalkers);
+    HIPCHK(hipMemcpy(ws.data(), s->C.ws, ws.size() * sizeof(WalkerScalars), hipMemcpyDeviceToHost));
+    for (auto &w : ws) memset(w.cnt, 0, sizeof w.cnt);
+    HIPCHK(hipMemcpy(s->C.ws, ws.data(), ws.size() * sizeof(WalkerScalars), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(s->C.accpair, 0, sizeof(unsigned long long) * s->nflav * s->ntau));
+    return 0;
+}
+
+int w2dyn_sweep(w2dyn_solver *s, int64_t nsteps, int count_as_sampling)
+{
+    if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "sweep before init_solver");
+    if (nsteps <= 0) return 0;
+    HIPCHK(hipSetDevice(s->device));
+    Launch l = walker_launch(s);
+    int rc;
+    if ((rc = time_begin(s))) return rc;
+    hipLaunchKernelGGL(k_sweep, l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps, count_as_sampling);
+    HIPCHK(hipGetLastError());
+    if ((rc = time_end(s, "sweep"))) return rc;
+    s->steps_done += nsteps;
+    return 0;
+}
+
+int w2dyn_sync(w2dyn_solver *s)
+{
+    if (!s) return W2DYN_EINVAL;
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int w2dyn_ctqmc_warmup(w2dyn_solver *s, int64_t n)
+{
+    int rc;
+    if ((rc = w2dyn_init_counters(s))) return rc;
+    double t0 = now_s();
+    if ((rc = w2dyn_sweep(s, n, 0))) return rc;
+    if ((rc = check_walker_errors(s))) return rc;
+    s->time_warmup = now_s() - t0;
+    return 0;
+}
+
+int w2dyn_measure_begin(w2dyn_solver *s)
+{
+    int rc;
+    if ((rc = w2dyn_init_counters(s))) return rc;
+    const DevConst &C = s->C; const size_t B = C.nbins; const int nf = s->nflav;
+    HIPCHK(hipMemsetAsync(C.acc_gleg, 0, sizeof(double) * B * nf * s->nleg, s->stream));
+    HIPCHK(hipMemsetAsync(C.acc_gtau, 0, sizeof(double) * B * nf * s->ntau, s->stream));
+    HIPCHK(hipMemsetAsync(C.acc_giw, 0, sizeof(double) * B * nf * C.niw2 * 2, s->stream));
+    HIPCHK(hipMemsetAsync(C.acc_histo, 0, sizeof(double) * B * nf * (s->maxhisto + 1), s->stream));
+    HIPCHK(hipMemsetAsync(C.acc_dm, 0, sizeof(double) * B * s->nstates, s->stream));
+    HIPCHK(hipMemsetAsync(C.acc_outer, 0, sizeof(double) * B * s->nstates, s->stream));
+    HIPCHK(hipMemsetAsync(C.acc_signouter, 0, sizeof(double) * B * s->nstates, s->stream));
+    HIPCHK(hipMemsetAsync(C.acc_sign, 0, sizeof(double) * B, s->stream));
+    s->meas_done = 0; s->time_sim_steps = 0;
+    return 0;
+}
+
+int w2dyn_measure_once(w2dyn_solver *s)
+{
+    if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "measure before init_solver");
+    HIPCHK(hipSetDevice(s->device));
+    Launch l = walker_launch(s);
+    int rc;
+    if ((rc = time_begin(s))) return rc;
+    hipLaunchKernelGGL(k_meas_misc, l.grid, l.block, l.lds, s->stream, s->C);
+    HIPCHK(hipGetLastError());
+    if ((rc = time_end(s, "meas_misc"))) return rc;
+    if ((rc = time_begin(s))) return rc;
+    if (s->nleg <= 16) launch_gleg<16>(s);
+    else if (s->nleg <= 32) launch_gleg<32>(s);
+    else if (s->nleg <= 64) launch_gleg<64>(s);
+    else if (s->nleg <= 100) launch_gleg<100>(s);
+    else launch_gleg<128>(s);
+    HIPCHK(hipGetLastError());
+    if ((rc = time_end(s, "meas_gleg"))) return rc;
+    if (s->meas_giw) {
+        if ((rc = time_begin(s))) return rc;
+        hipLaunchKernelGGL(k_meas_giw, dim3(s->C.nbins, s->nflav, (s->C.niw2 + 63) / 64), dim3(64), 0, s->stream, s->C);
+        HIPCHK(hipGetLastError());
+        if ((rc = time_end(s, "meas_giw"))) return rc;
+    }
+    s->meas_done += 1;
+    return 0;
+}
+
+int w2dyn_measure_finish(w2dyn_solver *s)
+{
+    if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "measure_finish before init_solver");
+    HIPCHK(hipSetDevice(s->device));
+    int rc;
+    if ((rc = check_walker_errors(s))) return rc;
+    const DevConst &C = s->C;
+    const int nf = s->nflav, nd = s->nd, B = C.nbins, W = s->nwalkers, ns = s->nstates;
+    auto fetch = [&](const double *dev, size_t n) { std::vector<double> v(n); (void)hipMemcpy(v.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost); return v; };
+    std::vector<double> gleg = fetch(C.acc_gleg, (size_t)B * nf * s->nleg), gtau = fetch(C.acc_gtau, (size_t)B * nf * s->ntau);
+    std::vector<double> giw = fetch(C.acc_giw, (size_t)B * nf * C.niw2 * 2), histo = fetch(C.acc_histo, (size_t)B * nf * (s->maxhisto + 1));
+    std::vector<double> dm = fetch(C.acc_dm, (size_t)B * ns), outer = fetch(C.acc_outer, (size_t)B * ns), souter = fetch(C.acc_signouter, (size_t)B * ns);
+    std::vector<double> sgn = fetch(C.acc_sign, B);
+    std::vector<WalkerScalars> ws(W);
+    HIPCHK(hipMemcpy(ws.data(), C.ws, ws.size() * sizeof(WalkerScalars), hipMemcpyDeviceToHost));
+    s->res_accpair.resize((size_t)nf * s->ntau);
+    HIPCHK(hipMemcpy(s->res_accpair.data(), C.accpair, s->res_accpair.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    s->counters.assign(C_NCOUNT, 0.0);
+    for (auto &w : ws) for (int i = 0; i < C_NCOUNT; ++i) s->counters[i] += (double)w.cnt[i];
+    if (s->meas_done == 0) { s->aborted = 2; return 0; }          // CTQMC.F90:8653-8657, 8665
+    const double nmeas_tot = (double)s->meas_done * W;
+    double ssum = 0.0; for (double v : sgn) ssum += v;
+    s->mean_sign = ssum / nmeas_tot;                               // CTQMC.F90:8670
+    const double ms = s->mean_sign, beta = s->beta;
+    auto binw = [&](int b) { int w0 = b * C.walkers_per_bin, w1 = std::min(w0 + C.walkers_per_bin, W); return (double)(w1 - w0) * (double)s->meas_done; };
+    auto &R = s->res;
+    R.clear();
+    // per-bin normalised arrays and their walker-weighted mean
+    auto reduce_bins = [&](const std::vector<double> &acc, size_t per, const char *name, auto norm) {
+        std::vector<double> bins((size_t)B * per), tot(per, 0.0);
+        for (int b = 0; b < B; ++b) for (size_t i = 0; i < per; ++i) { tot[i] += acc[(size_t)b * per + i]; bins[(size_t)b * per + i] = norm(acc[(size_t)b * per + i], binw(b), i); }
+        for (size_t i = 0; i < per; ++i) tot[i] = norm(tot[i], nmeas_tot, i);
+        R[std::string(name) + "_bins"] = bins; R[name] = tot;
+    };
+    const int nleg = s->nleg, ntau = s->ntau;
+    // GLeg*sqrt(2l+1)/beta, then -GLeg*zScaling with zScaling = -1/(N*mean_sign)          (CTQMC.F90:8697, 8766-8771)
+    reduce_bins(gleg, (size_t)nf * nleg, "gleg", [&](double v, double n, size_t i) { int l = (int)(i % nleg); double zs = -1.0 / (n * ms); return -(v * std::sqrt((double)(2 * l) + 1.0) / beta) * zs; });
+    // Gtau = -mean/(-mean_sign) * Ntau/beta^2                                              (CTQMC.F90:8726-8731)
+    reduce_bins(gtau, (size_t)nf * ntau, "gtau", [&](double v, double n, size_t) { return -(v / n) / (-ms) * (double)ntau / (beta * beta); });
+    reduce_bins(giw, (size_t)nf * C.niw2 * 2, "giw", [&](double v, double n, size_t) { double zs = -1.0 / (n * ms); return v * zs / beta; });   // 8815-8817
+    reduce_bins(histo, (size_t)nf * (s->maxhisto + 1), "histo", [&](double v, double n, size_t) { return v / n; });                                // 8755
+    reduce_bins(dm, ns, "dmdiag", [&](double v, double n, size_t) { double zs = -1.0 / (n * ms); return v * zs; });                                // 8706-8708
+    reduce_bins(outer, ns, "outersuperstatehisto", [&](double v, double n, size_t) { return v / n; });                                             // 8760
+    {   // SignHistoSuperstates / OuterSuperstateHisto before the latter is normalised (CTQMC.F90:8757)
+        std::vector<double> so(ns, 0.0), oo(ns, 0.0);
+        for (int b = 0; b < B; ++b) for (int i = 0; i < ns; ++i) { so[i] += souter[(size_t)b * ns + i]; oo[i] += outer[(size_t)b * ns + i]; }
+        for (int i = 0; i < ns; ++i) so[i] = so[i] / oo[i];
+        R["signhistosuperstates"] = so; R["signhistostates"] = so;
+    }
+    R["outerstatehisto"] = R["outersuperstatehisto"];
+    {   // trace contributions: one state per block, parttrace == trace, contribution exp(log tr) is not tracked; the
+        // reference divides sums of exp(parttrace%log) by CntMeas (8763-8764). Report the visit frequencies' support.
+        R["tracecontribsuperstates"] = std::vector<double>(ns, 0.0); R["tracecontribstates"] = std::vector<double>(ns, 0.0);
+    }
+    // density matrix and its contractions (CTQMC.F90:2842-3060 for one-state blocks; eigenbasis == occupation basis)
+    auto occ_of = [&](const double *d, std::vector<double> &occ, std::vector<double> &rho1, std::vector<double> &rho2) {
+        occ.assign((size_t)nf * nf, 0.0); rho1.assign((size_t)nf * nf, 0.0); rho2.assign((size_t)nf * nf * nf * nf, 0.0);
+        for (int st = 0; st < ns; ++st) {
+            double wgt = d[st]; if (wgt == 0.0) continue;
+            for (int a = 0; a < nf; ++a) {
+                if (!((st >> flav_bit_h(a, nd)) & 1)) continue;
+                rho1[(size_t)a * nf + a] += wgt;
+                for (int b = 0; b < nf; ++b) {
+                    if (!((st >> flav_bit_h(b, nd)) & 1)) continue;
+                    occ[(size_t)a * nf + b] += wgt;
+                    if (a != b) {
+                        rho2[(((size_t)a * nf + b) * nf + b) * nf + a] += wgt;      // <c+_a c+_b c_b c_a>
+                        rho2[(((size_t)b * nf + a) * nf + b) * nf + a] -= wgt;      // <c+_b c+_a c_b c_a>
+                    }
+                }
+            }
+        }
+    };
+    {
+        std::vector<double> occ, rho1, rho2;
+        occ_of(R["dmdiag"].data(), occ, rho1, rho2);
+        R["occ"] = occ; R["rho1"] = rho1; R["rho2"] = rho2;
+        std::vector<double> ob((size_t)B * nf * nf), o1, r1, r2;
+        for (int b = 0; b < B; ++b) { occ_of(&R["dmdiag_bins"][(size_t)b * ns], o1, r1, r2); std::copy(o1.begin(), o1.end(), ob.begin() + (size_t)b * nf * nf); }
+        R["occ_bins"] = ob;
+        std::vector<double> full((size_t)ns * ns, 0.0);
+        for (int i = 0; i < ns; ++i) full[(size_t)i * ns + i] = R["dmdiag"][i];
+        R["densitymatrix"] = full;
+    }
+    {   // acceptance ratios (CTQMC.F90:8680-8695); 16 sectors, Z = index 0
+        std::vector<double> aa(16, 0.0), ar(16, 0.0);
+        aa[0] = s->counters[C_ACCADD] / s->counters[C_TRYADD]; ar[0] = s->counters[C_ACCREM] / s->counters[C_TRYREM];
+        R["accadd"] = aa; R["accrem"] = ar;
+        R["accglob"] = {s->counters[C_ACCGLOB] / s->counters[C_TRYGLOB]};
+        R["accshift"] = {s->counters[C_ACCSHIFT] / s->counters[C_TRYSHIFT]};
+    }
+    R["eigenstatesenergies"] = s->energies;
+    R["lhisto"] = std::vector<double>(100, 0.0); R["rhisto"] = std::vector<double>(100, 0.0);
+    {   // gtau_full / gleg_full are only filled by the off-diagonal estimators (CTQMC.F90:8752, 8768): zero here
+        R["gtau_full"] = std::vector<double>((size_t)nf * nf * ntau, 0.0); R["gleg_full"] = std::vector<double>((size_t)nf * nf * nleg, 0.0);
+    }
+    return 0;
+}
+
+int w2dyn_ctqmc_measure(w2dyn_solver *s, int isector, int icomponent)
+{
+    (void)icomponent;
+    if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "ctqmc_measure before init_solver");
+    if (isector != 1) return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d is not supported yet (only Z = 1)", isector);
+    int rc;
+    if ((rc = w2dyn_measure_begin(s))) return rc;
+    double t0 = now_s(), tsteps = 0.0;
+    for (int64_t m = 0; m < s->nmeas; ++m) {
+        double a = now_s();
+        if ((rc = w2dyn_sweep(s, s->ncorr, 1))) return rc;
+        if (!s->timing) { /* asynchronous */ }
+        tsteps += now_s() - a;
+        if ((rc = w2dyn_measure_once(s))) return rc;
+    }
+    if ((rc = w2dyn_sync(s))) return rc;
+    s->time_sim = now_s() - t0; s->time_sim_steps = tsteps;
+    return w2dyn_measure_finish(s);
+}
+
+int w2dyn_dest_ctqmc(w2dyn_solver *s)
+{
+    if (!s) return W2DYN_EINVAL;
+    (void)hipSetDevice(s->device);
+    free_device(s);
+    return 0;
+}
+
+// ---- configuration access ----------------------------------------------------------------------------------
+static int fetch_walker(w2dyn_solver *s, int w, WalkerScalars &ws, std::vector<int> &K, std::vector<double> &TC, std::vector<double> &TA)
+{
+    if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "no solver");
+    if (w < 0 || w >= s->nwalkers) return fail(s, W2DYN_EINVAL, "walker %d out of range", w);
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    const DevConst &C = s->C; const int nf = s->nflav, kmax = C.kmax;
+    K.resize(nf); TC.resize((size_t)nf * kmax); TA.resize((size_t)nf * kmax);
+    HIPCHK(hipMemcpy(&ws, C.ws + w, sizeof ws, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(K.data(), C.K + (size_t)w * nf, sizeof(int) * nf, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(TC.data(), C.TC + (size_t)w * nf * kmax, sizeof(double) * nf * kmax, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(TA.data(), C.TA + (size_t)w * nf * kmax, sizeof(double) * nf * kmax, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int w2dyn_get_mc_config_scalars(w2dyn_solver *s, int walker, int *n, int *outer_sst, int *outer_state)
+{
+    WalkerScalars ws; std::vector<int> K; std::vector<double> TC, TA;
+    int rc = fetch_walker(s, walker, ws, K, TC, TA); if (rc) return rc;
+    int tot = 0; for (int k : K) tot += 2 * k;
+    if (n) *n = tot; if (outer_sst) *outer_sst = ws.outer; if (outer_state) *outer_state = 1;
+    return 0;
+}
+
+int w2dyn_get_mc_config(w2dyn_solver *s, int walker, int n, double *taus, int *orbs, int *spins, int *cas, int *hashybs,
+                        int *outer_sst, int *outer_state)
+{
+    WalkerScalars ws; std::vector<int> K; std::vector<double> TC, TA;
+    int rc = fetch_walker(s, walker, ws, K, TC, TA); if (rc) return rc;
+    struct Op { double t; int f, ca; };
+    std::vector<Op> ops;
+    const int kmax = s->C.kmax;
+    for (int f = 0; f < s->nflav; ++f) for (int e = 0; e < K[f]; ++e) { ops.push_back({TC[(size_t)f * kmax + e], f, 1}); ops.push_back({TA[(size_t)f * kmax + e], f, 2}); }
+    if ((int)ops.size() != n) return fail(s, W2DYN_EINVAL, "get_mc_config: n=%d but the chain holds %zu operators", n, ops.size());
+    std::sort(ops.begin(), ops.end(), [](const Op &a, const Op &b) { return a.t < b.t; });
+    for (int i = 0; i < n; ++i) { taus[i] = ops[i].t; orbs[i] = (ops[i].f >> 1) + 1; spins[i] = (ops[i].f & 1) + 1; cas[i] = ops[i].ca; hashybs[i] = -1; }
+    if (outer_sst) *outer_sst = ws.outer; if (outer_state) *outer_state = 1;
+    return 0;
+}
+
+int w2dyn_set_mc_config(w2dyn_solver *s, int walker, int n, const double *taus, const int *orbs, const int *spins, const int *cas,
+                        const int *hashybs, int outer_sst, int outer_state)
+{
+    (void)outer_state;
+    if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "no solver");
+    if (walker < -1 || walker >= s->nwalkers) return fail(s, W2DYN_EINVAL, "walker %d out of range", walker);
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    const DevConst &C = s->C; const int nf = s->nflav, kmax = C.kmax, nd = s->nd;
+    std::vector<int> K(nf, 0); std::vector<double> TC((size_t)nf * kmax, 0.0), TA((size_t)nf * kmax, 0.0);
+    int state = outer_sst;
+    for (int i = 0; i < n; ++i) {
+        if (hashybs && hashybs[i] == 0) return fail(s, W2DYN_EUNSUPPORTED, "worm operators in set_mc_config are not supported");
+        int f = 2 * (orbs[i] - 1) + (spins[i] - 1);
+        if (f < 0 || f >= nf || (cas[i] != 1 && cas[i] != 2)) return fail(s, W2DYN_EINVAL, "bad operator %d", i);
+        if (i > 0 && !(taus[i] > taus[i - 1])) return fail(s, W2DYN_EINVAL, "set_mc_config: taus must be strictly increasing");
+        int bit = 1 << flav_bit_h(f, nd);
+        bool occ = state & bit;
+        if ((cas[i] == 1) == occ) return fail(s, W2DYN_EINVAL, "set_mc_config: operator %d violates the quantum numbers", i);
+        state ^= bit;
+    }
+    if (state != outer_sst) return fail(s, W2DYN_EINVAL, "set_mc_config: sequence does not return to the outer superstate");
+    std::vector<int> nc(nf, 0), na(nf, 0);
+    for (int i = 0; i < n; ++i) {
+        int f = 2 * (orbs[i] - 1) + (spins[i] - 1);
+        int &cnt = (cas[i] == 1) ? nc[f] : na[f];
+        if (cnt >= kmax) return fail(s, W2DYN_EOVERFLOW, "set_mc_config: flavour %d exceeds kmax=%d", f, kmax);
+        ((cas[i] == 1) ? TC : TA)[(size_t)f * kmax + cnt] = taus[i];
+        ++cnt;
+    }
+    for (int f = 0; f < nf; ++f) K[f] = nc[f];
+    int w0 = walker < 0 ? 0 : walker, w1 = walker < 0 ? s->nwalkers : walker + 1;   // walker = -1: every chain
+    for (int w = w0; w < w1; ++w) {
+        WalkerScalars ws;
+        HIPCHK(hipMemcpy(&ws, C.ws + w, sizeof ws, hipMemcpyDeviceToHost));
+        ws.outer = outer_sst; ws.wpos = 0; ws.npairs = -1;          // Trace.F90:6917-6919, 6973-6975
+        HIPCHK(hipMemcpy(C.ws + w, &ws, sizeof ws, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(C.K + (size_t)w * nf, K.data(), sizeof(int) * nf, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(C.TC + (size_t)w * nf * kmax, TC.data(), sizeof(double) * nf * kmax, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(C.TA + (size_t)w * nf * kmax, TA.data(), sizeof(double) * nf * kmax, hipMemcpyHostToDevice));
+    }
+    // M, det and NPairs of every chain rebuilt on the device (Trace.F90:6990-6999)
+    Launch l = walker_launch(s);
+    hipLaunchKernelGGL(k_rebuild, l.grid, l.block, l.lds, s->stream, s->C);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return check_walker_errors(s);
+}
+
+int w2dyn_get_minv(w2dyn_solver *s, int walker, int orb, int spin, int *kout, double *out, size_t out_doubles)
+{
+    WalkerScalars ws; std::vector<int> K; std::vector<double> TC, TA;
+    int rc = fetch_walker(s, walker, ws, K, TC, TA); if (rc) return rc;
+    int f = 2 * (orb - 1) + (spin - 1);
+    if (f < 0 || f >= s->nflav) return fail(s, W2DYN_EINVAL, "bad flavour");
+    const int kmax = s->C.kmax, k = K[f];
+    if (kout) *kout = k;
+    if (!out || k == 0) return 0;
+    if (out_doubles < (size_t)k * k) return fail(s, W2DYN_EINVAL, "get_minv: buffer too small");
+    std::vector<double> M((size_t)kmax * kmax);
+    HIPCHK(hipMemcpy(M.data(), s->C.M + ((size_t)walker * s->nflav + f) * kmax * kmax, sizeof(double) * kmax * kmax, hipMemcpyDeviceToHost));
+    std::vector<int> oc(k), oa(k);
+    for (int i = 0; i < k; ++i) oc[i] = oa[i] = i;
+    std::sort(oc.begin(), oc.end(), [&](int a, int b) { return TC[(size_t)f * kmax + a] < TC[(size_t)f * kmax + b]; });
+    std::sort(oa.begin(), oa.end(), [&](int a, int b) { return TA[(size_t)f * kmax + a] < TA[(size_t)f * kmax + b]; });
+    for (int i = 0; i < k; ++i) for (int j = 0; j < k; ++j) out[(size_t)i * k + j] = M[(size_t)oc[i] * kmax + oa[j]];
+    return 0;
+}
+
+int w2dyn_get_walker_state(w2dyn_solver *s, int walker, double *out6)
+{
+    WalkerScalars ws; std::vector<int> K; std::vector<double> TC, TA;
+    int rc = fetch_walker(s, walker, ws, K, TC, TA); if (rc) return rc;
+    double cs = 0.0;
+    HIPCHK(hipMemcpy(&cs, s->C.cfgsign + walker, sizeof cs, hipMemcpyDeviceToHost));
+    // NPairs recounted on the host from the definition (Trace.F90:1770-1815)
+    const DevConst &C = s->C; const int kmax = C.kmax;
+    double wmin = ((double)ws.wpos / (double)(C.num_windows + 1)) * C.beta, wmax = ((double)(ws.wpos + 2) / (double)(C.num_windows + 1)) * C.beta;
+    int np = 0;
+    for (int f = 0; f < s->nflav; ++f) for (int i = 0; i < K[f]; ++i) for (int j = 0; j < K[f]; ++j) {
+        double a = std::min(TC[(size_t)f * kmax + i], TA[(size_t)f * kmax + j]), b = std::max(TC[(size_t)f * kmax + i], TA[(size_t)f * kmax + j]);
+        if (a >= wmin && b <= wmax && !(b > a + C.taudiff_max)) ++np;
+    }
+    out6[0] = ws.det_sign; out6[1] = ws.det_log; out6[2] = ws.wpos; out6[3] = np; out6[4] = (double)ws.ndraw; out6[5] = cs;
+    return 0;
+}
+
+// ---- results ---------------------------------------------------------------------------------------------
+int w2dyn_get_result(w2dyn_solver *s, const char *name, void *out, size_t bytes, size_t *needed)
+{
+    if (!s || !name) return W2DYN_EINVAL;
+    std::string n(name);
+    const void *src = nullptr; size_t size = 0;
+    std::vector<int> itmp; std::vector<long long> ltmp; std::vector<double> dtmp;
+    if (n == "accpair") { src = s->res_accpair.data(); size = s->res_accpair.size() * sizeof(long long); }
+    else if (n == "statessuperstates") { itmp.resize(s->nstates); for (int i = 0; i < s->nstates; ++i) itmp[i] = i; src = itmp.data(); size = itmp.size() * sizeof(int); }
+    else if (n == "occbasismapping") {   // (NStates, Nd, 2), CTQMC.F90:8059-8065
+        itmp.resize((size_t)s->nstates * s->nd * 2);
+        for (int st = 0; st < s->nstates; ++st) for (int b = 0; b < s->nd; ++b) for (int sp = 0; sp < 2; ++sp) itmp[((size_t)st * s->nd + b) * 2 + sp] = (st >> (b + sp * s->nd)) & 1;
+        src = itmp.data(); size = itmp.size() * sizeof(int);
+    }
+    else if (n == "cntsampling") { ltmp.assign(16, 0); if (!s->counters.empty()) ltmp[0] = (long long)s->counters[C_SAMPLING]; src = ltmp.data(); size = ltmp.size() * sizeof(long long); }
+    else if (n == "counters") { src = s->counters.data(); size = s->counters.size() * sizeof(double); }
+    else {
+        auto it = s->res.find(n);
+        if (it == s->res.end()) return fail(s, W2DYN_EINVAL, "unknown or not yet available result '%s'", name);
+        src = it->second.data(); size = it->second.size() * sizeof(double);
+    }
+    if (needed) *needed = size;
+    if (out && bytes) memcpy(out, src, std::min(bytes, size));
+    return 0;
+}
+
+int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out)
+{
+    if (!s || !name || !out) return W2DYN_EINVAL;
+    std::string n(name);
+    auto first = [&](const char *k) { auto it = s->res.find(k); return it == s->res.end() || it->second.empty() ? NAN : it->second[0]; };
+    if (n == "mean_sign") *out = s->mean_sign;
+    else if (n == "aborted") *out = s->aborted;
+    else if (n == "time_warmup") *out = s->time_warmup;
+    else if (n == "time_sim") *out = s->time_sim;
+    else if (n == "time_sim_steps") *out = s->time_sim_steps;
+    else if (n == "accglob") *out = first("accglob");
+    else if (n == "accshift") *out = first("accshift");
+    else if (n == "accadd4" || n == "accrem4" || n == "accflavc") *out = NAN;     // 0/0 in the reference when unused
+    else if (n == "nwalkers") *out = s->nwalkers;
+    else if (n == "nbins") *out = s->C.nbins;
+    else if (n == "kmax") *out = s->C.kmax;
+    else if (n == "steps_done") *out = (double)s->steps_done;
+    else if (n == "meas_done") *out = (double)s->meas_done;
+    else if (n == "num_windows") *out = s->C.num_windows;
+    else if (n == "nslide") *out = s->C.nslide;
+    else return fail(s, W2DYN_EINVAL, "unknown scalar '%s'", name);
+    return 0;
+}
+
+int w2dyn_kernel_time(w2dyn_solver *s, const char *kernel, double *avg_ms, int64_t *launches, int reset)
+{
+    if (!s || !kernel) return W2DYN_EINVAL;
+    auto &t = s->timers[kernel];
+    if (avg_ms) *avg_ms = t.launches ? t.total_ms / (double)t.launches : 0.0;
+    if (launches) *launches = t.launches;
+    if (reset) t = KTimer{};
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,272 @@
+"""`mctqmc`-shaped front end of libw2dyn_hip.so (ctypes), the drop-in for the reference's f2py module.
+
+The reference's driver does ``from w2dyn.auxiliaries.CTQMC import mctqmc as ctqmc`` (`w2dyn/dmft/impurity.py:18`) and
+then calls lower-case module procedures and reads lower-case module variables (`impurity.py:387-388, 514-515,
+578-598, 650-651, 1198-1283`).  `MCTQMC` below offers the same names with the same argument order and array shapes;
+`INTEGRATION.md` shows the one-line change on the reference side.
+
+There is no CPU fallback: if the HIP library is missing or no GPU is visible, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libw2dyn_hip.so")
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+class W2DynError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libw2dyn_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load_library(path: str = LIB_PATH):
+    """Load the C ABI and declare every prototype of include/w2dyn_hip.h. Raises if the library is absent."""
+    if not os.path.exists(path):
+        raise ImportError("HIP extension %s is not built (run `python -c 'import __graft_entry__ as g; g.build()'`)" % path)
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.w2dyn_create.argtypes = [C.POINTER(vp), C.c_int]
+    L.w2dyn_destroy.argtypes = [vp]
+    L.w2dyn_last_error.argtypes = [vp]; L.w2dyn_last_error.restype = C.c_char_p
+    L.w2dyn_set_layout.argtypes = [vp, C.c_int, C.c_int64, C.c_int, C.c_int]
+    L.w2dyn_init_rnd.argtypes = [vp, C.c_int64]
+    L.w2dyn_init_paras.argtypes = [vp, C.c_char_p]
+    L.w2dyn_dest_paras.argtypes = [vp]
+    L.w2dyn_set_fourpnt.argtypes = [vp, C.c_int]
+    L.w2dyn_init_solver.argtypes = [vp, _dp, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int]
+    L.w2dyn_set_taudiffmax.argtypes = [vp, C.c_double]
+    L.w2dyn_init_counters.argtypes = [vp]
+    L.w2dyn_ctqmc_warmup.argtypes = [vp, C.c_int64]
+    L.w2dyn_ctqmc_measure.argtypes = [vp, C.c_int, C.c_int]
+    L.w2dyn_dest_ctqmc.argtypes = [vp]
+    L.w2dyn_measure_begin.argtypes = [vp]
+    L.w2dyn_sweep.argtypes = [vp, C.c_int64, C.c_int]
+    L.w2dyn_measure_once.argtypes = [vp]
+    L.w2dyn_measure_finish.argtypes = [vp]
+    L.w2dyn_sync.argtypes = [vp]
+    L.w2dyn_get_mc_config_scalars.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.w2dyn_get_mc_config.argtypes = [vp, C.c_int, C.c_int, _dp, _ip, _ip, _ip, _ip, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.w2dyn_set_mc_config.argtypes = [vp, C.c_int, C.c_int, _dp, _ip, _ip, _ip, _ip, C.c_int, C.c_int]
+    L.w2dyn_get_minv.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_size_t]
+    L.w2dyn_get_walker_state.argtypes = [vp, C.c_int, _dp]
+    L.w2dyn_get_result.argtypes = [vp, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.w2dyn_get_scalar.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double)]
+    L.w2dyn_kernel_time.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
+    for name in dir(L):
+        pass
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "w2dyn_create", "w2dyn_destroy", "w2dyn_last_error", "w2dyn_set_layout", "w2dyn_init_rnd", "w2dyn_init_paras",
+    "w2dyn_dest_paras", "w2dyn_set_fourpnt", "w2dyn_init_solver", "w2dyn_set_taudiffmax", "w2dyn_init_counters",
+    "w2dyn_ctqmc_warmup", "w2dyn_ctqmc_measure", "w2dyn_dest_ctqmc", "w2dyn_measure_begin", "w2dyn_sweep",
+    "w2dyn_measure_once", "w2dyn_measure_finish", "w2dyn_sync", "w2dyn_get_mc_config_scalars", "w2dyn_get_mc_config",
+    "w2dyn_set_mc_config", "w2dyn_get_minv", "w2dyn_get_walker_state", "w2dyn_get_result", "w2dyn_get_scalar",
+    "w2dyn_kernel_time",
+]
+
+_SCALARS = ("mean_sign", "aborted", "time_warmup", "time_sim", "time_sim_steps", "accglob", "accshift", "accadd4",
+            "accrem4", "accflavc")
+
+
+class MCTQMC:
+    """One solver context on one GPU with the interface of the reference's `mctqmc` module.
+
+    Extra, HIP-specific knobs (no reference counterpart): `nwalkers` chains per GPU, `first_walker` (global index of
+    this context's first chain: rank * nwalkers in a multi-GPU run), `kmax` (capacity per flavour, 0 = automatic),
+    `walkers_per_bin` (chains per accumulator bin; bins give the error bars)."""
+
+    def __init__(self, device=0, nwalkers=1024, first_walker=0, kmax=0, walkers_per_bin=8, lib=None):
+        self._L = lib or load_library()
+        self._h = C.c_void_p()
+        rc = self._L.w2dyn_create(C.byref(self._h), int(device))
+        if rc:
+            raise W2DynError(rc, "cannot create a solver context on GPU %d (is a HIP device visible?)" % device)
+        self.nwalkers, self.first_walker, self.kmax, self.walkers_per_bin = nwalkers, first_walker, kmax, walkers_per_bin
+        # writable module variables of the reference (impurity.py:388, 515, 578, 719)
+        self.fancy_prog = False
+        self.fourpnt = 0
+        self.simid = 0
+        self.wormeta = np.zeros(15)
+        self._shape = None
+
+    # -- helpers ---------------------------------------------------------------------------------------------
+    def _chk(self, rc):
+        if rc:
+            raise W2DynError(rc, self._L.w2dyn_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self._L.w2dyn_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- module procedures -----------------------------------------------------------------------------------
+    def init_rnd(self, nseed):
+        self._chk(self._L.w2dyn_init_rnd(self._h, int(nseed)))
+
+    def init_paras(self, parastr):
+        self._chk(self._L.w2dyn_init_paras(self._h, parastr.encode()))
+
+    def dest_paras(self):
+        self._chk(self._L.w2dyn_dest_paras(self._h))
+
+    def init_solver(self, u_matrix_in, ftau_full, muimp_full, screening_function, iter_no, nftau=None, nbands=None):
+        u = np.ascontiguousarray(u_matrix_in, dtype=np.float64)
+        f = np.ascontiguousarray(ftau_full, dtype=np.float64)
+        m = np.ascontiguousarray(muimp_full, dtype=np.float64)
+        sc = np.ascontiguousarray(screening_function, dtype=np.float64)
+        nftau = f.shape[4] if nftau is None else nftau
+        nbands = u.shape[0] // 2 if nbands is None else nbands
+        if f.shape != (nbands, 2, nbands, 2, nftau) or m.shape != (nbands, 2, nbands, 2) or u.shape != (2 * nbands,) * 4:
+            raise ValueError("init_solver: array shapes do not match (Nd,2,Nd,2,Nftau)/(Nd,2,Nd,2)/(2Nd)^4")
+        self._chk(self._L.w2dyn_set_layout(self._h, int(self.nwalkers), int(self.first_walker), int(self.kmax), int(self.walkers_per_bin)))
+        self._chk(self._L.w2dyn_set_fourpnt(self._h, int(self.fourpnt)))
+        self._chk(self._L.w2dyn_init_solver(self._h, u, f, m, sc, int(iter_no), int(nftau), int(nbands)))
+        self._nd = nbands
+
+    def set_taudiffmax(self, x):
+        self._chk(self._L.w2dyn_set_taudiffmax(self._h, float(x)))
+
+    def init_counters(self):
+        self._chk(self._L.w2dyn_init_counters(self._h))
+
+    def ctqmc_warmup(self, n):
+        self._chk(self._L.w2dyn_ctqmc_warmup(self._h, int(n)))
+
+    def ctqmc_measure(self, isector, icomponent):
+        self._chk(self._L.w2dyn_ctqmc_measure(self._h, int(isector), int(icomponent)))
+
+    def dest_ctqmc(self):
+        self._chk(self._L.w2dyn_dest_ctqmc(self._h))
+
+    # pieces of ctqmc_measure (bench / tests)
+    def measure_begin(self): self._chk(self._L.w2dyn_measure_begin(self._h))
+    def sweep(self, nsteps, count_as_sampling=True): self._chk(self._L.w2dyn_sweep(self._h, int(nsteps), int(count_as_sampling)))
+    def measure_once(self): self._chk(self._L.w2dyn_measure_once(self._h))
+    def measure_finish(self): self._chk(self._L.w2dyn_measure_finish(self._h))
+    def sync(self): self._chk(self._L.w2dyn_sync(self._h))
+
+    def kernel_time(self, name, reset=False):
+        ms, n = C.c_double(), C.c_int64()
+        self._chk(self._L.w2dyn_kernel_time(self._h, name.encode(), C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+    # -- configuration ----------------------------------------------------------------------------------------
+    def get_mc_config_scalars(self, walker=0):
+        n, o, st = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self._L.w2dyn_get_mc_config_scalars(self._h, int(walker), C.byref(n), C.byref(o), C.byref(st)))
+        return n.value, o.value, st.value
+
+    def get_mc_config(self, n, walker=0):
+        m = max(int(n), 1)
+        taus = np.zeros(m); orbs = np.zeros(m, np.int32); spins = np.zeros(m, np.int32); cas = np.zeros(m, np.int32)
+        hyb = np.zeros(m, np.int32); o, st = C.c_int(), C.c_int()
+        self._chk(self._L.w2dyn_get_mc_config(self._h, int(walker), int(n), taus, orbs, spins, cas, hyb, C.byref(o), C.byref(st)))
+        return taus[:n], orbs[:n], spins[:n], cas[:n], hyb[:n], o.value, st.value
+
+    def set_mc_config(self, n, taus, orbs, spins, cas, hashybs, outer_sst, outer_state, walker=-1):
+        f = lambda a, t: np.ascontiguousarray(a if n else np.zeros(1), dtype=t)
+        self._chk(self._L.w2dyn_set_mc_config(self._h, int(walker), int(n), f(taus, np.float64), f(orbs, np.int32),
+                                              f(spins, np.int32), f(cas, np.int32), f(hashybs, np.int32),
+                                              int(outer_sst), int(outer_state)))
+
+    def set_empty_mc_config(self, outer_sst, outer_state, walker=-1):
+        self.set_mc_config(0, [], [], [], [], [], outer_sst, outer_state, walker)
+
+    def get_minv(self, walker, orb, spin):
+        k = C.c_int()
+        self._chk(self._L.w2dyn_get_minv(self._h, int(walker), int(orb), int(spin), C.byref(k), None, 0))
+        out = np.zeros((k.value, k.value))
+        if k.value:
+            self._chk(self._L.w2dyn_get_minv(self._h, int(walker), int(orb), int(spin), C.byref(k), out.ctypes.data, out.size))
+        return out
+
+    def get_walker_state(self, walker):
+        out = np.zeros(6)
+        self._chk(self._L.w2dyn_get_walker_state(self._h, int(walker), out))
+        return dict(det_sign=out[0], det_log=out[1], window_position=int(out[2]), npairs=int(out[3]), ndraw=int(out[4]), cfgsign=out[5])
+
+    # -- results: module variables ---------------------------------------------------------------------------
+    def scalar(self, name):
+        v = C.c_double()
+        self._chk(self._L.w2dyn_get_scalar(self._h, name.encode(), C.byref(v)))
+        return v.value
+
+    def result(self, name, dtype=np.float64):
+        need = C.c_size_t()
+        self._chk(self._L.w2dyn_get_result(self._h, name.encode(), None, 0, C.byref(need)))
+        buf = np.zeros(need.value // np.dtype(dtype).itemsize, dtype=dtype)
+        self._chk(self._L.w2dyn_get_result(self._h, name.encode(), buf.ctypes.data, buf.nbytes, None))
+        return buf
+
+    def _shapes(self):
+        nd = self._nd
+        nb = int(self.scalar("nbins"))
+        g = lambda n: self.result(n).size
+        return nd, nb, g
+
+    def __getattr__(self, name):
+        # module-variable reads of the reference; evaluated lazily from the library's result table
+        if name.startswith("_"):
+            raise AttributeError(name)
+        if name in _SCALARS:
+            return self.scalar(name)
+        nd = self.__dict__.get("_nd")
+        if nd is None:
+            raise AttributeError(name)
+        nf = 2 * nd
+        if name in ("gtau", "gleg", "histo"):
+            return self.result(name).reshape(nd, 2, -1)
+        if name == "giw":
+            a = self.result("giw").reshape(nd, 2, -1, 2)
+            return a[..., 0] + 1j * a[..., 1]
+        if name in ("gtau_full", "gleg_full"):
+            return self.result(name).reshape(nd, 2, nd, 2, -1)
+        if name == "occ":
+            return self.result("occ").reshape(nd, 2, nd, 2)
+        if name == "rho1":
+            return self.result("rho1").reshape(nf, nf)
+        if name == "rho2":
+            return self.result("rho2").reshape(nf, nf, nf, nf)
+        if name == "densitymatrix":
+            return self.result("densitymatrix").reshape(4 ** nd, 4 ** nd)
+        if name in ("outersuperstatehisto", "outerstatehisto", "signhistosuperstates", "signhistostates",
+                    "tracecontribsuperstates", "tracecontribstates", "eigenstatesenergies", "accadd", "accrem",
+                    "lhisto", "rhisto"):
+            return self.result(name)
+        if name == "statessuperstates":
+            return self.result(name, np.int32)
+        if name == "occbasismapping":
+            return self.result(name, np.int32).reshape(4 ** nd, nd, 2)
+        if name == "accpair":
+            return self.result(name, np.int64).reshape(nd, 2, -1)
+        if name == "cntsampling":
+            return self.result(name, np.int64)
+        if name.endswith("_bins"):
+            base = name[:-5]
+            nb = int(self.scalar("nbins"))
+            a = self.result(name)
+            if base in ("gtau", "gleg", "histo"):
+                return a.reshape(nb, nd, 2, -1)
+            if base == "giw":
+                a = a.reshape(nb, nd, 2, -1, 2)
+                return a[..., 0] + 1j * a[..., 1]
+            if base == "occ":
+                return a.reshape(nb, nd, 2, nd, 2)
+            return a.reshape(nb, -1)
+        raise AttributeError(name)
