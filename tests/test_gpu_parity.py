@@ -1,0 +1,195 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the CPU oracle and the reference's golden vectors.
+
+Chain of evidence: reference == oracle(std::mt19937) [test_oracle_golden.py, fixtures made by the reference];
+oracle(philox, walker w) == HIP chain w [here], same seeded inputs, every move type.  Tolerance 1e-10 relative
+(north_star: "within 1e-10 relative in fp64"); configurations 1e-11 absolute.
+"""
+import numpy as np
+import pytest
+
+import pyoracle
+import util
+from w2dynamics_amd.mctqmc import MCTQMC, W2DynError
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300)
+
+
+def make_gpu(p, ps, seed, nw, wpb=1, kmax=0):
+    q = MCTQMC(nwalkers=nw, walkers_per_bin=wpb, kmax=kmax)
+    q.init_rnd(seed); q.init_paras(ps)
+    q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+    return q
+
+
+BASE = dict(Ntau=100, NLegMax=12, Niw=8, MeasGiw=1, NLookup_nfft=0)
+TRAJ = [
+    ("C1", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=20, TaudiffMax=2.0, PercentageGlobalMove=0.0, PercentageTauShiftMove=0.0), 1234),
+    ("C1", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=20, TaudiffMax=-1.0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 99),
+    ("C3", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=6.0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 77),
+    ("C2", 2001, dict(BASE, Nwarmups=20000, Nmeas=10, NCorr=200, TaudiffMax=10.0, NLegMax=100, Ntau=1000), 5),
+    ("C5Z", 501, dict(BASE, Nwarmups=4000, Nmeas=10, NCorr=100, TaudiffMax=10.0, NLegMax=40), 31),
+]
+
+
+@pytest.mark.parametrize("cfg,nftau,over,seed", TRAJ, ids=["C1-addrem", "C1-1window-allmoves", "C3-allmoves", "C2-default", "C5Z-default"])
+def test_chains_retrace_oracle(cfg, nftau, over, seed):
+    """Every chain: same configuration, M, sign, window and NPairs after warm-up; same estimators after sampling."""
+    p, ps, pset = util.setup(cfg, nftau, over)
+    nw = 6
+    q = make_gpu(p, ps, seed, nw)
+    tdm = pset.get_real("TaudiffMax")
+    q.set_taudiffmax(tdm)
+    q.ctqmc_warmup(over["Nwarmups"])
+    oracles = []
+    for w in range(nw):
+        o = pyoracle.OracleWalker(p, pset, ("philox", seed, w))
+        o.set_taudiffmax(tdm); o.warmup(over["Nwarmups"])
+        c = o.get_config(); so = o.state()
+        n, osst, _ = q.get_mc_config_scalars(w)
+        assert n == len(c["taus"]), "chain %d" % w
+        assert osst == c["outer_sst"]
+        g = q.get_mc_config(n, w)
+        if n:
+            assert np.abs(g[0] - c["taus"]).max() < 1e-11
+            assert np.array_equal(g[1], c["orbs"]) and np.array_equal(g[2], c["spins"]) and np.array_equal(g[3], c["cas"])
+        st = q.get_walker_state(w)
+        assert st["det_sign"] == so["det_sign"] and st["window_position"] == so["window_position"] and st["npairs"] == so["npairs"]
+        assert st["det_log"] == pytest.approx(so["det_log"], abs=1e-8)
+        for orb in range(1, p.nd + 1):
+            for sp in (1, 2):
+                a, b = q.get_minv(w, orb, sp), o.minv(orb, sp)
+                assert a.shape == b.shape
+                if a.size:
+                    assert rel(a, b) < TOL
+        oracles.append(o)
+    q.ctqmc_measure(1, 1)
+    assert q.mean_sign == -1.0
+    bins = {k: getattr(q, k + "_bins") for k in ("gleg", "gtau", "giw", "histo", "occ")}
+    tot = {k: 0.0 for k in bins}
+    for w, o in enumerate(oracles):
+        o.measure(); r = o.results()
+        for k in bins:
+            assert rel(bins[k][w], r[k]) < TOL, (k, w)
+            tot[k] = tot[k] + r[k] / nw
+        assert q.get_walker_state(w)["cfgsign"] == o.state()["cfgsign"]
+        o.close()
+    for k in bins:      # the module-level arrays are the means over chains
+        assert rel(getattr(q, k), tot[k]) < TOL, k
+    q.dest_ctqmc(); q.close()
+
+
+@pytest.mark.parametrize("name", ["C1", "C3", "C2"])
+def test_recorded_configuration_vs_reference_golden(name):
+    """set_mc_config (full rebuild of M on the device) + one measurement == what the REFERENCE printed."""
+    g = util.load_golden("meas_%s.npz" % name)
+    over = g["overrides"]
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    q = make_gpu(p, ps, int(g["seed"]), 4, wpb=4)
+    q.set_taudiffmax(over["TaudiffMax"])
+    c = util.cfg_from(g, "cfg_")
+    q.set_mc_config(len(c["taus"]), c["taus"], c["orbs"], c["spins"], c["cas"], c["hashybs"], c["outer_sst"], c["outer_state"])
+    q.ctqmc_measure(1, 1)
+    for k in ("gleg", "gtau", "giw", "occ", "histo"):
+        assert rel(getattr(q, k), g["res_" + k]) < TOL, k
+    assert q.mean_sign == float(g["res_mean_sign"])
+    q.dest_ctqmc(); q.close()
+
+
+def test_ragged_and_empty_chains():
+    """Empty configurations (k=0 everywhere), chains with very different orders in one launch, walker count not a
+    multiple of the block size."""
+    p, ps, pset = util.setup("C1", 501, dict(BASE, Nwarmups=0, Nmeas=1, NCorr=0, TaudiffMax=2.0))
+    q = make_gpu(p, ps, 1, 7, wpb=1)
+    q.set_taudiffmax(2.0)
+    q.ctqmc_measure(1, 1)                       # all empty
+    assert np.all(q.gleg == 0.0) and np.all(q.histo[:, :, 0] == 1.0)
+    occ_e = q.occ_bins
+    for w in range(7):
+        n, osst, _ = q.get_mc_config_scalars(w)
+        assert n == 0
+        up, dn = osst & 1, (osst >> 1) & 1
+        assert occ_e[w, 0, 0, 0, 0] == up and occ_e[w, 0, 1, 0, 1] == dn
+    # one chain gets a long configuration, the others stay empty
+    k = 20
+    taus = np.sort(np.random.default_rng(0).uniform(0.01, p.beta - 0.01, 2 * k))
+    cas = np.array([1, 2] * k, np.int32)
+    q.set_mc_config(2 * k, taus, np.ones(2 * k, np.int32), np.ones(2 * k, np.int32), cas, -np.ones(2 * k, np.int32), 0, 1, walker=3)
+    o = pyoracle.OracleWalker(p, pset, ("philox", 1, 3))
+    o.set_taudiffmax(2.0)
+    o.set_config(dict(taus=taus, orbs=np.ones(2 * k, np.int32), spins=np.ones(2 * k, np.int32), cas=cas, outer_sst=0))
+    assert rel(q.get_minv(3, 1, 1), o.minv(1, 1)) < TOL
+    q.ctqmc_measure(1, 1)
+    o.measure()
+    assert rel(q.gleg_bins[3], o.results()["gleg"]) < TOL
+    assert np.all(q.gleg_bins[2] == 0.0)
+    o.close(); q.dest_ctqmc(); q.close()
+
+
+def test_capacity_overflow_is_reported():
+    p, ps, pset = util.setup("C1", 501, dict(BASE, Nwarmups=3000, Nmeas=1, NCorr=1, TaudiffMax=-1.0))
+    q = make_gpu(p, ps, 3, 8, kmax=2)
+    q.set_taudiffmax(-1.0)
+    with pytest.raises(W2DynError) as e:
+        q.ctqmc_warmup(3000)
+    assert e.value.code == -4
+    q.close()
+
+
+def test_unsupported_modes_are_refused():
+    p, _, _ = util.setup("C1", 501, {})
+    for over in (dict(segment=1), dict(offdiag=1), dict(statesampling=1), dict(Percentage4OperatorMove=0.1),
+                 dict(PercentageOuterMove=0.1), dict(EnableOuterTruncation="YES"), dict(PercentageWormInsert=0.2)):
+        _, ps, _ = util.setup("C1", 501, over)
+        q = MCTQMC(nwalkers=4)
+        q.init_rnd(1); q.init_paras(ps)
+        with pytest.raises(W2DynError) as e:
+            q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+        assert e.value.code == -2, over
+        q.close()
+    # Kanamori spin-flip / pair-hopping terms: not density-density
+    U = p.umatrix.copy().reshape(1, 2, 1, 2, 1, 2, 1, 2)
+    from w2dynamics_amd import synth
+    p2 = synth.config("C3", 501)
+    U = p2.umatrix.copy(); U[0, 1, 3, 2] = 0.25
+    _, ps, _ = util.setup("C3", 501, {})
+    q = MCTQMC(nwalkers=4); q.init_rnd(1); q.init_paras(ps)
+    with pytest.raises(W2DynError):
+        q.init_solver(U, p2.ftau, p2.muimp, p2.screening, 1)
+    q.close()
+
+
+@pytest.mark.parametrize("name", ["C1", "C2", "C3"])
+def test_full_run_statistics_vs_reference(name):
+    """Full-run observables agree with long REFERENCE runs (8 seeds, tests/golden/stat_*.npz) within error bars.
+
+    chi^2-style check: |HIP - ref| < 5 sigma_combined element-wise for occ and the leading Legendre coefficients,
+    and the reduced chi^2 over those elements < 2."""
+    g = util.load_golden("stat_%s.npz" % name)
+    over = dict(g["overrides"])
+    nwalk = 512
+    over.update(Nmeas=max(50, int(over["Nmeas"]) * 8 // nwalk * 2))
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    q = make_gpu(p, ps, 2024, nwalk, wpb=16)
+    q.set_taudiffmax(over["TaudiffMax"])
+    q.ctqmc_warmup(over["Nwarmups"] // 4)
+    q.ctqmc_measure(1, 1)
+    chi = []
+    for key in ("occ", "gleg"):
+        b = getattr(q, key + "_bins"); nb = b.shape[0]
+        mean = b.mean(axis=0); err = b.std(axis=0, ddof=1) / np.sqrt(nb)
+        ref, referr = g[key + "_mean"], g[key + "_err"]
+        if key == "gleg":
+            mean, err, ref, referr = mean[..., :10:2], err[..., :10:2], ref[..., :10:2], referr[..., :10:2]
+        sig = np.sqrt(err ** 2 + referr ** 2)
+        mask = sig > 0
+        z = (mean[mask] - ref[mask]) / sig[mask]
+        assert np.abs(z).max() < 5.0, (key, np.abs(z).max())
+        chi.append((z ** 2).mean())
+    assert np.mean(chi) < 2.0, chi
+    assert abs(q.accadd[0] - float(g["accadd_mean"][0])) < 5 * float(g["accadd_err"][0]) + 0.003
+    q.dest_ctqmc(); q.close()

@@ -1,0 +1,131 @@
+"""CPU: the oracle (C restatement) against fixtures produced by the reference itself (tests/golden/gen_golden.py).
+
+traj_*: the oracle driven by std::mt19937 (the generator the reference wraps) must retrace the reference's chain:
+same configuration after warm-up, same observables after the measurement run.  Tolerances: configurations exact to
+1e-12, observables 1e-10 relative (north_star) - the observed agreement is ~1e-15.
+meas_*: recorded configuration -> one measurement.
+"""
+import numpy as np
+import pytest
+
+import pyoracle
+import util
+
+CASES = ["C1", "C3", "C2"]
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_retraces_reference_chain(name):
+    g = util.load_golden("traj_%s.npz" % name)
+    over = g["overrides"]
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    assert abs(p.ftau.sum() - float(g["ftau_sum"])) < 1e-9 * abs(float(g["ftau_sum"]))
+    w = pyoracle.OracleWalker(p, pset, ("std", int(g["seed"])))
+    w.set_taudiffmax(over["TaudiffMax"])
+    w.warmup(over["Nwarmups"])
+    c = w.get_config()
+    assert len(c["taus"]) == len(g["cfg_taus"])
+    assert c["outer_sst"] == int(g["cfg_outer_sst"])
+    assert np.array_equal(c["orbs"], g["cfg_orbs"]) and np.array_equal(c["spins"], g["cfg_spins"]) and np.array_equal(c["cas"], g["cfg_cas"])
+    assert np.abs(c["taus"] - g["cfg_taus"]).max() < 1e-12
+    w.measure()
+    r = w.results()
+    c2 = w.get_config()
+    assert np.abs(c2["taus"] - g["end_taus"]).max() < 1e-12
+    for k in ("gleg", "gtau", "giw", "histo", "occ", "outersuperstatehisto"):
+        assert rel(r[k], g["res_" + k]) < 1e-10, k
+    assert np.array_equal(r["accpair"], g["res_accpair"])
+    assert r["mean_sign"] == pytest.approx(float(g["res_mean_sign"]), abs=1e-14)
+    cnt = r["counters"]
+    assert cnt[1] / cnt[0] == pytest.approx(float(g["res_accadd"][0]), rel=1e-12)
+    assert cnt[4] / cnt[3] == pytest.approx(float(g["res_accrem"][0]), rel=1e-12)
+    if cnt[6] > 0:
+        assert cnt[7] / cnt[6] == pytest.approx(float(g["res_accglob"]), rel=1e-12)
+    assert rel(r["eigenstatesenergies"], g["res_eigenstatesenergies"]) < 1e-13
+    assert rel(np.diag(g["res_densitymatrix"]), r["dm_diag"]) < 1e-10
+    w.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_recorded_configuration_measurement(name):
+    g = util.load_golden("meas_%s.npz" % name)
+    over = g["overrides"]
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    w = pyoracle.OracleWalker(p, pset, ("std", int(g["seed"])))
+    w.set_taudiffmax(over["TaudiffMax"])
+    assert w.set_config(util.cfg_from(g, "cfg_")) == 0
+    w.measure()
+    r = w.results()
+    for k in ("gleg", "gtau", "giw", "occ", "histo"):
+        assert rel(r[k], g["res_" + k]) < 1e-10, k
+    w.close()
+
+
+def test_matrix_update_primitives_against_exact_inverse(oracle_lib):
+    """MatrixUpdate.F90:489-631 (the reference's disabled self-test) idea: fast updates vs a fresh inverse."""
+    L = oracle_lib
+    rng = np.random.default_rng(3)
+    for k in (1, 2, 5, 9):
+        A = rng.normal(size=(k + 1, k + 1)) + 3 * np.eye(k + 1)      # F with row=annihilator, col=creator
+        for pc in range(k + 1):
+            for pa in (0, k // 2, k):
+                keep_a = [i for i in range(k + 1) if i != pa]; keep_c = [j for j in range(k + 1) if j != pc]
+                Fold = A[np.ix_(keep_a, keep_c)]
+                M = np.ascontiguousarray(np.linalg.inv(Fold)) if k else np.zeros((0, 0))   # M[c][a]
+                Q = np.ascontiguousarray(A[keep_a, pc]); R = np.ascontiguousarray(A[pa, keep_c])
+                S = L.ora_detrat_add(M if k else np.zeros(1), k, Q if k else np.zeros(1), R if k else np.zeros(1), A[pa, pc])
+                # Schur complement times the cofactor sign (Trace.F90:2828) is the determinant ratio
+                assert S * (-1) ** (pc + pa) == pytest.approx(np.linalg.det(A) / (np.linalg.det(Fold) if k else 1.0), rel=1e-9)
+                out = np.zeros((k + 1, k + 1))
+                L.ora_mat_add(M if k else np.zeros(1), k, Q if k else np.zeros(1), R if k else np.zeros(1), S, pc, pa, out)
+                assert np.allclose(out, np.linalg.inv(A), rtol=1e-9, atol=1e-11)
+                if k:
+                    back = np.zeros((k, k))
+                    L.ora_mat_rem(out, k + 1, pc, pa, back)
+                    assert np.allclose(back, M, rtol=1e-9, atol=1e-11)
+
+
+def test_inverse_logdet(oracle_lib):
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    for k in (1, 3, 17):
+        A = rng.normal(size=(k, k))
+        B = np.ascontiguousarray(A.copy())
+        ld, sg = C.c_double(), C.c_double()
+        assert oracle_lib.ora_inverse_logdet(B, k, C.byref(ld), C.byref(sg)) == 0
+        s, l = np.linalg.slogdet(A)
+        assert sg.value == s and ld.value == pytest.approx(l, rel=1e-12)
+        assert np.allclose(B, np.linalg.inv(A), rtol=1e-9, atol=1e-10)
+
+
+def test_hybr_interpolation(oracle_lib):
+    beta, n = 7.0, 11
+    tab = np.linspace(1.0, 2.0, n)
+    assert oracle_lib.ora_hybr(tab, n, beta, 0.0) == 1.0
+    assert oracle_lib.ora_hybr(tab, n, beta, beta / 2) == pytest.approx(1.5)
+    assert oracle_lib.ora_hybr(tab, n, beta, -beta / 2) == pytest.approx(-1.5)     # antiperiodic (Trace.F90:1024-1026)
+    assert oracle_lib.ora_hybr(tab, n, beta, 0.35 * beta) == pytest.approx(1.35)
+
+
+def test_legendre_estimator_matches_numpy(oracle_lib):
+    """Independent numpy restatement of CTQMC.F90:2349-2393 for one flavour."""
+    from numpy.polynomial import legendre
+    rng = np.random.default_rng(11)
+    k, beta, nleg, ntau = 6, 13.0, 20, 50
+    M = np.ascontiguousarray(rng.normal(size=(k, k))); tc = np.sort(rng.uniform(0, beta, k)); ta = np.sort(rng.uniform(0, beta, k))
+    gl = np.zeros(nleg); gt = np.zeros(ntau)
+    oracle_lib.ora_meas_flavour(M, k, tc, ta, beta, -1.0, nleg, gl.ctypes.data, ntau, gt.ctypes.data, 0, None)
+    ref_l = np.zeros(nleg); ref_t = np.zeros(ntau)
+    for ic in range(k):
+        for ia in range(k):
+            d = ta[ia] - tc[ic]; m = M[ic, ia]
+            if d <= 0: d += beta; m = -m
+            m *= -1.0
+            x = 2 * d / beta - 1
+            ref_l += m * np.array([legendre.legval(x, [0] * l + [1]) for l in range(nleg)])
+            ref_t[min(int(d / beta * ntau), ntau - 1)] += m
+    assert np.allclose(gl, ref_l, rtol=1e-11, atol=1e-12) and np.allclose(gt, ref_t, rtol=1e-12, atol=1e-13)
