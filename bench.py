@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Benchmark of the CT-HYB hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[1]): 1-band Hubbard model, Bethe lattice D=1, U=2, beta=100, half filling,
+TaudiffMax=10 (9 sliding windows), reference defaults otherwise (Ntau=1000, NLegMax=100, Nftau=5001,
+PercentageGlobalMove = PercentageTauShiftMove = 0.005) and NCorr=200 as in BASELINE.md.
+One bench "step" = one pass of the hot path over the batch of chains of every GPU: NCorr Monte-Carlo steps for each
+chain (sweep kernel) followed by one pass of the Z-space estimators (sign/histograms, Legendre + tau bins).
+`value` = Metropolis steps per second of the whole job = n_gpus * chains * NCorr * K / time; measurements/s is
+reported next to it.  Chains are thermalised before the timed region; all state is resident in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+FP64_PEAK_TFLOPS = 78.6     # MI355X fp64 vector == matrix peak (the microarch guide lists no fp64 row)
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
+
+WORKLOAD = dict(config="C2", nftau=5001,
+                overrides=dict(Nftau=5001, NCorr=200, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Nwarmups=0, Nmeas=1))
+
+
+def _cpu_chain(args):
+    """One reference (or oracle) chain on one core; returns (mc_steps, seconds, kind)."""
+    seed, nmeas, nwarm = args
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from w2dynamics_amd import params, synth
+    p = synth.config(WORKLOAD["config"], nftau=WORKLOAD["nftau"])
+    over = dict(WORKLOAD["overrides"]); over.update(Nmeas=nmeas, Nwarmups=nwarm)
+    ps = params.make_pstring(over, beta=p.beta, Nd=p.nd)
+    try:
+        import refdrive
+        if not refdrive.available():
+            raise ImportError("oracle/_ref not built")
+        s = refdrive.RefSolver(p, ps, seed)
+        s.set_taudiffmax(over["TaudiffMax"])
+        s.warmup(nwarm)
+        t0 = time.perf_counter(); s.measure(); dt = time.perf_counter() - t0
+        s.close()
+        return nmeas * over["NCorr"], dt, "reference"
+    except Exception:
+        import pyoracle
+        w = pyoracle.OracleWalker(p, params.ParameterSet(ps), ("std", seed))
+        w.set_taudiffmax(over["TaudiffMax"])
+        w.warmup(nwarm)
+        t0 = time.perf_counter(); w.measure(); dt = time.perf_counter() - t0
+        w.close()
+        return nmeas * over["NCorr"], dt, "port"
+
+
+def cpu_baseline(cores, nmeas=6000, nwarm=50000):
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_chain, [(1000 + i, nmeas, nwarm) for i in range(cores)])
+    rate = sum(s / t for s, t, _ in res)
+    kind = res[0][2]
+    return {"value": rate, "unit": "MC steps/s", "cores": cores, "kind": kind,
+            "meas_per_s": sum((s / WORKLOAD["overrides"]["NCorr"]) / t for s, t, _ in res),
+            "sample": "%d independent chains (one per core, as the reference's MPI ranks), each %d warm-up steps untimed + "
+                      "%d measurements x NCorr=%d steps timed, same C2 workload" % (cores, nwarm, nmeas, WORKLOAD["overrides"]["NCorr"])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--walkers", type=int, default=int(os.environ.get("W2DYN_WALKERS", 8192)), help="chains per GPU")
+    ap.add_argument("--walkers-per-bin", type=int, default=int(os.environ.get("W2DYN_WPB", 8)))
+    ap.add_argument("--thermal", type=int, default=20000, help="untimed thermalisation MC steps per chain")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cores", type=int, default=0)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from w2dynamics_amd import params, synth
+    from w2dynamics_amd.mctqmc import MCTQMC
+    from w2dynamics_amd.statistics import TorchComm
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    comm = TorchComm()
+
+    over = WORKLOAD["overrides"]
+    prob = synth.config(WORKLOAD["config"], nftau=WORKLOAD["nftau"])
+    ps = params.make_pstring(over, beta=prob.beta, Nd=prob.nd)
+    q = MCTQMC(device=local_rank, nwalkers=a.walkers, first_walker=rank * a.walkers, walkers_per_bin=a.walkers_per_bin)
+    q.init_rnd(43890); q.init_paras(ps)
+    q.init_solver(prob.umatrix, prob.ftau, prob.muimp, prob.screening, 1)
+    q.set_taudiffmax(over["TaudiffMax"])
+    q.ctqmc_warmup(a.thermal)                      # thermalise (untimed)
+    q.measure_begin()
+    ncorr = over["NCorr"]
+    for _ in range(a.warmup):
+        q.sweep(ncorr); q.measure_once()
+    q.sync()
+    for k in ("sweep", "meas_misc", "meas_gleg"):
+        q.kernel_time(k, reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        q.sweep(ncorr); q.measure_once()
+    q.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # the exchange step of the path: accumulators of all ranks combined by one all-reduce (untimed here, it runs once
+    # per solve; its duration is reported)
+    q.measure_finish()
+    t1 = time.perf_counter()
+    gl, gt, oc, hi = comm.allreduce_packed([q.gleg, q.gtau, q.occ, q.histo])
+    t_reduce = time.perf_counter() - t1
+    gl /= world; oc /= world; hi /= world
+
+    sweep_ms, nsweep = q.kernel_time("sweep")
+    gleg_ms, ngleg = q.kernel_time("meas_gleg")
+    misc_ms, _ = q.kernel_time("meas_misc")
+    if rank == 0:
+        W = a.walkers
+        cnt = q.result("counters")
+        names = ["tryadd", "accadd", "qnadd", "tryrem", "accrem", "qnrem", "tryglob", "accglob", "qnglob", "tryshift", "accshift", "sampling"]
+        c = dict(zip(names, cnt))
+        ks = np.arange(hi.shape[-1])
+        k1 = float((hi * ks).sum(-1).mean()); k2 = float((hi * ks ** 2).sum(-1).mean())
+        nlaunch_steps = W * ncorr * (a.steps + a.warmup)     # counters cover warm-up rounds too
+        scale = (W * ncorr) / nlaunch_steps                   # per-launch share
+        # algorithmic bytes of one sweep launch: det-ratio proposals that pass the quantum-number
+        # check read M (8k^2), 2k F-table pairs (32k) and both tau arrays (16k); every accepted pair move rewrites M
+        # (read 8k^2 + write 8k^2); a removal proposal reads one element.
+        prop = (c["tryadd"] - c["qnadd"]) * (8 * k2 + 48 * k1)
+        acc = (c["accadd"] + c["accrem"]) * 16 * k2
+        rem = c["tryrem"] * 8
+        bytes_sweep = (prop + acc + rem) * scale
+        ach_gbs = bytes_sweep / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+        flops_gleg = W * prob.nd * 2 * k2 * (5 * over["NLegMax"] + 6)
+        ach_tf = flops_gleg / (gleg_ms * 1e-3) / 1e12 if gleg_ms > 0 else 0.0
+        value = world * W * ncorr * a.steps / dt
+        out = {
+            "metric": "Metropolis steps/sec (node)", "value": value, "unit": "MC steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2: 1-band Hubbard, Bethe D=1, U=2, beta=100, half filling, TaudiffMax=10, NCorr=200, "
+                                   "NLegMax=100, Ntau=1000, Nftau=5001, default move mix", "chains_per_gpu": W,
+                       "walkers_per_bin": a.walkers_per_bin, "parallelism": "chains sharded over %d GPU(s), no data-path collective" % world},
+            "measurements_per_s": world * W * a.steps / dt,
+            "mean_order_per_flavour": k1, "accept_ins": c["accadd"] / max(c["tryadd"], 1), "occ_double": float(oc[0, 0, 0, 1]),
+            "allreduce_ms": t_reduce * 1e3,
+            "roofline": {"kernel": "k_sweep", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": sweep_ms, "launches": nsweep,
+                         "algorithmic_bytes_per_launch": bytes_sweep},
+            "roofline_meas": {"kernel": "k_meas_gleg", "bound": "mfma", "note": "fp64 vector FMA bound (fp64 vector peak == fp64 MFMA peak on MI355X)",
+                              "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS,
+                              "traffic": None, "avg_launch_ms": gleg_ms, "launches": ngleg, "algorithmic_flops_per_launch": flops_gleg},
+            "kernel_ms": {"k_sweep": sweep_ms, "k_meas_gleg": gleg_ms, "k_meas_misc": misc_ms},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            cores = a.cpu_cores or max(1, min(16, os.cpu_count() or 1))
+            try:
+                out["cpu_baseline"] = cpu_baseline(cores)
+                out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            except Exception as e:  # pragma: no cover
+                out["cpu_baseline"] = {"value": None, "unit": "MC steps/s", "cores": cores, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    q.dest_ctqmc(); q.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

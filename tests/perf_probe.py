@@ -1,0 +1,33 @@
+"""Not a test: throughput probe of the sweep / estimator kernels for several chain counts (run on the GPU box)."""
+import sys, os, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import util
+from w2dynamics_amd.mctqmc import MCTQMC
+
+def probe(cfg, nftau, over, nw, kmax=0, rounds=5, thermal=20000):
+    p, ps, pset = util.setup(cfg, nftau, over)
+    q = MCTQMC(nwalkers=nw, walkers_per_bin=8, kmax=kmax)
+    q.init_rnd(1); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+    q.set_taudiffmax(over["TaudiffMax"]); q.ctqmc_warmup(thermal); q.measure_begin()
+    q.sweep(over["NCorr"]); q.measure_once(); q.sync()
+    for k in ("sweep", "meas_gleg", "meas_misc"): q.kernel_time(k, reset=True)
+    for _ in range(rounds): q.sweep(over["NCorr"]); q.measure_once()
+    q.sync()
+    s, _ = q.kernel_time("sweep"); g, _ = q.kernel_time("meas_gleg"); m, _ = q.kernel_time("meas_misc")
+    print("%s nw=%6d kmax=%3d sweep %.3f ms (%.1f Msteps/s, %.2f us/step/chain-slot) gleg %.3f ms misc %.3f ms" % (
+        cfg, nw, int(q.scalar("kmax")), s, nw * over["NCorr"] / s / 1e3, s * 1e3 / over["NCorr"], g, m), flush=True)
+    q.measure_finish()
+    c = q.result("counters")
+    if len(c) >= 16 and c[12] > 0:
+        tot = c[12] + c[13] + c[14] + c[15]
+        print("   cycles/move: add %.0f (n=%d) rem %.0f (n=%d) glob %.0f (n=%d) shift %.0f (n=%d); share add %.2f rem %.2f glob %.2f shift %.2f" % (
+            c[12] / max(c[0], 1), c[0], c[13] / max(c[3], 1), c[3], c[14] / max(c[6], 1), c[6], c[15] / max(c[9], 1), c[9],
+            c[12] / tot, c[13] / tot, c[14] / tot, c[15] / tot), flush=True)
+    q.dest_ctqmc(); q.close()
+
+if __name__ == "__main__":
+    over = dict(NCorr=200, TaudiffMax=10.0, Ntau=1000, NLegMax=100)
+    for nw in [int(x) for x in (sys.argv[1:] or ["256", "2048", "8192", "16384"])]:
+        probe("C2", 5001, over, nw)

@@ -1,9 +1,11 @@
 // Device side of libw2dyn_hip.so: batched-walker CT-HYB sampler and estimators for gfx950 (MI355X).
 //
 // Execution model: ONE WAVEFRONT (64 lanes) PER MARKOV CHAIN.  All control flow of a chain is wave-uniform; lanes
-// parallelise over matrix elements / operators.  A 256-thread block holds four independent chains (no block-level
-// barrier anywhere).  Chain state stays resident in HBM between launches (structure of arrays over walkers); the
-// working set of one step (k_f^2 doubles of one M block, the tau arrays) is L2/L1 resident.
+// parallelise over matrix columns / operators.  A 256-thread block holds four independent chains (no block-level
+// barrier anywhere).  Chain state stays resident in HBM between launches (structure of arrays over walkers).  During
+// a sweep launch the chain's operator times, orders and counters live in the wave's LDS slice; the inverse
+// hybridisation matrices stay in global memory (L2 resident: k_f^2 doubles per flavour) and are touched with
+// coalesced row segments (lane = column).
 //
 // Data layout per walker w (capacity KMAX per flavour):
 //   K [w][f]                      expansion order of flavour f
@@ -12,11 +14,14 @@
 // Slot order replaces the reference's time-ordered rows/columns (MatrixUpdate.F90:410-482 shifts and reallocates on
 // every accepted move): an insertion appends one row/column in place, a removal is a rank-one update plus moving
 // the last row/column into the hole, a tau-shift is a pure sign flip.  Time-ordered ranks, where the reference
-// needs them (FPos parity, Trace.F90:2828), are obtained by wave-parallel counting.
+// needs them (FPos parity, Trace.F90:2828), are obtained by wave-parallel counting (ballot + popcount).
 //
 // Local problem: density-density, every block of H_loc holds one Fock state (reference "scalar" trace path,
 // Trace.F90:5556-5727).  The local trace ratio of a pair move is evaluated in closed form from occupied-length
 // integrals (no time-ordered walk), which is exact for this class of Hamiltonians.
+//
+// Random numbers: the chain's Philox stream (include/w2dyn_rng.h) is generated 128 draws at a time, lane i
+// evaluating block 64*chunk+i, and handed out with v_readlane - the stream itself is unchanged.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,11 +29,13 @@
 
 namespace w2dyn {
 
-constexpr int WCAP = 256;        // max operators inside the sliding window handled by the removal proposal
 constexpr int MAXFLAV = 16;
+constexpr int KMAX_LIMIT = 256;
 
 enum Counter { C_TRYADD, C_ACCADD, C_QNADD, C_TRYREM, C_ACCREM, C_QNREM, C_TRYGLOB, C_ACCGLOB, C_QNGLOB,
-               C_TRYSHIFT, C_ACCSHIFT, C_SAMPLING, C_NCOUNT };
+               C_TRYSHIFT, C_ACCSHIFT, C_SAMPLING,
+               C_CYC_ADD, C_CYC_REM, C_CYC_GLOB, C_CYC_SHIFT,   // shader cycles per move type (diagnostic build -DW2DYN_STAMPS only)
+               C_NCOUNT };
 
 enum WalkerErr { ERR_NONE = 0, ERR_KMAX = 1, ERR_WCAP = 2, ERR_DETRAT = 4, ERR_SINGULAR = 8 };
 
@@ -41,12 +48,11 @@ struct WalkerScalars {
     double det_sign;            // sign of det F in the reference's time order (Trace%Det%sign)
     double det_log;             // log|det F|
     unsigned long long cnt[C_NCOUNT];
-    unsigned long long pad[1];
 };
 
 struct DevConst {
     int nd, nflav, nstates, nftau, ntau, nleg, niw2, kmax, nwalkers, num_windows, nslide, has_szt, maxhisto;
-    int walkers_per_bin, nbins, lds_per_wave;   // lds_per_wave in bytes
+    int walkers_per_bin, nbins, lds_per_wave, wcap;   // lds_per_wave in bytes; wcap: window-list capacity
     double beta, taudiff_max, p_glob, p_shift, egs;
     unsigned long long seed, first_walker;
     const double *ftab;      // [nflav][nftau]
@@ -72,11 +78,18 @@ struct DevConst {
     unsigned long long *accpair;  // [nflav][ntau]
 };
 
+// bytes of LDS one wave needs (host and device agree through this one function)
+__host__ __device__ inline size_t lds_bytes_per_wave(int nflav, int kmax, int wcap)
+{
+    size_t d = (size_t)2 * nflav * kmax + 4 * (size_t)kmax + wcap;          // tc, ta, Q, R, MQ, RM, wt
+    size_t i = (size_t)2 * wcap + MAXFLAV;                                     // wm, wc, K
+    size_t b = d * sizeof(double) + C_NCOUNT * sizeof(unsigned long long) + i * sizeof(int);
+    return (b + 15) & ~(size_t)15;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // wave helpers
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
-
 __device__ __forceinline__ void wave_sync()
 {
     // cross-lane hand-off through LDS / global memory inside ONE wave: order the memory operations for the
@@ -86,26 +99,51 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni(double v)
+{
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_d(double v, int l)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// Sum over the 64 lanes, result wave-uniform.  DPP inside the 16-lane rows (quad_perm [1,0,3,2], [2,3,0,1],
+// row_half_mirror, row_mirror), then four v_readlane.  Must be called with all lanes active.
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_d<0xB1>(v);
+    v += dpp_d<0x4E>(v);
+    v += dpp_d<0x141>(v);
+    v += dpp_d<0x140>(v);
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
 }
 __device__ __forceinline__ int wave_sum(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 __device__ __forceinline__ double wave_min(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmin(v, dpp_d<0xB1>(v));
+    v = fmin(v, dpp_d<0x4E>(v));
+    v = fmin(v, dpp_d<0x141>(v));
+    v = fmin(v, dpp_d<0x140>(v));
+    return fmin(fmin(readlane_d(v, 0), readlane_d(v, 16)), fmin(readlane_d(v, 32), readlane_d(v, 48)));
 }
 __device__ __forceinline__ int count_pred(bool p) { return __popcll(__ballot(p)); }
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // Trace.F90:1014-1033 get_HybrF
 __device__ __forceinline__ double hybr(const double *ft, int nftau, double beta, double dtau)
@@ -126,24 +164,44 @@ __device__ __forceinline__ int flav_bit(int f, int nd) { return (f >> 1) + nd * 
 struct Ctx {
     const DevConst &C;
     int w, lane;
-    int *K;
-    double *TC, *TA, *M;
-    // LDS scratch of this wave
-    double *Q, *R, *MQ, *RM, *wt;
-    int *wm, *wc;
+    double *M;                       // global: this walker's matrices
+    // LDS slice of this wave
+    double *tc_, *ta_, *Q, *R, *MQ, *RM, *wt;
+    int *wm, *wc, *K;
+    unsigned long long *cnt;
     // wave-uniform scalars
-    unsigned long long ndraw;
-    int outer, npairs, wpos, err;
+    unsigned long long chunk;        // index of the 128-draw chunk held in rbuf
+    int rpos;                        // next draw inside the chunk (0..128)
+    double rbuf0, rbuf1;             // lane i: draws 2i and 2i+1 of the chunk
+    int outer, npairs, wpos, err, nwin;
     double det_sign, det_log;
-    unsigned long long cnt[C_NCOUNT];
     double wmin, wmax;
 
     __device__ Ctx(const DevConst &c) : C(c) {}
 
+    __device__ __forceinline__ void rng_fill()
+    {
+        unsigned long long blk = chunk * 64ull + (unsigned long long)lane;
+        unsigned long long wk = C.first_walker + (unsigned long long)w;
+        uint32_t c[4] = { (uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)wk, (uint32_t)(wk >> 32) };
+        w2dyn_philox4x32_10(c, (uint32_t)C.seed, (uint32_t)(C.seed >> 32));
+        unsigned long long m0 = ((unsigned long long)(c[0] >> 5) << 26) | (unsigned long long)(c[1] >> 6);
+        unsigned long long m1 = ((unsigned long long)(c[2] >> 5) << 26) | (unsigned long long)(c[3] >> 6);
+        rbuf0 = (double)m0 * (1.0 / 9007199254740992.0);
+        rbuf1 = (double)m1 * (1.0 / 9007199254740992.0);
+    }
+    __device__ __forceinline__ void rng_seek(unsigned long long ndraw)
+    {
+        chunk = ndraw >> 7; rpos = (int)(ndraw & 127ull);
+        rng_fill();
+    }
+    __device__ __forceinline__ unsigned long long rng_tell() const { return (chunk << 7) + (unsigned long long)rpos; }
     __device__ __forceinline__ double draw()
     {
-        double u = w2dyn_uniform_at(C.seed, C.first_walker + (unsigned long long)w, ndraw);
-        ndraw += 1;
+        if (rpos == 128) { chunk += 1; rpos = 0; rng_fill(); }
+        int l = rpos >> 1;
+        double u = (rpos & 1) ? readlane_d(rbuf1, l) : readlane_d(rbuf0, l);
+        rpos += 1;
         return u;
     }
     __device__ __forceinline__ int randint(int lo, int hi)
@@ -158,9 +216,11 @@ struct Ctx {
         wmin = ((double)wpos / (double)(C.num_windows + 1)) * C.beta;
         wmax = ((double)(wpos + 2) / (double)(C.num_windows + 1)) * C.beta;
     }
-    __device__ __forceinline__ double *tc(int f) const { return TC + (size_t)f * C.kmax; }
-    __device__ __forceinline__ double *ta(int f) const { return TA + (size_t)f * C.kmax; }
+    __device__ __forceinline__ double *tc(int f) const { return tc_ + f * C.kmax; }
+    __device__ __forceinline__ double *ta(int f) const { return ta_ + f * C.kmax; }
     __device__ __forceinline__ double *mat(int f) const { return M + (size_t)f * C.kmax * C.kmax; }
+    __device__ __forceinline__ int order(int f) const { return uni(K[f]); }
+    __device__ __forceinline__ void count(int c) { if (lane == 0) cnt[c] += 1ull; }
 };
 
 // pair (x,y) of one creator and one annihilator of equal flavour counts as removable (Trace.F90:1794-1814)
@@ -171,13 +231,13 @@ __device__ __forceinline__ bool pair_ok(double x, double y, double wmin, double 
 }
 
 // Collect the operators inside the window into LDS (wt: tau, wm: f | ca<<8 | slot<<16) and count, for each of them,
-// its partners at later times (wc).  Returns the total = NPairs (Trace.F90:1770-1815).
+// its partners at later times (wc).  Returns the total = NPairs (Trace.F90:1770-1815); x.nwin = list length.
 __device__ int build_window(Ctx &x)
 {
     const DevConst &C = x.C;
     int nw = 0;
     for (int f = 0; f < C.nflav; ++f) {
-        int k = x.K[f];
+        int k = x.order(f);
         const double *tcp = x.tc(f), *tap = x.ta(f);
         for (int base = 0; base < 2 * k; base += 64) {
             int idx = base + x.lane;
@@ -188,22 +248,25 @@ __device__ int build_window(Ctx &x)
             bool inw = valid && tau >= x.wmin && tau <= x.wmax;
             unsigned long long mask = __ballot(inw);
             int pos = nw + __popcll(mask & ((1ull << x.lane) - 1ull));
-            if (inw && pos < WCAP) { x.wt[pos] = tau; x.wm[pos] = f | (ca << 8) | (slot << 16); }
+            if (inw && pos < C.wcap) { x.wt[pos] = tau; x.wm[pos] = f | (ca << 8) | (slot << 16); }
             nw += __popcll(mask);
         }
     }
     nw = uni(nw);
-    if (nw > WCAP) { x.err |= ERR_WCAP; nw = WCAP; }
+    if (nw > C.wcap) { x.err |= ERR_WCAP; nw = C.wcap; }
+    x.nwin = nw;
     wave_sync();
     int total = 0;
-    for (int e = x.lane; e < ((nw + 63) & ~63); e += 64) {
+    for (int base = 0; base < nw; base += 64) {
+        int e = base + x.lane;
         int c = 0;
         if (e < nw) {
             double te = x.wt[e]; int me = x.wm[e] & 0xffff;
+            double thi = te + C.taudiff_max;
+            int want = me ^ 0x300;                       // same flavour, other type (ca 1 <-> 2)
             for (int q = 0; q < nw; ++q) {
                 double tq = x.wt[q]; int mq = x.wm[q] & 0xffff;
-                bool partner = ((mq & 0xff) == (me & 0xff)) && ((mq >> 8) != (me >> 8)) && (tq > te) && !(tq > te + C.taudiff_max);
-                c += partner ? 1 : 0;
+                c += (mq == want && tq > te && !(tq > thi)) ? 1 : 0;
             }
             x.wc[e] = c;
         }
@@ -211,8 +274,7 @@ __device__ int build_window(Ctx &x)
     }
     total = wave_sum(total);
     wave_sync();
-    x.wt[WCAP] = (double)nw;   // stash n_w for the pick
-    return uni(total);
+    return total;
 }
 
 // integral over (lo,hi) of  eps_f + sum_g U_fg n_g(tau)   for the current configuration (flavour f itself excluded)
@@ -225,7 +287,7 @@ __device__ double level_integral(Ctx &x, int f, double lo, double hi)
         if (g == f) continue;
         double u = C.udd[f * C.nflav + g];
         if (u == 0.0) continue;
-        int k = x.K[g];
+        int k = x.order(g);
         if ((x.outer >> flav_bit(g, C.nd)) & 1) base += u;
         const double *tcp = x.tc(g), *tap = x.ta(g);
         for (int e = x.lane; e < k; e += 64) {
@@ -252,7 +314,7 @@ __device__ __forceinline__ void accpair_add(Ctx &x, int f, double dt)
 __device__ void step_add(Ctx &x)
 {
     const DevConst &C = x.C;
-    x.cnt[C_TRYADD] += 1;
+    x.count(C_TRYADD);
     double width1 = x.wmax - x.wmin;
     double tau1 = x.wmin + width1 * x.draw();                 // annihilator
     int orb = x.randint(1, C.nd);
@@ -262,11 +324,12 @@ __device__ void step_add(Ctx &x)
     double tau2 = tmin + width2 * x.draw();                   // creator
     double tdf = width1 * width2;
     int f = 2 * (orb - 1) + (spin - 1);
-    int k = x.K[f];
+    int k = x.order(f);
     const int kmax = C.kmax;
-    double *tcp = x.tc(f), *tap = x.ta(f), *Mf = x.mat(f);
-    const double *ft = C.ftab + (size_t)f * C.nftau;
+    double *tcp = x.tc(f), *tap = x.ta(f);
 
+    // quantum numbers (Trace.F90:1243-1302 for one-state blocks): no operator of flavour f between the new pair and
+    // the right occupation below it; equal times are rejected like QN violations (CTQMC.F90:3405-3416)
     double lo = fmin(tau1, tau2), hi = fmax(tau1, tau2);
     int c_lo = 0, a_lo = 0, c_hi = 0, a_hi = 0, pc = 0, pa = 0, eq = (tau1 == tau2);
     for (int base = 0; base < k; base += 64) {
@@ -277,25 +340,37 @@ __device__ void step_add(Ctx &x)
         c_hi += count_pred(tce < hi); a_hi += count_pred(tae < hi);
         pc += count_pred(tce < tau2); pa += count_pred(tae < tau1);
         eq |= __ballot(v && (tce == tau1 || tce == tau2 || tae == tau1 || tae == tau2)) != 0ull;
-        if (v) {   // Q_j = F(tau_a_j - tau_c_new), R_i = F(tau_a_new - tau_c_i)   (Trace.F90:2814-2817)
-            x.Q[e] = hybr(ft, C.nftau, C.beta, tae - tau2);
-            x.R[e] = hybr(ft, C.nftau, C.beta, tau1 - tce);
-        }
     }
     int between = (c_hi + a_hi) - (c_lo + a_lo);
     int occ_lo = ((x.outer >> flav_bit(f, C.nd)) & 1) + c_lo - a_lo;
     bool creator_first = tau2 < tau1;
     bool valid = !eq && between == 0 && occ_lo == (creator_first ? 0 : 1);
-    if (!valid) { x.cnt[C_QNADD] += 1; return; }
-    if (k >= kmax) { x.err |= ERR_KMAX; x.cnt[C_QNADD] += 1; return; }
+    if (!valid) { x.count(C_QNADD); return; }
+    if (k >= kmax) { x.err |= ERR_KMAX; x.count(C_QNADD); return; }
 
+    // determinant ratio S = F(tau_a-tau_c) - R^T M Q with Q_j = F(tau_a_j - tau_c_new), R_i = F(tau_a_new - tau_c_i)
+    // (Trace.F90:2806-2825).  lane = column j: RM_j = sum_i R_i M_ij in k coalesced row reads, S = S0 - sum_j RM_j Q_j.
+    double *Mf = x.mat(f);
+    const double *ft = C.ftab + (size_t)f * C.nftau;
+    for (int e = x.lane; e < k; e += 64) {
+        x.Q[e] = hybr(ft, C.nftau, C.beta, tap[e] - tau2);
+        x.R[e] = hybr(ft, C.nftau, C.beta, tau1 - tcp[e]);
+    }
+    double S0 = hybr(ft, C.nftau, C.beta, tau1 - tau2);
     wave_sync();
     double acc = 0.0;
-    for (int e = x.lane; e < k * k; e += 64) {
-        int i = e / k, j = e - i * k;
-        acc += x.R[i] * Mf[i * kmax + j] * x.Q[j];
+    for (int j0 = 0; j0 < k; j0 += 64) {
+        int j = j0 + x.lane;
+        double rm = 0.0;
+        if (j < k) {
+            const double *col = Mf + j;
+#pragma unroll 4
+            for (int i = 0; i < k; ++i) rm += x.R[i] * col[(size_t)i * kmax];
+            x.RM[j] = rm;
+            acc += rm * x.Q[j];
+        }
     }
-    double S = hybr(ft, C.nftau, C.beta, tau1 - tau2) - wave_sum(acc);
+    double S = S0 - wave_sum(acc);
     double sig = ((pc - pa) & 1) ? -1.0 : 1.0;
 
     double I = level_integral(x, f, lo, hi);
@@ -307,8 +382,9 @@ __device__ void step_add(Ctx &x)
     for (int base = 0; base < k; base += 64) {
         int e = base + x.lane;
         bool v = e < k;
-        dnp += count_pred(v && pair_ok(tau2, tap[e], x.wmin, x.wmax, C.taudiff_max));
-        dnp += count_pred(v && pair_ok(tcp[e], tau1, x.wmin, x.wmax, C.taudiff_max));
+        double tce = v ? tcp[e] : 0.0, tae = v ? tap[e] : 0.0;
+        dnp += count_pred(v && pair_ok(tau2, tae, x.wmin, x.wmax, C.taudiff_max));
+        dnp += count_pred(v && pair_ok(tce, tau1, x.wmin, x.wmax, C.taudiff_max));
     }
     dnp += pair_ok(tau2, tau1, x.wmin, x.wmax, C.taudiff_max) ? 1 : 0;
     int np_new = x.npairs + dnp;
@@ -317,31 +393,38 @@ __device__ void step_add(Ctx &x)
     if (!(rnd < prob)) return;
 
     // accepted: M' = [[M + MQ RM^T / S, -MQ/S], [-RM^T/S, 1/S]] with the new row/column appended at slot k
-    for (int base = 0; base < k; base += 64) {
-        int e = base + x.lane;
-        if (e < k) {
-            double rm = 0.0, mq = 0.0;
-            for (int i = 0; i < k; ++i) rm += x.R[i] * Mf[i * kmax + e];
-            for (int j = 0; j < k; ++j) mq += Mf[e * kmax + j] * x.Q[j];
-            x.RM[e] = rm; x.MQ[e] = mq;
+    for (int i0 = 0; i0 < k; i0 += 64) {
+        int i = i0 + x.lane;
+        if (i < k) {
+            const double *row = Mf + (size_t)i * kmax;
+            double mq = 0.0;
+#pragma unroll 4
+            for (int j = 0; j < k; ++j) mq += row[j] * x.Q[j];
+            x.MQ[i] = mq;
         }
     }
     wave_sync();
     double invS = 1.0 / S;
-    for (int e = x.lane; e < k * k; e += 64) {
-        int i = e / k, j = e - i * k;
-        Mf[i * kmax + j] += S * (-x.MQ[i] * invS) * (-x.RM[j] * invS);
+    for (int j0 = 0; j0 <= k; j0 += 64) {
+        int j = j0 + x.lane;
+        if (j < k) {
+            double nr = -x.RM[j] * invS;                     // new row element
+            double *col = Mf + j;
+#pragma unroll 4
+            for (int i = 0; i < k; ++i) col[(size_t)i * kmax] += S * (-x.MQ[i] * invS) * nr;
+            col[(size_t)k * kmax] = nr;
+        } else if (j == k) {
+            double *col = Mf + k;
+            for (int i = 0; i < k; ++i) col[(size_t)i * kmax] = -x.MQ[i] * invS;
+            col[(size_t)k * kmax] = invS;
+            tcp[k] = tau2; tap[k] = tau1; x.K[f] = k + 1;
+        }
     }
-    for (int e = x.lane; e < k; e += 64) {
-        Mf[e * kmax + k] = -x.MQ[e] * invS;
-        Mf[k * kmax + e] = -x.RM[e] * invS;
-    }
-    if (x.lane == 0) { Mf[k * kmax + k] = invS; tcp[k] = tau2; tap[k] = tau1; x.K[f] = k + 1; }
     wave_sync();
     x.det_sign *= (S < 0.0 ? -1.0 : 1.0) * sig;
     x.det_log += log(fabs(S));
     x.npairs = np_new;
-    x.cnt[C_ACCADD] += 1;
+    x.count(C_ACCADD);
     accpair_add(x, f, hi - lo);
 }
 
@@ -351,13 +434,13 @@ __device__ void step_add(Ctx &x)
 __device__ void step_rem(Ctx &x)
 {
     const DevConst &C = x.C;
-    x.cnt[C_TRYREM] += 1;
+    x.count(C_TRYREM);
     // the window list is needed for the pick in any case
     int np = build_window(x);
     x.npairs = np;
-    if (np <= 0) { x.cnt[C_QNREM] += 1; return; }
+    if (np <= 0) { x.count(C_QNREM); return; }
     int pick = x.randint(1, np);
-    int nw = (int)x.wt[WCAP];
+    const int nw = x.nwin;
 
     // first operator of the pick-th pair in the reference's enumeration (time order of the earlier operator)
     int estar = -1, rnk = 0;
@@ -374,19 +457,20 @@ __device__ void step_rem(Ctx &x)
     }
     estar = uni(estar); rnk = uni(rnk);
     double t1 = x.wt[estar]; int m1 = x.wm[estar];
+    const int want = (m1 & 0xffff) ^ 0x300;
+    const double thi = t1 + C.taudiff_max;
     int qstar = -1;
     for (int base = 0; base < nw; base += 64) {
         int q = base + x.lane;
         bool hit = false;
         if (q < nw) {
-            double tq = x.wt[q]; int mq = x.wm[q];
-            bool partner = ((mq & 0xff) == (m1 & 0xff)) && (((mq >> 8) & 0xff) != ((m1 >> 8) & 0xff)) && (tq > t1) && !(tq > t1 + C.taudiff_max);
+            double tq = x.wt[q];
+            bool partner = ((x.wm[q] & 0xffff) == want) && (tq > t1) && !(tq > thi);
             if (partner) {
                 int r = 0;
                 for (int p = 0; p < nw; ++p) {
-                    double tp = x.wt[p]; int mp = x.wm[p];
-                    bool pp = ((mp & 0xff) == (m1 & 0xff)) && (((mp >> 8) & 0xff) != ((m1 >> 8) & 0xff)) && (tp > t1) && !(tp > t1 + C.taudiff_max);
-                    r += (pp && tp < tq) ? 1 : 0;
+                    double tp = x.wt[p];
+                    r += (((x.wm[p] & 0xffff) == want) && (tp > t1) && !(tp > thi) && tp < tq) ? 1 : 0;
                 }
                 hit = (r == rnk - 1);
             }
@@ -404,7 +488,7 @@ __device__ void step_rem(Ctx &x)
     double hybf = (double)np / ((x.wmax - x.wmin) *
                                 (fmin(tau_a + C.taudiff_max, x.wmax) - fmax(tau_a - C.taudiff_max, x.wmin)));
 
-    int k = x.K[f];
+    int k = x.order(f);
     const int kmax = C.kmax;
     double *tcp = x.tc(f), *tap = x.ta(f), *Mf = x.mat(f);
     int between = 0, pc = 0, pa = 0;
@@ -415,9 +499,9 @@ __device__ void step_rem(Ctx &x)
         between += count_pred(v && tce > t1 && tce < t2) + count_pred(v && tae > t1 && tae < t2);
         pc += count_pred(tce < tau_c); pa += count_pred(tae < tau_a);
     }
-    if (between != 0) { x.cnt[C_QNREM] += 1; return; }
+    if (between != 0) { x.count(C_QNREM); return; }
 
-    double S = Mf[ic * kmax + ia];
+    double S = uni(Mf[(size_t)ic * kmax + ia]);
     double sig = ((pc - pa) & 1) ? -1.0 : 1.0;
     bool creator_first = tau_c < tau_a;
     // the pair's own operators sit on the boundary of (t1,t2) and belong to flavour f, which level_integral skips
@@ -428,22 +512,38 @@ __device__ void step_rem(Ctx &x)
     if (!(rnd < prob)) return;
     if (fabs(S) < 1e-12) { x.err |= ERR_DETRAT; return; }   // CTQMC.F90:4062 stops here
 
-    for (int e = x.lane; e < k; e += 64) { x.RM[e] = Mf[ic * kmax + e]; x.MQ[e] = Mf[e * kmax + ia]; }
+    // NPairs after the removal: every pair that contains one of the two operators disappears
+    int dnp = 0;
+    for (int base = 0; base < k; base += 64) {
+        int e = base + x.lane;
+        bool v = e < k;
+        double tce = v ? tcp[e] : 0.0, tae = v ? tap[e] : 0.0;
+        dnp += count_pred(v && e != ia && pair_ok(tau_c, tae, x.wmin, x.wmax, C.taudiff_max));
+        dnp += count_pred(v && e != ic && pair_ok(tce, tau_a, x.wmin, x.wmax, C.taudiff_max));
+    }
+    dnp += 1;   // the removed pair itself (it was picked from the removable ones)
+
+    for (int e = x.lane; e < k; e += 64) { x.RM[e] = Mf[(size_t)ic * kmax + e]; x.MQ[e] = Mf[(size_t)e * kmax + ia]; }
     wave_sync();
     const int last = k - 1;
-    for (int e = x.lane; e < k * k; e += 64) {
-        int i = e / k, j = e - i * k;
-        if (i == ic || j == ia) continue;
-        double v = Mf[i * kmax + j] - x.MQ[i] * x.RM[j] / S;
-        int id = (i == last) ? ic : i, jd = (j == last) ? ia : j;
-        Mf[id * kmax + jd] = v;
+    for (int j0 = 0; j0 < k; j0 += 64) {
+        int j = j0 + x.lane;
+        if (j < k && j != ia) {
+            int jd = (j == last) ? ia : j;
+            for (int i = 0; i < k; ++i) {
+                if (i == ic) continue;
+                int id = (i == last) ? ic : i;
+                double v = Mf[(size_t)i * kmax + j] - x.MQ[i] * x.RM[j] / S;
+                Mf[(size_t)id * kmax + jd] = v;
+            }
+        }
     }
     if (x.lane == 0) { tcp[ic] = tcp[last]; tap[ia] = tap[last]; x.K[f] = last; }
     wave_sync();
     x.det_sign *= (S < 0.0 ? -1.0 : 1.0) * sig;
     x.det_log += log(fabs(S));
-    x.npairs = -1;
-    x.cnt[C_ACCREM] += 1;
+    x.npairs = np - dnp;
+    x.count(C_ACCREM);
     accpair_add(x, f, t2 - t1);
 }
 
@@ -469,16 +569,16 @@ __device__ void step_shift(Ctx &x)
 {
     const DevConst &C = x.C;
     int nops = 0;
-    for (int f = 0; f < C.nflav; ++f) nops += 2 * x.K[f];
+    for (int f = 0; f < C.nflav; ++f) nops += 2 * x.order(f);
     if (nops == 0) { step_change_outer(x); return; }
     double dt = x.draw() * C.beta;
     if (dt == 0.0 || dt == C.beta) return;
-    x.cnt[C_TRYSHIFT] += 1;
+    x.count(C_TRYSHIFT);
     const int kmax = C.kmax;
     int outer = x.outer;
     double detrat = 1.0;
     for (int f = 0; f < C.nflav; ++f) {
-        int k = x.K[f];
+        int k = x.order(f);
         if (k == 0) continue;
         double *tcp = x.tc(f), *tap = x.ta(f), *Mf = x.mat(f);
         int wcnt = 0, wacnt = 0;
@@ -489,10 +589,15 @@ __device__ void step_shift(Ctx &x)
         }
         if ((wcnt + wacnt) & 1) outer ^= 1 << flav_bit(f, C.nd);
         if (!((wcnt == 0 && wacnt == 0) || (wcnt == k && wacnt == k))) {
-            for (int e = x.lane; e < k * k; e += 64) {
-                int i = e / k, j = e - i * k;
-                double s = ((tcp[i] < dt) ? -1.0 : 1.0) * ((tap[j] < dt) ? -1.0 : 1.0);
-                if (s < 0.0) Mf[i * kmax + j] = -Mf[i * kmax + j];
+            for (int j0 = 0; j0 < k; j0 += 64) {
+                int j = j0 + x.lane;
+                if (j < k) {
+                    double sj = (tap[j] < dt) ? -1.0 : 1.0;
+                    for (int i = 0; i < k; ++i) {
+                        double s = ((tcp[i] < dt) ? -1.0 : 1.0) * sj;
+                        if (s < 0.0) Mf[(size_t)i * kmax + j] = -Mf[(size_t)i * kmax + j];
+                    }
+                }
             }
         }
         if ((k & 1) && ((wcnt + wacnt) & 1)) detrat = -detrat;
@@ -513,32 +618,29 @@ __device__ void step_shift(Ctx &x)
         x.window_bounds();
     }
     x.npairs = -1;
-    x.cnt[C_ACCSHIFT] += 1;
+    x.count(C_ACCSHIFT);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // global moves: CTQMC.F90:4433-4554, Trace.F90:1083-1198, 1306-1433, 2126-2188, 2279-2333
 // ---------------------------------------------------------------------------------------------------------------
 
-// log of the scalar local trace of the current configuration, up to the constant Egs*beta:
+// log of the scalar local trace of a configuration, up to the constant Egs*beta:
 //   -int_0^beta E(n(tau)) dtau  with  E(n) = sum_f eps_f n_f + sum_{f<g} U_fg n_f n_g
 // n_f(tau) = n_f(0) + #creators before tau - #annihilators before tau.  Pair sums over operators of different
-// flavours are distributed over the lanes.
-__device__ double full_logtrace(Ctx &x, const int *Kv, const double *TCb, const double *TAb, int outer)
+// flavours are distributed over the lanes.  Creators of flavour f at TCb + f*fstride, annihilators at TAb + f*fstride.
+__device__ double full_logtrace(Ctx &x, const int *Kv, const double *TCb, const double *TAb, int fstride, int outer)
 {
     const DevConst &C = x.C;
-    const int kmax = C.kmax;
     const double beta = C.beta;
     double part = 0.0, uni_part = 0.0;
-    // per-flavour occupied length L_f = n0 beta + sum_c (beta - tc) - sum_a (beta - ta)
     for (int f = 0; f < C.nflav; ++f) {
         int k = Kv[f];
         double n0 = (double)((outer >> flav_bit(f, C.nd)) & 1);
         uni_part += C.eps[f] * n0 * beta;
-        for (int e = x.lane; e < k; e += 64)
-            part += C.eps[f] * ((beta - TCb[(size_t)f * kmax + e]) - (beta - TAb[(size_t)f * kmax + e]));
+        const double *cf = TCb + (size_t)f * fstride, *af = TAb + (size_t)f * fstride;
+        for (int e = x.lane; e < k; e += 64) part += C.eps[f] * ((beta - cf[e]) - (beta - af[e]));
     }
-    // overlaps O_fg = int n_f n_g
     for (int f = 0; f < C.nflav; ++f) {
         for (int g = f + 1; g < C.nflav; ++g) {
             double u = C.udd[f * C.nflav + g];
@@ -546,12 +648,10 @@ __device__ double full_logtrace(Ctx &x, const int *Kv, const double *TCb, const 
             int kf = Kv[f], kg = Kv[g];
             double nf0 = (double)((outer >> flav_bit(f, C.nd)) & 1), ng0 = (double)((outer >> flav_bit(g, C.nd)) & 1);
             uni_part += u * nf0 * ng0 * beta;
-            const double *cf = TCb + (size_t)f * kmax, *af = TAb + (size_t)f * kmax;
-            const double *cg = TCb + (size_t)g * kmax, *ag = TAb + (size_t)g * kmax;
-            // n_f0 * sum_y s_y (beta - tau_y) and n_g0 * sum_x s_x (beta - tau_x)
+            const double *cf = TCb + (size_t)f * fstride, *af = TAb + (size_t)f * fstride;
+            const double *cg = TCb + (size_t)g * fstride, *ag = TAb + (size_t)g * fstride;
             for (int e = x.lane; e < kg; e += 64) part += u * nf0 * ((beta - cg[e]) - (beta - ag[e]));
             for (int e = x.lane; e < kf; e += 64) part += u * ng0 * ((beta - cf[e]) - (beta - af[e]));
-            // sum over operator pairs s_x s_y (beta - max(tau_x, tau_y)); x in {c_f, a_f}, y in {c_g, a_g}
             int nx = 2 * kf, ny = 2 * kg;
             for (int e = x.lane; e < nx * ny; e += 64) {
                 int ix = e / ny, iy = e - ix * ny;
@@ -567,7 +667,7 @@ __device__ double full_logtrace(Ctx &x, const int *Kv, const double *TCb, const 
 // Build F(tau_a_i - tau_c_j) of one flavour in `A` (row = annihilator slot, column = creator slot, stride kmax) and
 // invert it in place by Gauss-Jordan with partial pivoting; the result read as [creator][annihilator] is M.
 // Returns log|det F| and its sign in slot order.  What the reference obtains from dgetrf/dgetri
-// (Trace.F90:2279-2333, MatrixUpdate.F90:41-99).
+// (Trace.F90:2279-2333, MatrixUpdate.F90:41-99).  lane = column.
 __device__ void build_and_invert(Ctx &x, int f, int k, const double *tcp, const double *tap, double *A,
                                  double &logdet, double &sgn)
 {
@@ -576,16 +676,15 @@ __device__ void build_and_invert(Ctx &x, int f, int k, const double *tcp, const 
     const double *ft = C.ftab + (size_t)f * C.nftau;
     logdet = 0.0; sgn = 1.0;
     if (k == 0) return;
-    for (int e = x.lane; e < k * k; e += 64) {
-        int a = e / k, c = e - a * k;
-        A[a * kmax + c] = hybr(ft, C.nftau, C.beta, tap[a] - tcp[c]);
+    for (int c0 = 0; c0 < k; c0 += 64) {
+        int c = c0 + x.lane;
+        if (c < k) { double tcc = tcp[c]; for (int a = 0; a < k; ++a) A[(size_t)a * kmax + c] = hybr(ft, C.nftau, C.beta, tap[a] - tcc); }
     }
     wave_sync();
-    int *piv = x.wm;                 // k <= kmax <= WCAP entries of LDS
+    int *piv = x.wm;                 // k <= kmax <= wcap entries of LDS
     for (int p = 0; p < k; ++p) {
-        // pivot search in column p, rows p..k-1
         double best = -1.0; int bi = p;
-        for (int r = p + x.lane; r < k; r += 64) { double v = fabs(A[r * kmax + p]); if (v > best) { best = v; bi = r; } }
+        for (int r = p + x.lane; r < k; r += 64) { double v = fabs(A[(size_t)r * kmax + p]); if (v > best) { best = v; bi = r; } }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             double ob = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
@@ -595,29 +694,33 @@ __device__ void build_and_invert(Ctx &x, int f, int k, const double *tcp, const 
         if (!(best > 0.0)) { x.err |= ERR_SINGULAR; return; }
         if (x.lane == 0) piv[p] = bi;
         if (bi != p) {
-            for (int j = x.lane; j < k; j += 64) { double t = A[p * kmax + j]; A[p * kmax + j] = A[bi * kmax + j]; A[bi * kmax + j] = t; }
+            for (int j = x.lane; j < k; j += 64) { double t = A[(size_t)p * kmax + j]; A[(size_t)p * kmax + j] = A[(size_t)bi * kmax + j]; A[(size_t)bi * kmax + j] = t; }
             sgn = -sgn;
             wave_sync();
         }
-        double d = A[p * kmax + p];
+        double d = uni(A[(size_t)p * kmax + p]);
         logdet += log(fabs(d)); if (d < 0.0) sgn = -sgn;
         double id = 1.0 / d;
-        // scaled pivot row (with the inverse's entry in column p) -> LDS; pivot column -> LDS
-        for (int j = x.lane; j < k; j += 64) { x.RM[j] = (j == p) ? id : A[p * kmax + j] * id; x.MQ[j] = A[j * kmax + p]; }
+        for (int j = x.lane; j < k; j += 64) x.MQ[j] = A[(size_t)j * kmax + p];       // pivot column
         wave_sync();
-        for (int e = x.lane; e < k * k; e += 64) {
-            int r = e / k, j = e - r * k;
-            double v;
-            if (r == p) v = x.RM[j];
-            else v = ((j == p) ? 0.0 : A[r * kmax + j]) - x.MQ[r] * x.RM[j];
-            A[r * kmax + j] = v;
+        for (int j0 = 0; j0 < k; j0 += 64) {
+            int j = j0 + x.lane;
+            if (j < k) {
+                double rp = (j == p) ? id : A[(size_t)p * kmax + j] * id;             // scaled pivot row, lane-private
+                for (int r = 0; r < k; ++r) {
+                    double v;
+                    if (r == p) v = rp;
+                    else v = ((j == p) ? 0.0 : A[(size_t)r * kmax + j]) - x.MQ[r] * rp;
+                    A[(size_t)r * kmax + j] = v;
+                }
+            }
         }
         wave_sync();
     }
     for (int p = k - 1; p >= 0; --p) {    // undo the row interchanges as column interchanges
         int bi = piv[p];
         if (bi != p) {
-            for (int r = x.lane; r < k; r += 64) { double t = A[r * kmax + p]; A[r * kmax + p] = A[r * kmax + bi]; A[r * kmax + bi] = t; }
+            for (int r = x.lane; r < k; r += 64) { double t = A[(size_t)r * kmax + p]; A[(size_t)r * kmax + p] = A[(size_t)r * kmax + bi]; A[(size_t)r * kmax + bi] = t; }
             wave_sync();
         }
     }
@@ -627,7 +730,7 @@ __device__ void build_and_invert(Ctx &x, int f, int k, const double *tcp, const 
 __device__ double sort_parity(Ctx &x, const double *t, int k)
 {
     int inv = 0;
-    for (int e = x.lane; e < k * k; e += 64) { int i = e / k, j = e - i * k; inv += (i < j && t[i] > t[j]) ? 1 : 0; }
+    for (int j = x.lane; j < k; j += 64) { double tj = t[j]; for (int i = 0; i < j; ++i) inv += (t[i] > tj) ? 1 : 0; }
     return (wave_sum(inv) & 1) ? -1.0 : 1.0;
 }
 
@@ -635,9 +738,9 @@ __device__ void step_glob(Ctx &x)
 {
     const DevConst &C = x.C;
     const int nf = C.nflav, nd = C.nd, kmax = C.kmax;
-    x.cnt[C_TRYGLOB] += 1;
+    x.count(C_TRYGLOB);
     int nops = 0;
-    for (int f = 0; f < nf; ++f) nops += 2 * x.K[f];
+    for (int f = 0; f < nf; ++f) nops += 2 * x.order(f);
     if (nops == 0) return;
     int gu[MAXFLAV + 1];
     double r = x.draw();
@@ -651,13 +754,13 @@ __device__ void step_glob(Ctx &x)
     }
     // relabelled copy of the tau arrays in scratch: TS[g][0] = creators, TS[g][1] = annihilators of new flavour g
     double *TS = C.TS + (size_t)x.w * nf * 2 * kmax;
-    int Kn[MAXFLAV];
+    int Kn[MAXFLAV], Ko[MAXFLAV];
     for (int f = 0; f < nf; ++f) {
         int num = (f >> 1) + nd * (f & 1) + 1;
         int t = gu[num];
         int g = 2 * ((t - 1) % nd) + (t - 1) / nd;
-        int k = x.K[f];
-        Kn[g] = k;
+        int k = x.order(f);
+        Kn[g] = k; Ko[f] = k;
         const double *srcc = gu[0] ? x.ta(f) : x.tc(f), *srca = gu[0] ? x.tc(f) : x.ta(f);
         for (int e = x.lane; e < k; e += 64) { TS[(size_t)(2 * g) * kmax + e] = srcc[e]; TS[(size_t)(2 * g + 1) * kmax + e] = srca[e]; }
     }
@@ -685,7 +788,7 @@ __device__ void step_glob(Ctx &x)
         outer_new = fixed;
         for (int b = 0, used = 0; b < 2 * nd; ++b) if ((freemask >> b) & 1) { if ((kk >> used) & 1) outer_new |= 1 << b; ++used; }
     }
-    if (sst_factor == 0.0) { x.cnt[C_QNGLOB] += 1; return; }
+    if (sst_factor == 0.0) { x.count(C_QNGLOB); return; }
 
     // new inverse matrices into the second buffer, determinant in the reference's time order
     double *MBw = C.MB + (size_t)x.w * nf * kmax * kmax;
@@ -697,44 +800,8 @@ __device__ void step_glob(Ctx &x)
         if (Kn[g] > 0) sg *= sort_parity(x, tcg, Kn[g]) * sort_parity(x, tag, Kn[g]);
         logdet_new += ld; sign_new *= sg;
     }
-    int Ko[MAXFLAV];
-    for (int f = 0; f < nf; ++f) Ko[f] = x.K[f];
-    double ltr_old = full_logtrace(x, Ko, x.TC, x.TA, x.outer);
-    // TS is laid out [g][2][kmax]; full_logtrace wants separate creator/annihilator bases with flavour stride kmax:
-    // pass TS with stride trick: creators at TS + 2g*kmax -> use a strided view through temporary pointers
-    double ltr_new;
-    {
-        // copy the relabelled taus into TC/TA only on acceptance; evaluate the new trace from TS via a local view
-        // (flavour stride 2*kmax): done by a second variant of the integrals below
-        const double beta = C.beta;
-        double part = 0.0, up = 0.0;
-        for (int f = 0; f < nf; ++f) {
-            int k = Kn[f];
-            double n0 = (double)((outer_new >> flav_bit(f, nd)) & 1);
-            up += C.eps[f] * n0 * beta;
-            const double *cf = TS + (size_t)(2 * f) * kmax, *af = TS + (size_t)(2 * f + 1) * kmax;
-            for (int e = x.lane; e < k; e += 64) part += C.eps[f] * ((beta - cf[e]) - (beta - af[e]));
-        }
-        for (int f = 0; f < nf; ++f) for (int g = f + 1; g < nf; ++g) {
-            double u = C.udd[f * nf + g];
-            if (u == 0.0) continue;
-            int kf = Kn[f], kg = Kn[g];
-            double nf0 = (double)((outer_new >> flav_bit(f, nd)) & 1), ng0 = (double)((outer_new >> flav_bit(g, nd)) & 1);
-            up += u * nf0 * ng0 * beta;
-            const double *cf = TS + (size_t)(2 * f) * kmax, *af = TS + (size_t)(2 * f + 1) * kmax;
-            const double *cg = TS + (size_t)(2 * g) * kmax, *ag = TS + (size_t)(2 * g + 1) * kmax;
-            for (int e = x.lane; e < kg; e += 64) part += u * nf0 * ((beta - cg[e]) - (beta - ag[e]));
-            for (int e = x.lane; e < kf; e += 64) part += u * ng0 * ((beta - cf[e]) - (beta - af[e]));
-            int nx = 2 * kf, ny = 2 * kg;
-            for (int e = x.lane; e < nx * ny; e += 64) {
-                int ix = e / ny, iy = e - ix * ny;
-                double tx = ix < kf ? cf[ix] : af[ix - kf]; double sx = ix < kf ? 1.0 : -1.0;
-                double ty = iy < kg ? cg[iy] : ag[iy - kg]; double sy = iy < kg ? 1.0 : -1.0;
-                part += u * sx * sy * (beta - fmax(tx, ty));
-            }
-        }
-        ltr_new = -(up + wave_sum(part));
-    }
+    double ltr_old = full_logtrace(x, Ko, x.tc_, x.ta_, kmax, x.outer);
+    double ltr_new = full_logtrace(x, Kn, TS, TS + kmax, 2 * kmax, outer_new);
     double rnd = x.draw();
     if (x.err & ERR_SINGULAR) return;
     double ratio = fabs(exp((ltr_new - ltr_old) + (logdet_new - x.det_log)) * sst_factor);
@@ -745,18 +812,18 @@ __device__ void step_glob(Ctx &x)
         double *tcp = x.tc(g), *tap = x.ta(g), *Mg = x.mat(g);
         const double *Mn = MBw + (size_t)g * kmax * kmax;
         for (int e = x.lane; e < k; e += 64) { tcp[e] = TS[(size_t)(2 * g) * kmax + e]; tap[e] = TS[(size_t)(2 * g + 1) * kmax + e]; }
-        for (int e = x.lane; e < k * k; e += 64) { int i = e / k, j = e - i * k; Mg[i * kmax + j] = Mn[i * kmax + j]; }
+        for (int j0 = 0; j0 < k; j0 += 64) { int j = j0 + x.lane; if (j < k) for (int i = 0; i < k; ++i) Mg[(size_t)i * kmax + j] = Mn[(size_t)i * kmax + j]; }
         if (x.lane == 0) x.K[g] = k;
     }
     wave_sync();
     x.outer = outer_new;
     x.det_log = logdet_new; x.det_sign = sign_new;
     x.npairs = -1;
-    x.cnt[C_ACCGLOB] += 1;
+    x.count(C_ACCGLOB);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// sweep kernel: nsteps iterations of the Z-space loop (CTQMC.F90:8213-8257 / 8428-8533) for every chain
+// chain state: HBM <-> LDS/registers
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void ctx_setup(Ctx &x, unsigned char *smem)
 {
@@ -765,36 +832,63 @@ __device__ __forceinline__ void ctx_setup(Ctx &x, unsigned char *smem)
     x.lane = threadIdx.x & 63;
     x.w = uni((int)(blockIdx.x * (blockDim.x >> 6) + wib));
     unsigned char *base = smem + (size_t)wib * C.lds_per_wave;
-    x.Q = (double *)base; x.R = x.Q + C.kmax; x.MQ = x.R + C.kmax; x.RM = x.MQ + C.kmax;
-    x.wt = x.RM + C.kmax;                 // WCAP + 1 doubles
-    x.wm = (int *)(x.wt + WCAP + 2); x.wc = x.wm + WCAP;
+    x.tc_ = (double *)base; x.ta_ = x.tc_ + C.nflav * C.kmax;
+    x.Q = x.ta_ + C.nflav * C.kmax; x.R = x.Q + C.kmax; x.MQ = x.R + C.kmax; x.RM = x.MQ + C.kmax;
+    x.wt = x.RM + C.kmax;
+    x.cnt = (unsigned long long *)(x.wt + C.wcap);
+    x.wm = (int *)(x.cnt + C_NCOUNT); x.wc = x.wm + C.wcap; x.K = x.wc + C.wcap;
 }
 
 __device__ __forceinline__ void ctx_load(Ctx &x)
 {
     const DevConst &C = x.C;
-    int w = x.w;
-    x.K = C.K + (size_t)w * C.nflav;
-    x.TC = C.TC + (size_t)w * C.nflav * C.kmax;
-    x.TA = C.TA + (size_t)w * C.nflav * C.kmax;
-    x.M = C.M + (size_t)w * C.nflav * C.kmax * C.kmax;
+    const int w = x.w, nf = C.nflav, kmax = C.kmax;
+    x.M = C.M + (size_t)w * nf * kmax * kmax;
     const WalkerScalars &s = C.ws[w];
-    x.ndraw = s.ndraw; x.outer = s.outer; x.npairs = s.npairs; x.wpos = s.wpos; x.err = s.err;
-    x.det_sign = s.det_sign; x.det_log = s.det_log;
-    for (int i = 0; i < C_NCOUNT; ++i) x.cnt[i] = s.cnt[i];
+    x.outer = uni(s.outer); x.npairs = uni(s.npairs); x.wpos = uni(s.wpos); x.err = uni(s.err);
+    x.det_sign = uni(s.det_sign); x.det_log = uni(s.det_log);
+    unsigned long long nd_ = s.ndraw;
+    nd_ = ((unsigned long long)(unsigned)uni((int)(nd_ >> 32)) << 32) | (unsigned long long)(unsigned)uni((int)nd_);
+    if (x.lane < C_NCOUNT) x.cnt[x.lane] = s.cnt[x.lane];
+    if (x.lane < nf) x.K[x.lane] = C.K[(size_t)w * nf + x.lane];
+    wave_sync();
+    for (int f = 0; f < nf; ++f) {
+        int k = x.order(f);
+        const double *gc = C.TC + ((size_t)w * nf + f) * kmax, *ga = C.TA + ((size_t)w * nf + f) * kmax;
+        for (int e = x.lane; e < k; e += 64) { x.tc(f)[e] = gc[e]; x.ta(f)[e] = ga[e]; }
+    }
+    x.nwin = 0;
     x.window_bounds();
+    x.rng_seek(nd_);
+    wave_sync();
 }
 
 __device__ __forceinline__ void ctx_store(Ctx &x)
 {
+    const DevConst &C = x.C;
+    const int w = x.w, nf = C.nflav, kmax = C.kmax;
+    wave_sync();
+    for (int f = 0; f < nf; ++f) {
+        int k = x.order(f);
+        double *gc = C.TC + ((size_t)w * nf + f) * kmax, *ga = C.TA + ((size_t)w * nf + f) * kmax;
+        for (int e = x.lane; e < k; e += 64) { gc[e] = x.tc(f)[e]; ga[e] = x.ta(f)[e]; }
+    }
+    WalkerScalars &s = C.ws[w];
+    if (x.lane < C_NCOUNT) s.cnt[x.lane] = x.cnt[x.lane];
+    if (x.lane < nf) C.K[(size_t)w * nf + x.lane] = x.K[x.lane];
     if (x.lane == 0) {
-        WalkerScalars &s = x.C.ws[x.w];
-        s.ndraw = x.ndraw; s.outer = x.outer; s.npairs = x.npairs; s.wpos = x.wpos; s.err = x.err;
+        s.ndraw = x.rng_tell(); s.outer = x.outer; s.npairs = x.npairs; s.wpos = x.wpos; s.err = x.err;
         s.det_sign = x.det_sign; s.det_log = x.det_log;
-        for (int i = 0; i < C_NCOUNT; ++i) s.cnt[i] = x.cnt[i];
     }
 }
 
+#ifdef W2DYN_STAMPS
+#define STAMP_KIND(c) which_ = (c)
+#else
+#define STAMP_KIND(c)
+#endif
+
+// sweep kernel: nsteps iterations of the Z-space loop (CTQMC.F90:8213-8257 / 8428-8533) for every chain
 __global__ __launch_bounds__(256) void k_sweep(DevConst C, long long nsteps, int count_sampling)
 {
     extern __shared__ unsigned char smem[];
@@ -803,21 +897,31 @@ __global__ __launch_bounds__(256) void k_sweep(DevConst C, long long nsteps, int
     if (x.w >= C.nwalkers) return;
     ctx_load(x);
     const double pg = C.p_glob, ps = C.p_shift;
+    // position inside the window-shift period: (TryAdd+TryRem) mod NSlide (CTQMC.F90:8255, 8531)
+    unsigned int phase = (unsigned int)((x.cnt[C_TRYADD] + x.cnt[C_TRYREM]) % (unsigned long long)C.nslide);
+    phase = (unsigned int)uni((int)phase);
     for (long long it = 0; it < nsteps; ++it) {
-        if (count_sampling) x.cnt[C_SAMPLING] += 1;
         double r = x.draw();
-        if (r < (1.0 - ps - pg) / 2.0) { (void)x.draw(); (void)x.draw(); step_add(x); }
-        else if (r <= 1.0 - ps - pg) { (void)x.draw(); (void)x.draw(); step_rem(x); }
-        else if (r <= 1.0 - ps) step_glob(x);
-        else step_shift(x);
-        unsigned long long tries = x.cnt[C_TRYADD] + x.cnt[C_TRYREM];
-        if (tries % (unsigned long long)C.nslide == 0ull) {       // shift_window, Trace.F90:1652-1678
+#ifdef W2DYN_STAMPS
+        unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+        int which_;
+#endif
+        if (r < (1.0 - ps - pg) / 2.0) { (void)x.draw(); (void)x.draw(); step_add(x); STAMP_KIND(C_CYC_ADD); phase += 1; }
+        else if (r <= 1.0 - ps - pg) { (void)x.draw(); (void)x.draw(); step_rem(x); STAMP_KIND(C_CYC_REM); phase += 1; }
+        else if (r <= 1.0 - ps) { step_glob(x); STAMP_KIND(C_CYC_GLOB); }
+        else { step_shift(x); STAMP_KIND(C_CYC_SHIFT); }
+#ifdef W2DYN_STAMPS
+        if (x.lane == 0) x.cnt[which_] += __builtin_amdgcn_s_memtime() - t0_;
+#endif
+        if (phase == (unsigned int)C.nslide) phase = 0;
+        if (phase == 0) {                                        // shift_window, Trace.F90:1652-1678
             if (C.num_windows > 1) {
                 x.wpos += 1; if (x.wpos == C.num_windows) x.wpos = 0;
                 x.window_bounds(); x.npairs = -1;
             } else x.wpos = 0;
         }
     }
+    if (count_sampling && x.lane == 0) x.cnt[C_SAMPLING] += (unsigned long long)nsteps;
     ctx_store(x);
 }
 
@@ -832,7 +936,7 @@ __global__ __launch_bounds__(256) void k_rebuild(DevConst C)
     double ld = 0.0, sg = 1.0;
     for (int f = 0; f < C.nflav; ++f) {
         double l, s;
-        int k = x.K[f];
+        int k = x.order(f);
         build_and_invert(x, f, k, x.tc(f), x.ta(f), x.mat(f), l, s);
         if (k > 0) s *= sort_parity(x, x.tc(f), k) * sort_parity(x, x.ta(f), k);
         ld += l; sg *= s;
@@ -860,32 +964,34 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
     ctx_setup(x, smem);
     if (x.w >= C.nwalkers) return;
     ctx_load(x);
-    const int nf = C.nflav, nd = C.nd, kmax = C.kmax;
-    // flat operator index space: op = (f, ca, slot); offsets in LDS ints
-    int off[MAXFLAV + 1]; off[0] = 0;
-    for (int f = 0; f < nf; ++f) off[f + 1] = off[f] + 2 * x.K[f];
-    int N = off[nf];
+    const int nf = C.nflav, nd = C.nd;
     int par = 0;
-    // pair loop: every lane takes operators i = lane, lane+64, ... and scans all j
-    for (int i = x.lane; i < N; i += 64) {
-        int fi = 0; while (i >= off[fi + 1]) ++fi;
-        int li = i - off[fi]; int ki = x.K[fi];
-        bool ci = li < ki;
-        double ti = ci ? x.TC[(size_t)fi * kmax + li] : x.TA[(size_t)fi * kmax + (li - ki)];
+    // every lane takes operators (f, type, slot) and scans the operators that can contribute a transposition
+    for (int fi = 0; fi < nf; ++fi) {
+        int ki = x.order(fi);
         int biti = flav_bit(fi, nd);
-        for (int fj = 0; fj < nf; ++fj) {
-            int kj = x.K[fj];
-            int bitj = flav_bit(fj, nd);
-            bool wtr = bitj < biti, wbl = fj < fi, wsame = (fj == fi) && ci;
-            if (!(wtr || wbl || wsame)) continue;
-            for (int lj = 0; lj < 2 * kj; ++lj) {
-                double tj = lj < kj ? x.TC[(size_t)fj * kmax + lj] : x.TA[(size_t)fj * kmax + (lj - kj)];
-                if (wtr && tj < ti) par ^= 1;
-                if (wbl && tj > ti) par ^= 1;
-                if (wsame && tj > ti) par ^= 1;
+        for (int li = x.lane; li < 2 * ki; li += 64) {
+            bool ci = li < ki;
+            double ti = ci ? x.tc(fi)[li] : x.ta(fi)[li - ki];
+            for (int fj = 0; fj < nf; ++fj) {
+                int kj = x.order(fj);
+                int bitj = flav_bit(fj, nd);
+                bool wtr = bitj < biti, wbl = fj < fi, wsame = (fj == fi) && ci;
+                if (!(wtr || wbl || wsame)) continue;
+                const double *cj = x.tc(fj), *aj = x.ta(fj);
+                int below = 0, above = 0;
+                for (int lj = 0; lj < kj; ++lj) {
+                    double t1 = cj[lj], t2 = aj[lj];
+                    below += (t1 < ti) + (t2 < ti); above += (t1 > ti) + (t2 > ti);
+                }
+                if (wtr) par ^= below & 1;
+                if (wbl) par ^= above & 1;
+                if (wsame) par ^= above & 1;
             }
         }
     }
+    int N = 0;
+    for (int f = 0; f < nf; ++f) N += 2 * x.order(f);
     par = wave_sum(par) & 1;
     if ((N / 2) & 1) par ^= 1;
     double sign = x.det_sign * (par ? -1.0 : 1.0);
@@ -893,10 +999,10 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
     // state alive at beta/2 (Trace.F90:6334: operators with tau <= beta/2 have acted)
     int sb2 = x.outer;
     for (int f = 0; f < nf; ++f) {
-        int k = x.K[f], c = 0;
+        int k = x.order(f), c = 0;
         for (int base = 0; base < k; base += 64) {
             int e = base + x.lane; bool v = e < k;
-            c += count_pred(v && x.TC[(size_t)f * kmax + e] <= 0.5 * C.beta) + count_pred(v && x.TA[(size_t)f * kmax + e] <= 0.5 * C.beta);
+            c += count_pred(v && x.tc(f)[e] <= 0.5 * C.beta) + count_pred(v && x.ta(f)[e] <= 0.5 * C.beta);
         }
         if (c & 1) sb2 ^= 1 << flav_bit(f, nd);
     }

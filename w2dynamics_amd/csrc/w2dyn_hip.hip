@@ -142,7 +142,6 @@ void host_init_window(w2dyn_solver *s, double tdm, int &num_windows, double &tau
     } else { taudiff_max = s->beta; num_windows = 1; }
 }
 
-size_t lds_per_wave(int kmax) { return (size_t)(4 * kmax + WCAP + 2) * sizeof(double) + (size_t)2 * WCAP * sizeof(int); }
 
 struct Launch { dim3 grid, block; size_t lds; };
 Launch walker_launch(const w2dyn_solver *s)
@@ -173,7 +172,7 @@ int check_walker_errors(w2dyn_solver *s)
     int e = 0;
     for (auto &w : ws) e |= w.err;
     if (e & ERR_KMAX) return fail(s, W2DYN_EOVERFLOW, "a chain reached the expansion-order capacity kmax=%d; raise it with w2dyn_set_layout", s->C.kmax);
-    if (e & ERR_WCAP) return fail(s, W2DYN_EOVERFLOW, "more than %d operators inside the sliding window; reduce TaudiffMax", WCAP);
+    if (e & ERR_WCAP) return fail(s, W2DYN_EOVERFLOW, "more than %d operators inside the sliding window; reduce TaudiffMax or raise kmax", s->C.wcap);
     if (e & ERR_DETRAT) return fail(s, W2DYN_ENUMERIC, "DetRat too small in removal");
     if (e & ERR_SINGULAR) return fail(s, W2DYN_ENUMERIC, "singular hybridisation matrix in full rebuild");
     return 0;
@@ -221,7 +220,7 @@ int w2dyn_set_layout(w2dyn_solver *s, int nwalkers, int64_t first_walker, int km
 {
     if (!s) return W2DYN_EINVAL;
     if (s->have_solver) return fail(s, W2DYN_EINVAL, "set_layout must precede init_solver");
-    if (nwalkers <= 0 || first_walker < 0 || kmax < 0 || kmax > WCAP || walkers_per_bin <= 0)
+    if (nwalkers <= 0 || first_walker < 0 || kmax < 0 || kmax > KMAX_LIMIT || walkers_per_bin <= 0)
         return fail(s, W2DYN_EINVAL, "bad layout (nwalkers=%d kmax=%d walkers_per_bin=%d)", nwalkers, kmax, walkers_per_bin);
     s->nwalkers = nwalkers; s->first_walker = first_walker; s->kmax_req = kmax; s->walkers_per_bin = walkers_per_bin;
     return 0;
@@ -353,10 +352,12 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     C = DevConst{};
     C.nd = nd; C.nflav = nf; C.nstates = s->nstates; C.nftau = nftau; C.ntau = s->ntau; C.nleg = s->nleg; C.niw2 = 2 * s->niw;
     int kmax = s->kmax_req;
-    if (kmax == 0) { kmax = (int)(1.2 * s->beta) + 24; kmax = (kmax + 7) & ~7; if (kmax > WCAP) kmax = WCAP; }
+    if (kmax == 0) { kmax = (int)(0.4 * s->beta) + 24; kmax = (kmax + 7) & ~7; if (kmax > KMAX_LIMIT) kmax = KMAX_LIMIT; }   // overflow is detected and reported
     C.kmax = kmax; C.nwalkers = s->nwalkers; C.has_szt = s->has_szt; C.maxhisto = s->maxhisto;
     C.walkers_per_bin = s->walkers_per_bin; C.nbins = (s->nwalkers + s->walkers_per_bin - 1) / s->walkers_per_bin;
-    C.lds_per_wave = (int)lds_per_wave(kmax);
+    C.wcap = std::max(kmax, std::min(2 * nf * kmax, 256));
+    C.lds_per_wave = (int)lds_bytes_per_wave(nf, kmax, C.wcap);
+    if (4 * (size_t)C.lds_per_wave > 160 * 1024) return fail(s, W2DYN_EUNSUPPORTED, "kmax=%d needs %d bytes of LDS per chain: too large", kmax, C.lds_per_wave);
     C.beta = s->beta; C.p_glob = s->p_glob; C.p_shift = s->p_shift; C.egs = s->egs;
     C.seed = (unsigned long long)s->seed; C.first_walker = (unsigned long long)s->first_walker;
     host_init_window(s, s->taudiffmax_param, C.num_windows, C.taudiff_max);           // Trace.F90:605

@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libw2dyn_hip.so")
+LIB_PATH = os.environ.get("W2DYN_HIP_LIB", os.path.join(_HERE, "libw2dyn_hip.so"))   # override: diagnostic builds
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
