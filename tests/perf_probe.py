@@ -25,6 +25,9 @@ def probe(cfg, nftau, over, nw, kmax=0, rounds=5, thermal=20000):
         print("   cycles/move: add %.0f (n=%d) rem %.0f (n=%d) glob %.0f (n=%d) shift %.0f (n=%d); share add %.2f rem %.2f glob %.2f shift %.2f" % (
             c[12] / max(c[0], 1), c[0], c[13] / max(c[3], 1), c[3], c[14] / max(c[6], 1), c[6], c[15] / max(c[9], 1), c[9],
             c[12] / tot, c[13] / tot, c[14] / tot, c[15] / tot), flush=True)
+        if len(c) >= 24:
+            print("   rem stages (cycles per rem try): window %.0f pick %.0f between %.0f trace+prob %.0f | add: draws+qn %.0f (per try), detratio %.0f trace/np/prob %.0f (per valid=%d), accept-update %.0f (per acc=%d)" % (
+                c[16] / c[3], c[17] / c[3], c[18] / c[3], c[19] / c[3], c[20] / c[0], c[21] / max(c[0] - c[2], 1), c[22] / max(c[0] - c[2], 1), c[0] - c[2], c[23] / max(c[1], 1), c[1]), flush=True)
     q.dest_ctqmc(); q.close()
 
 if __name__ == "__main__":

@@ -24,6 +24,13 @@
 // evaluating block 64*chunk+i, and handed out with v_readlane - the stream itself is unchanged.
 #pragma once
 #include <hip/hip_runtime.h>
+#ifdef W2DYN_STAMPS
+#define DBG_STAMP(x, c) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((x).lane == 0) (x).cnt[c] += t_ - (x).tstamp; (x).tstamp = t_; } while (0)
+#define DBG_START(x) (x).tstamp = __builtin_amdgcn_s_memtime()
+#else
+#define DBG_STAMP(x, c)
+#define DBG_START(x)
+#endif
 #include <stdint.h>
 #include "../../include/w2dyn_rng.h"
 
@@ -35,6 +42,7 @@ constexpr int KMAX_LIMIT = 256;
 enum Counter { C_TRYADD, C_ACCADD, C_QNADD, C_TRYREM, C_ACCREM, C_QNREM, C_TRYGLOB, C_ACCGLOB, C_QNGLOB,
                C_TRYSHIFT, C_ACCSHIFT, C_SAMPLING,
                C_CYC_ADD, C_CYC_REM, C_CYC_GLOB, C_CYC_SHIFT,   // shader cycles per move type (diagnostic build -DW2DYN_STAMPS only)
+               C_DBG0, C_DBG1, C_DBG2, C_DBG3, C_DBG4, C_DBG5, C_DBG6, C_DBG7,   // stage stamps (diagnostic build)
                C_NCOUNT };
 
 enum WalkerErr { ERR_NONE = 0, ERR_KMAX = 1, ERR_WCAP = 2, ERR_DETRAT = 4, ERR_SINGULAR = 8 };
@@ -52,7 +60,7 @@ struct WalkerScalars {
 
 struct DevConst {
     int nd, nflav, nstates, nftau, ntau, nleg, niw2, kmax, nwalkers, num_windows, nslide, has_szt, maxhisto;
-    int walkers_per_bin, nbins, lds_per_wave, wcap;   // lds_per_wave in bytes; wcap: window-list capacity
+    int walkers_per_bin, nbins, lds_per_wave, wcap, kgj;   // lds_per_wave in bytes; wcap: window-list capacity; kgj: LDS inversion order limit
     double beta, taudiff_max, p_glob, p_shift, egs;
     unsigned long long seed, first_walker;
     const double *ftab;      // [nflav][nftau]
@@ -79,9 +87,9 @@ struct DevConst {
 };
 
 // bytes of LDS one wave needs (host and device agree through this one function)
-__host__ __device__ inline size_t lds_bytes_per_wave(int nflav, int kmax, int wcap)
+__host__ __device__ inline size_t lds_bytes_per_wave(int nflav, int kmax, int wcap, int kgj)
 {
-    size_t d = (size_t)2 * nflav * kmax + 4 * (size_t)kmax + wcap;          // tc, ta, Q, R, MQ, RM, wt
+    size_t d = (size_t)2 * nflav * kmax + 4 * (size_t)kmax + wcap + (size_t)kgj * kgj;   // tc, ta, Q, R, MQ, RM, wt, gj
     size_t i = (size_t)2 * wcap + MAXFLAV;                                     // wm, wc, K
     size_t b = d * sizeof(double) + C_NCOUNT * sizeof(unsigned long long) + i * sizeof(int);
     return (b + 15) & ~(size_t)15;
@@ -143,6 +151,14 @@ __device__ __forceinline__ double wave_min(double v)
     v = fmin(v, dpp_d<0x140>(v));
     return fmin(fmin(readlane_d(v, 0), readlane_d(v, 16)), fmin(readlane_d(v, 32), readlane_d(v, 48)));
 }
+__device__ __forceinline__ double wave_max(double v)
+{
+    v = fmax(v, dpp_d<0xB1>(v));
+    v = fmax(v, dpp_d<0x4E>(v));
+    v = fmax(v, dpp_d<0x141>(v));
+    v = fmax(v, dpp_d<0x140>(v));
+    return fmax(fmax(readlane_d(v, 0), readlane_d(v, 16)), fmax(readlane_d(v, 32), readlane_d(v, 48)));
+}
 __device__ __forceinline__ int count_pred(bool p) { return __popcll(__ballot(p)); }
 
 // Trace.F90:1014-1033 get_HybrF
@@ -166,7 +182,7 @@ struct Ctx {
     int w, lane;
     double *M;                       // global: this walker's matrices
     // LDS slice of this wave
-    double *tc_, *ta_, *Q, *R, *MQ, *RM, *wt;
+    double *tc_, *ta_, *Q, *R, *MQ, *RM, *wt, *gj;
     int *wm, *wc, *K;
     unsigned long long *cnt;
     // wave-uniform scalars
@@ -176,6 +192,9 @@ struct Ctx {
     int outer, npairs, wpos, err, nwin;
     double det_sign, det_log;
     double wmin, wmax;
+    unsigned long long tstamp;
+    int kreg;                        // lane g: expansion order of flavour g
+    double wr_t; int wr_m, wr_c;     // lane e: window-list entry e (tau, f|ca<<8|slot<<16, partner count) when nwin <= 64
 
     __device__ Ctx(const DevConst &c) : C(c) {}
 
@@ -219,7 +238,8 @@ struct Ctx {
     __device__ __forceinline__ double *tc(int f) const { return tc_ + f * C.kmax; }
     __device__ __forceinline__ double *ta(int f) const { return ta_ + f * C.kmax; }
     __device__ __forceinline__ double *mat(int f) const { return M + (size_t)f * C.kmax * C.kmax; }
-    __device__ __forceinline__ int order(int f) const { return uni(K[f]); }
+    __device__ __forceinline__ int order(int f) const { return __builtin_amdgcn_readlane(kreg, f); }
+    __device__ __forceinline__ void set_order(int f, int k) { if (lane == f) kreg = k; }
     __device__ __forceinline__ void count(int c) { if (lane == 0) cnt[c] += 1ull; }
 };
 
@@ -230,8 +250,9 @@ __device__ __forceinline__ bool pair_ok(double x, double y, double wmin, double 
     return (a >= wmin) && (b <= wmax) && !(b > a + tdm);
 }
 
-// Collect the operators inside the window into LDS (wt: tau, wm: f | ca<<8 | slot<<16) and count, for each of them,
-// its partners at later times (wc).  Returns the total = NPairs (Trace.F90:1770-1815); x.nwin = list length.
+// Collect the operators inside the window (wt: tau, wm: f | ca<<8 | slot<<16) and count, for each of them, its partners
+// at later times (wc).  Returns the total = NPairs (Trace.F90:1770-1815); x.nwin = list length.  Up to 64 entries
+// the list lives in registers (lane e = entry e) and is scanned with v_readlane; longer lists stay in LDS.
 __device__ int build_window(Ctx &x)
 {
     const DevConst &C = x.C;
@@ -257,23 +278,37 @@ __device__ int build_window(Ctx &x)
     x.nwin = nw;
     wave_sync();
     int total = 0;
-    for (int base = 0; base < nw; base += 64) {
-        int e = base + x.lane;
+    if (nw <= 64) {
+        bool live = x.lane < nw;
+        double te = live ? x.wt[x.lane] : -1.0; int me = live ? x.wm[x.lane] : -1;
+        double thi = te + C.taudiff_max;
+        int want = (me & 0xffff) ^ 0x300;                // same flavour, other type (ca 1 <-> 2)
         int c = 0;
-        if (e < nw) {
-            double te = x.wt[e]; int me = x.wm[e] & 0xffff;
-            double thi = te + C.taudiff_max;
-            int want = me ^ 0x300;                       // same flavour, other type (ca 1 <-> 2)
-            for (int q = 0; q < nw; ++q) {
-                double tq = x.wt[q]; int mq = x.wm[q] & 0xffff;
-                c += (mq == want && tq > te && !(tq > thi)) ? 1 : 0;
-            }
-            x.wc[e] = c;
+        for (int q = 0; q < nw; ++q) {
+            double tq = readlane_d(te, q); int mq = __builtin_amdgcn_readlane(me, q) & 0xffff;
+            c += (live && mq == want && tq > te && !(tq > thi)) ? 1 : 0;
         }
-        total += c;
+        x.wr_t = te; x.wr_m = me; x.wr_c = c;
+        total = wave_sum(c);
+    } else {
+        for (int base = 0; base < nw; base += 64) {
+            int e = base + x.lane;
+            int c = 0;
+            if (e < nw) {
+                double te = x.wt[e]; int me = x.wm[e] & 0xffff;
+                double thi = te + C.taudiff_max;
+                int want = me ^ 0x300;
+                for (int q = 0; q < nw; ++q) {
+                    double tq = x.wt[q]; int mq = x.wm[q] & 0xffff;
+                    c += (mq == want && tq > te && !(tq > thi)) ? 1 : 0;
+                }
+                x.wc[e] = c;
+            }
+            total += c;
+        }
+        total = wave_sum(total);
+        wave_sync();
     }
-    total = wave_sum(total);
-    wave_sync();
     return total;
 }
 
@@ -315,6 +350,7 @@ __device__ void step_add(Ctx &x)
 {
     const DevConst &C = x.C;
     x.count(C_TRYADD);
+    DBG_START(x);
     double width1 = x.wmax - x.wmin;
     double tau1 = x.wmin + width1 * x.draw();                 // annihilator
     int orb = x.randint(1, C.nd);
@@ -345,11 +381,13 @@ __device__ void step_add(Ctx &x)
     int occ_lo = ((x.outer >> flav_bit(f, C.nd)) & 1) + c_lo - a_lo;
     bool creator_first = tau2 < tau1;
     bool valid = !eq && between == 0 && occ_lo == (creator_first ? 0 : 1);
+    DBG_STAMP(x, C_DBG4);
     if (!valid) { x.count(C_QNADD); return; }
     if (k >= kmax) { x.err |= ERR_KMAX; x.count(C_QNADD); return; }
 
     // determinant ratio S = F(tau_a-tau_c) - R^T M Q with Q_j = F(tau_a_j - tau_c_new), R_i = F(tau_a_new - tau_c_i)
-    // (Trace.F90:2806-2825).  lane = column j: RM_j = sum_i R_i M_ij in k coalesced row reads, S = S0 - sum_j RM_j Q_j.
+    // (Trace.F90:2806-2825, MatrixUpdate.F90:392-407).  Flat element loop: all loads of M are independent, one
+    // memory round trip for k^2 <= 64 * 4.
     double *Mf = x.mat(f);
     const double *ft = C.ftab + (size_t)f * C.nftau;
     for (int e = x.lane; e < k; e += 64) {
@@ -358,20 +396,29 @@ __device__ void step_add(Ctx &x)
     }
     double S0 = hybr(ft, C.nftau, C.beta, tau1 - tau2);
     wave_sync();
+    const int kk = k * k;
+    const unsigned magic = k > 0 ? (1u << 24) / (unsigned)k + 1u : 0u;      // e / k == (e * magic) >> 24 for e < 65536
     double acc = 0.0;
-    for (int j0 = 0; j0 < k; j0 += 64) {
-        int j = j0 + x.lane;
-        double rm = 0.0;
-        if (j < k) {
-            const double *col = Mf + j;
-#pragma unroll 4
-            for (int i = 0; i < k; ++i) rm += x.R[i] * col[(size_t)i * kmax];
-            x.RM[j] = rm;
-            acc += rm * x.Q[j];
+    for (int e0 = 0; e0 < kk; e0 += 256) {
+        double mv[4]; int iv[4], jv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int e = e0 + u * 64 + x.lane;
+            int ec = e < kk ? e : kk - 1;
+            int i = (int)(((unsigned)ec * magic) >> 24), j = ec - i * k;
+            iv[u] = i; jv[u] = j;
+            mv[u] = Mf[(size_t)i * kmax + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int e = e0 + u * 64 + x.lane;
+            double t = x.R[iv[u]] * mv[u] * x.Q[jv[u]];
+            acc += (e < kk) ? t : 0.0;
         }
     }
     double S = S0 - wave_sum(acc);
     double sig = ((pc - pa) & 1) ? -1.0 : 1.0;
+    DBG_STAMP(x, C_DBG5);
 
     double I = level_integral(x, f, lo, hi);
     double dlogtr = creator_first ? -I : I;
@@ -389,41 +436,60 @@ __device__ void step_add(Ctx &x)
     dnp += pair_ok(tau2, tau1, x.wmin, x.wmax, C.taudiff_max) ? 1 : 0;
     int np_new = x.npairs + dnp;
 
-    double prob = fabs(tdf * (double)(2 * C.nd) / (double)np_new * exp(dlogtr + log(fabs(S))));
+    double prob = fabs(tdf * (double)(2 * C.nd) / (double)np_new * fabs(S) * exp(dlogtr));
+    DBG_STAMP(x, C_DBG6);
     if (!(rnd < prob)) return;
 
-    // accepted: M' = [[M + MQ RM^T / S, -MQ/S], [-RM^T/S, 1/S]] with the new row/column appended at slot k
-    for (int i0 = 0; i0 < k; i0 += 64) {
-        int i = i0 + x.lane;
-        if (i < k) {
-            const double *row = Mf + (size_t)i * kmax;
-            double mq = 0.0;
-#pragma unroll 4
-            for (int j = 0; j < k; ++j) mq += row[j] * x.Q[j];
-            x.MQ[i] = mq;
+    // accepted: M' = [[M + MQ RM^T / S, -MQ/S], [-RM^T/S, 1/S]] with the new row/column appended at slot k.
+    // lane l computes RM_l (column sum, coalesced) and MQ_l (row sum) together, eight rows/columns per round trip.
+    for (int l0 = 0; l0 < k; l0 += 64) {
+        int l = l0 + x.lane;
+        int lc = l < k ? l : k - 1;
+        double rm = 0.0, mq = 0.0;
+        for (int i0 = 0; i0 < k; i0 += 8) {
+            double mc[8], mr[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                int i = i0 + u < k ? i0 + u : k - 1;
+                mc[u] = Mf[(size_t)i * kmax + lc];
+                mr[u] = Mf[(size_t)lc * kmax + i];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + u < k) { rm += x.R[i0 + u] * mc[u]; mq += mr[u] * x.Q[i0 + u]; }
+            }
         }
+        if (l < k) { x.RM[l] = rm; x.MQ[l] = mq; }
     }
     wave_sync();
     double invS = 1.0 / S;
-    for (int j0 = 0; j0 <= k; j0 += 64) {
-        int j = j0 + x.lane;
-        if (j < k) {
-            double nr = -x.RM[j] * invS;                     // new row element
-            double *col = Mf + j;
-#pragma unroll 4
-            for (int i = 0; i < k; ++i) col[(size_t)i * kmax] += S * (-x.MQ[i] * invS) * nr;
-            col[(size_t)k * kmax] = nr;
-        } else if (j == k) {
-            double *col = Mf + k;
-            for (int i = 0; i < k; ++i) col[(size_t)i * kmax] = -x.MQ[i] * invS;
-            col[(size_t)k * kmax] = invS;
-            tcp[k] = tau2; tap[k] = tau1; x.K[f] = k + 1;
+    for (int e0 = 0; e0 < kk; e0 += 256) {
+        double mv[4]; int iv[4], jv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int e = e0 + u * 64 + x.lane;
+            int ec = e < kk ? e : kk - 1;
+            int i = (int)(((unsigned)ec * magic) >> 24), j = ec - i * k;
+            iv[u] = i; jv[u] = j;
+            mv[u] = Mf[(size_t)i * kmax + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int e = e0 + u * 64 + x.lane;
+            if (e < kk) Mf[(size_t)iv[u] * kmax + jv[u]] = mv[u] + S * (-x.MQ[iv[u]] * invS) * (-x.RM[jv[u]] * invS);
         }
     }
+    for (int e = x.lane; e < k; e += 64) {
+        Mf[(size_t)e * kmax + k] = -x.MQ[e] * invS;
+        Mf[(size_t)k * kmax + e] = -x.RM[e] * invS;
+    }
+    if (x.lane == 0) { Mf[(size_t)k * kmax + k] = invS; tcp[k] = tau2; tap[k] = tau1; }
+    x.set_order(f, k + 1);
     wave_sync();
     x.det_sign *= (S < 0.0 ? -1.0 : 1.0) * sig;
     x.det_log += log(fabs(S));
     x.npairs = np_new;
+    DBG_STAMP(x, C_DBG7);
     x.count(C_ACCADD);
     accpair_add(x, f, hi - lo);
 }
@@ -435,51 +501,83 @@ __device__ void step_rem(Ctx &x)
 {
     const DevConst &C = x.C;
     x.count(C_TRYREM);
+    DBG_START(x);
     // the window list is needed for the pick in any case
     int np = build_window(x);
+    DBG_STAMP(x, C_DBG0);
     x.npairs = np;
     if (np <= 0) { x.count(C_QNREM); return; }
     int pick = x.randint(1, np);
     const int nw = x.nwin;
 
-    // first operator of the pick-th pair in the reference's enumeration (time order of the earlier operator)
-    int estar = -1, rnk = 0;
-    for (int base = 0; base < nw; base += 64) {
-        int e = base + x.lane;
-        int P = 0; bool hit = false;
-        if (e < nw) {
-            double te = x.wt[e];
-            for (int q = 0; q < nw; ++q) P += (x.wt[q] < te) ? x.wc[q] : 0;
-            hit = (P < pick) && (pick <= P + x.wc[e]);
+    // first operator of the pick-th pair in the reference's enumeration (time order of the earlier operator),
+    // then its rnk-th partner in time order
+    double t1, t2; int m1, m2;
+    if (nw <= 64) {
+        const double te = x.wr_t; const int me = x.wr_m, ce = x.wr_c;
+        const bool live = x.lane < nw;
+        int P = 0;
+        for (int q = 0; q < nw; ++q) {
+            double tq = readlane_d(te, q); int cq = __builtin_amdgcn_readlane(ce, q);
+            P += (tq < te) ? cq : 0;
         }
-        unsigned long long m = __ballot(hit);
-        if (m) { int src = __ffsll((long long)m) - 1; estar = base + src; rnk = pick - __shfl(P, src, 64); }
-    }
-    estar = uni(estar); rnk = uni(rnk);
-    double t1 = x.wt[estar]; int m1 = x.wm[estar];
-    const int want = (m1 & 0xffff) ^ 0x300;
-    const double thi = t1 + C.taudiff_max;
-    int qstar = -1;
-    for (int base = 0; base < nw; base += 64) {
-        int q = base + x.lane;
-        bool hit = false;
-        if (q < nw) {
-            double tq = x.wt[q];
-            bool partner = ((x.wm[q] & 0xffff) == want) && (tq > t1) && !(tq > thi);
-            if (partner) {
-                int r = 0;
-                for (int p = 0; p < nw; ++p) {
-                    double tp = x.wt[p];
-                    r += (((x.wm[p] & 0xffff) == want) && (tp > t1) && !(tp > thi) && tp < tq) ? 1 : 0;
-                }
-                hit = (r == rnk - 1);
+        unsigned long long m = __ballot(live && (P < pick) && (pick <= P + ce));
+        int estar = __ffsll((long long)m) - 1;
+        int rnk = pick - __builtin_amdgcn_readlane(P, estar);
+        t1 = readlane_d(te, estar); m1 = __builtin_amdgcn_readlane(me, estar);
+        const int want = (m1 & 0xffff) ^ 0x300;
+        const double thi = t1 + C.taudiff_max;
+        bool partner = live && ((me & 0xffff) == want) && (te > t1) && !(te > thi);
+        unsigned long long pm = __ballot(partner);
+        int r = 0;
+        while (pm) {                                     // rank of each partner among the partners, by time
+            int p = __ffsll((long long)pm) - 1; pm &= pm - 1ull;
+            double tp = readlane_d(te, p);
+            r += (tp < te) ? 1 : 0;
+        }
+        unsigned long long hm = __ballot(partner && r == rnk - 1);
+        int qstar = __ffsll((long long)hm) - 1;
+        t2 = readlane_d(te, qstar); m2 = __builtin_amdgcn_readlane(me, qstar);
+    } else {
+        int estar = -1, rnk = 0;
+        for (int base = 0; base < nw; base += 64) {
+            int e = base + x.lane;
+            int P = 0; bool hit = false;
+            if (e < nw) {
+                double te = x.wt[e];
+                for (int q = 0; q < nw; ++q) P += (x.wt[q] < te) ? x.wc[q] : 0;
+                hit = (P < pick) && (pick <= P + x.wc[e]);
             }
+            unsigned long long m = __ballot(hit);
+            if (m) { int src = __ffsll((long long)m) - 1; estar = base + src; rnk = pick - __shfl(P, src, 64); }
         }
-        unsigned long long m = __ballot(hit);
-        if (m) qstar = base + __ffsll((long long)m) - 1;
+        estar = uni(estar); rnk = uni(rnk);
+        t1 = x.wt[estar]; m1 = x.wm[estar];
+        const int want = (m1 & 0xffff) ^ 0x300;
+        const double thi = t1 + C.taudiff_max;
+        int qstar = -1;
+        for (int base = 0; base < nw; base += 64) {
+            int q = base + x.lane;
+            bool hit = false;
+            if (q < nw) {
+                double tq = x.wt[q];
+                bool partner = ((x.wm[q] & 0xffff) == want) && (tq > t1) && !(tq > thi);
+                if (partner) {
+                    int r = 0;
+                    for (int p = 0; p < nw; ++p) {
+                        double tp = x.wt[p];
+                        r += (((x.wm[p] & 0xffff) == want) && (tp > t1) && !(tp > thi) && tp < tq) ? 1 : 0;
+                    }
+                    hit = (r == rnk - 1);
+                }
+            }
+            unsigned long long m = __ballot(hit);
+            if (m) qstar = base + __ffsll((long long)m) - 1;
+        }
+        qstar = uni(qstar);
+        t2 = x.wt[qstar]; m2 = x.wm[qstar];
     }
-    qstar = uni(qstar);
-    double t2 = x.wt[qstar]; int m2 = x.wm[qstar];
+    DBG_STAMP(x, C_DBG1);
     int f = m1 & 0xff;
     int ca1 = (m1 >> 8) & 0xff;
     int ic = (ca1 == 1) ? (m1 >> 16) : (m2 >> 16);
@@ -499,6 +597,7 @@ __device__ void step_rem(Ctx &x)
         between += count_pred(v && tce > t1 && tce < t2) + count_pred(v && tae > t1 && tae < t2);
         pc += count_pred(tce < tau_c); pa += count_pred(tae < tau_a);
     }
+    DBG_STAMP(x, C_DBG2);
     if (between != 0) { x.count(C_QNREM); return; }
 
     double S = uni(Mf[(size_t)ic * kmax + ia]);
@@ -507,8 +606,9 @@ __device__ void step_rem(Ctx &x)
     // the pair's own operators sit on the boundary of (t1,t2) and belong to flavour f, which level_integral skips
     double I = level_integral(x, f, t1, t2);
     double dlogtr = creator_first ? I : -I;
-    double prob = fabs(hybf / (double)(2 * C.nd) * exp(dlogtr + log(fabs(S))));
+    double prob = fabs(hybf / (double)(2 * C.nd) * fabs(S) * exp(dlogtr));
     double rnd = x.draw();
+    DBG_STAMP(x, C_DBG3);
     if (!(rnd < prob)) return;
     if (fabs(S) < 1e-12) { x.err |= ERR_DETRAT; return; }   // CTQMC.F90:4062 stops here
 
@@ -525,20 +625,35 @@ __device__ void step_rem(Ctx &x)
 
     for (int e = x.lane; e < k; e += 64) { x.RM[e] = Mf[(size_t)ic * kmax + e]; x.MQ[e] = Mf[(size_t)e * kmax + ia]; }
     wave_sync();
+    // M'_ij = M_ij - M_i,ia M_ic,j / M_ic,ia for i != ic, j != ia; the last row/column move into the freed slots.
+    // Every source element is read by exactly one lane before anything is written over it (row ic / column ia are
+    // only read above), so the update is done in place.
     const int last = k - 1;
-    for (int j0 = 0; j0 < k; j0 += 64) {
-        int j = j0 + x.lane;
-        if (j < k && j != ia) {
-            int jd = (j == last) ? ia : j;
-            for (int i = 0; i < k; ++i) {
-                if (i == ic) continue;
-                int id = (i == last) ? ic : i;
-                double v = Mf[(size_t)i * kmax + j] - x.MQ[i] * x.RM[j] / S;
-                Mf[(size_t)id * kmax + jd] = v;
+    const int kk = k * k;
+    const unsigned magic = (1u << 24) / (unsigned)k + 1u;
+    for (int e0 = 0; e0 < kk; e0 += 256) {
+        double mv[4]; int iv[4], jv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int e = e0 + u * 64 + x.lane;
+            int ec = e < kk ? e : kk - 1;
+            int i = (int)(((unsigned)ec * magic) >> 24), j = ec - i * k;
+            iv[u] = i; jv[u] = j;
+            mv[u] = Mf[(size_t)i * kmax + j];
+        }
+        wave_sync();      // all loads of this batch are done before any store of it (a store may hit another lane's source)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int e = e0 + u * 64 + x.lane;
+            int i = iv[u], j = jv[u];
+            if (e < kk && i != ic && j != ia) {
+                int id = (i == last) ? ic : i, jd = (j == last) ? ia : j;
+                Mf[(size_t)id * kmax + jd] = mv[u] - x.MQ[i] * x.RM[j] / S;
             }
         }
     }
-    if (x.lane == 0) { tcp[ic] = tcp[last]; tap[ia] = tap[last]; x.K[f] = last; }
+    if (x.lane == 0) { tcp[ic] = tcp[last]; tap[ia] = tap[last]; }
+    x.set_order(f, last);
     wave_sync();
     x.det_sign *= (S < 0.0 ? -1.0 : 1.0) * sig;
     x.det_log += log(fabs(S));
@@ -664,10 +779,11 @@ __device__ double full_logtrace(Ctx &x, const int *Kv, const double *TCb, const 
     return -(uni_part + wave_sum(part));
 }
 
-// Build F(tau_a_i - tau_c_j) of one flavour in `A` (row = annihilator slot, column = creator slot, stride kmax) and
-// invert it in place by Gauss-Jordan with partial pivoting; the result read as [creator][annihilator] is M.
-// Returns log|det F| and its sign in slot order.  What the reference obtains from dgetrf/dgetri
-// (Trace.F90:2279-2333, MatrixUpdate.F90:41-99).  lane = column.
+// Build F(tau_a_r - tau_c_c) of one flavour (row = annihilator slot, column = creator slot) and invert it by
+// Gauss-Jordan with partial pivoting; the result read as [creator][annihilator] is M and is stored to `A` (global,
+// row stride kmax).  Returns log|det F| and its sign in slot order.  What the reference obtains from dgetrf/dgetri
+// (Trace.F90:2279-2333, MatrixUpdate.F90:41-99).  For k <= kgj the whole elimination runs in the wave's LDS scratch
+// (compact stride k); larger matrices are eliminated in place in global memory.
 __device__ void build_and_invert(Ctx &x, int f, int k, const double *tcp, const double *tap, double *A,
                                  double &logdet, double &sgn)
 {
@@ -676,53 +792,91 @@ __device__ void build_and_invert(Ctx &x, int f, int k, const double *tcp, const 
     const double *ft = C.ftab + (size_t)f * C.nftau;
     logdet = 0.0; sgn = 1.0;
     if (k == 0) return;
-    for (int c0 = 0; c0 < k; c0 += 64) {
-        int c = c0 + x.lane;
-        if (c < k) { double tcc = tcp[c]; for (int a = 0; a < k; ++a) A[(size_t)a * kmax + c] = hybr(ft, C.nftau, C.beta, tap[a] - tcc); }
+    const bool in_lds = k <= C.kgj;
+    double *G = in_lds ? x.gj : A;                 // working matrix and its row stride
+    const int gs = in_lds ? k : kmax;
+    const int kk = k * k;
+    const unsigned magic = (1u << 24) / (unsigned)k + 1u;
+    for (int e = x.lane; e < kk; e += 64) {
+        int r = (int)(((unsigned)e * magic) >> 24), c = e - r * k;
+        double v = hybr(ft, C.nftau, C.beta, tap[r] - tcp[c]);
+        if (in_lds) x.gj[r * k + c] = v; else A[(size_t)r * kmax + c] = v;
     }
     wave_sync();
     int *piv = x.wm;                 // k <= kmax <= wcap entries of LDS
     for (int p = 0; p < k; ++p) {
-        double best = -1.0; int bi = p;
-        for (int r = p + x.lane; r < k; r += 64) { double v = fabs(A[(size_t)r * kmax + p]); if (v > best) { best = v; bi = r; } }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            double ob = __shfl_xor(best, o, 64); int oi = __shfl_xor(bi, o, 64);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        double best = -1.0; int brow = p;
+        for (int r = p + x.lane; r < k; r += 64) {
+            double v = fabs(in_lds ? x.gj[r * gs + p] : A[(size_t)r * gs + p]);
+            if (v > best) { best = v; brow = r; }
         }
-        bi = uni(bi);
-        if (!(best > 0.0)) { x.err |= ERR_SINGULAR; return; }
+        double mx = wave_max(best);
+        if (!(mx > 0.0)) { x.err |= ERR_SINGULAR; return; }
+        unsigned long long m = __ballot(best == mx);
+        int bi = __builtin_amdgcn_readlane(brow, __ffsll((long long)m) - 1);
         if (x.lane == 0) piv[p] = bi;
         if (bi != p) {
-            for (int j = x.lane; j < k; j += 64) { double t = A[(size_t)p * kmax + j]; A[(size_t)p * kmax + j] = A[(size_t)bi * kmax + j]; A[(size_t)bi * kmax + j] = t; }
+            for (int j = x.lane; j < k; j += 64) {
+                if (in_lds) { double t = x.gj[p * gs + j]; x.gj[p * gs + j] = x.gj[bi * gs + j]; x.gj[bi * gs + j] = t; }
+                else { double t = A[(size_t)p * gs + j]; A[(size_t)p * gs + j] = A[(size_t)bi * gs + j]; A[(size_t)bi * gs + j] = t; }
+            }
             sgn = -sgn;
             wave_sync();
         }
-        double d = uni(A[(size_t)p * kmax + p]);
+        double d = uni(in_lds ? x.gj[p * gs + p] : A[(size_t)p * gs + p]);
         logdet += log(fabs(d)); if (d < 0.0) sgn = -sgn;
         double id = 1.0 / d;
-        for (int j = x.lane; j < k; j += 64) x.MQ[j] = A[(size_t)j * kmax + p];       // pivot column
+        for (int j = x.lane; j < k; j += 64) {
+            double rv = in_lds ? x.gj[p * gs + j] : A[(size_t)p * gs + j];
+            double cv = in_lds ? x.gj[j * gs + p] : A[(size_t)j * gs + p];
+            x.RM[j] = (j == p) ? id : rv * id;            // scaled pivot row
+            x.MQ[j] = cv;                                  // pivot column
+        }
         wave_sync();
-        for (int j0 = 0; j0 < k; j0 += 64) {
-            int j = j0 + x.lane;
-            if (j < k) {
-                double rp = (j == p) ? id : A[(size_t)p * kmax + j] * id;             // scaled pivot row, lane-private
-                for (int r = 0; r < k; ++r) {
-                    double v;
-                    if (r == p) v = rp;
-                    else v = ((j == p) ? 0.0 : A[(size_t)r * kmax + j]) - x.MQ[r] * rp;
-                    A[(size_t)r * kmax + j] = v;
+        if (in_lds) {
+            for (int e = x.lane; e < kk; e += 64) {
+                int r = (int)(((unsigned)e * magic) >> 24), c = e - r * k;
+                double rp = x.RM[c];
+                double v = (r == p) ? rp : (((c == p) ? 0.0 : x.gj[e]) - x.MQ[r] * rp);
+                x.gj[e] = v;
+            }
+        } else {
+            for (int e0 = 0; e0 < kk; e0 += 256) {
+                double mv[4]; int rv[4], cv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    int e = e0 + u * 64 + x.lane; int ec = e < kk ? e : kk - 1;
+                    int r = (int)(((unsigned)ec * magic) >> 24), c = ec - r * k;
+                    rv[u] = r; cv[u] = c; mv[u] = A[(size_t)r * kmax + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    int e = e0 + u * 64 + x.lane;
+                    if (e < kk) {
+                        double rp = x.RM[cv[u]];
+                        A[(size_t)rv[u] * kmax + cv[u]] = (rv[u] == p) ? rp : (((cv[u] == p) ? 0.0 : mv[u]) - x.MQ[rv[u]] * rp);
+                    }
                 }
             }
         }
         wave_sync();
     }
     for (int p = k - 1; p >= 0; --p) {    // undo the row interchanges as column interchanges
-        int bi = piv[p];
+        int bi = uni(piv[p]);
         if (bi != p) {
-            for (int r = x.lane; r < k; r += 64) { double t = A[(size_t)r * kmax + p]; A[(size_t)r * kmax + p] = A[(size_t)r * kmax + bi]; A[(size_t)r * kmax + bi] = t; }
+            for (int r = x.lane; r < k; r += 64) {
+                if (in_lds) { double t = x.gj[r * gs + p]; x.gj[r * gs + p] = x.gj[r * gs + bi]; x.gj[r * gs + bi] = t; }
+                else { double t = A[(size_t)r * gs + p]; A[(size_t)r * gs + p] = A[(size_t)r * gs + bi]; A[(size_t)r * gs + bi] = t; }
+            }
             wave_sync();
         }
+    }
+    if (in_lds) {
+        for (int e = x.lane; e < kk; e += 64) {
+            int r = (int)(((unsigned)e * magic) >> 24), c = e - r * k;
+            A[(size_t)r * kmax + c] = x.gj[e];
+        }
+        wave_sync();
     }
 }
 
@@ -813,7 +967,7 @@ __device__ void step_glob(Ctx &x)
         const double *Mn = MBw + (size_t)g * kmax * kmax;
         for (int e = x.lane; e < k; e += 64) { tcp[e] = TS[(size_t)(2 * g) * kmax + e]; tap[e] = TS[(size_t)(2 * g + 1) * kmax + e]; }
         for (int j0 = 0; j0 < k; j0 += 64) { int j = j0 + x.lane; if (j < k) for (int i = 0; i < k; ++i) Mg[(size_t)i * kmax + j] = Mn[(size_t)i * kmax + j]; }
-        if (x.lane == 0) x.K[g] = k;
+        x.set_order(g, k);
     }
     wave_sync();
     x.outer = outer_new;
@@ -835,7 +989,8 @@ __device__ __forceinline__ void ctx_setup(Ctx &x, unsigned char *smem)
     x.tc_ = (double *)base; x.ta_ = x.tc_ + C.nflav * C.kmax;
     x.Q = x.ta_ + C.nflav * C.kmax; x.R = x.Q + C.kmax; x.MQ = x.R + C.kmax; x.RM = x.MQ + C.kmax;
     x.wt = x.RM + C.kmax;
-    x.cnt = (unsigned long long *)(x.wt + C.wcap);
+    x.gj = x.wt + C.wcap;
+    x.cnt = (unsigned long long *)(x.gj + C.kgj * C.kgj);
     x.wm = (int *)(x.cnt + C_NCOUNT); x.wc = x.wm + C.wcap; x.K = x.wc + C.wcap;
 }
 
@@ -850,7 +1005,7 @@ __device__ __forceinline__ void ctx_load(Ctx &x)
     unsigned long long nd_ = s.ndraw;
     nd_ = ((unsigned long long)(unsigned)uni((int)(nd_ >> 32)) << 32) | (unsigned long long)(unsigned)uni((int)nd_);
     if (x.lane < C_NCOUNT) x.cnt[x.lane] = s.cnt[x.lane];
-    if (x.lane < nf) x.K[x.lane] = C.K[(size_t)w * nf + x.lane];
+    x.kreg = (x.lane < nf) ? C.K[(size_t)w * nf + x.lane] : 0;
     wave_sync();
     for (int f = 0; f < nf; ++f) {
         int k = x.order(f);
@@ -875,7 +1030,7 @@ __device__ __forceinline__ void ctx_store(Ctx &x)
     }
     WalkerScalars &s = C.ws[w];
     if (x.lane < C_NCOUNT) s.cnt[x.lane] = x.cnt[x.lane];
-    if (x.lane < nf) C.K[(size_t)w * nf + x.lane] = x.K[x.lane];
+    if (x.lane < nf) C.K[(size_t)w * nf + x.lane] = x.kreg;
     if (x.lane == 0) {
         s.ndraw = x.rng_tell(); s.outer = x.outer; s.npairs = x.npairs; s.wpos = x.wpos; s.err = x.err;
         s.det_sign = x.det_sign; s.det_log = x.det_log;
@@ -906,10 +1061,26 @@ __global__ __launch_bounds__(256) void k_sweep(DevConst C, long long nsteps, int
         unsigned long long t0_ = __builtin_amdgcn_s_memtime();
         int which_;
 #endif
-        if (r < (1.0 - ps - pg) / 2.0) { (void)x.draw(); (void)x.draw(); step_add(x); STAMP_KIND(C_CYC_ADD); phase += 1; }
-        else if (r <= 1.0 - ps - pg) { (void)x.draw(); (void)x.draw(); step_rem(x); STAMP_KIND(C_CYC_REM); phase += 1; }
-        else if (r <= 1.0 - ps) { step_glob(x); STAMP_KIND(C_CYC_GLOB); }
-        else { step_shift(x); STAMP_KIND(C_CYC_SHIFT); }
+        if (r < (1.0 - ps - pg) / 2.0) { (void)x.draw(); (void)x.draw();
+#ifndef W2DYN_NO_ADD
+            step_add(x);
+#endif
+            STAMP_KIND(C_CYC_ADD); phase += 1; }
+        else if (r <= 1.0 - ps - pg) { (void)x.draw(); (void)x.draw();
+#ifndef W2DYN_NO_REM
+            step_rem(x);
+#endif
+            STAMP_KIND(C_CYC_REM); phase += 1; }
+        else if (r <= 1.0 - ps) {
+#ifndef W2DYN_NO_GLOB
+            step_glob(x);
+#endif
+            STAMP_KIND(C_CYC_GLOB); }
+        else {
+#ifndef W2DYN_NO_SHIFT
+            step_shift(x);
+#endif
+            STAMP_KIND(C_CYC_SHIFT); }
 #ifdef W2DYN_STAMPS
         if (x.lane == 0) x.cnt[which_] += __builtin_amdgcn_s_memtime() - t0_;
 #endif
@@ -1013,10 +1184,11 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
         atomicAdd(&C.acc_outer[(size_t)bin * C.nstates + x.outer], 1.0);
         atomicAdd(&C.acc_signouter[(size_t)bin * C.nstates + x.outer], cfgsign);
         atomicAdd(&C.acc_dm[(size_t)bin * C.nstates + sb2], -cfgsign);
-        for (int f = 0; f < nf; ++f) {
-            int k = x.K[f]; int h = k < C.maxhisto ? k : C.maxhisto;
-            atomicAdd(&C.acc_histo[((size_t)bin * nf + f) * (C.maxhisto + 1) + h], 1.0);
-        }
+    }
+    if (x.lane < nf) {      // lane f holds the order of flavour f
+        int bin = x.w / C.walkers_per_bin;
+        int h = x.kreg < C.maxhisto ? x.kreg : C.maxhisto;
+        atomicAdd(&C.acc_histo[((size_t)bin * nf + x.lane) * (C.maxhisto + 1) + h], 1.0);
     }
 }
 

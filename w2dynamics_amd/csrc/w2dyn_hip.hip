@@ -356,7 +356,8 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     C.kmax = kmax; C.nwalkers = s->nwalkers; C.has_szt = s->has_szt; C.maxhisto = s->maxhisto;
     C.walkers_per_bin = s->walkers_per_bin; C.nbins = (s->nwalkers + s->walkers_per_bin - 1) / s->walkers_per_bin;
     C.wcap = std::max(kmax, std::min(2 * nf * kmax, 256));
-    C.lds_per_wave = (int)lds_bytes_per_wave(nf, kmax, C.wcap);
+    C.kgj = std::min(kmax, 32);
+    C.lds_per_wave = (int)lds_bytes_per_wave(nf, kmax, C.wcap, C.kgj);
     if (4 * (size_t)C.lds_per_wave > 160 * 1024) return fail(s, W2DYN_EUNSUPPORTED, "kmax=%d needs %d bytes of LDS per chain: too large", kmax, C.lds_per_wave);
     C.beta = s->beta; C.p_glob = s->p_glob; C.p_shift = s->p_shift; C.egs = s->egs;
     C.seed = (unsigned long long)s->seed; C.first_walker = (unsigned long long)s->first_walker;
