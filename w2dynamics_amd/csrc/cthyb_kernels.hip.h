@@ -194,7 +194,8 @@ struct Ctx {
     double wmin, wmax;
     unsigned long long tstamp;
     int kreg;                        // lane g: expansion order of flavour g
-    double wr_t; int wr_m, wr_c;     // lane e: window-list entry e (tau, f|ca<<8|slot<<16, partner count) when nwin <= 64
+    double wr_t; int wr_m, wr_c, wr_p;  // lane e: window-list entry e (tau, f|ca<<8|slot<<16, partner count, pairs before e) when nwin <= 64
+    int wvalid;                      // window list (registers or LDS) matches the current configuration and window
 
     __device__ Ctx(const DevConst &c) : C(c) {}
 
@@ -288,7 +289,12 @@ __device__ int build_window(Ctx &x)
             double tq = readlane_d(te, q); int mq = __builtin_amdgcn_readlane(me, q) & 0xffff;
             c += (live && mq == want && tq > te && !(tq > thi)) ? 1 : 0;
         }
-        x.wr_t = te; x.wr_m = me; x.wr_c = c;
+        int P = 0;                                       // pairs whose earlier operator precedes entry e in time
+        for (int q = 0; q < nw; ++q) {
+            double tq = readlane_d(te, q); int cq = __builtin_amdgcn_readlane(c, q);
+            P += (tq < te) ? cq : 0;
+        }
+        x.wr_t = te; x.wr_m = me; x.wr_c = c; x.wr_p = P;
         total = wave_sum(c);
     } else {
         for (int base = 0; base < nw; base += 64) {
@@ -309,6 +315,7 @@ __device__ int build_window(Ctx &x)
         total = wave_sum(total);
         wave_sync();
     }
+    x.wvalid = 1;
     return total;
 }
 
@@ -367,20 +374,17 @@ __device__ void step_add(Ctx &x)
     // quantum numbers (Trace.F90:1243-1302 for one-state blocks): no operator of flavour f between the new pair and
     // the right occupation below it; equal times are rejected like QN violations (CTQMC.F90:3405-3416)
     double lo = fmin(tau1, tau2), hi = fmax(tau1, tau2);
-    int c_lo = 0, a_lo = 0, c_hi = 0, a_hi = 0, pc = 0, pa = 0, eq = (tau1 == tau2);
+    int c_lo = 0, a_lo = 0; bool blocked = (tau1 == tau2);
     for (int base = 0; base < k; base += 64) {
         int e = base + x.lane;
         bool v = e < k;
         double tce = v ? tcp[e] : 2.0 * C.beta, tae = v ? tap[e] : 2.0 * C.beta;
         c_lo += count_pred(tce < lo); a_lo += count_pred(tae < lo);
-        c_hi += count_pred(tce < hi); a_hi += count_pred(tae < hi);
-        pc += count_pred(tce < tau2); pa += count_pred(tae < tau1);
-        eq |= __ballot(v && (tce == tau1 || tce == tau2 || tae == tau1 || tae == tau2)) != 0ull;
+        blocked |= __ballot((tce >= lo && tce <= hi) || (tae >= lo && tae <= hi)) != 0ull;
     }
-    int between = (c_hi + a_hi) - (c_lo + a_lo);
     int occ_lo = ((x.outer >> flav_bit(f, C.nd)) & 1) + c_lo - a_lo;
     bool creator_first = tau2 < tau1;
-    bool valid = !eq && between == 0 && occ_lo == (creator_first ? 0 : 1);
+    bool valid = !blocked && occ_lo == (creator_first ? 0 : 1);
     DBG_STAMP(x, C_DBG4);
     if (!valid) { x.count(C_QNADD); return; }
     if (k >= kmax) { x.err |= ERR_KMAX; x.count(C_QNADD); return; }
@@ -390,16 +394,30 @@ __device__ void step_add(Ctx &x)
     // memory round trip for k^2 <= 64 * 4.
     double *Mf = x.mat(f);
     const double *ft = C.ftab + (size_t)f * C.nftau;
+    const int kk = k * k;
+    const unsigned magic = k > 0 ? (1u << 24) / (unsigned)k + 1u : 0u;      // e / k == (e * magic) >> 24 for e < 65536
+    double mv0[4]; int iv0[4], jv0[4];                   // first 256 elements of M: loads in flight during the F lookups
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        int e = u * 64 + x.lane;
+        int ec = e < kk ? e : (kk > 0 ? kk - 1 : 0);
+        int i = (int)(((unsigned)ec * magic) >> 24), j = ec - i * k;
+        iv0[u] = i; jv0[u] = j;
+        mv0[u] = (kk > 0) ? Mf[(size_t)i * kmax + j] : 0.0;
+    }
     for (int e = x.lane; e < k; e += 64) {
         x.Q[e] = hybr(ft, C.nftau, C.beta, tap[e] - tau2);
         x.R[e] = hybr(ft, C.nftau, C.beta, tau1 - tcp[e]);
     }
     double S0 = hybr(ft, C.nftau, C.beta, tau1 - tau2);
     wave_sync();
-    const int kk = k * k;
-    const unsigned magic = k > 0 ? (1u << 24) / (unsigned)k + 1u : 0u;      // e / k == (e * magic) >> 24 for e < 65536
     double acc = 0.0;
-    for (int e0 = 0; e0 < kk; e0 += 256) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        int e = u * 64 + x.lane;
+        if (e < kk) acc += x.R[iv0[u]] * mv0[u] * x.Q[jv0[u]];
+    }
+    for (int e0 = 256; e0 < kk; e0 += 256) {
         double mv[4]; int iv[4], jv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -417,7 +435,6 @@ __device__ void step_add(Ctx &x)
         }
     }
     double S = S0 - wave_sum(acc);
-    double sig = ((pc - pa) & 1) ? -1.0 : 1.0;
     DBG_STAMP(x, C_DBG5);
 
     double I = level_integral(x, f, lo, hi);
@@ -440,6 +457,15 @@ __device__ void step_add(Ctx &x)
     DBG_STAMP(x, C_DBG6);
     if (!(rnd < prob)) return;
 
+    // time-ordered ranks of the new operators for the cofactor sign (-1)^|FPos1-FPos2| (Trace.F90:2828)
+    int pc = 0, pa = 0;
+    for (int base = 0; base < k; base += 64) {
+        int e = base + x.lane;
+        bool v = e < k;
+        double tce = v ? tcp[e] : 2.0 * C.beta, tae = v ? tap[e] : 2.0 * C.beta;
+        pc += count_pred(tce < tau2); pa += count_pred(tae < tau1);
+    }
+    const double sig = ((pc - pa) & 1) ? -1.0 : 1.0;
     // accepted: M' = [[M + MQ RM^T / S, -MQ/S], [-RM^T/S, 1/S]] with the new row/column appended at slot k.
     // lane l computes RM_l (column sum, coalesced) and MQ_l (row sum) together, eight rows/columns per round trip.
     for (int l0 = 0; l0 < k; l0 += 64) {
@@ -489,6 +515,7 @@ __device__ void step_add(Ctx &x)
     x.det_sign *= (S < 0.0 ? -1.0 : 1.0) * sig;
     x.det_log += log(fabs(S));
     x.npairs = np_new;
+    x.wvalid = 0;
     DBG_STAMP(x, C_DBG7);
     x.count(C_ACCADD);
     accpair_add(x, f, hi - lo);
@@ -502,10 +529,10 @@ __device__ void step_rem(Ctx &x)
     const DevConst &C = x.C;
     x.count(C_TRYREM);
     DBG_START(x);
-    // the window list is needed for the pick in any case
-    int np = build_window(x);
+    // window list, partner counts and prefix counts are kept until the configuration or the window changes
+    if (!x.wvalid || x.npairs < 0) x.npairs = build_window(x);
+    const int np = x.npairs;
     DBG_STAMP(x, C_DBG0);
-    x.npairs = np;
     if (np <= 0) { x.count(C_QNREM); return; }
     int pick = x.randint(1, np);
     const int nw = x.nwin;
@@ -514,13 +541,8 @@ __device__ void step_rem(Ctx &x)
     // then its rnk-th partner in time order
     double t1, t2; int m1, m2;
     if (nw <= 64) {
-        const double te = x.wr_t; const int me = x.wr_m, ce = x.wr_c;
+        const double te = x.wr_t; const int me = x.wr_m, ce = x.wr_c, P = x.wr_p;
         const bool live = x.lane < nw;
-        int P = 0;
-        for (int q = 0; q < nw; ++q) {
-            double tq = readlane_d(te, q); int cq = __builtin_amdgcn_readlane(ce, q);
-            P += (tq < te) ? cq : 0;
-        }
         unsigned long long m = __ballot(live && (P < pick) && (pick <= P + ce));
         int estar = __ffsll((long long)m) - 1;
         int rnk = pick - __builtin_amdgcn_readlane(P, estar);
@@ -589,39 +611,49 @@ __device__ void step_rem(Ctx &x)
     int k = x.order(f);
     const int kmax = C.kmax;
     double *tcp = x.tc(f), *tap = x.ta(f), *Mf = x.mat(f);
-    int between = 0, pc = 0, pa = 0;
-    for (int base = 0; base < k; base += 64) {
-        int e = base + x.lane;
-        bool v = e < k;
-        double tce = v ? tcp[e] : 2.0 * C.beta, tae = v ? tap[e] : 2.0 * C.beta;
-        between += count_pred(v && tce > t1 && tce < t2) + count_pred(v && tae > t1 && tae < t2);
-        pc += count_pred(tce < tau_c); pa += count_pred(tae < tau_a);
+    double Sv = Mf[(size_t)ic * kmax + ia];            // issued early, consumed after the trace integral
+    // quantum numbers: the pair may go iff no operator of its flavour lies strictly between (both are in the window,
+    // so anything between them is in the window list too)
+    bool blocked;
+    if (nw <= 64) {
+        blocked = __ballot(x.lane < nw && (x.wr_m & 0xff) == f && x.wr_t > t1 && x.wr_t < t2) != 0ull;
+    } else {
+        int between = 0;
+        for (int base = 0; base < k; base += 64) {
+            int e = base + x.lane;
+            bool v = e < k;
+            double tce = v ? tcp[e] : 2.0 * C.beta, tae = v ? tap[e] : 2.0 * C.beta;
+            between += count_pred(tce > t1 && tce < t2) + count_pred(tae > t1 && tae < t2);
+        }
+        blocked = between != 0;
     }
     DBG_STAMP(x, C_DBG2);
-    if (between != 0) { x.count(C_QNREM); return; }
+    if (blocked) { x.count(C_QNREM); return; }
 
-    double S = uni(Mf[(size_t)ic * kmax + ia]);
-    double sig = ((pc - pa) & 1) ? -1.0 : 1.0;
     bool creator_first = tau_c < tau_a;
     // the pair's own operators sit on the boundary of (t1,t2) and belong to flavour f, which level_integral skips
     double I = level_integral(x, f, t1, t2);
     double dlogtr = creator_first ? I : -I;
+    double S = uni(Sv);
     double prob = fabs(hybf / (double)(2 * C.nd) * fabs(S) * exp(dlogtr));
     double rnd = x.draw();
     DBG_STAMP(x, C_DBG3);
     if (!(rnd < prob)) return;
     if (fabs(S) < 1e-12) { x.err |= ERR_DETRAT; return; }   // CTQMC.F90:4062 stops here
 
-    // NPairs after the removal: every pair that contains one of the two operators disappears
-    int dnp = 0;
+    // NPairs after the removal: every pair that contains one of the two operators disappears; time-ordered ranks
+    // of the two operators for the cofactor sign (Trace.F90:2958-2959)
+    int dnp = 0, pc = 0, pa = 0;
     for (int base = 0; base < k; base += 64) {
         int e = base + x.lane;
         bool v = e < k;
-        double tce = v ? tcp[e] : 0.0, tae = v ? tap[e] : 0.0;
+        double tce = v ? tcp[e] : 2.0 * C.beta, tae = v ? tap[e] : 2.0 * C.beta;
+        pc += count_pred(tce < tau_c); pa += count_pred(tae < tau_a);
         dnp += count_pred(v && e != ia && pair_ok(tau_c, tae, x.wmin, x.wmax, C.taudiff_max));
         dnp += count_pred(v && e != ic && pair_ok(tce, tau_a, x.wmin, x.wmax, C.taudiff_max));
     }
     dnp += 1;   // the removed pair itself (it was picked from the removable ones)
+    const double sig = ((pc - pa) & 1) ? -1.0 : 1.0;
 
     for (int e = x.lane; e < k; e += 64) { x.RM[e] = Mf[(size_t)ic * kmax + e]; x.MQ[e] = Mf[(size_t)e * kmax + ia]; }
     wave_sync();
@@ -658,6 +690,7 @@ __device__ void step_rem(Ctx &x)
     x.det_sign *= (S < 0.0 ? -1.0 : 1.0) * sig;
     x.det_log += log(fabs(S));
     x.npairs = np - dnp;
+    x.wvalid = 0;
     x.count(C_ACCREM);
     accpair_add(x, f, t2 - t1);
 }
@@ -732,7 +765,7 @@ __device__ void step_shift(Ctx &x)
         x.wpos = (((x.wpos - a) % nw) + nw) % nw;
         x.window_bounds();
     }
-    x.npairs = -1;
+    x.npairs = -1; x.wvalid = 0;
     x.count(C_ACCSHIFT);
 }
 
@@ -896,6 +929,7 @@ __device__ void step_glob(Ctx &x)
     int nops = 0;
     for (int f = 0; f < nf; ++f) nops += 2 * x.order(f);
     if (nops == 0) return;
+    x.wvalid = 0;                    // the inversion below uses the window list's LDS as pivot storage
     int gu[MAXFLAV + 1];
     double r = x.draw();
     bool spinflip = false;
@@ -1012,7 +1046,7 @@ __device__ __forceinline__ void ctx_load(Ctx &x)
         const double *gc = C.TC + ((size_t)w * nf + f) * kmax, *ga = C.TA + ((size_t)w * nf + f) * kmax;
         for (int e = x.lane; e < k; e += 64) { x.tc(f)[e] = gc[e]; x.ta(f)[e] = ga[e]; }
     }
-    x.nwin = 0;
+    x.nwin = 0; x.wvalid = 0;
     x.window_bounds();
     x.rng_seek(nd_);
     wave_sync();
@@ -1088,7 +1122,7 @@ __global__ __launch_bounds__(256) void k_sweep(DevConst C, long long nsteps, int
         if (phase == 0) {                                        // shift_window, Trace.F90:1652-1678
             if (C.num_windows > 1) {
                 x.wpos += 1; if (x.wpos == C.num_windows) x.wpos = 0;
-                x.window_bounds(); x.npairs = -1;
+                x.window_bounds(); x.npairs = -1; x.wvalid = 0;
             } else x.wpos = 0;
         }
     }
