@@ -72,12 +72,29 @@ def cpu_baseline(cores, nmeas=6000, nwarm=50000):
                       "%d measurements x NCorr=%d steps timed, same C2 workload" % (cores, nwarm, nmeas, WORKLOAD["overrides"]["NCorr"])}
 
 
+def pmc_traffic(kernel, chains):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*_pmc.json, made by
+    profiles/collect.sh + pmc_summary.py on the same command); None when no pass exists for this chain count."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("chains_per_gpu") != chains:
+            continue
+        for name, v in d.get("kernels", {}).items():
+            if name.startswith(kernel):
+                return v["traffic"], os.path.basename(f)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--walkers", type=int, default=int(os.environ.get("W2DYN_WALKERS", 8192)), help="chains per GPU")
+    ap.add_argument("--walkers", type=int, default=int(os.environ.get("W2DYN_WALKERS", 16384)), help="chains per GPU")
     ap.add_argument("--walkers-per-bin", type=int, default=int(os.environ.get("W2DYN_WPB", 8)))
     ap.add_argument("--thermal", type=int, default=20000, help="untimed thermalisation MC steps per chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -159,6 +176,8 @@ def main():
         flops_gleg = W * prob.nd * 2 * k2 * (5 * over["NLegMax"] + 6)
         ach_tf = flops_gleg / (gleg_ms * 1e-3) / 1e12 if gleg_ms > 0 else 0.0
         value = world * W * ncorr * a.steps / dt
+        tr_sweep, tr_src = pmc_traffic("k_sweep", W)
+        tr_gleg, _ = pmc_traffic("k_meas_gleg", W)
         out = {
             "metric": "Metropolis steps/sec (node)", "value": value, "unit": "MC steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -170,11 +189,11 @@ def main():
             "mean_order_per_flavour": k1, "accept_ins": c["accadd"] / max(c["tryadd"], 1), "occ_double": float(oc[0, 0, 0, 1]),
             "allreduce_ms": t_reduce * 1e3,
             "roofline": {"kernel": "k_sweep", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": sweep_ms, "launches": nsweep,
+                         "frac": ach_gbs / HBM_PEAK_GBS, "traffic": tr_sweep, "traffic_source": tr_src, "avg_launch_ms": sweep_ms, "launches": nsweep,
                          "algorithmic_bytes_per_launch": bytes_sweep},
             "roofline_meas": {"kernel": "k_meas_gleg", "bound": "mfma", "note": "fp64 vector FMA bound (fp64 vector peak == fp64 MFMA peak on MI355X)",
                               "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS,
-                              "traffic": None, "avg_launch_ms": gleg_ms, "launches": ngleg, "algorithmic_flops_per_launch": flops_gleg},
+                              "traffic": tr_gleg, "avg_launch_ms": gleg_ms, "launches": ngleg, "algorithmic_flops_per_launch": flops_gleg},
             "kernel_ms": {"k_sweep": sweep_ms, "k_meas_gleg": gleg_ms, "k_meas_misc": misc_ms},
         }
         if world == 1 and not a.no_cpu_baseline:
