@@ -122,9 +122,11 @@ def main():
     q.init_rnd(43890); q.init_paras(ps)
     q.init_solver(prob.umatrix, prob.ftau, prob.muimp, prob.screening, 1)
     q.set_taudiffmax(over["TaudiffMax"])
-    q.ctqmc_warmup(a.thermal)                      # thermalise (untimed)
-    q.measure_begin()
     ncorr = over["NCorr"]
+    q.ctqmc_warmup(ncorr)                          # thermalise (untimed), in launches of the same size as the timed ones
+    for _ in range(max(a.thermal // ncorr - 1, 0)):
+        q.sweep(ncorr)
+    q.measure_begin()
     for _ in range(a.warmup):
         q.sweep(ncorr); q.measure_once()
     q.sync()

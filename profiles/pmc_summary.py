@@ -24,7 +24,7 @@ def per_kernel(d, counter):
         for r in csv.DictReader(f):
             if r.get("Counter_Name") != counter:
                 continue
-            name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip().split("::")[-1]
             rows.setdefault(name, []).append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     out = {}
     for name, v in rows.items():

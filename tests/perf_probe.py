@@ -6,7 +6,7 @@ import numpy as np
 import util
 from w2dynamics_amd.mctqmc import MCTQMC
 
-def probe(cfg, nftau, over, nw, kmax=0, rounds=5, thermal=20000):
+def probe(cfg, nftau, over, nw, kmax=0, rounds=int(os.environ.get('PROBE_ROUNDS', 5)), thermal=20000):
     p, ps, pset = util.setup(cfg, nftau, over)
     q = MCTQMC(nwalkers=nw, walkers_per_bin=8, kmax=kmax)
     q.init_rnd(1); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)

@@ -1230,51 +1230,128 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
 // One wave per (bin, flavour).  The wave walks the chains of its bin; lanes take (creator, annihilator) pairs; every
 // lane runs the Legendre three-term recursion for its pair and accumulates m*P_l into NLEG register accumulators,
 // which are reduced across the wave once per launch and added to the bin's accumulator (no atomics: one owner).
-template <int NLEG_TILE>
-__global__ __launch_bounds__(64) void k_meas_gleg(DevConst C)
+//
+// Work list: the (creator, annihilator) pairs of all chains of the bin, flattened (prefix sums of k_w^2 in LDS, binary
+// search per element), two elements per lane and pass so that two independent recursions are in flight.
+// Recursion in the rescaled form R_l = P_l / alpha_l with alpha_{l+1} = b_l alpha_{l-1} (alpha_0 = alpha_1 = 1):
+//   P_{l+1} = a_l x P_l - b_l P_{l-1}  (a_l = (2l+1)/(l+1), b_l = l/(l+1);  CTQMC.F90:2371-2388)
+//   R_{l+1} = c_l x R_l - R_{l-1},  c_l = a_l alpha_l / alpha_{l+1}
+// i.e. one multiply, one FMA and one accumulate-FMA per order and pair; alpha_l is applied once per launch.
+template <int N> struct GlegAlpha {
+    double a[N];
+    constexpr GlegAlpha() : a{} { for (int l = 0; l < N; ++l) a[l] = l < 2 ? 1.0 : ((double)(l - 1) / (double)l) * a[l - 2]; }
+};
+__device__ __constant__ GlegAlpha<128> g_gleg_alpha = GlegAlpha<128>();
+constexpr int GLEG_RED_ROWS = 16, GLEG_RED_STRIDE = 65;      // LDS transpose tile of the end-of-launch reduction
+
+struct GlegRaw { double m, ta, tc; int j; };      // loads only, so that the next pass can be in flight during the recursion
+struct GlegElem { double m, x; int idt; };
+
+__device__ __forceinline__ GlegRaw gleg_fetch(const DevConst &C, int f, int wc, const int *pre, const int *kpre, int g, int total)
 {
+    GlegRaw r; r.m = 0.0; r.ta = 0.0; r.tc = 0.0; r.j = -1;
+    if (g < total) {
+        int j = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1) if (pre[j + step] <= g) j += step;
+        const int k = kpre[j], e = g - pre[j], kmax = C.kmax;
+        const int ic = (int)(((float)e + 0.5f) * __frcp_rn((float)k)), ia = e - ic * k;   // exact: e < 2^16, k <= 256
+        const size_t wf = (size_t)(wc + j) * C.nflav + f;
+        r.m = C.M[wf * kmax * kmax + (size_t)ic * kmax + ia];
+        r.ta = C.TA[wf * kmax + ia]; r.tc = C.TC[wf * kmax + ic];
+        r.j = j;
+    }
+    return r;
+}
+
+__device__ __forceinline__ GlegElem gleg_finish(const DevConst &C, const GlegRaw &r, const double *csl)
+{
+    GlegElem o; o.m = 0.0; o.x = 0.0; o.idt = -1;
+    if (r.j >= 0) {
+        double m = r.m, d = r.ta - r.tc;
+        if (!(d > 0.0)) { d = C.beta + r.ta - r.tc; m = -m; }
+        o.m = m * csl[r.j];
+        int idt = (int)(d / C.beta * (double)C.ntau) + 1;
+        o.idt = (idt > C.ntau ? C.ntau : idt) - 1;
+        o.x = 2.0 / C.beta * d - 1.0;
+    }
+    return o;
+}
+
+template <int NLEG_TILE>
+__global__ __launch_bounds__(64) void k_meas_gleg(DevConst C, int lds_hist)
+{
+    extern __shared__ double hist[];            // tau-bin histogram of this (bin, flavour): ntau doubles when lds_hist
+    __shared__ int pre[65], kpre[64];
+    __shared__ double csl[64];
     const int bin = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
-    const int kmax = C.kmax, nleg = C.nleg;
-    const double beta = C.beta;
+    const int nleg = C.nleg, ntau = C.ntau;
     double acc[NLEG_TILE];
 #pragma unroll
     for (int l = 0; l < NLEG_TILE; ++l) acc[l] = 0.0;
-    double *gt = C.acc_gtau + ((size_t)bin * C.nflav + f) * C.ntau;
-    int w0 = bin * C.walkers_per_bin, w1 = min(w0 + C.walkers_per_bin, C.nwalkers);
-    for (int w = w0; w < w1; ++w) {
-        int k = C.K[(size_t)w * C.nflav + f];
-        if (k == 0) continue;
-        const double *tcp = C.TC + ((size_t)w * C.nflav + f) * kmax, *tap = C.TA + ((size_t)w * C.nflav + f) * kmax;
-        const double *Mf = C.M + ((size_t)w * C.nflav + f) * kmax * kmax;
-        double cs = C.cfgsign[w];
-        for (int e = lane; e < k * k; e += 64) {
-            int ic = e / k, ia = e - ic * k;
-            double m = Mf[ic * kmax + ia];
-            double d = tap[ia] - tcp[ic];
-            if (!(d > 0.0)) { d = beta + tap[ia] - tcp[ic]; m = -m; }
-            m *= cs;
-            int idt = (int)(d / beta * (double)C.ntau) + 1;
-            if (idt > C.ntau) idt = C.ntau;
-            atomicAdd(&gt[idt - 1], m);
-            double xx = 2.0 / beta * d - 1.0;
-            double plm1 = 1.0, pl = xx;
-            acc[0] += m;
-            if (NLEG_TILE > 1) acc[1] += m * xx;
+    double *gt = C.acc_gtau + ((size_t)bin * C.nflav + f) * ntau;
+    if (lds_hist)
+        for (int i = lane; i < ntau; i += 64) hist[i] = 0.0;
+    const int w0 = bin * C.walkers_per_bin, w1 = min(w0 + C.walkers_per_bin, C.nwalkers);
+    for (int wc = w0; wc < w1; wc += 64) {
+        wave_sync();
+        int km = (wc + lane < w1) ? C.K[(size_t)(wc + lane) * C.nflav + f] : 0;
+        int incl = km * km;
 #pragma unroll
-            for (int il = 2; il < NLEG_TILE; ++il) {
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        pre[lane + 1] = incl; kpre[lane] = km;
+        csl[lane] = (wc + lane < w1) ? C.cfgsign[wc + lane] : 0.0;
+        if (lane == 0) pre[0] = 0;
+        wave_sync();
+        const int total = pre[64];
+        GlegRaw r0 = gleg_fetch(C, f, wc, pre, kpre, lane, total), r1 = gleg_fetch(C, f, wc, pre, kpre, 64 + lane, total);
+        for (int base = 0; base < total; base += 128) {
+            const GlegElem e0 = gleg_finish(C, r0, csl), e1 = gleg_finish(C, r1, csl);
+            r0 = gleg_fetch(C, f, wc, pre, kpre, base + 128 + lane, total);     // next pass: loads overlap the recursion
+            r1 = gleg_fetch(C, f, wc, pre, kpre, base + 192 + lane, total);
+#ifndef W2DYN_GLEG_NOHIST
+            if (e0.idt >= 0) { if (lds_hist) atomicAdd(&hist[e0.idt], e0.m); else atomicAdd(&gt[e0.idt], e0.m); }
+            if (e1.idt >= 0) { if (lds_hist) atomicAdd(&hist[e1.idt], e1.m); else atomicAdd(&gt[e1.idt], e1.m); }
+#endif
+            double p0 = 1.0, q0 = e0.x, p1 = 1.0, q1 = e1.x;      // R_{l-1}, R_l of the two elements
+            acc[0] += e0.m; acc[0] += e1.m;
+            if (NLEG_TILE > 1) { acc[1] = fma(e0.m, q0, acc[1]); acc[1] = fma(e1.m, q1, acc[1]); }
+            double alm1 = 1.0, al = 1.0;                           // alpha_{l-1}, alpha_l: folded at compile time
+#pragma unroll
+            for (int il = 2; il < NLEG_TILE; ++il) {               // orders >= nleg are computed but never stored
                 const int l = il - 1;
                 const double a = (2.0 * (double)l + 1.0) / (double)(l + 1), b = (double)l / (double)(l + 1);
-                double pn = a * xx * pl - b * plm1;
-                if (il < nleg) acc[il] += m * pn;
-                plm1 = pl; pl = pn;
+                const double aln = b * alm1, c = a * al / aln;
+                double n0 = fma(c * e0.x, q0, -p0), n1 = fma(c * e1.x, q1, -p1);
+                acc[il] = fma(e0.m, n0, acc[il]); acc[il] = fma(e1.m, n1, acc[il]);
+                p0 = q0; q0 = n0; p1 = q1; q1 = n1;
+                alm1 = al; al = aln;
             }
         }
     }
+    // cross-lane reduction of the NLEG accumulators through an LDS transpose, 16 orders at a time: lane = (order, quarter)
+    // sums 16 lanes' partials, two DPP steps finish the quarter sum.  (100 separate wave reductions cost ~6000 instr.)
     double *gl = C.acc_gleg + ((size_t)bin * C.nflav + f) * nleg;
+    double *red = hist + (lds_hist ? ntau : 0);
 #pragma unroll
-    for (int l = 0; l < NLEG_TILE; ++l) {
-        double v = wave_sum(acc[l]);
-        if (lane == 0 && l < nleg) gl[l] += v;
+    for (int c0 = 0; c0 < NLEG_TILE; c0 += GLEG_RED_ROWS) {
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < GLEG_RED_ROWS; ++i)
+            if (c0 + i < NLEG_TILE) red[i * GLEG_RED_STRIDE + lane] = acc[c0 + i];
+        wave_sync();
+        const int lo = lane >> 2, part = lane & 3;
+        double sres = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sres += red[lo * GLEG_RED_STRIDE + part * 16 + j];
+        sres += dpp_d<0xB1>(sres);          // quad_perm [1,0,3,2]
+        sres += dpp_d<0x4E>(sres);          // quad_perm [2,3,0,1]
+        const int l = c0 + lo;
+        if (part == 0 && l < nleg && l < NLEG_TILE) gl[l] += g_gleg_alpha.a[l] * sres;
+    }
+    if (lds_hist) {
+        wave_sync();
+        for (int i = lane; i < ntau; i += 64) { double h = hist[i]; if (h != 0.0) gt[i] += h; }
     }
 }
 

@@ -180,7 +180,9 @@ int check_walker_errors(w2dyn_solver *s)
 
 template <int T> void launch_gleg(w2dyn_solver *s)
 {
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_gleg<T>), dim3(s->C.nbins, s->nflav), dim3(64), 0, s->stream, s->C);
+    const int lds_hist = s->C.ntau <= 7000;       // tau histogram in LDS (< 64 KB with the reduction tile), else global atomics
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_gleg<T>), dim3(s->C.nbins, s->nflav), dim3(64),
+                       sizeof(double) * ((lds_hist ? s->C.ntau : 0) + GLEG_RED_ROWS * GLEG_RED_STRIDE), s->stream, s->C, lds_hist);
 }
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
