@@ -38,7 +38,7 @@ def _cpu_chain(args):
     from w2dynamics_amd import params, synth
     p = synth.config(WORKLOAD["config"], nftau=WORKLOAD["nftau"])
     over = dict(WORKLOAD["overrides"]); over.update(Nmeas=nmeas, Nwarmups=nwarm)
-    ps = params.make_pstring(over, beta=p.beta, Nd=p.nd)
+    ps = params.make_pstring(over, beta=p.beta, Nd=p.nd, Hamiltonian=p.hamiltonian, QuantumNumbers=p.quantum_numbers)
     try:
         import refdrive
         if not refdrive.available():
@@ -117,7 +117,7 @@ def main():
 
     over = WORKLOAD["overrides"]
     prob = synth.config(WORKLOAD["config"], nftau=WORKLOAD["nftau"])
-    ps = params.make_pstring(over, beta=prob.beta, Nd=prob.nd)
+    ps = params.make_pstring(over, beta=prob.beta, Nd=prob.nd, Hamiltonian=prob.hamiltonian, QuantumNumbers=prob.quantum_numbers)
     q = MCTQMC(device=local_rank, nwalkers=a.walkers, first_walker=rank * a.walkers, walkers_per_bin=a.walkers_per_bin)
     q.init_rnd(43890); q.init_paras(ps)
     q.init_solver(prob.umatrix, prob.ftau, prob.muimp, prob.screening, 1)

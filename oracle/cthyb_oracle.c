@@ -11,9 +11,11 @@
  *   Fock bit of flavour: (orb-1) + Nd*(spin-1)   (States.F90:198-199, 328-334)
  *   global-move flavour number i = orb + Nd*(spin-1)   (Trace.F90:2148-2151)
  *   ca: 1 = creator, 2 = annihilator              (Trace.F90:35-38)
- *   superstate index = Fock state integer (one state per block; States.F90:149-184 with "Nt Szt Azt")
+ *   superstate (block) index: order of first appearance of its quantum numbers over the Fock states 0..4^Nd-1
+ *   (States.F90:149-184); with "Nt Szt Azt" every block holds one state and the index is the Fock integer
  */
 #include "cthyb_oracle.h"
+#include "locprob.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -34,9 +36,12 @@ struct ora_walker {
     ora_params p;
     ora_rng *rng;
     int nflav, nstates;
+    ora_locprob *lp; int nsst;
     double *ftab;   /* [nflav][nftau] diagonal F(tau) */
-    double *E;      /* [nstates] <n|H_loc|n> */
+    double *E;      /* [nstates] eigenvalues of H_loc in block order (= lp->eval) */
     double Egs;
+    logval *ptr;    /* [nsmax] partial traces of the outer states (parttrace, Trace.F90:6118) */
+    double *dmblk; int *dmoff; int dmsize;   /* density matrix in the eigenbasis, block b at dmoff[b], [bra][ket] row major */
     /* configuration */
     op_t *ops; int nops, cap;
     double *M[MAXFLAV]; int k[MAXFLAV];
@@ -223,49 +228,10 @@ void ora_meas_flavour(const double *M, int k, const double *tau_c, const double 
 
 static inline int flav_bit(const ora_walker *w, int f) { return (f >> 1) + w->p.nd * (f & 1); }
 
-/* Connect(orb,spin,ca) of Operator.F90:145-197 for single-state blocks: new Fock state or -1 */
-static inline int connect(const ora_walker *w, int state, int f, int ca)
+/* Connect(orb,spin,ca) of block `sst` (Operator.F90:145-197): target block or -1 */
+static inline int connect(const ora_walker *w, int sst, int f, int ca)
 {
-    int bit = 1 << flav_bit(w, f);
-    if (ca == 1) return (state & bit) ? -1 : (state | bit);
-    return (state & bit) ? (state & ~bit) : -1;
-}
-
-/* fermionic sign of c/c+ acting on `state` (Operator.F90:158-171): (-1)^(occupied bits below the flavour's bit) */
-static inline double fsign(const ora_walker *w, int state, int f)
-{
-    int b = flav_bit(w, f);
-    int below = state & ((1 << b) - 1);
-    return (__builtin_popcount((unsigned)below) & 1) ? -1.0 : 1.0;
-}
-
-/* diagonal of H_loc = sum muimp c+c + 1/2 sum U_1234 c+1 c+2 c4 c3  (Operator.F90:482-542, 1042-1107) */
-static int build_energies(ora_walker *w, const double *U, const double *mu_full)
-{
-    int nf = w->nflav, nd = w->p.nd;
-    /* refuse anything that is not density-density: every U element that can connect different Fock states */
-    for (int a = 0; a < nf; ++a) for (int b = 0; b < nf; ++b) for (int c = 0; c < nf; ++c) for (int d = 0; d < nf; ++d) {
-        double u = U[((a * nf + b) * nf + c) * nf + d];
-        if (u == 0.0) continue;
-        int diag = (a == c && b == d) || (a == d && b == c);
-        if (!diag && a != b && c != d) return 1;
-    }
-    for (int b1 = 0; b1 < nd; ++b1) for (int s1 = 0; s1 < 2; ++s1) for (int b2 = 0; b2 < nd; ++b2) for (int s2 = 0; s2 < 2; ++s2)
-        if ((b1 != b2 || s1 != s2) && mu_full[((b1 * 2 + s1) * nd + b2) * 2 + s2] != 0.0) return 1;
-    for (int st = 0; st < w->nstates; ++st) {
-        double e = 0.0;
-        for (int f = 0; f < nf; ++f) {
-            if (!(st >> flav_bit(w, f) & 1)) continue;
-            int b = f >> 1, s = f & 1;
-            e += mu_full[((b * 2 + s) * nd + b) * 2 + s];
-            for (int g = 0; g < nf; ++g) {
-                if (g == f || !(st >> flav_bit(w, g) & 1)) continue;
-                e += 0.5 * (U[((f * nf + g) * nf + f) * nf + g] - U[((f * nf + g) * nf + g) * nf + f]);
-            }
-        }
-        w->E[st] = e;
-    }
-    return 0;
+    return ora_lp_conn(w->lp, sst, f, ca);
 }
 
 /* ------------------------------------------------------------------------------------------------------- */
@@ -316,22 +282,96 @@ static int sequence_valid(const ora_walker *w, int outer)
     return s == outer;
 }
 
-/* scalar local trace from scratch: Trace.F90:5556-5727 with FullR/FullL */
-static logval full_trace(const ora_walker *w, int outer)
+static logval lv_add(logval a, logval b)       /* addLogTr, Trace.F90:298-309 */
 {
-    logval t = { 0.0, 1.0 };
-    int s = outer; double tprev = 0.0;
-    for (int i = 0; i < w->nops; ++i) {
-        t.log += -(w->E[s] - w->Egs) * (w->ops[i].tau - tprev);
-        t.sign *= fsign(w, s, w->ops[i].flav);
-        s = connect(w, s, w->ops[i].flav, w->ops[i].ca);
-        if (s < 0) { t.log = -HUGE_VAL; t.sign = 0.0; return t; }
-        tprev = w->ops[i].tau;
-    }
-    if (s != outer) { t.log = -HUGE_VAL; t.sign = 0.0; return t; }
-    t.log += -(w->E[s] - w->Egs) * (w->p.beta - tprev);
-    return t;
+    logval r;
+    if (a.sign == 0.0) return b;
+    if (b.sign == 0.0) return a;
+    if (a.log >= b.log) { r.log = a.log + log(1.0 + a.sign * b.sign * exp(b.log - a.log)); r.sign = a.sign; }
+    else { r.log = b.log + log(1.0 + a.sign * b.sign * exp(a.log - b.log)); r.sign = b.sign; }
+    return r;
 }
+
+static void split_log(double *v, int n, double *lf)   /* Trace.F90:5341-5348 */
+{
+    double mv = 0.0;
+    for (int i = 0; i < n; ++i) if (fabs(v[i]) > mv) mv = fabs(v[i]);
+    if (mv > 0.0) for (int i = 0; i < n; ++i) v[i] /= mv;
+    *lf += log(mv);
+}
+
+/* one step of the ket propagation: exp(-dt H) in block sst, then the operator (Trace.F90:5802-5829);
+ * v has n(sst) entries on entry and n(target) on exit; returns the target block */
+static int propagate(const ora_walker *w, int sst, double dt, int f, int ca, double *v, double *lf)
+{
+    const ora_locprob *lp = w->lp;
+    int n = lp->sst_n[sst], nsst = connect(w, sst, f, ca);
+    if (nsst < 0) return -1;
+    int nn = lp->sst_n[nsst];
+    const double *E = lp->eval + lp->sst_off[sst], *O = ora_lp_op(lp, sst, f, ca);
+    double tmp[64], out[64];
+    if (n > 1) {
+        for (int i = 0; i < n; ++i) tmp[i] = exp(-(E[i] - E[0]) * dt) * v[i];
+        *lf += -(E[0] - w->Egs) * dt;
+        split_log(tmp, n, lf);
+        for (int i = 0; i < nn; ++i) { double a = 0.0; for (int j = 0; j < n; ++j) a += O[i + nn * j] * tmp[j]; out[i] = a; }
+        split_log(out, nn, lf);
+    } else {
+        *lf += -(E[0] - w->Egs) * dt;
+        for (int i = 0; i < nn; ++i) out[i] = v[0] * O[i];
+    }
+    for (int i = 0; i < nn; ++i) v[i] = out[i];
+    return nsst;
+}
+
+/* local trace from scratch (FullR/FullL): scalar path Trace.F90:5556-5727 when every block holds one state,
+ * matrix path Trace.F90:5734-6033 otherwise (sum over the states of the outer block).  If part != NULL it receives
+ * the partial traces (tparttrace). */
+static logval full_trace_part(const ora_walker *w, int outer, logval *part)
+{
+    const ora_locprob *lp = w->lp;
+    logval zero = { -HUGE_VAL, 0.0 };
+    if (lp->nsmax == 1) {
+        logval t = { 0.0, 1.0 };
+        int s = outer; double tprev = 0.0;
+        for (int i = 0; i < w->nops; ++i) {
+            int ns = connect(w, s, w->ops[i].flav, w->ops[i].ca);
+            if (ns < 0) return zero;
+            double o11 = ora_lp_op(lp, s, w->ops[i].flav, w->ops[i].ca)[0];
+            t.log += -(lp->eval[lp->sst_off[s]] - w->Egs) * (w->ops[i].tau - tprev);
+            t.log += log(fabs(o11));
+            t.sign *= (o11 < 0.0) ? -1.0 : 1.0;
+            s = ns; tprev = w->ops[i].tau;
+        }
+        if (s != outer) return zero;
+        t.log += -(lp->eval[lp->sst_off[s]] - w->Egs) * (w->p.beta - tprev);
+        if (part) part[0] = t;
+        return t;
+    }
+    logval tot = zero;
+    int nout = lp->sst_n[outer];
+    for (int st = 0; st < nout; ++st) {
+        double v[64]; double lf = 0.0;
+        for (int i = 0; i < nout; ++i) v[i] = (i == st) ? 1.0 : 0.0;
+        int s = outer; double tprev = 0.0;
+        for (int i = 0; i < w->nops; ++i) {
+            s = propagate(w, s, w->ops[i].tau - tprev, w->ops[i].flav, w->ops[i].ca, v, &lf);
+            if (s < 0) return zero;
+            tprev = w->ops[i].tau;
+        }
+        if (s != outer) return zero;
+        const double *E = lp->eval + lp->sst_off[s];
+        double bk = exp(-(E[st] - E[0]) * (w->p.beta - tprev)) * v[st];     /* <st| exp(-(beta-t)H) |ket> */
+        lf += -(E[0] - w->Egs) * (w->p.beta - tprev);
+        logval pt;
+        if (bk == 0.0) { pt = zero; } else { pt.log = lf + log(fabs(bk)); pt.sign = bk < 0.0 ? -1.0 : 1.0; }
+        if (part) part[st] = pt;
+        tot = lv_add(tot, pt);
+    }
+    return tot;
+}
+
+static logval full_trace(const ora_walker *w, int outer) { return full_trace_part(w, outer, NULL); }
 
 /* Trace.F90:3594-3618 */
 static double block_sign(const ora_walker *w)
@@ -636,7 +676,7 @@ static void apply_global(ora_walker *w, const int *gu)
 /* Trace.F90:1402-1433 check_qn_all_ssts */
 static int check_all_ssts(const ora_walker *w, int *ssts)
 {
-    int n = w->nstates, possible = n;
+    int n = w->nsst, possible = n;
     for (int k = 0; k < n; ++k) ssts[k] = k;
     for (int i = 0; i < w->nops; ++i) {
         for (int k = 0; k < n; ++k) {
@@ -678,12 +718,13 @@ static void step_glob(ora_walker *w)
     memcpy(saved, w->ops, sizeof(op_t) * (size_t)w->nops);
     double sst_factor;
     if (spinflip && w->p.has_szt) {                  /* perform_spinflip_check_qn, Trace.F90:1306-1339 */
-        int down = outer_old & ((1 << nd) - 1), up = (outer_old >> nd) & ((1 << nd) - 1);
-        w->outer_sst = up | (down << nd);
+        int old_state = w->lp->states[w->lp->sst_off[outer_old]];        /* first Fock state of the block */
+        int down = old_state & ((1 << nd) - 1), up = (old_state >> nd) & ((1 << nd) - 1);
+        w->outer_sst = w->lp->sst_of_state[up | (down << nd)];
         apply_global(w, gu);
         sst_factor = sequence_valid(w, w->outer_sst) ? 1.0 : 0.0;
     } else {                                         /* perform_global_check_qn, Trace.F90:1345-1394 */
-        int *so = (int *)malloc(sizeof(int) * (size_t)w->nstates), *sn = (int *)malloc(sizeof(int) * (size_t)w->nstates);
+        int *so = (int *)malloc(sizeof(int) * (size_t)w->nsst), *sn = (int *)malloc(sizeof(int) * (size_t)w->nsst);
         int pold = check_all_ssts(w, so);
         if (pold <= 0) { fprintf(stderr, "impossible old configuration\n"); abort(); }
         apply_global(w, gu);
@@ -692,7 +733,7 @@ static void step_glob(ora_walker *w)
         else {
             sst_factor = (double)pnew / (double)pold;
             int kk = RINT(w, 1, pnew);
-            for (int i = 0; i < w->nstates; ++i) if (sn[i] != -1) { if (--kk <= 0) { w->outer_sst = sn[i]; break; } }
+            for (int i = 0; i < w->nsst; ++i) if (sn[i] != -1) { if (--kk <= 0) { w->outer_sst = sn[i]; break; } }
         }
         free(so); free(sn);
     }
@@ -721,19 +762,24 @@ static void step_glob(ora_walker *w)
 }
 
 /* CTQMC.F90:4570-4638 StepChangeOuter (no state sampling): draw the outer superstate of the empty configuration */
-static void step_change_outer(ora_walker *w)
+static int draw_outer(ora_walker *w)
 {
-    int n = w->nstates; double sum = 0.0;
+    int n = w->nsst; double sum = 0.0;
     double *v = (double *)malloc(sizeof(double) * (size_t)n);
-    for (int s = 0; s < n; ++s) { v[s] = exp(-(w->E[s] - w->Egs) * w->p.beta); sum += v[s]; }
+    for (int s = 0; s < n; ++s) { logval t = full_trace_part(w, s, NULL); v[s] = t.sign * exp(t.log); sum += v[s]; }
     for (int s = 0; s < n; ++s) v[s] /= sum;
     double r = U01(w), acc = 0.0;
     int sel = n - 1;
     for (int s = 0; s < n; ++s) { acc += v[s]; sel = s; if (acc >= r && v[s] != 0.0) break; }
-    w->outer_sst = sel;
-    w->tr = full_trace(w, sel);
-    w->cfgsign = -get_sign(w);
     free(v);
+    return sel;
+}
+
+static void step_change_outer(ora_walker *w)
+{
+    w->outer_sst = draw_outer(w);
+    w->tr = full_trace(w, w->outer_sst);
+    w->cfgsign = -get_sign(w);
 }
 
 /* CTQMC.F90:4641-4835 StepShiftTau_proper + Trace.F90:2355-2457 */
@@ -833,10 +879,16 @@ ora_walker *ora_create(const ora_params *p, const double *U, const double *ftau_
     w->p = *p; w->rng = rng;
     w->nflav = 2 * p->nd; w->nstates = 1 << (2 * p->nd);
     if (w->nflav > MAXFLAV) { free(w); return NULL; }
-    w->E = (double *)calloc((size_t)w->nstates, sizeof(double));
-    if (build_energies(w, U, mu_full)) { free(w->E); free(w); return NULL; }
-    w->Egs = w->E[0];
-    for (int s = 0; s < w->nstates; ++s) if (w->E[s] < w->Egs) w->Egs = w->E[s];   /* Trace.F90:576-583 */
+    w->lp = ora_locprob_build(p->nd, U, mu_full, p->qns, p->epsevec);
+    if (!w->lp || w->lp->nsmax > 64) { ora_locprob_free(w->lp); free(w); return NULL; }
+    w->nsst = w->lp->nsst;
+    w->E = w->lp->eval;
+    w->Egs = w->lp->egs;                                                            /* Trace.F90:576-583 */
+    w->ptr = (logval *)calloc((size_t)w->lp->nsmax, sizeof(logval));
+    w->dmoff = (int *)calloc((size_t)w->nsst + 1, sizeof(int));
+    for (int b = 0; b < w->nsst; ++b) w->dmoff[b + 1] = w->dmoff[b] + w->lp->sst_n[b] * w->lp->sst_n[b];
+    w->dmsize = w->dmoff[w->nsst];
+    w->dmblk = (double *)calloc((size_t)w->dmsize, sizeof(double));
     int nd = p->nd, nft = p->nftau;
     w->ftab = (double *)malloc(sizeof(double) * (size_t)w->nflav * nft);
     for (int b = 0; b < nd; ++b) for (int s = 0; s < 2; ++s)                        /* CTQMC.F90:7950-7955 */
@@ -854,16 +906,7 @@ ora_walker *ora_create(const ora_params *p, const double *U, const double *ftau_
     w->cfgsign = -1.0;                                                              /* Trace.F90:129 */
     init_window(w, p->taudiffmax);                                                  /* Trace.F90:605 */
     /* initial outer superstate ~ empty-trace weight, Trace.F90:644-665 */
-    {
-        int n = w->nstates; double sum = 0.0;
-        double *v = (double *)malloc(sizeof(double) * (size_t)n);
-        for (int s = 0; s < n; ++s) { v[s] = exp(-(w->E[s] - w->Egs) * p->beta); sum += v[s]; }
-        for (int s = 0; s < n; ++s) v[s] /= sum;
-        double r = U01(w), acc = 0.0; int sel = n - 1;
-        for (int s = 0; s < n; ++s) { acc += v[s]; sel = s; if (acc >= r && v[s] != 0.0) break; }
-        w->outer_sst = sel;
-        free(v);
-    }
+    w->outer_sst = draw_outer(w);
     w->tr = full_trace(w, w->outer_sst);
     {   /* CTQMC.F90:8069 */
         int a = 2 * nd, b = (int)floor((double)p->ncorr / (double)w->num_windows);
@@ -877,7 +920,7 @@ void ora_destroy(ora_walker *w)
 {
     if (!w) return;
     for (int f = 0; f < w->nflav; ++f) free(w->M[f]);
-    free(w->ops); free(w->ftab); free(w->E); free(w->accpair); free(w->gleg); free(w->gtau); free(w->giw);
+    free(w->ops); free(w->ftab); ora_locprob_free(w->lp); free(w->ptr); free(w->dmblk); free(w->dmoff); free(w->accpair); free(w->gleg); free(w->gtau); free(w->giw);
     free(w->histo); free(w->dm); free(w->outer_histo); free(w);
 }
 
@@ -896,6 +939,53 @@ void ora_sweep(ora_walker *w, int64_t nsteps)
     for (int64_t i = 0; i < nsteps; ++i) { w->cnt_sampling += 1; one_step(w); }
 }
 
+/* MeasDensityMatrix_beta_half, CTQMC.F90:3088-3151 with update_b2_states_eb, Trace.F90:6213-6470: for every state of
+ * the outer block the ket is propagated from 0 to beta/2 through the operators with tau <= beta/2, the bra from beta
+ * down to beta/2; rho(bra index, ket index) += -cfgsign * sign(tr) * bra x ket * exp(lk + lb - log|tr|) */
+static void meas_densitymatrix(ora_walker *w)
+{
+    const ora_locprob *lp = w->lp;
+    const double b2 = w->p.beta / 2.0;
+    int outer = w->outer_sst, nout = lp->sst_n[outer];
+    if (w->nops == 0) {
+        full_trace_part(w, outer, w->ptr);           /* parttrace of the current (accepted) configuration */
+        for (int st = 0; st < nout; ++st) {
+            double r = w->ptr[st].sign * w->tr.sign * exp(w->ptr[st].log - w->tr.log);
+            w->dmblk[w->dmoff[outer] + st * nout + st] -= w->cfgsign * r;
+        }
+        return;
+    }
+    int nk = 0; while (nk < w->nops && w->ops[nk].tau <= b2) ++nk;
+    for (int st = 0; st < nout; ++st) {
+        double ket[64], bra[64], lk = 0.0, lb = 0.0;
+        for (int i = 0; i < nout; ++i) ket[i] = bra[i] = (i == st) ? 1.0 : 0.0;
+        int s = outer; double tp = 0.0;
+        for (int i = 0; i < nk; ++i) { s = propagate(w, s, w->ops[i].tau - tp, w->ops[i].flav, w->ops[i].ca, ket, &lk); tp = w->ops[i].tau; }
+        {
+            int n = lp->sst_n[s]; const double *E = lp->eval + lp->sst_off[s];
+            for (int i = 0; i < n; ++i) ket[i] *= exp(-(E[i] - E[0]) * (b2 - tp));
+            split_log(ket, n, &lk);
+            lk += -(E[0] - w->Egs) * (b2 - tp);
+        }
+        int sk = s;
+        s = outer; tp = w->p.beta;
+        for (int i = w->nops - 1; i >= nk; --i) {     /* bra: the operator acts with the other type (Trace.F90:5927) */
+            s = propagate(w, s, tp - w->ops[i].tau, w->ops[i].flav, 3 - w->ops[i].ca, bra, &lb); tp = w->ops[i].tau;
+        }
+        {
+            int n = lp->sst_n[s]; const double *E = lp->eval + lp->sst_off[s];
+            for (int i = 0; i < n; ++i) bra[i] *= exp(-(E[i] - E[0]) * (tp - b2));
+            split_log(bra, n, &lb);
+            lb += -(E[0] - w->Egs) * (tp - b2);
+        }
+        if (s != sk) { fprintf(stderr, "beta/2 blocks differ\n"); abort(); }
+        int n = lp->sst_n[s];
+        double fac = -w->cfgsign * w->tr.sign * exp(lk + lb - w->tr.log);
+        for (int i1 = 0; i1 < n; ++i1) for (int i2 = 0; i2 < n; ++i2)
+            w->dmblk[w->dmoff[s] + i1 * n + i2] += bra[i1] * fac * ket[i2];
+    }
+}
+
 void ora_measure_once(ora_walker *w)
 {
     int nf = w->nflav;
@@ -906,12 +996,7 @@ void ora_measure_once(ora_walker *w)
         int k = w->k[f], last = w->p.maxhisto;
         w->histo[(size_t)f * (last + 1) + (k < last ? k : last)] += 1.0;
     }
-    {   /* MeasDensityMatrix_beta_half, CTQMC.F90:3088-3151 with Trace.F90:6213-6470 (scalar case): the state alive
-         * at beta/2, weight -cfgsign * sign(bra)sign(ket)/sign(trace) = -cfgsign */
-        int s = w->outer_sst;
-        for (int i = 0; i < w->nops && w->ops[i].tau <= w->p.beta / 2.0; ++i) s = connect(w, s, w->ops[i].flav, w->ops[i].ca);
-        w->dm[s] += -w->cfgsign;
-    }
+    meas_densitymatrix(w);
     for (int f = 0; f < nf; ++f) {                                      /* MeasGtauRem + measure_giw_nfft */
         int k = w->k[f];
         if (k == 0) continue;
@@ -928,13 +1013,37 @@ void ora_measure_once(ora_walker *w)
     }
 }
 
+/* Transform_DensityMatrix_EB_to_OCCB (CTQMC.F90:3163-3179): Evec rho Evec^T per block; keeps the diagonal in w->dm */
+static void dm_occbasis(const ora_walker *w, int b, double *out)
+{
+    const ora_locprob *lp = w->lp; int n = lp->sst_n[b];
+    const double *R = w->dmblk + w->dmoff[b], *V = lp->evec[b];
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+        double a = 0.0;
+        for (int k = 0; k < n; ++k) for (int l = 0; l < n; ++l) a += V[i + n * k] * R[k * n + l] * V[j + n * l];
+        out[i * n + j] = a;
+    }
+}
+
+static void finish_densitymatrix(ora_walker *w)
+{
+    const ora_locprob *lp = w->lp;
+    double tmp[64 * 64];
+    for (int b = 0; b < lp->nsst; ++b) {
+        int n = lp->sst_n[b];
+        dm_occbasis(w, b, tmp);
+        for (int i = 0; i < n; ++i) w->dm[lp->sst_off[b] + i] = tmp[i * n + i];
+    }
+}
+
 void ora_measure_finish(ora_walker *w)
 {
     int nf = w->nflav; double beta = w->p.beta;
     if (w->cnt_meas == 0) { w->aborted = 2; return; }
     w->mean_sign = w->meas_sign / (double)w->cnt_sign;                                  /* CTQMC.F90:8670 */
     double zs = -1.0 / (w->cnt_meas * w->mean_sign);                                     /* 8697 */
-    for (int s = 0; s < w->nstates; ++s) w->dm[s] *= zs;                                /* 8706-8708 */
+    for (int i = 0; i < w->dmsize; ++i) w->dmblk[i] *= zs;                              /* 8706-8708 */
+    finish_densitymatrix(w);
     for (size_t i = 0; i < (size_t)nf * w->p.ntau; ++i)                                 /* 8726-8731 */
         w->gtau[i] = -(w->gtau[i] / w->cnt_meas) / (-w->mean_sign) * (double)w->p.ntau / (beta * beta);
     for (size_t i = 0; i < (size_t)nf * (w->p.maxhisto + 1); ++i) w->histo[i] /= w->cnt_meas;   /* 8755 */
@@ -1011,6 +1120,70 @@ void ora_get_densitymatrix_diag(const ora_walker *w, double *o) { memcpy(o, w->d
 void ora_get_outer_histo(const ora_walker *w, double *o) { memcpy(o, w->outer_histo, sizeof(double) * (size_t)w->nstates); }
 void ora_get_accpair(const ora_walker *w, int64_t *o) { memcpy(o, w->accpair, sizeof(int64_t) * (size_t)w->nflav * w->p.ntau); }
 void ora_get_energies(const ora_walker *w, double *o) { memcpy(o, w->E, sizeof(double) * (size_t)w->nstates); }
+int ora_nsst(const ora_walker *w) { return w->nsst; }
+int ora_nsmax(const ora_walker *w) { return w->lp->nsmax; }
+void ora_get_blocks(const ora_walker *w, int *n, int *off, int *st)
+{
+    memcpy(n, w->lp->sst_n, sizeof(int) * (size_t)w->nsst); memcpy(off, w->lp->sst_off, sizeof(int) * (size_t)w->nsst);
+    memcpy(st, w->lp->states, sizeof(int) * (size_t)w->nstates);
+}
+void ora_get_densitymatrix(const ora_walker *w, double *o)
+{
+    const ora_locprob *lp = w->lp; size_t N = (size_t)w->nstates;
+    double tmp[64 * 64];
+    memset(o, 0, sizeof(double) * N * N);
+    for (int b = 0; b < lp->nsst; ++b) {
+        int n = lp->sst_n[b], off = lp->sst_off[b];
+        dm_occbasis(w, b, tmp);
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) o[(size_t)(off + i) * N + off + j] = tmp[i * n + j];
+    }
+}
+
+/* <A> = sum_blocks tr(rho_b A_bb) for operator strings given as (flavour, ca) applied right to left, evaluated in the
+ * eigenbasis like Meas*_from_Densitymatrix (CTQMC.F90:2842-3060) */
+static double dm_expect(const ora_walker *w, int nop, const int *fl, const int *ca)
+{
+    const ora_locprob *lp = w->lp; double tot = 0.0;
+    for (int b = 0; b < lp->nsst; ++b) {
+        int n = lp->sst_n[b];
+        for (int col = 0; col < n; ++col) {            /* A |col> */
+            double v[64], out[64]; int s = b, ok = 1;
+            for (int i = 0; i < n; ++i) v[i] = (i == col) ? 1.0 : 0.0;
+            for (int q = 0; q < nop && ok; ++q) {
+                int t = connect(w, s, fl[q], ca[q]);
+                if (t < 0) { ok = 0; break; }
+                int ns = lp->sst_n[s], nt = lp->sst_n[t]; const double *O = ora_lp_op(lp, s, fl[q], ca[q]);
+                for (int i = 0; i < nt; ++i) { double a = 0.0; for (int j = 0; j < ns; ++j) a += O[i + nt * j] * v[j]; out[i] = a; }
+                for (int i = 0; i < nt; ++i) v[i] = out[i];
+                s = t;
+            }
+            if (!ok || s != b) continue;
+            for (int row = 0; row < n; ++row) tot += w->dmblk[w->dmoff[b] + col * n + row] * v[row];   /* rho(col,row) A(row,col) */
+        }
+    }
+    return tot;
+}
+
+void ora_get_occ(const ora_walker *w, double *occ, double *rho1, double *rho2)
+{
+    int nf = w->nflav;
+    for (int f1 = 0; f1 < nf; ++f1) for (int f2 = 0; f2 < nf; ++f2) {
+        {   /* occ(b1,s1,b2,s2) = <c+_1 c_1 c+_2 c_2> (2884-2942) */
+            int fl[4] = { f2, f2, f1, f1 }, ca[4] = { 2, 1, 2, 1 };
+            occ[f1 * nf + f2] = dm_expect(w, 4, fl, ca);
+        }
+        {   /* rho1(f2, f1) = <c+_2 c_1> (3020-3060) */
+            int fl[2] = { f1, f2 }, ca[2] = { 2, 1 };
+            rho1[f2 * nf + f1] = dm_expect(w, 2, fl, ca);
+        }
+    }
+    if (rho2)
+        for (int f1 = 0; f1 < nf; ++f1) for (int f2 = 0; f2 < nf; ++f2) for (int f3 = 0; f3 < nf; ++f3) for (int f4 = 0; f4 < nf; ++f4) {
+            /* rho2(f4,f3,f2,f1) = <c+_4 c+_3 c_2 c_1> (2945-3017) */
+            int fl[4] = { f1, f2, f3, f4 }, ca[4] = { 2, 2, 1, 1 };
+            rho2[((f4 * nf + f3) * nf + f2) * nf + f1] = dm_expect(w, 4, fl, ca);
+        }
+}
 double ora_mean_sign(const ora_walker *w) { return w->mean_sign; }
 void ora_get_counters(const ora_walker *w, double *o)
 {

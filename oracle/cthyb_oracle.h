@@ -1,7 +1,8 @@
 /* TEST INFRASTRUCTURE ONLY (oracle): CPU restatement of the reference CT-HYB hot path.
  *
- * Single Markov chain, density-density local problem (every block of H_loc holds one Fock state: the
- * reference's "scalar" trace path, Trace.F90:5556-5727), diagonal hybridisation.  Plain arrays instead of the
+ * Single Markov chain, diagonal hybridisation.  Local problem: blocks of H_loc from the QuantumNumbers string
+ * (locprob.h); one-state blocks use the reference's "scalar" trace path (Trace.F90:5556-5727), larger blocks the
+ * matrix path (Trace.F90:5734-6033).  Plain arrays instead of the
  * reference's linked lists; the move logic, proposal volumes, acceptance ratios, random-number consumption
  * order and estimator arithmetic follow the reference function by function (citations in cthyb_oracle.c).
  *
@@ -38,14 +39,15 @@ typedef struct ora_params {
     double p_shift;         /* PercentageTauShiftMove */
     double taudiffmax;      /* TaudiffMax from the parameter string (window at init_solver, NSlide) */
     int has_szt;            /* "Szt" in QuantumNumbers (CTQMC.F90 glob_has_Szt) */
+    char qns[64];           /* QuantumNumbers string (States.F90:164) */
+    double epsevec;         /* EPSEVEC (Operator.F90:784) */
 } ora_params;
 
 typedef struct ora_walker ora_walker;
 
-/* init_solver (CTQMC.F90:7894-8085) for the density-density scalar case.
+/* init_solver (CTQMC.F90:7894-8085).
  * umatrix (2Nd)^4, ftau_full (Nd,2,Nd,2,Nftau), muimp_full (Nd,2,Nd,2) [already negated], C order.
- * Consumes one uniform() for the initial outer superstate (Trace.F90:657-663). Returns NULL when the local
- * Hamiltonian is not diagonal in the occupation basis. */
+ * Consumes one uniform() for the initial outer superstate (Trace.F90:657-663). Returns NULL on failure. */
 ora_walker *ora_create(const ora_params *p, const double *umatrix, const double *ftau_full,
                        const double *muimp_full, ora_rng *rng);
 void ora_destroy(ora_walker *w);
@@ -75,8 +77,14 @@ void ora_get_gleg(const ora_walker *w, double *out);      /* (Nd,2,NLegMax) */
 void ora_get_gtau(const ora_walker *w, double *out);      /* (Nd,2,Ntau) */
 void ora_get_giw(const ora_walker *w, double *out_reim);  /* (Nd,2,2Niw) complex interleaved */
 void ora_get_histo(const ora_walker *w, double *out);     /* (Nd,2,MaxHisto+1) */
-void ora_get_densitymatrix_diag(const ora_walker *w, double *out);  /* 4^Nd */
-void ora_get_outer_histo(const ora_walker *w, double *out);         /* 4^Nd */
+void ora_get_densitymatrix_diag(const ora_walker *w, double *out);  /* 4^Nd, occupation basis, block order */
+void ora_get_densitymatrix(const ora_walker *w, double *out);       /* (4^Nd)^2 row major, occupation basis, block order
+                                                                       (after Transform_DensityMatrix_EB_to_OCCB, CTQMC.F90:3163) */
+void ora_get_outer_histo(const ora_walker *w, double *out);         /* first nsst entries: OuterSuperstateHisto */
+int ora_nsst(const ora_walker *w);
+int ora_nsmax(const ora_walker *w);
+void ora_get_blocks(const ora_walker *w, int *sst_n, int *sst_off, int *states);  /* [nsst],[nsst],[4^Nd] */
+void ora_get_occ(const ora_walker *w, double *occ, double *rho1, double *rho2);   /* (Nd,2,Nd,2), (2Nd)^2, (2Nd)^4: CTQMC.F90:2884-3060 */
 void ora_get_accpair(const ora_walker *w, int64_t *out);  /* (Nd,2,Ntau) */
 void ora_get_energies(const ora_walker *w, double *out);  /* 4^Nd eigenstate energies */
 double ora_mean_sign(const ora_walker *w);

@@ -18,7 +18,7 @@ class OraParams(C.Structure):
     _fields_ = [("nd", C.c_int), ("beta", C.c_double), ("nftau", C.c_int), ("ntau", C.c_int), ("nlegmax", C.c_int),
                 ("niw", C.c_int), ("meas_giw", C.c_int), ("ncorr", C.c_int), ("nmeas", C.c_int64),
                 ("maxhisto", C.c_int), ("p_glob", C.c_double), ("p_shift", C.c_double), ("taudiffmax", C.c_double),
-                ("has_szt", C.c_int)]
+                ("has_szt", C.c_int), ("qns", C.c_char * 64), ("epsevec", C.c_double)]
 
 
 def build():
@@ -58,6 +58,11 @@ def lib():
     L.ora_get_state.argtypes = [vp] + [C.POINTER(C.c_double)] * 5 + [C.POINTER(C.c_int)] * 2
     for n in ("gleg", "gtau", "giw", "histo", "densitymatrix_diag", "outer_histo", "energies"):
         getattr(L, "ora_get_" + n).argtypes = [vp, dp]
+    L.ora_get_densitymatrix.argtypes = [vp, dp]
+    L.ora_nsst.argtypes = [vp]; L.ora_nsst.restype = C.c_int
+    L.ora_nsmax.argtypes = [vp]; L.ora_nsmax.restype = C.c_int
+    L.ora_get_blocks.argtypes = [vp, ip, ip, ip]
+    L.ora_get_occ.argtypes = [vp, dp, dp, C.c_void_p]
     L.ora_get_accpair.argtypes = [vp, lp]
     L.ora_get_counters.argtypes = [vp, dp]
     L.ora_mean_sign.argtypes = [vp]; L.ora_mean_sign.restype = C.c_double
@@ -79,7 +84,8 @@ def params_from_pstring(ps, nd, beta):
                      nlegmax=ps.get_int("NLegMax"), niw=ps.get_int("Niw"), meas_giw=ps.get_int("MeasGiw"),
                      ncorr=ps.get_int("NCorr"), nmeas=ps.get_int("Nmeas"), maxhisto=ps.get_int("MaxHisto"),
                      p_glob=ps.get_real("PercentageGlobalMove"), p_shift=ps.get_real("PercentageTauShiftMove"),
-                     taudiffmax=ps.get_real("TaudiffMax"), has_szt=int("Szt" in ps.get_str("QuantumNumbers")))
+                     taudiffmax=ps.get_real("TaudiffMax"), has_szt=int("Szt" in ps.get_str("QuantumNumbers")),
+                     qns=ps.get_str("QuantumNumbers").encode()[:63], epsevec=ps.get_real("EPSEVEC"))
 
 
 class OracleWalker:
@@ -96,7 +102,8 @@ class OracleWalker:
         self.nd = problem.nd
         self.h = self.L.ora_create(C.byref(self.p), problem.umatrix, problem.ftau, problem.muimp, self.rng)
         if not self.h:
-            raise ValueError("oracle: local Hamiltonian is not density-density")
+            raise ValueError("oracle: local problem could not be built")
+        self.nsst = self.L.ora_nsst(self.h); self.nsmax = self.L.ora_nsmax(self.h)
 
     def set_taudiffmax(self, x): self.L.ora_set_taudiffmax(self.h, float(x))
     def warmup(self, n): self.L.ora_warmup(self.h, int(n))
@@ -141,13 +148,25 @@ class OracleWalker:
         a = np.zeros((nd, 2, 2 * p.niw, 2)); self.L.ora_get_giw(self.h, a); r["giw"] = a[..., 0] + 1j * a[..., 1]
         a = np.zeros((nd, 2, p.maxhisto + 1)); self.L.ora_get_histo(self.h, a); r["histo"] = a
         a = np.zeros(4 ** nd); self.L.ora_get_densitymatrix_diag(self.h, a); r["dm_diag"] = a
-        a = np.zeros(4 ** nd); self.L.ora_get_outer_histo(self.h, a); r["outersuperstatehisto"] = a
+        a = np.zeros(4 ** nd); self.L.ora_get_outer_histo(self.h, a); r["outersuperstatehisto"] = a[:self.nsst].copy()
         a = np.zeros(4 ** nd); self.L.ora_get_energies(self.h, a); r["eigenstatesenergies"] = a
         a = np.zeros((nd, 2, p.ntau), np.int64); self.L.ora_get_accpair(self.h, a); r["accpair"] = a
         a = np.zeros(13); self.L.ora_get_counters(self.h, a); r["counters"] = a
         r["mean_sign"] = self.L.ora_mean_sign(self.h)
-        r["occ"] = occ_from_dm(r["dm_diag"], nd)
+        occ = np.zeros((nd, 2, nd, 2)); rho1 = np.zeros((2 * nd, 2 * nd))
+        rho2 = np.zeros((2 * nd,) * 4) if nd <= 3 else None
+        self.L.ora_get_occ(self.h, occ, rho1, rho2.ctypes.data if rho2 is not None else None)
+        r["occ"] = occ; r["rho1"] = rho1
+        if rho2 is not None:
+            r["rho2"] = rho2
+        if nd <= 3:
+            a = np.zeros((4 ** nd, 4 ** nd)); self.L.ora_get_densitymatrix(self.h, a); r["densitymatrix"] = a
         return r
+
+    def blocks(self):
+        n = np.zeros(self.nsst, np.int32); off = np.zeros(self.nsst, np.int32); st = np.zeros(4 ** self.nd, np.int32)
+        self.L.ora_get_blocks(self.h, n, off, st)
+        return n, off, st
 
     def close(self):
         if self.h:

@@ -34,6 +34,13 @@ TRAJ = {
                            NLookup_nfft=0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 77),
     "C2": ("C2", 5001, dict(Nwarmups=20000, Nmeas=200, NCorr=200, TaudiffMax=10.0, Nftau=5001, Niw=16, MeasGiw=1,
                             NLookup_nfft=0), 5),
+    # matrix local-trace path (blocks with more than one state)
+    "C4S": ("C4S", 501, dict(Nwarmups=3000, Nmeas=300, NCorr=30, TaudiffMax=3.0, Ntau=100, NLegMax=12, Niw=8, MeasGiw=1,
+                             NLookup_nfft=0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 4242),
+    "C3Q": ("C3Q", 501, dict(Nwarmups=3000, Nmeas=200, NCorr=30, TaudiffMax=5.0, Ntau=100, NLegMax=12, Niw=8, MeasGiw=1,
+                             NLookup_nfft=0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 99),
+    "C4": ("C4", 1001, dict(Nwarmups=10000, Nmeas=100, NCorr=100, TaudiffMax=10.0, Ntau=200, NLegMax=20, Niw=8, MeasGiw=1,
+                            NLookup_nfft=0), 31),
 }
 
 KEYS = ("gleg", "gtau", "giw", "histo", "occ", "outersuperstatehisto", "accpair", "mean_sign", "accadd", "accrem",
@@ -44,11 +51,13 @@ def pstring_for(cfgname, nftau, over):
     p = synth.config(cfgname, nftau=nftau)
     o = dict(over)
     o.setdefault("Nftau", nftau)
-    return p, params.make_pstring(o, beta=p.beta, Nd=p.nd)
+    return p, params.make_pstring(o, beta=p.beta, Nd=p.nd, Hamiltonian=p.hamiltonian, QuantumNumbers=p.quantum_numbers)
 
 
-def gen_traj():
+def gen_traj(only=None):
     for name, (cfg, nftau, over, seed) in TRAJ.items():
+        if only and name not in only:
+            continue
         p, ps = pstring_for(cfg, nftau, over)
         s = refdrive.RefSolver(p, ps, seed)
         s.set_taudiffmax(over["TaudiffMax"])
@@ -83,11 +92,14 @@ STAT = {
     "C1": ("C1", 501, dict(Nwarmups=20000, Nmeas=20000, NCorr=50, TaudiffMax=10.0, Ntau=100, NLegMax=30), 8),
     "C2": ("C2", 2001, dict(Nwarmups=100000, Nmeas=10000, NCorr=200, TaudiffMax=10.0, Ntau=100, NLegMax=30), 8),
     "C3": ("C3", 1001, dict(Nwarmups=100000, Nmeas=10000, NCorr=100, TaudiffMax=10.0, Ntau=100, NLegMax=30), 8),
+    "C4": ("C4", 1001, dict(Nwarmups=50000, Nmeas=5000, NCorr=100, TaudiffMax=10.0, Ntau=100, NLegMax=30), 8),
 }
 
 
-def gen_stat():
+def gen_stat(only=None):
     for name, (cfg, nftau, over, nseeds) in STAT.items():
+        if only and name not in only:
+            continue
         p, ps = pstring_for(cfg, nftau, over)
         acc = {k: [] for k in ("gleg", "gtau", "occ", "histo", "accadd", "accrem")}
         for i in range(nseeds):
@@ -112,8 +124,9 @@ def gen_stat():
 if __name__ == "__main__":
     if not refdrive.available():
         raise SystemExit("oracle/_ref is not built: run oracle/build_ref.sh in the build container")
-    which = sys.argv[1:] or ["traj", "stat"]
+    which = [a for a in sys.argv[1:] if a in ("traj", "stat")] or ["traj", "stat"]
+    only = [a for a in sys.argv[1:] if a not in ("traj", "stat")] or None      # e.g.: gen_golden.py traj C4S C4
     if "traj" in which:
-        gen_traj()
+        gen_traj(only)
     if "stat" in which:
-        gen_stat()
+        gen_stat(only)

@@ -11,7 +11,7 @@ import pytest
 import pyoracle
 import util
 
-CASES = ["C1", "C3", "C2"]
+CASES = ["C1", "C3", "C2", "C4S", "C3Q", "C4"]
 
 
 def rel(a, b):
@@ -47,6 +47,9 @@ def test_oracle_retraces_reference_chain(name):
         assert cnt[7] / cnt[6] == pytest.approx(float(g["res_accglob"]), rel=1e-12)
     assert rel(r["eigenstatesenergies"], g["res_eigenstatesenergies"]) < 1e-13
     assert rel(np.diag(g["res_densitymatrix"]), r["dm_diag"]) < 1e-10
+    for k in ("densitymatrix", "rho1", "rho2"):      # full density matrix (occupation basis) and its contractions
+        if k in r:
+            assert rel(r[k].ravel(), np.asarray(g["res_" + k]).ravel()) < 1e-10, k
     w.close()
 
 

@@ -20,7 +20,7 @@ def load_golden(name):
 def setup(cfgname, nftau, overrides):
     p = synth.config(cfgname, nftau=nftau)
     o = dict(overrides); o.setdefault("Nftau", nftau)
-    ps = params.make_pstring(o, beta=p.beta, Nd=p.nd)
+    ps = params.make_pstring(o, beta=p.beta, Nd=p.nd, Hamiltonian=p.hamiltonian, QuantumNumbers=p.quantum_numbers)
     return p, ps, params.ParameterSet(ps)
 
 

@@ -46,6 +46,19 @@ def density_umatrix(nd: int, u: float, v: float = 0.0, j: float = 0.0) -> np.nda
     return U.reshape((2 * nd,) * 4)
 
 
+def kanamori_umatrix(nd: int, u: float, v: float = 0.0, j: float = 0.0) -> np.ndarray:
+    """Kanamori U tensor (interaction.py:232-241): density-density part plus pair hopping and spin flip."""
+    U = density_umatrix(nd, u, v, j).reshape((nd, 2) * 4)
+    for b1 in range(nd):
+        for b2 in range(nd):
+            if b1 == b2:
+                continue
+            for s in (0, 1):
+                U[b1, s, b1, 1 - s, b2, s, b2, 1 - s] = j      # pair hopping
+                U[b1, s, b2, 1 - s, b2, s, b1, 1 - s] = j      # spin flip
+    return U.reshape((2 * nd,) * 4)
+
+
 class Problem:
     """One impurity problem in the layout `init_solver` expects."""
 
@@ -66,7 +79,8 @@ class Problem:
 
 
 def make_problem(nd: int, beta: float, u: float, j: float = 0.0, v: float | None = None, mu: float | None = None,
-                 D: float = 1.0, nftau: int = 5001, spin_split: float = 0.0) -> Problem:
+                 D: float = 1.0, nftau: int = 5001, spin_split: float = 0.0, kanamori: bool = False,
+                 quantum_numbers: str | None = None) -> Problem:
     """Half-filled (by default) density-density problem on a Bethe bath.
 
     mu defaults to U/2 + (Nd-1)(V - J/2) (particle-hole symmetric point for this interaction).
@@ -82,10 +96,13 @@ def make_problem(nd: int, beta: float, u: float, j: float = 0.0, v: float | None
         for s in (0, 1):
             ftau[b, s, b, s, :] = f * (1.0 + 0.05 * b)    # mildly orbital dependent: catches flavour mix-ups
             muimp[b, s, b, s] = -(mu + (0.5 - s) * 2.0 * spin_split)
-    return Problem(nd, beta, density_umatrix(nd, u, v, j), ftau, muimp)
+    if kanamori:
+        return Problem(nd, beta, kanamori_umatrix(nd, u, v, j), ftau, muimp, hamiltonian="Kanamori",
+                       quantum_numbers=quantum_numbers or "Nt Szt Qzt")
+    return Problem(nd, beta, density_umatrix(nd, u, v, j), ftau, muimp, quantum_numbers=quantum_numbers or "Nt Szt Azt")
 
 
-# the five BASELINE.json configurations (density-density ones are runnable by the HIP path this round)
+# the BASELINE.json configurations (C5's worm part is not covered yet) and small variants for tests
 def config(name: str, nftau: int = 5001) -> Problem:
     name = name.upper()
     if name == "C1":
@@ -94,6 +111,12 @@ def config(name: str, nftau: int = 5001) -> Problem:
         return make_problem(1, 100.0, 2.0, nftau=nftau)
     if name == "C3":
         return make_problem(2, 50.0, 2.0, j=0.25, nftau=nftau)
+    if name == "C4":
+        return make_problem(3, 50.0, 2.0, j=0.25, nftau=nftau, kanamori=True)
+    if name == "C4S":      # small Kanamori case for fast parity tests
+        return make_problem(2, 10.0, 2.0, j=0.25, nftau=nftau, kanamori=True)
+    if name == "C3Q":      # density-density U with blocks larger than one state (QNs without Azt): matrix trace path
+        return make_problem(2, 20.0, 2.0, j=0.25, nftau=nftau, quantum_numbers="Nt Szt")
     if name == "C5Z":
         return make_problem(5, 100.0, 2.0, j=0.25, nftau=nftau)
     raise ValueError("unknown or not-yet-supported configuration %r" % name)
