@@ -33,10 +33,15 @@ TRAJ = [
     ("C3", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=6.0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 77),
     ("C2", 2001, dict(BASE, Nwarmups=20000, Nmeas=10, NCorr=200, TaudiffMax=10.0, NLegMax=100, Ntau=1000), 5),
     ("C5Z", 501, dict(BASE, Nwarmups=4000, Nmeas=10, NCorr=100, TaudiffMax=10.0, NLegMax=40), 31),
+    # matrix local-trace path: Kanamori (blocks of 1-3 states) and density-density U with coarse quantum numbers
+    ("C4S", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=3.0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 4242),
+    ("C3Q", 501, dict(BASE, Nwarmups=3000, Nmeas=20, NCorr=30, TaudiffMax=5.0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 99),
+    ("C4", 1001, dict(BASE, Nwarmups=6000, Nmeas=10, NCorr=100, TaudiffMax=10.0, NLegMax=20, Ntau=200), 31),
 ]
 
 
-@pytest.mark.parametrize("cfg,nftau,over,seed", TRAJ, ids=["C1-addrem", "C1-1window-allmoves", "C3-allmoves", "C2-default", "C5Z-default"])
+@pytest.mark.parametrize("cfg,nftau,over,seed", TRAJ, ids=["C1-addrem", "C1-1window-allmoves", "C3-allmoves", "C2-default", "C5Z-default",
+                              "C4S-kanamori-allmoves", "C3Q-coarse-blocks-allmoves", "C4-kanamori-default"])
 def test_chains_retrace_oracle(cfg, nftau, over, seed):
     """Every chain: same configuration, M, sign, window and NPairs after warm-up; same estimators after sampling."""
     p, ps, pset = util.setup(cfg, nftau, over)
@@ -68,22 +73,32 @@ def test_chains_retrace_oracle(cfg, nftau, over, seed):
                     assert rel(a, b) < TOL
         oracles.append(o)
     q.ctqmc_measure(1, 1)
-    assert q.mean_sign == -1.0
     bins = {k: getattr(q, k + "_bins") for k in ("gleg", "gtau", "giw", "histo", "occ")}
     tot = {k: 0.0 for k in bins}
+    msign = 0.0; dm = 0.0; rho1 = 0.0
     for w, o in enumerate(oracles):
         o.measure(); r = o.results()
         for k in bins:
             assert rel(bins[k][w], r[k]) < TOL, (k, w)
             tot[k] = tot[k] + r[k] / nw
+        msign += r["mean_sign"] / nw
         assert q.get_walker_state(w)["cfgsign"] == o.state()["cfgsign"]
+        # every chain has the same number of measurements, so sign-weighted chain results average like this
+        if "densitymatrix" in r:
+            dm = dm + r["densitymatrix"] * r["mean_sign"]; rho1 = rho1 + r["rho1"] * r["mean_sign"]
         o.close()
-    for k in bins:      # the module-level arrays are the means over chains
-        assert rel(getattr(q, k), tot[k]) < TOL, k
+    assert q.mean_sign == pytest.approx(msign, abs=1e-12)
+    if msign == -1.0:
+        for k in bins:      # the module-level arrays are the means over chains
+            assert rel(getattr(q, k), tot[k]) < TOL, k
+    if p.nd <= 3:
+        assert rel(q.densitymatrix, dm / nw / msign) < TOL
+        assert rel(q.rho1, rho1 / nw / msign) < TOL
+    assert np.abs(q.eigenstatesenergies - r["eigenstatesenergies"]).max() < 1e-12
     q.dest_ctqmc(); q.close()
 
 
-@pytest.mark.parametrize("name", ["C1", "C3", "C2"])
+@pytest.mark.parametrize("name", ["C1", "C3", "C2", "C4S", "C3Q", "C4"])
 def test_recorded_configuration_vs_reference_golden(name):
     """set_mc_config (full rebuild of M on the device) + one measurement == what the REFERENCE printed."""
     g = util.load_golden("meas_%s.npz" % name)
@@ -151,19 +166,18 @@ def test_unsupported_modes_are_refused():
             q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
         assert e.value.code == -2, over
         q.close()
-    # Kanamori spin-flip / pair-hopping terms: not density-density
-    U = p.umatrix.copy().reshape(1, 2, 1, 2, 1, 2, 1, 2)
-    from w2dynamics_amd import synth
-    p2 = synth.config("C3", 501)
-    U = p2.umatrix.copy(); U[0, 1, 3, 2] = 0.25
-    _, ps, _ = util.setup("C3", 501, {})
+    # automatic block partitioning ("All") is only available for density-density interactions
+    from w2dynamics_amd import params, synth
+    p2 = synth.config("C4S", 501)
+    ps = params.make_pstring({}, beta=p2.beta, Nd=p2.nd, Hamiltonian="Kanamori", QuantumNumbers="All")
     q = MCTQMC(nwalkers=4); q.init_rnd(1); q.init_paras(ps)
-    with pytest.raises(W2DynError):
-        q.init_solver(U, p2.ftau, p2.muimp, p2.screening, 1)
+    with pytest.raises(W2DynError) as e:
+        q.init_solver(p2.umatrix, p2.ftau, p2.muimp, p2.screening, 1)
+    assert e.value.code == -2
     q.close()
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4"])
 def test_full_run_statistics_vs_reference(name):
     """Full-run observables agree with long REFERENCE runs (8 seeds, tests/golden/stat_*.npz) within error bars.
 

@@ -84,13 +84,20 @@ struct DevConst {
     double *acc_signouter;// [nbins][nstates]
     double *acc_sign;     // [nbins]
     unsigned long long *accpair;  // [nflav][ntau]
+    // local problem in block form.  nouter = number of outer blocks (= nstates for one-state blocks); dmsize = doubles of
+    // the block-diagonal density matrix; mat != 0 selects the matrix local-trace path (cthyb_matrix.hip.h)
+    int nouter, dmsize, mat, nsst, nsm, shared_lds, op_in_lds;
+    const int *sst_n, *sst_off, *conn, *sst_first, *sst_of_state, *dmoff;   // [nsst] [nsst] [nsst][nflav][2] [nsst] [nstates] [nsst+1]
+    const double *sst_eval;       // [nstates] eigenvalues in block order
+    const double *opmat;          // [nsst][nflav][2][nsm][nsm] operators in the eigenbasis, row = target state, zero padded
 };
 
 // bytes of LDS one wave needs (host and device agree through this one function)
-__host__ __device__ inline size_t lds_bytes_per_wave(int nflav, int kmax, int wcap, int kgj)
+__host__ __device__ inline size_t lds_bytes_per_wave(int nflav, int kmax, int wcap, int kgj, int mat)
 {
     size_t d = (size_t)2 * nflav * kmax + 4 * (size_t)kmax + wcap + (size_t)kgj * kgj;   // tc, ta, Q, R, MQ, RM, wt, gj
     size_t i = (size_t)2 * wcap + MAXFLAV;                                     // wm, wc, K
+    if (mat) { d += wcap + 2; i += (size_t)2 * wcap + 4; }                     // ot; om, osst
     size_t b = d * sizeof(double) + C_NCOUNT * sizeof(unsigned long long) + i * sizeof(int);
     return (b + 15) & ~(size_t)15;
 }
@@ -196,6 +203,11 @@ struct Ctx {
     int kreg;                        // lane g: expansion order of flavour g
     double wr_t; int wr_m, wr_c, wr_p;  // lane e: window-list entry e (tau, f|ca<<8|slot<<16, partner count, pairs before e) when nwin <= 64
     int wvalid;                      // window list (registers or LDS) matches the current configuration and window
+    // matrix local-trace path
+    double *ot; int *om, *osst; int nops;            // time-ordered operator list and block sequence (LDS)
+    const int *t_conn, *t_n, *t_off; const double *t_eval, *t_op;   // block-shared tables (LDS); t_op null: operators stay in global memory
+    double tr_log, tr_sign;                          // current local trace
+    int ms_, mi_;                                    // lane = (outer state ms_, component mi_)
 
     __device__ Ctx(const DevConst &c) : C(c) {}
 
@@ -350,9 +362,12 @@ __device__ __forceinline__ void accpair_add(Ctx &x, int f, double dt)
     }
 }
 
+#include "cthyb_matrix.hip.h"
+
 // ---------------------------------------------------------------------------------------------------------------
 // pair insertion: CTQMC.F90:3353-3612 (StepAdd), Trace.F90:3657-3698, 2775-2832, MatrixUpdate.F90:392-442
 // ---------------------------------------------------------------------------------------------------------------
+template <bool MAT>
 __device__ void step_add(Ctx &x)
 {
     const DevConst &C = x.C;
@@ -374,6 +389,26 @@ __device__ void step_add(Ctx &x)
     // quantum numbers (Trace.F90:1243-1302 for one-state blocks): no operator of flavour f between the new pair and
     // the right occupation below it; equal times are rejected like QN violations (CTQMC.F90:3405-3416)
     double lo = fmin(tau1, tau2), hi = fmax(tau1, tau2);
+    bool creator_first = tau2 < tau1;
+    bool valid;
+    int p_lo = 0, p_hi = 0;                              // MAT: insertion indices of the two operators in the old list
+    if constexpr (MAT) {
+        // general blocks: walk the block sequence over the changed span (Trace.F90:1243-1302); equal times are rejected
+        bool eq = (tau1 == tau2);
+        for (int base = 0; base < x.nops; base += 64) {
+            int e = base + x.lane;
+            double t = e < x.nops ? x.ot[e] : -1.0;
+            eq |= __ballot(t == tau1 || t == tau2) != 0ull;
+        }
+        p_lo = mat_lower(x, lo); p_hi = mat_lower(x, hi);
+        const int nf2 = 2 * C.nflav;
+        const int code_lo = mat_code(f, creator_first ? 1 : 2), code_hi = mat_code(f, creator_first ? 2 : 1);
+        int sq = uni(x.osst[p_lo]);
+        sq = uni(x.t_conn[sq * nf2 + code_lo]);
+        for (int i = p_lo; i < p_hi && sq >= 0; ++i) sq = uni(x.t_conn[sq * nf2 + uni(x.om[i])]);
+        if (sq >= 0) sq = uni(x.t_conn[sq * nf2 + code_hi]);
+        valid = !eq && sq >= 0 && sq == uni(x.osst[p_hi]);
+    } else {
     int c_lo = 0, a_lo = 0; bool blocked = (tau1 == tau2);
     for (int base = 0; base < k; base += 64) {
         int e = base + x.lane;
@@ -383,8 +418,8 @@ __device__ void step_add(Ctx &x)
         blocked |= __ballot((tce >= lo && tce <= hi) || (tae >= lo && tae <= hi)) != 0ull;
     }
     int occ_lo = ((x.outer >> flav_bit(f, C.nd)) & 1) + c_lo - a_lo;
-    bool creator_first = tau2 < tau1;
-    bool valid = !blocked && occ_lo == (creator_first ? 0 : 1);
+    valid = !blocked && occ_lo == (creator_first ? 0 : 1);
+    }
     DBG_STAMP(x, C_DBG4);
     if (!valid) { x.count(C_QNADD); return; }
     if (k >= kmax) { x.err |= ERR_KMAX; x.count(C_QNADD); return; }
@@ -437,8 +472,17 @@ __device__ void step_add(Ctx &x)
     double S = S0 - wave_sum(acc);
     DBG_STAMP(x, C_DBG5);
 
-    double I = level_integral(x, f, lo, hi);
-    double dlogtr = creator_first ? -I : I;
+    double dlogtr, tl_new = 0.0, ts_new = 1.0;
+    if constexpr (MAT) {
+        if (x.nops + 2 > C.wcap) { x.err |= ERR_WCAP; return; }
+        const int code_lo = mat_code(f, creator_first ? 1 : 2), code_hi = mat_code(f, creator_first ? 2 : 1);
+        mat_insert(x, p_lo, lo, code_lo); mat_insert(x, p_hi + 1, hi, code_hi);
+        mat_trace(x, x.outer, -1, -1, tl_new, ts_new);
+        dlogtr = tl_new - x.tr_log;
+    } else {
+        double I = level_integral(x, f, lo, hi);
+        dlogtr = creator_first ? -I : I;
+    }
     double rnd = x.draw();
 
     if (x.npairs < 0) x.npairs = build_window(x);
@@ -454,8 +498,12 @@ __device__ void step_add(Ctx &x)
     int np_new = x.npairs + dnp;
 
     double prob = fabs(tdf * (double)(2 * C.nd) / (double)np_new * fabs(S) * exp(dlogtr));
+    if constexpr (MAT) { if (ts_new == 0.0) prob = 0.0; }
     DBG_STAMP(x, C_DBG6);
-    if (!(rnd < prob)) return;
+    if (!(rnd < prob)) {
+        if constexpr (MAT) { mat_remove(x, p_hi + 1); mat_remove(x, p_lo); }
+        return;
+    }
 
     // time-ordered ranks of the new operators for the cofactor sign (-1)^|FPos1-FPos2| (Trace.F90:2828)
     int pc = 0, pa = 0;
@@ -516,6 +564,7 @@ __device__ void step_add(Ctx &x)
     x.det_log += log(fabs(S));
     x.npairs = np_new;
     x.wvalid = 0;
+    if constexpr (MAT) { x.tr_log = tl_new; x.tr_sign = ts_new; mat_walk_sst(x); }
     DBG_STAMP(x, C_DBG7);
     x.count(C_ACCADD);
     accpair_add(x, f, hi - lo);
@@ -524,6 +573,7 @@ __device__ void step_add(Ctx &x)
 // ---------------------------------------------------------------------------------------------------------------
 // pair removal: CTQMC.F90:3892-4150 (StepRem), Trace.F90:4851-4950, 2937-2963, MatrixUpdate.F90:445-482
 // ---------------------------------------------------------------------------------------------------------------
+template <bool MAT>
 __device__ void step_rem(Ctx &x)
 {
     const DevConst &C = x.C;
@@ -615,7 +665,14 @@ __device__ void step_rem(Ctx &x)
     // quantum numbers: the pair may go iff no operator of its flavour lies strictly between (both are in the window,
     // so anything between them is in the window list too)
     bool blocked;
-    if (nw <= 64) {
+    int i1 = 0, i2 = 0;                                // MAT: list indices of the two operators
+    if constexpr (MAT) {
+        i1 = mat_lower(x, t1); i2 = mat_lower(x, t2);
+        const int nf2 = 2 * C.nflav;
+        int sq = uni(x.osst[i1]);
+        for (int i = i1 + 1; i < i2 && sq >= 0; ++i) sq = uni(x.t_conn[sq * nf2 + uni(x.om[i])]);
+        blocked = !(sq >= 0 && sq == uni(x.osst[i2 + 1]));
+    } else if (nw <= 64) {
         blocked = __ballot(x.lane < nw && (x.wr_m & 0xff) == f && x.wr_t > t1 && x.wr_t < t2) != 0ull;
     } else {
         int between = 0;
@@ -631,11 +688,18 @@ __device__ void step_rem(Ctx &x)
     if (blocked) { x.count(C_QNREM); return; }
 
     bool creator_first = tau_c < tau_a;
-    // the pair's own operators sit on the boundary of (t1,t2) and belong to flavour f, which level_integral skips
-    double I = level_integral(x, f, t1, t2);
-    double dlogtr = creator_first ? I : -I;
+    double dlogtr, tl_new = 0.0, ts_new = 1.0;
+    if constexpr (MAT) {
+        mat_trace(x, x.outer, i1, i2, tl_new, ts_new);
+        dlogtr = tl_new - x.tr_log;
+    } else {
+        // the pair's own operators sit on the boundary of (t1,t2) and belong to flavour f, which level_integral skips
+        double I = level_integral(x, f, t1, t2);
+        dlogtr = creator_first ? I : -I;
+    }
     double S = uni(Sv);
     double prob = fabs(hybf / (double)(2 * C.nd) * fabs(S) * exp(dlogtr));
+    if constexpr (MAT) { if (ts_new == 0.0) prob = 0.0; }
     double rnd = x.draw();
     DBG_STAMP(x, C_DBG3);
     if (!(rnd < prob)) return;
@@ -691,6 +755,7 @@ __device__ void step_rem(Ctx &x)
     x.det_log += log(fabs(S));
     x.npairs = np - dnp;
     x.wvalid = 0;
+    if constexpr (MAT) { mat_remove(x, i2); mat_remove(x, i1); x.tr_log = tl_new; x.tr_sign = ts_new; mat_walk_sst(x); }
     x.count(C_ACCREM);
     accpair_add(x, f, t2 - t1);
 }
@@ -702,28 +767,37 @@ __device__ void step_change_outer(Ctx &x)
 {
     const DevConst &C = x.C;
     double r = x.draw();
-    int sel = C.nstates - 1;
+    int sel = C.nouter - 1;
     bool found = false;
-    for (int base = 0; base < C.nstates && !found; base += 64) {
+    for (int base = 0; base < C.nouter && !found; base += 64) {
         int s = base + x.lane;
-        bool hit = s < C.nstates && C.outer_cum[s] >= r && C.outer_w[s] != 0.0;
+        bool hit = s < C.nouter && C.outer_cum[s] >= r && C.outer_w[s] != 0.0;
         unsigned long long m = __ballot(hit);
         if (m) { sel = base + __ffsll((long long)m) - 1; found = true; }
     }
     x.outer = uni(sel);
 }
 
+template <bool MAT>
 __device__ void step_shift(Ctx &x)
 {
     const DevConst &C = x.C;
     int nops = 0;
     for (int f = 0; f < C.nflav; ++f) nops += 2 * x.order(f);
-    if (nops == 0) { step_change_outer(x); return; }
+    if (nops == 0) {
+        step_change_outer(x);
+        if constexpr (MAT) { mat_walk_sst(x); mat_trace(x, x.outer, -1, -1, x.tr_log, x.tr_sign); }
+        return;
+    }
     double dt = x.draw() * C.beta;
     if (dt == 0.0 || dt == C.beta) return;
     x.count(C_TRYSHIFT);
     const int kmax = C.kmax;
     int outer = x.outer;
+    if constexpr (MAT) {       // block in front of the first operator that does not wrap (CTQMC.F90:4717)
+        int first = mat_lower(x, dt);
+        if (first < x.nops) outer = uni(x.osst[first]);
+    }
     double detrat = 1.0;
     for (int f = 0; f < C.nflav; ++f) {
         int k = x.order(f);
@@ -735,7 +809,7 @@ __device__ void step_shift(Ctx &x)
             bool v = e < k;
             wcnt += count_pred(v && tcp[e] < dt); wacnt += count_pred(v && tap[e] < dt);
         }
-        if ((wcnt + wacnt) & 1) outer ^= 1 << flav_bit(f, C.nd);
+        if constexpr (!MAT) { if ((wcnt + wacnt) & 1) outer ^= 1 << flav_bit(f, C.nd); }
         if (!((wcnt == 0 && wacnt == 0) || (wcnt == k && wacnt == k))) {
             for (int j0 = 0; j0 < k; j0 += 64) {
                 int j = j0 + x.lane;
@@ -766,6 +840,7 @@ __device__ void step_shift(Ctx &x)
         x.window_bounds();
     }
     x.npairs = -1; x.wvalid = 0;
+    if constexpr (MAT) { mat_build_list(x); mat_walk_sst(x); mat_trace(x, x.outer, -1, -1, x.tr_log, x.tr_sign); }
     x.count(C_ACCSHIFT);
 }
 
@@ -1019,13 +1094,44 @@ __device__ __forceinline__ void ctx_setup(Ctx &x, unsigned char *smem)
     int wib = threadIdx.x >> 6;
     x.lane = threadIdx.x & 63;
     x.w = uni((int)(blockIdx.x * (blockDim.x >> 6) + wib));
-    unsigned char *base = smem + (size_t)wib * C.lds_per_wave;
+    unsigned char *base = smem + C.shared_lds + (size_t)wib * C.lds_per_wave;
     x.tc_ = (double *)base; x.ta_ = x.tc_ + C.nflav * C.kmax;
     x.Q = x.ta_ + C.nflav * C.kmax; x.R = x.Q + C.kmax; x.MQ = x.R + C.kmax; x.RM = x.MQ + C.kmax;
     x.wt = x.RM + C.kmax;
     x.gj = x.wt + C.wcap;
     x.cnt = (unsigned long long *)(x.gj + C.kgj * C.kgj);
     x.wm = (int *)(x.cnt + C_NCOUNT); x.wc = x.wm + C.wcap; x.K = x.wc + C.wcap;
+    x.nops = 0; x.tr_log = 0.0; x.tr_sign = 1.0; x.ms_ = 0; x.mi_ = 0;
+    if (C.mat) {
+        // per-wave list arrays behind the common slice; block-shared tables at the start of the dynamic LDS
+        x.om = x.K + MAXFLAV; x.osst = x.om + C.wcap;
+        x.ot = (double *)(((size_t)(x.osst + C.wcap + 4) + 7) & ~(size_t)7);
+        const int nf2 = 2 * C.nflav;
+        int *ti = (int *)smem;
+        x.t_conn = ti; x.t_n = ti + C.nsst * nf2; x.t_off = x.t_n + C.nsst;
+        double *td = (double *)(((size_t)(x.t_off + C.nsst) + 7) & ~(size_t)7);
+        x.t_eval = td;
+        x.t_op = C.op_in_lds ? td + C.nstates : nullptr;
+        x.ms_ = x.lane / C.nsm; x.mi_ = x.lane - x.ms_ * C.nsm;
+    }
+}
+
+// stage the block-shared tables of the local problem (all threads of the workgroup; call before any early return)
+__device__ __forceinline__ void stage_shared_tables(const DevConst &C, unsigned char *smem)
+{
+    if (!C.mat) return;
+    const int nf2 = 2 * C.nflav;
+    int *ti = (int *)smem;
+    int *t_n = ti + C.nsst * nf2, *t_off = t_n + C.nsst;
+    double *td = (double *)(((size_t)(t_off + C.nsst) + 7) & ~(size_t)7);
+    for (int i = threadIdx.x; i < C.nsst * nf2; i += blockDim.x) ti[i] = C.conn[i];
+    for (int i = threadIdx.x; i < C.nsst; i += blockDim.x) { t_n[i] = C.sst_n[i]; t_off[i] = C.sst_off[i]; }
+    for (int i = threadIdx.x; i < C.nstates; i += blockDim.x) td[i] = C.sst_eval[i];
+    if (C.op_in_lds) {
+        const int nop = C.nsst * nf2 * C.nsm * C.nsm;
+        for (int i = threadIdx.x; i < nop; i += blockDim.x) td[C.nstates + i] = C.opmat[i];
+    }
+    __syncthreads();
 }
 
 __device__ __forceinline__ void ctx_load(Ctx &x)
@@ -1050,6 +1156,11 @@ __device__ __forceinline__ void ctx_load(Ctx &x)
     x.window_bounds();
     x.rng_seek(nd_);
     wave_sync();
+    if (C.mat) {      // time-ordered list, block sequence and trace of the stored configuration
+        mat_build_list(x);
+        mat_walk_sst(x);
+        mat_trace(x, x.outer, -1, -1, x.tr_log, x.tr_sign);
+    }
 }
 
 __device__ __forceinline__ void ctx_store(Ctx &x)
@@ -1078,9 +1189,11 @@ __device__ __forceinline__ void ctx_store(Ctx &x)
 #endif
 
 // sweep kernel: nsteps iterations of the Z-space loop (CTQMC.F90:8213-8257 / 8428-8533) for every chain
+template <bool MAT>
 __global__ __launch_bounds__(256) void k_sweep(DevConst C, long long nsteps, int count_sampling)
 {
     extern __shared__ unsigned char smem[];
+    stage_shared_tables(C, smem);
     Ctx x(C);
     ctx_setup(x, smem);
     if (x.w >= C.nwalkers) return;
@@ -1097,22 +1210,22 @@ __global__ __launch_bounds__(256) void k_sweep(DevConst C, long long nsteps, int
 #endif
         if (r < (1.0 - ps - pg) / 2.0) { (void)x.draw(); (void)x.draw();
 #ifndef W2DYN_NO_ADD
-            step_add(x);
+            step_add<MAT>(x);
 #endif
             STAMP_KIND(C_CYC_ADD); phase += 1; }
         else if (r <= 1.0 - ps - pg) { (void)x.draw(); (void)x.draw();
 #ifndef W2DYN_NO_REM
-            step_rem(x);
+            step_rem<MAT>(x);
 #endif
             STAMP_KIND(C_CYC_REM); phase += 1; }
         else if (r <= 1.0 - ps) {
 #ifndef W2DYN_NO_GLOB
-            step_glob(x);
+            if constexpr (MAT) step_glob_mat(x); else step_glob(x);
 #endif
             STAMP_KIND(C_CYC_GLOB); }
         else {
 #ifndef W2DYN_NO_SHIFT
-            step_shift(x);
+            step_shift<MAT>(x);
 #endif
             STAMP_KIND(C_CYC_SHIFT); }
 #ifdef W2DYN_STAMPS
@@ -1134,6 +1247,7 @@ __global__ __launch_bounds__(256) void k_sweep(DevConst C, long long nsteps, int
 __global__ __launch_bounds__(256) void k_rebuild(DevConst C)
 {
     extern __shared__ unsigned char smem[];
+    stage_shared_tables(C, smem);
     Ctx x(C);
     ctx_setup(x, smem);
     if (x.w >= C.nwalkers) return;
@@ -1162,9 +1276,11 @@ __global__ __launch_bounds__(256) void k_rebuild(DevConst C)
 //   trace sign   : pairs (i,j) with tau_j < tau_i and Fock bit(f_j) < bit(f_i)          (Operator.F90:158-171)
 //   block sign   : pairs (i,j) with tau_j > tau_i and flavour index f_j < f_i             (Trace.F90:3594-3618)
 //   permaltca    : for every creator, operators of its flavour at later times; +1 if N/2 is odd (3554-3588)
+template <bool MAT>
 __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
 {
     extern __shared__ unsigned char smem[];
+    stage_shared_tables(C, smem);
     Ctx x(C);
     ctx_setup(x, smem);
     if (x.w >= C.nwalkers) return;
@@ -1181,7 +1297,7 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
             for (int fj = 0; fj < nf; ++fj) {
                 int kj = x.order(fj);
                 int bitj = flav_bit(fj, nd);
-                bool wtr = bitj < biti, wbl = fj < fi, wsame = (fj == fi) && ci;
+                bool wtr = !MAT && bitj < biti, wbl = fj < fi, wsame = (fj == fi) && ci;
                 if (!(wtr || wbl || wsame)) continue;
                 const double *cj = x.tc(fj), *aj = x.ta(fj);
                 int below = 0, above = 0;
@@ -1200,7 +1316,40 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
     par = wave_sum(par) & 1;
     if ((N / 2) & 1) par ^= 1;
     double sign = x.det_sign * (par ? -1.0 : 1.0);
+    if constexpr (MAT) sign *= x.tr_sign;            // the trace sign comes with the matrix elements (Trace.F90:3488)
     double cfgsign = -sign;
+    const int bin = x.w / C.walkers_per_bin;
+    if constexpr (MAT) {
+        // MeasDensityMatrix_beta_half (CTQMC.F90:3088-3151): kets from 0 to beta/2 through the operators with
+        // tau <= beta/2, bras from beta down to beta/2, for all states of the outer block at once
+        const double b2 = 0.5 * C.beta;
+        const int nsm = C.nsm, nout = uni(x.t_n[x.outer]);
+        const bool dg = x.lane < nsm * nsm && x.ms_ == x.mi_ && x.ms_ < nout;
+        const int nk = mat_lower_eq(x, b2);
+        double ket = dg ? 1.0 : 0.0, lk = 0.0, tp = 0.0;
+        int sk = x.outer;
+        for (int i = 0; i < nk; ++i) {
+            const double tau = uni(x.ot[i]);
+            sk = mat_apply(x, sk, uni(x.om[i]), tau - tp, ket, lk); tp = tau;
+            if ((i & 3) == 3) mat_rescale(ket, lk);
+        }
+        mat_evolve(x, sk, b2 - tp, ket, lk);
+        double bra = dg ? 1.0 : 0.0, lb = 0.0;
+        int sb = x.outer; tp = C.beta;
+        for (int i = x.nops - 1; i >= nk; --i) {          // the bra sees the operator of the other type (Trace.F90:5927)
+            const double tau = uni(x.ot[i]);
+            sb = mat_apply(x, sb, uni(x.om[i]) ^ 1, tp - tau, bra, lb); tp = tau;
+            if ((i & 3) == 3) mat_rescale(bra, lb);
+        }
+        mat_evolve(x, sb, tp - b2, bra, lb);
+        const int n = uni(x.t_n[sk]);
+        const double fac = -cfgsign * x.tr_sign * exp(lk + lb - x.tr_log);
+        double *dmb = C.acc_dm + (size_t)bin * C.dmsize + C.dmoff[sk];
+        for (int j = 0; j < n; ++j) {                    // rho(i1 = bra index, i2 = ket index)
+            const double kj = __shfl(ket, x.ms_ * nsm + j, 64);
+            if (x.lane < nsm * nsm && x.ms_ < nout && x.mi_ < n && sb == sk) atomicAdd(&dmb[x.mi_ * n + j], bra * fac * kj);
+        }
+    } else {
     // state alive at beta/2 (Trace.F90:6334: operators with tau <= beta/2 have acted)
     int sb2 = x.outer;
     for (int f = 0; f < nf; ++f) {
@@ -1211,16 +1360,15 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
         }
         if (c & 1) sb2 ^= 1 << flav_bit(f, nd);
     }
+    if (x.lane == 0) atomicAdd(&C.acc_dm[(size_t)bin * C.dmsize + sb2], -cfgsign);
+    }
     if (x.lane == 0) {
-        int bin = x.w / C.walkers_per_bin;
         C.cfgsign[x.w] = cfgsign;
         atomicAdd(&C.acc_sign[bin], cfgsign);
-        atomicAdd(&C.acc_outer[(size_t)bin * C.nstates + x.outer], 1.0);
-        atomicAdd(&C.acc_signouter[(size_t)bin * C.nstates + x.outer], cfgsign);
-        atomicAdd(&C.acc_dm[(size_t)bin * C.nstates + sb2], -cfgsign);
+        atomicAdd(&C.acc_outer[(size_t)bin * C.nouter + x.outer], 1.0);
+        atomicAdd(&C.acc_signouter[(size_t)bin * C.nouter + x.outer], cfgsign);
     }
     if (x.lane < nf) {      // lane f holds the order of flavour f
-        int bin = x.w / C.walkers_per_bin;
         int h = x.kreg < C.maxhisto ? x.kreg : C.maxhisto;
         atomicAdd(&C.acc_histo[((size_t)bin * nf + x.lane) * (C.maxhisto + 1) + h], 1.0);
     }

@@ -1,0 +1,191 @@
+// Host-side construction of the local impurity problem in block form - what init_solver does before the sampler
+// starts (CTQMC.F90:7957-8031): Fock states, blocks from the QuantumNumbers string (States.F90:149-184, 98-144),
+// creation/annihilation operators and Connect (Operator.F90:115-245), H_loc = one-particle part + U
+// (482-542, 1042-1125), its eigen-decomposition per block (637-670, 754-801) and the operators in the eigenbasis
+// (1130-1168).  The eigen-solver is a cyclic Jacobi iteration (blocks are small); eigenvectors are only defined up
+// to sign / rotations inside degenerate subspaces, which leaves every trace and every basis-independent observable
+// unchanged.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <vector>
+
+namespace w2dyn {
+
+struct LocalProblem {
+    int nd = 0, nflav = 0, nstates = 0, nsst = 0, nsmax = 0;
+    std::vector<int> sst_of_state, sst_n, sst_off, states, idx_in_block;   // idx_in_block[Fock state] = position in its block
+    std::vector<double> eval;                       // block order, ascending inside a block
+    std::vector<std::vector<double>> evec;          // per block, column major n x n: evec[b][j + n*i] = <Fock j|eigen i>
+    std::vector<int> conn;                          // [(sst*nflav + f)*2 + (ca-1)]
+    std::vector<std::vector<double>> op;            // same index: n_target x n_source column major (empty if not connected)
+    double egs = 0.0;
+    bool identity_blocks = false;                   // every block holds exactly its own Fock state (index == state)
+
+    int bit(int f) const { return (f >> 1) + nd * (f & 1); }
+    static double fsign(int state, int b) { return (__builtin_popcount((unsigned)state & ((1u << b) - 1u)) & 1) ? -1.0 : 1.0; }
+    int connect(int sst, int f, int ca) const { return conn[((size_t)sst * nflav + f) * 2 + (ca - 1)]; }
+    const std::vector<double> &oper(int sst, int f, int ca) const { return op[((size_t)sst * nflav + f) * 2 + (ca - 1)]; }
+
+    // quantum numbers of a Fock state (States.F90:188-325)
+    double qn(int which, int s) const
+    {
+        double v = 0.0;
+        switch (which) {
+        case 0: return (double)__builtin_popcount((unsigned)s);                                                     // Nt
+        case 1: for (int b = 0; b < nd; ++b) { if (s >> b & 1) v -= 0.5; if (s >> (b + nd) & 1) v += 0.5; } return v;   // Szt
+        case 2: { double p = 1.0; for (int b = 0; b < nd; ++b, p *= 10.0) if ((s >> b & 1) != (s >> (b + nd) & 1)) v += p; return v; }   // Qzt
+        case 3: { double p = 1.0; for (int b = 0; b < 2 * nd; ++b, p *= 10.0) if (s >> b & 1) v += p; return v; }  // Azt
+        case 4: for (int sp = 0; sp < 2; ++sp) for (int b = 1; b <= nd; ++b) if (s >> ((b - 1) + nd * sp) & 1) v += (double)b - (double)(nd + 1) / 2.0; return v;   // Lzt
+        default: return qn(4, s) + qn(1, s);                                                                        // Jzt
+        }
+    }
+
+    static void jacobi(std::vector<double> &A, int n, double *w, std::vector<double> &V)
+    {
+        V.assign((size_t)n * n, 0.0);
+        for (int i = 0; i < n; ++i) V[i + (size_t)n * i] = 1.0;
+        for (int sweep = 0; sweep < 100; ++sweep) {
+            double off = 0.0;
+            for (int p = 0; p < n; ++p) for (int q = p + 1; q < n; ++q) off += A[p * n + q] * A[p * n + q];
+            if (off < 1e-300) break;
+            for (int p = 0; p < n; ++p) for (int q = p + 1; q < n; ++q) {
+                const double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < n; ++k) { double x = A[k * n + p], y = A[k * n + q]; A[k * n + p] = c * x - sn * y; A[k * n + q] = sn * x + c * y; }
+                for (int k = 0; k < n; ++k) { double x = A[p * n + k], y = A[q * n + k]; A[p * n + k] = c * x - sn * y; A[q * n + k] = sn * x + c * y; }
+                for (int k = 0; k < n; ++k) { double x = V[k + (size_t)n * p], y = V[k + (size_t)n * q]; V[k + (size_t)n * p] = c * x - sn * y; V[k + (size_t)n * q] = sn * x + c * y; }
+            }
+        }
+        for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
+        for (int i = 0; i < n; ++i) {
+            int m = i;
+            for (int j = i + 1; j < n; ++j) if (w[j] < w[m]) m = j;
+            if (m != i) { std::swap(w[i], w[m]); for (int k = 0; k < n; ++k) std::swap(V[k + (size_t)n * i], V[k + (size_t)n * m]); }
+        }
+    }
+
+    // U: (2Nd)^4 with flavour 2*orb+spin; mu_full: (Nd,2,Nd,2) as passed to init_solver; qns: QuantumNumbers string
+    void build(int nd_, const double *U, const double *mu_full, std::string qns, double epsevec)
+    {
+        nd = nd_; nflav = 2 * nd; nstates = 1 << nflav;
+        const int nf = nflav, ns = nstates;
+        if (qns.find("All") != std::string::npos) qns = "Nt Szt Azt";      // caller guarantees a density-density H here
+        const char *names[6] = {"Nt", "Szt", "Qzt", "Azt", "Lzt", "Jzt"};
+        bool use[6];
+        for (int q = 0; q < 6; ++q) use[q] = qns.find(names[q]) != std::string::npos;
+        sst_of_state.assign(ns, -1);
+        nsst = 0;
+        for (int s1 = 0; s1 < ns; ++s1) {
+            if (sst_of_state[s1] != -1) continue;
+            sst_of_state[s1] = nsst++;
+            for (int s2 = s1; s2 < ns; ++s2) {
+                if (sst_of_state[s2] != -1) continue;
+                bool same = true;
+                for (int q = 0; q < 6 && same; ++q) if (use[q] && !(std::fabs(qn(q, s1) - qn(q, s2)) < 1e-12)) same = false;
+                if (same) sst_of_state[s2] = nsst - 1;
+            }
+        }
+        sst_n.assign(nsst, 0); sst_off.assign(nsst, 0); states.assign(ns, 0); idx_in_block.assign(ns, 0);
+        for (int s = 0; s < ns; ++s) sst_n[sst_of_state[s]] += 1;
+        for (int b = 1; b < nsst; ++b) sst_off[b] = sst_off[b - 1] + sst_n[b - 1];
+        {
+            std::vector<int> fill(nsst, 0);
+            for (int s = 0; s < ns; ++s) { int b = sst_of_state[s]; idx_in_block[s] = fill[b]; states[sst_off[b] + fill[b]++] = s; }
+        }
+        nsmax = *std::max_element(sst_n.begin(), sst_n.end());
+        identity_blocks = nsmax == 1;
+        for (int s = 0; s < ns && identity_blocks; ++s) if (sst_of_state[s] != s) identity_blocks = false;
+
+        conn.assign((size_t)nsst * nf * 2, -1);
+        for (int s = 0; s < ns; ++s) for (int f = 0; f < nf; ++f) {
+            int t = s ^ (1 << bit(f)), b = sst_of_state[s], tb = sst_of_state[t];
+            if (tb != b) conn[((size_t)b * nf + f) * 2 + (t > s ? 0 : 1)] = tb;
+        }
+
+        std::vector<std::vector<double>> H(nsst);
+        for (int b = 0; b < nsst; ++b) H[b].assign((size_t)sst_n[b] * sst_n[b], 0.0);
+        auto add = [&](int src, int dst, double v) {
+            int b = sst_of_state[src];
+            if (sst_of_state[dst] != b) return;
+            H[b][(size_t)idx_in_block[dst] * sst_n[b] + idx_in_block[src]] += v;
+        };
+        auto annihilate = [&](int &st, double &sg, int f) { int b = bit(f); if (!(st >> b & 1)) return false; sg *= fsign(st, b); st ^= 1 << b; return true; };
+        auto create = [&](int &st, double &sg, int f) { int b = bit(f); if (st >> b & 1) return false; sg *= fsign(st, b); st ^= 1 << b; return true; };
+        for (int f1 = 0; f1 < nf; ++f1) for (int f2 = 0; f2 < nf; ++f2) {
+            double mu = mu_full[((size_t)((f1 >> 1) * 2 + (f1 & 1)) * nd + (f2 >> 1)) * 2 + (f2 & 1)];
+            if (mu == 0.0) continue;
+            for (int s = 0; s < ns; ++s) { int t = s; double sg = 1.0; if (annihilate(t, sg, f2) && create(t, sg, f1)) add(s, t, mu * sg); }
+        }
+        for (int f1 = 0; f1 < nf; ++f1) for (int f2 = 0; f2 < nf; ++f2) for (int f3 = 0; f3 < nf; ++f3) for (int f4 = 0; f4 < nf; ++f4) {
+            double u = 0.5 * U[(((size_t)f1 * nf + f2) * nf + f3) * nf + f4];
+            if (u == 0.0) continue;
+            for (int s = 0; s < ns; ++s) {
+                int t = s; double sg = 1.0;
+                if (annihilate(t, sg, f3) && annihilate(t, sg, f4) && create(t, sg, f2) && create(t, sg, f1)) add(s, t, u * sg);
+            }
+        }
+        eval.assign(ns, 0.0); evec.assign(nsst, {});
+        for (int b = 0; b < nsst; ++b) {
+            const int n = sst_n[b];
+            for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) { double v = (H[b][i * n + j] + H[b][j * n + i]) / 2.0; H[b][i * n + j] = H[b][j * n + i] = v; }
+            jacobi(H[b], n, &eval[sst_off[b]], evec[b]);
+            for (int i = 0; i < n; ++i) {                              // EPSEVEC and the reference's renormalisation
+                double sum = 0.0;
+                for (int j = 0; j < n; ++j) { double &v = evec[b][j + (size_t)n * i]; if (std::fabs(v) < epsevec) v = 0.0; sum += v * v; }
+                for (int j = 0; j < n; ++j) evec[b][j + (size_t)n * i] /= sum;
+            }
+        }
+        egs = eval[0];
+        for (int b = 0; b < nsst; ++b) egs = std::min(egs, eval[sst_off[b]]);
+
+        op.assign((size_t)nsst * nf * 2, {});
+        for (int b = 0; b < nsst; ++b) for (int f = 0; f < nf; ++f) for (int ca = 1; ca <= 2; ++ca) {
+            const int tb = connect(b, f, ca);
+            if (tb < 0) continue;
+            const int n1 = sst_n[b], n2 = sst_n[tb], bt = bit(f);
+            std::vector<double> P((size_t)n2 * n1, 0.0), T((size_t)n2 * n1, 0.0), O((size_t)n2 * n1, 0.0);
+            for (int i1 = 0; i1 < n1; ++i1) {
+                int s = states[sst_off[b] + i1];
+                if ((ca == 1) == (bool)(s >> bt & 1)) continue;
+                int t = s ^ (1 << bt);
+                if (sst_of_state[t] == tb) P[idx_in_block[t] + (size_t)n2 * i1] = fsign(s, bt);
+            }
+            for (int i = 0; i < n2; ++i) for (int j = 0; j < n1; ++j) { double a = 0.0; for (int k = 0; k < n1; ++k) a += P[i + (size_t)n2 * k] * evec[b][k + (size_t)n1 * j]; T[i + (size_t)n2 * j] = a; }
+            for (int i = 0; i < n2; ++i) for (int j = 0; j < n1; ++j) { double a = 0.0; for (int k = 0; k < n2; ++k) a += evec[tb][k + (size_t)n2 * i] * T[k + (size_t)n2 * j]; O[i + (size_t)n2 * j] = a; }
+            op[((size_t)b * nf + f) * 2 + (ca - 1)] = std::move(O);
+        }
+    }
+
+    // <A> = sum_b tr(rho_b A_bb), A = product of operators applied right to left: (fl[0],ca[0]) acts first.
+    // rho: block-diagonal density matrix in the eigenbasis, block b at dmoff[b], [bra][ket] row major (CTQMC.F90:2842-3060)
+    double expect(const double *rho, const std::vector<int> &dmoff, int nop, const int *fl, const int *ca) const
+    {
+        double tot = 0.0;
+        std::vector<double> v(nsmax), out(nsmax);
+        for (int b = 0; b < nsst; ++b) {
+            const int n = sst_n[b];
+            for (int col = 0; col < n; ++col) {
+                std::fill(v.begin(), v.end(), 0.0); v[col] = 1.0;
+                int s = b; bool ok = true;
+                for (int q = 0; q < nop; ++q) {
+                    int t = connect(s, fl[q], ca[q]);
+                    if (t < 0) { ok = false; break; }
+                    const int n1 = sst_n[s], n2 = sst_n[t]; const std::vector<double> &O = oper(s, fl[q], ca[q]);
+                    for (int i = 0; i < n2; ++i) { double a = 0.0; for (int j = 0; j < n1; ++j) a += O[i + (size_t)n2 * j] * v[j]; out[i] = a; }
+                    for (int i = 0; i < n2; ++i) v[i] = out[i];
+                    s = t;
+                }
+                if (!ok || s != b) continue;
+                for (int row = 0; row < n; ++row) tot += rho[dmoff[b] + col * n + row] * v[row];
+            }
+        }
+        return tot;
+    }
+};
+
+}  // namespace w2dyn

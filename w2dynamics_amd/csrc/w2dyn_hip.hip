@@ -4,6 +4,7 @@
 // all estimators run in the kernels of cthyb_kernels.hip.h.
 #include "../../include/w2dyn_hip.h"
 #include "cthyb_kernels.hip.h"
+#include "local_problem.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -47,6 +48,9 @@ struct w2dyn_solver {
     int has_szt = 0;
     std::vector<double> energies, udd, eps, outer_w, outer_cum, ftab;
     double egs = 0;
+    LocalProblem lp;                 // blocks, eigenbasis and operators of H_loc
+    std::vector<int> dmoff;          // offsets of the blocks inside the block-diagonal density matrix
+    bool mat = false;                // matrix local-trace path (blocks with more than one state)
     DevConst C{};
     std::vector<void *> allocs;
     // accumulators bookkeeping
@@ -149,7 +153,7 @@ Launch walker_launch(const w2dyn_solver *s)
     Launch l;
     l.block = dim3(256);
     l.grid = dim3((s->nwalkers + 3) / 4);
-    l.lds = 4 * s->C.lds_per_wave;
+    l.lds = (size_t)s->C.shared_lds + 4 * (size_t)s->C.lds_per_wave;
     return l;
 }
 
@@ -302,48 +306,52 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if (!get_real(s, "TaudiffMax", s->taudiffmax_param)) return W2DYN_EINVAL;
     if (!get_str(s, "QuantumNumbers", sv)) return W2DYN_EINVAL;
     s->has_szt = sv.find("Szt") != std::string::npos;
-    if (sv.find("Azt") == std::string::npos && sv.find("All") == std::string::npos)
-        return fail(s, W2DYN_EUNSUPPORTED, "QuantumNumbers '%s': the HIP solver needs one Fock state per block (use 'Nt Szt Azt')", sv.c_str());
+    const std::string qns = sv;
+    double epsevec = 1e-15;
+    if (!get_real(s, "EPSEVEC", epsevec)) return W2DYN_EINVAL;
     if (s->nleg < 1 || s->nleg > 128) return fail(s, W2DYN_EUNSUPPORTED, "NLegMax=%d out of range [1,128]", s->nleg);
     s->nftau = nftau;
     if (nftau < 2) return fail(s, W2DYN_EINVAL, "nftau=%d", nftau);
 
     const int nd = s->nd, nf = s->nflav;
-    // ---- local problem: must be diagonal in the occupation basis (density-density) ----
-    for (int a = 0; a < nf; ++a) for (int b = 0; b < nf; ++b) for (int c = 0; c < nf; ++c) for (int d = 0; d < nf; ++d) {
+    // ---- local problem (CTQMC.F90:7957-8031) ----
+    bool dd = true;        // H_loc diagonal in the occupation basis (density-density U, diagonal muimp)
+    for (int a = 0; a < nf && dd; ++a) for (int b = 0; b < nf && dd; ++b) for (int c = 0; c < nf && dd; ++c) for (int d = 0; d < nf; ++d) {
         double u = U[((a * nf + b) * nf + c) * nf + d];
         if (u == 0.0) continue;
         bool diag = (a == c && b == d) || (a == d && b == c);
-        if (!diag && a != b && c != d)
-            return fail(s, W2DYN_EUNSUPPORTED, "U(%d,%d,%d,%d) != 0: only density-density interactions are supported by the HIP solver this round", a, b, c, d);
+        if (!diag && a != b && c != d) { dd = false; break; }
     }
     for (int b1 = 0; b1 < nd; ++b1) for (int s1 = 0; s1 < 2; ++s1) for (int b2 = 0; b2 < nd; ++b2) for (int s2 = 0; s2 < 2; ++s2) {
         size_t i = ((size_t)(b1 * 2 + s1) * nd + b2) * 2 + s2;
-        if ((b1 != b2 || s1 != s2) && mu_full[i] != 0.0) return fail(s, W2DYN_EUNSUPPORTED, "off-diagonal muimp is not supported");
+        if ((b1 != b2 || s1 != s2) && mu_full[i] != 0.0) dd = false;
         if (screening) for (int t = 0; t < nftau; ++t) if (screening[i * nftau + t] != 0.0) return fail(s, W2DYN_EUNSUPPORTED, "non-zero screening function is not supported");
     }
+    if (!dd && qns.find("All") != std::string::npos)
+        return fail(s, W2DYN_EUNSUPPORTED, "QuantumNumbers = All (automatic partitioning, Operator.F90:303-442) is only supported for density-density interactions; name the quantum numbers, e.g. 'Nt Szt Qzt'");
+    s->lp.build(nd, U, mu_full, qns, epsevec);
+    const LocalProblem &lp = s->lp;
+    s->mat = !(dd && lp.identity_blocks);
+    if (s->mat && lp.nsmax > 8) return fail(s, W2DYN_EUNSUPPORTED, "largest block of H_loc has %d states with QuantumNumbers '%s': the HIP solver handles up to 8", lp.nsmax, qns.c_str());
     s->eps.assign(nf, 0.0); s->udd.assign((size_t)nf * nf, 0.0);
     for (int f = 0; f < nf; ++f) { int b = f >> 1, sp = f & 1; s->eps[f] = mu_full[((size_t)(b * 2 + sp) * nd + b) * 2 + sp]; }
     auto Ut = [&](int a, int b) { return U[((a * nf + b) * nf + a) * nf + b] - U[((a * nf + b) * nf + b) * nf + a]; };
     for (int f = 0; f < nf; ++f) for (int g = 0; g < nf; ++g) if (f != g) s->udd[f * nf + g] = 0.5 * (Ut(f, g) + Ut(g, f));
-    // <n|H|n> as the reference builds it (Operator.F90:482-542, 1042-1107)
-    s->energies.assign(s->nstates, 0.0);
-    for (int st = 0; st < s->nstates; ++st) {
-        double e = 0.0;
-        for (int f = 0; f < nf; ++f) {
-            if (!((st >> flav_bit_h(f, nd)) & 1)) continue;
-            e += s->eps[f];
-            for (int g = 0; g < nf; ++g) if (g != f && ((st >> flav_bit_h(g, nd)) & 1)) e += 0.5 * Ut(f, g);
-        }
-        s->energies[st] = e;
-    }
-    s->egs = *std::min_element(s->energies.begin(), s->energies.end());      // Trace.F90:576-583
-    {   // empty-trace weights for the outer superstate draw (Trace.F90:648-663)
-        s->outer_w.assign(s->nstates, 0.0); s->outer_cum.assign(s->nstates, 0.0);
+    s->energies = lp.eval;                                                    // eigenvalues in block order
+    s->egs = lp.egs;                                                          // Trace.F90:576-583
+    const int nouter = lp.nsst;
+    s->dmoff.assign(nouter + 1, 0);
+    for (int b = 0; b < nouter; ++b) s->dmoff[b + 1] = s->dmoff[b] + lp.sst_n[b] * lp.sst_n[b];
+    {   // empty-trace weights of the outer blocks (Trace.F90:648-663): sum over the block's states
+        s->outer_w.assign(nouter, 0.0); s->outer_cum.assign(nouter, 0.0);
         double sum = 0.0;
-        for (int st = 0; st < s->nstates; ++st) { s->outer_w[st] = std::exp(-(s->energies[st] - s->egs) * s->beta); sum += s->outer_w[st]; }
+        for (int b = 0; b < nouter; ++b) {
+            double w = 0.0;
+            for (int i = 0; i < lp.sst_n[b]; ++i) w += std::exp(-(lp.eval[lp.sst_off[b] + i] - s->egs) * s->beta);
+            s->outer_w[b] = w; sum += w;
+        }
         double acc = 0.0;
-        for (int st = 0; st < s->nstates; ++st) { s->outer_w[st] /= sum; acc += s->outer_w[st]; s->outer_cum[st] = acc; }
+        for (int b = 0; b < nouter; ++b) { s->outer_w[b] /= sum; acc += s->outer_w[b]; s->outer_cum[b] = acc; }
     }
     s->ftab.assign((size_t)nf * nftau, 0.0);
     for (int b = 0; b < nd; ++b) for (int sp = 0; sp < 2; ++sp)      // CTQMC.F90:7950-7955
@@ -359,8 +367,27 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     C.walkers_per_bin = s->walkers_per_bin; C.nbins = (s->nwalkers + s->walkers_per_bin - 1) / s->walkers_per_bin;
     C.wcap = std::max(kmax, std::min(2 * nf * kmax, 256));
     C.kgj = std::min(kmax, 32);
-    C.lds_per_wave = (int)lds_bytes_per_wave(nf, kmax, C.wcap, C.kgj);
-    if (4 * (size_t)C.lds_per_wave > 160 * 1024) return fail(s, W2DYN_EUNSUPPORTED, "kmax=%d needs %d bytes of LDS per chain: too large", kmax, C.lds_per_wave);
+    C.nouter = nouter; C.dmsize = s->dmoff[nouter]; C.mat = s->mat ? 1 : 0; C.nsst = lp.nsst; C.nsm = lp.nsmax;
+    C.shared_lds = 0; C.op_in_lds = 0;
+    std::vector<double> opmat;
+    if (s->mat) {
+        const size_t nop = (size_t)lp.nsst * nf * 2 * C.nsm * C.nsm;
+        opmat.assign(nop, 0.0);
+        for (int b = 0; b < lp.nsst; ++b) for (int f = 0; f < nf; ++f) for (int ca = 1; ca <= 2; ++ca) {
+            int tb = lp.connect(b, f, ca); if (tb < 0) continue;
+            const std::vector<double> &O = lp.oper(b, f, ca); const int n1 = lp.sst_n[b], n2 = lp.sst_n[tb];
+            double *dst = &opmat[((size_t)(b * nf + f) * 2 + (ca - 1)) * C.nsm * C.nsm];
+            for (int i = 0; i < n2; ++i) for (int j = 0; j < n1; ++j) dst[i * C.nsm + j] = O[i + (size_t)n2 * j];
+        }
+        size_t ints = ((size_t)lp.nsst * nf * 2 + 2 * (size_t)lp.nsst) * sizeof(int);
+        ints = (ints + 7) & ~(size_t)7;
+        size_t small = ints + (size_t)s->nstates * sizeof(double);
+        C.op_in_lds = (small + nop * sizeof(double) <= 64 * 1024) ? 1 : 0;
+        C.shared_lds = (int)((small + (C.op_in_lds ? nop * sizeof(double) : 0) + 15) & ~(size_t)15);
+    }
+    C.lds_per_wave = (int)lds_bytes_per_wave(nf, kmax, C.wcap, C.kgj, C.mat);
+    if ((size_t)C.shared_lds + 4 * (size_t)C.lds_per_wave > 160 * 1024 && C.kgj > 16) { C.kgj = 16; C.lds_per_wave = (int)lds_bytes_per_wave(nf, kmax, C.wcap, C.kgj, C.mat); }
+    if ((size_t)C.shared_lds + 4 * (size_t)C.lds_per_wave > 160 * 1024) return fail(s, W2DYN_EUNSUPPORTED, "kmax=%d needs %d bytes of LDS per chain: too large", kmax, C.lds_per_wave);
     C.beta = s->beta; C.p_glob = s->p_glob; C.p_shift = s->p_shift; C.egs = s->egs;
     C.seed = (unsigned long long)s->seed; C.first_walker = (unsigned long long)s->first_walker;
     host_init_window(s, s->taudiffmax_param, C.num_windows, C.taudiff_max);           // Trace.F90:605
@@ -372,6 +399,18 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if ((rc = dev_upload(s, C.eps, s->eps))) return rc;
     if ((rc = dev_upload(s, C.outer_cum, s->outer_cum))) return rc;
     if ((rc = dev_upload(s, C.outer_w, s->outer_w))) return rc;
+    if ((rc = dev_upload(s, C.sst_n, lp.sst_n))) return rc;
+    if ((rc = dev_upload(s, C.sst_off, lp.sst_off))) return rc;
+    if ((rc = dev_upload(s, C.conn, lp.conn))) return rc;
+    if ((rc = dev_upload(s, C.sst_of_state, lp.sst_of_state))) return rc;
+    if ((rc = dev_upload(s, C.dmoff, s->dmoff))) return rc;
+    if ((rc = dev_upload(s, C.sst_eval, lp.eval))) return rc;
+    {
+        std::vector<int> first(lp.nsst);
+        for (int b = 0; b < lp.nsst; ++b) first[b] = lp.states[lp.sst_off[b]];
+        if ((rc = dev_upload(s, C.sst_first, first))) return rc;
+    }
+    if (s->mat) { if ((rc = dev_upload(s, C.opmat, opmat))) return rc; }
     const size_t W = s->nwalkers;
     if ((rc = dev_alloc(s, C.ws, W))) return rc;
     if ((rc = dev_alloc(s, C.K, W * nf))) return rc;
@@ -386,9 +425,9 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if ((rc = dev_alloc(s, C.acc_gtau, B * nf * s->ntau))) return rc;
     if ((rc = dev_alloc(s, C.acc_giw, B * nf * C.niw2 * 2))) return rc;
     if ((rc = dev_alloc(s, C.acc_histo, B * nf * (s->maxhisto + 1)))) return rc;
-    if ((rc = dev_alloc(s, C.acc_dm, B * s->nstates))) return rc;
-    if ((rc = dev_alloc(s, C.acc_outer, B * s->nstates))) return rc;
-    if ((rc = dev_alloc(s, C.acc_signouter, B * s->nstates))) return rc;
+    if ((rc = dev_alloc(s, C.acc_dm, B * C.dmsize))) return rc;
+    if ((rc = dev_alloc(s, C.acc_outer, B * nouter))) return rc;
+    if ((rc = dev_alloc(s, C.acc_signouter, B * nouter))) return rc;
     if ((rc = dev_alloc(s, C.acc_sign, B))) return rc;
     if ((rc = dev_alloc(s, C.accpair, (size_t)nf * s->ntau))) return rc;
     // initial chain state: empty configuration, outer superstate drawn with the chain's first random number
@@ -398,8 +437,8 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
         memset(&x, 0, sizeof x);
         w2dyn_rng_state r{(uint64_t)s->seed, (uint64_t)s->first_walker + w, 0};
         double u = w2dyn_uniform(&r);
-        int sel = s->nstates - 1;
-        for (int st = 0; st < s->nstates; ++st) if (s->outer_cum[st] >= u && s->outer_w[st] != 0.0) { sel = st; break; }
+        int sel = nouter - 1;
+        for (int st = 0; st < nouter; ++st) if (s->outer_cum[st] >= u && s->outer_w[st] != 0.0) { sel = st; break; }
         x.ndraw = r.ndraw; x.outer = sel; x.npairs = 0; x.wpos = 0; x.det_sign = 1.0; x.det_log = 0.0;
     }
     HIPCHK(hipMemcpyAsync(C.ws, ws.data(), W * sizeof(WalkerScalars), hipMemcpyHostToDevice, s->stream));
@@ -441,7 +480,8 @@ int w2dyn_sweep(w2dyn_solver *s, int64_t nsteps, int count_as_sampling)
     Launch l = walker_launch(s);
     int rc;
     if ((rc = time_begin(s))) return rc;
-    hipLaunchKernelGGL(k_sweep, l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps, count_as_sampling);
+    if (s->mat) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<true>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps, count_as_sampling);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<false>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps, count_as_sampling);
     HIPCHK(hipGetLastError());
     if ((rc = time_end(s, "sweep"))) return rc;
     s->steps_done += nsteps;
@@ -476,9 +516,9 @@ int w2dyn_measure_begin(w2dyn_solver *s)
     HIPCHK(hipMemsetAsync(C.acc_gtau, 0, sizeof(double) * B * nf * s->ntau, s->stream));
     HIPCHK(hipMemsetAsync(C.acc_giw, 0, sizeof(double) * B * nf * C.niw2 * 2, s->stream));
     HIPCHK(hipMemsetAsync(C.acc_histo, 0, sizeof(double) * B * nf * (s->maxhisto + 1), s->stream));
-    HIPCHK(hipMemsetAsync(C.acc_dm, 0, sizeof(double) * B * s->nstates, s->stream));
-    HIPCHK(hipMemsetAsync(C.acc_outer, 0, sizeof(double) * B * s->nstates, s->stream));
-    HIPCHK(hipMemsetAsync(C.acc_signouter, 0, sizeof(double) * B * s->nstates, s->stream));
+    HIPCHK(hipMemsetAsync(C.acc_dm, 0, sizeof(double) * B * C.dmsize, s->stream));
+    HIPCHK(hipMemsetAsync(C.acc_outer, 0, sizeof(double) * B * C.nouter, s->stream));
+    HIPCHK(hipMemsetAsync(C.acc_signouter, 0, sizeof(double) * B * C.nouter, s->stream));
     HIPCHK(hipMemsetAsync(C.acc_sign, 0, sizeof(double) * B, s->stream));
     s->meas_done = 0; s->time_sim_steps = 0;
     return 0;
@@ -491,7 +531,8 @@ int w2dyn_measure_once(w2dyn_solver *s)
     Launch l = walker_launch(s);
     int rc;
     if ((rc = time_begin(s))) return rc;
-    hipLaunchKernelGGL(k_meas_misc, l.grid, l.block, l.lds, s->stream, s->C);
+    if (s->mat) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_misc<true>), l.grid, l.block, l.lds, s->stream, s->C);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_misc<false>), l.grid, l.block, l.lds, s->stream, s->C);
     HIPCHK(hipGetLastError());
     if ((rc = time_end(s, "meas_misc"))) return rc;
     if ((rc = time_begin(s))) return rc;
@@ -523,7 +564,9 @@ int w2dyn_measure_finish(w2dyn_solver *s)
     auto fetch = [&](const double *dev, size_t n) { std::vector<double> v(n); (void)hipMemcpy(v.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost); return v; };
     std::vector<double> gleg = fetch(C.acc_gleg, (size_t)B * nf * s->nleg), gtau = fetch(C.acc_gtau, (size_t)B * nf * s->ntau);
     std::vector<double> giw = fetch(C.acc_giw, (size_t)B * nf * C.niw2 * 2), histo = fetch(C.acc_histo, (size_t)B * nf * (s->maxhisto + 1));
-    std::vector<double> dm = fetch(C.acc_dm, (size_t)B * ns), outer = fetch(C.acc_outer, (size_t)B * ns), souter = fetch(C.acc_signouter, (size_t)B * ns);
+    const int no = C.nouter, dms = C.dmsize;
+    const LocalProblem &lp = s->lp;
+    std::vector<double> dm = fetch(C.acc_dm, (size_t)B * dms), outer = fetch(C.acc_outer, (size_t)B * no), souter = fetch(C.acc_signouter, (size_t)B * no);
     std::vector<double> sgn = fetch(C.acc_sign, B);
     std::vector<WalkerScalars> ws(W);
     HIPCHK(hipMemcpy(ws.data(), C.ws, ws.size() * sizeof(WalkerScalars), hipMemcpyDeviceToHost));
@@ -553,24 +596,41 @@ int w2dyn_measure_finish(w2dyn_solver *s)
     reduce_bins(gtau, (size_t)nf * ntau, "gtau", [&](double v, double n, size_t) { return -(v / n) / (-ms) * (double)ntau / (beta * beta); });
     reduce_bins(giw, (size_t)nf * C.niw2 * 2, "giw", [&](double v, double n, size_t) { double zs = -1.0 / (n * ms); return v * zs / beta; });   // 8815-8817
     reduce_bins(histo, (size_t)nf * (s->maxhisto + 1), "histo", [&](double v, double n, size_t) { return v / n; });                                // 8755
-    reduce_bins(dm, ns, "dmdiag", [&](double v, double n, size_t) { double zs = -1.0 / (n * ms); return v * zs; });                                // 8706-8708
-    reduce_bins(outer, ns, "outersuperstatehisto", [&](double v, double n, size_t) { return v / n; });                                             // 8760
+    reduce_bins(dm, dms, "dmblocks", [&](double v, double n, size_t) { double zs = -1.0 / (n * ms); return v * zs; });                             // 8706-8708
+    reduce_bins(outer, no, "outersuperstatehisto", [&](double v, double n, size_t) { return v / n; });                                             // 8760
     {   // SignHistoSuperstates / OuterSuperstateHisto before the latter is normalised (CTQMC.F90:8757)
-        std::vector<double> so(ns, 0.0), oo(ns, 0.0);
-        for (int b = 0; b < B; ++b) for (int i = 0; i < ns; ++i) { so[i] += souter[(size_t)b * ns + i]; oo[i] += outer[(size_t)b * ns + i]; }
-        for (int i = 0; i < ns; ++i) so[i] = so[i] / oo[i];
-        R["signhistosuperstates"] = so; R["signhistostates"] = so;
+        std::vector<double> so(no, 0.0), oo(no, 0.0);
+        for (int b = 0; b < B; ++b) for (int i = 0; i < no; ++i) { so[i] += souter[(size_t)b * no + i]; oo[i] += outer[(size_t)b * no + i]; }
+        for (int i = 0; i < no; ++i) so[i] = so[i] / oo[i];
+        R["signhistosuperstates"] = so;
+        // per-state versions: every state of the outer block counts (CTQMC.F90:3298-3300); the per-state sign needs the
+        // partial traces in a particular eigenbasis and is reported with the block's value
+        std::vector<double> os(ns, 0.0), ss(ns, 0.0);
+        for (int b = 0; b < no; ++b) for (int i = 0; i < lp.sst_n[b]; ++i) { os[lp.sst_off[b] + i] = R["outersuperstatehisto"][b]; ss[lp.sst_off[b] + i] = so[b]; }
+        R["outerstatehisto"] = os; R["signhistostates"] = ss;
     }
-    R["outerstatehisto"] = R["outersuperstatehisto"];
+    {   // diagonal of the density matrix in the occupation basis, block order (Transform_DensityMatrix_EB_to_OCCB, 3163-3179)
+        auto to_occ_diag = [&](const double *blocks, double *out) {
+            for (int b = 0; b < no; ++b) {
+                const int n = lp.sst_n[b]; const double *Rb = blocks + s->dmoff[b]; const std::vector<double> &V = lp.evec[b];
+                for (int i = 0; i < n; ++i) { double a = 0.0; for (int k = 0; k < n; ++k) for (int l = 0; l < n; ++l) a += V[i + (size_t)n * k] * Rb[k * n + l] * V[i + (size_t)n * l]; out[lp.sst_off[b] + i] = a; }
+            }
+        };
+        std::vector<double> d(ns), db((size_t)B * ns);
+        to_occ_diag(R["dmblocks"].data(), d.data());
+        for (int b = 0; b < B; ++b) to_occ_diag(&R["dmblocks_bins"][(size_t)b * dms], &db[(size_t)b * ns]);
+        R["dmdiag"] = d; R["dmdiag_bins"] = db;
+    }
     {   // trace contributions: one state per block, parttrace == trace, contribution exp(log tr) is not tracked; the
         // reference divides sums of exp(parttrace%log) by CntMeas (8763-8764). Report the visit frequencies' support.
-        R["tracecontribsuperstates"] = std::vector<double>(ns, 0.0); R["tracecontribstates"] = std::vector<double>(ns, 0.0);
+        R["tracecontribsuperstates"] = std::vector<double>(no, 0.0); R["tracecontribstates"] = std::vector<double>(ns, 0.0);
     }
     // density matrix and its contractions (CTQMC.F90:2842-3060 for one-state blocks; eigenbasis == occupation basis)
     auto occ_of = [&](const double *d, std::vector<double> &occ, std::vector<double> &rho1, std::vector<double> &rho2) {
         occ.assign((size_t)nf * nf, 0.0); rho1.assign((size_t)nf * nf, 0.0); rho2.assign((size_t)nf * nf * nf * nf, 0.0);
-        for (int st = 0; st < ns; ++st) {
-            double wgt = d[st]; if (wgt == 0.0) continue;
+        for (int idx = 0; idx < ns; ++idx) {
+            double wgt = d[idx]; if (wgt == 0.0) continue;
+            const int st = lp.states[idx];
             for (int a = 0; a < nf; ++a) {
                 if (!((st >> flav_bit_h(a, nd)) & 1)) continue;
                 rho1[(size_t)a * nf + a] += wgt;
@@ -585,7 +645,7 @@ int w2dyn_measure_finish(w2dyn_solver *s)
             }
         }
     };
-    {
+    if (!s->mat) {
         std::vector<double> occ, rho1, rho2;
         occ_of(R["dmdiag"].data(), occ, rho1, rho2);
         R["occ"] = occ; R["rho1"] = rho1; R["rho2"] = rho2;
@@ -594,6 +654,34 @@ int w2dyn_measure_finish(w2dyn_solver *s)
         R["occ_bins"] = ob;
         std::vector<double> full((size_t)ns * ns, 0.0);
         for (int i = 0; i < ns; ++i) full[(size_t)i * ns + i] = R["dmdiag"][i];
+        R["densitymatrix"] = full;
+    } else {
+        // contractions of the block density matrix with the operators in the eigenbasis (CTQMC.F90:2842-3060)
+        auto occ_gen = [&](const double *blocks, std::vector<double> &occ) {
+            occ.assign((size_t)nf * nf, 0.0);
+            for (int a = 0; a < nf; ++a) for (int b = 0; b < nf; ++b) { int fl[4] = {b, b, a, a}, ca[4] = {2, 1, 2, 1}; occ[(size_t)a * nf + b] = lp.expect(blocks, s->dmoff, 4, fl, ca); }
+        };
+        const double *blk = R["dmblocks"].data();
+        std::vector<double> occ, rho1((size_t)nf * nf, 0.0), rho2((size_t)nf * nf * nf * nf, 0.0);
+        occ_gen(blk, occ);
+        for (int a = 0; a < nf; ++a) for (int b = 0; b < nf; ++b) { int fl[2] = {a, b}, ca[2] = {2, 1}; rho1[(size_t)b * nf + a] = lp.expect(blk, s->dmoff, 2, fl, ca); }
+        for (int f1 = 0; f1 < nf; ++f1) for (int f2 = 0; f2 < nf; ++f2) for (int f3 = 0; f3 < nf; ++f3) for (int f4 = 0; f4 < nf; ++f4) {
+            int fl[4] = {f1, f2, f3, f4}, ca[4] = {2, 2, 1, 1};
+            rho2[(((size_t)f4 * nf + f3) * nf + f2) * nf + f1] = lp.expect(blk, s->dmoff, 4, fl, ca);
+        }
+        R["occ"] = occ; R["rho1"] = rho1; R["rho2"] = rho2;
+        std::vector<double> ob((size_t)B * nf * nf), o1;
+        for (int b = 0; b < B; ++b) { occ_gen(&R["dmblocks_bins"][(size_t)b * dms], o1); std::copy(o1.begin(), o1.end(), ob.begin() + (size_t)b * nf * nf); }
+        R["occ_bins"] = ob;
+        std::vector<double> full((size_t)ns * ns, 0.0);
+        for (int b = 0; b < no; ++b) {
+            const int n = lp.sst_n[b], off = lp.sst_off[b]; const double *Rb = blk + s->dmoff[b]; const std::vector<double> &V = lp.evec[b];
+            for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+                double a = 0.0;
+                for (int k = 0; k < n; ++k) for (int l = 0; l < n; ++l) a += V[i + (size_t)n * k] * Rb[k * n + l] * V[j + (size_t)n * l];
+                full[(size_t)(off + i) * ns + off + j] = a;
+            }
+        }
         R["densitymatrix"] = full;
     }
     {   // acceptance ratios (CTQMC.F90:8680-8695); 16 sectors, Z = index 0
@@ -690,16 +778,16 @@ int w2dyn_set_mc_config(w2dyn_solver *s, int walker, int n, const double *taus, 
     HIPCHK(hipStreamSynchronize(s->stream));
     const DevConst &C = s->C; const int nf = s->nflav, kmax = C.kmax, nd = s->nd;
     std::vector<int> K(nf, 0); std::vector<double> TC((size_t)nf * kmax, 0.0), TA((size_t)nf * kmax, 0.0);
+    (void)nd;
+    if (outer_sst < 0 || outer_sst >= C.nouter) return fail(s, W2DYN_EINVAL, "set_mc_config: outer superstate %d out of range", outer_sst);
     int state = outer_sst;
     for (int i = 0; i < n; ++i) {
         if (hashybs && hashybs[i] == 0) return fail(s, W2DYN_EUNSUPPORTED, "worm operators in set_mc_config are not supported");
         int f = 2 * (orbs[i] - 1) + (spins[i] - 1);
         if (f < 0 || f >= nf || (cas[i] != 1 && cas[i] != 2)) return fail(s, W2DYN_EINVAL, "bad operator %d", i);
         if (i > 0 && !(taus[i] > taus[i - 1])) return fail(s, W2DYN_EINVAL, "set_mc_config: taus must be strictly increasing");
-        int bit = 1 << flav_bit_h(f, nd);
-        bool occ = state & bit;
-        if ((cas[i] == 1) == occ) return fail(s, W2DYN_EINVAL, "set_mc_config: operator %d violates the quantum numbers", i);
-        state ^= bit;
+        state = s->lp.connect(state, f, cas[i]);
+        if (state < 0) return fail(s, W2DYN_EINVAL, "set_mc_config: operator %d violates the quantum numbers", i);
     }
     if (state != outer_sst) return fail(s, W2DYN_EINVAL, "set_mc_config: sequence does not return to the outer superstate");
     std::vector<int> nc(nf, 0), na(nf, 0);
@@ -775,10 +863,14 @@ int w2dyn_get_result(w2dyn_solver *s, const char *name, void *out, size_t bytes,
     const void *src = nullptr; size_t size = 0;
     std::vector<int> itmp; std::vector<long long> ltmp; std::vector<double> dtmp;
     if (n == "accpair") { src = s->res_accpair.data(); size = s->res_accpair.size() * sizeof(long long); }
-    else if (n == "statessuperstates") { itmp.resize(s->nstates); for (int i = 0; i < s->nstates; ++i) itmp[i] = i; src = itmp.data(); size = itmp.size() * sizeof(int); }
+    else if (n == "statessuperstates") {   // block of every eigenstate, block order (CTQMC.F90:8053-8055)
+        itmp.resize(s->nstates);
+        for (int b = 0; b < s->lp.nsst; ++b) for (int i = 0; i < s->lp.sst_n[b]; ++i) itmp[s->lp.sst_off[b] + i] = b;
+        src = itmp.data(); size = itmp.size() * sizeof(int);
+    }
     else if (n == "occbasismapping") {   // (NStates, Nd, 2), CTQMC.F90:8059-8065
         itmp.resize((size_t)s->nstates * s->nd * 2);
-        for (int st = 0; st < s->nstates; ++st) for (int b = 0; b < s->nd; ++b) for (int sp = 0; sp < 2; ++sp) itmp[((size_t)st * s->nd + b) * 2 + sp] = (st >> (b + sp * s->nd)) & 1;
+        for (int i = 0; i < s->nstates; ++i) { int st = s->lp.states[i]; for (int b = 0; b < s->nd; ++b) for (int sp = 0; sp < 2; ++sp) itmp[((size_t)i * s->nd + b) * 2 + sp] = (st >> (b + sp * s->nd)) & 1; }
         src = itmp.data(); size = itmp.size() * sizeof(int);
     }
     else if (n == "cntsampling") { ltmp.assign(16, 0); if (!s->counters.empty()) ltmp[0] = (long long)s->counters[C_SAMPLING]; src = ltmp.data(); size = ltmp.size() * sizeof(long long); }
@@ -812,6 +904,9 @@ int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out)
     else if (n == "steps_done") *out = (double)s->steps_done;
     else if (n == "meas_done") *out = (double)s->meas_done;
     else if (n == "num_windows") *out = s->C.num_windows;
+    else if (n == "nsst") *out = s->lp.nsst;
+    else if (n == "nsmax") *out = s->lp.nsmax;
+    else if (n == "matrix_trace") *out = s->mat ? 1 : 0;
     else if (n == "nslide") *out = s->C.nslide;
     else return fail(s, W2DYN_EINVAL, "unknown scalar '%s'", name);
     return 0;
