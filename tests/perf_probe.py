@@ -31,6 +31,10 @@ def probe(cfg, nftau, over, nw, kmax=0, rounds=int(os.environ.get('PROBE_ROUNDS'
     q.dest_ctqmc(); q.close()
 
 if __name__ == "__main__":
-    over = dict(NCorr=200, TaudiffMax=10.0, Ntau=1000, NLegMax=100)
-    for nw in [int(x) for x in (sys.argv[1:] or ["256", "2048", "8192", "16384"])]:
-        probe("C2", 5001, over, nw)
+    args = sys.argv[1:]
+    cfg = "C2"
+    if args and not args[0].isdigit():
+        cfg = args.pop(0)
+    over = dict(NCorr=200 if cfg == "C2" else 100, TaudiffMax=10.0, Ntau=1000, NLegMax=100)
+    for nw in [int(x) for x in (args or ["256", "2048", "8192", "16384"])]:
+        probe(cfg, 5001, over, nw)

@@ -36,6 +36,9 @@
 
 namespace w2dyn {
 
+// the sweep kernel is one flat function per instantiation: a real call would force the chain context into scratch
+#define W2DYN_INLINE __attribute__((always_inline)) inline
+
 constexpr int MAXFLAV = 16;
 constexpr int KMAX_LIMIT = 256;
 
@@ -45,7 +48,7 @@ enum Counter { C_TRYADD, C_ACCADD, C_QNADD, C_TRYREM, C_ACCREM, C_QNREM, C_TRYGL
                C_DBG0, C_DBG1, C_DBG2, C_DBG3, C_DBG4, C_DBG5, C_DBG6, C_DBG7,   // stage stamps (diagnostic build)
                C_NCOUNT };
 
-enum WalkerErr { ERR_NONE = 0, ERR_KMAX = 1, ERR_WCAP = 2, ERR_DETRAT = 4, ERR_SINGULAR = 8 };
+enum WalkerErr { ERR_NONE = 0, ERR_KMAX = 1, ERR_WCAP = 2, ERR_DETRAT = 4, ERR_SINGULAR = 8, ERR_BLOCKSEQ = 16 };
 
 struct WalkerScalars {
     unsigned long long ndraw;   // random numbers consumed
@@ -97,7 +100,7 @@ __host__ __device__ inline size_t lds_bytes_per_wave(int nflav, int kmax, int wc
 {
     size_t d = (size_t)2 * nflav * kmax + 4 * (size_t)kmax + wcap + (size_t)kgj * kgj;   // tc, ta, Q, R, MQ, RM, wt, gj
     size_t i = (size_t)2 * wcap + MAXFLAV;                                     // wm, wc, K
-    if (mat) { d += wcap + 2; i += (size_t)2 * wcap + 4; }                     // ot; om, osst
+    if (mat) { d += wcap + 2; i += (size_t)3 * wcap + 8; }                     // ot; om, osst, tsst
     size_t b = d * sizeof(double) + C_NCOUNT * sizeof(unsigned long long) + i * sizeof(int);
     return (b + 15) & ~(size_t)15;
 }
@@ -204,7 +207,7 @@ struct Ctx {
     double wr_t; int wr_m, wr_c, wr_p;  // lane e: window-list entry e (tau, f|ca<<8|slot<<16, partner count, pairs before e) when nwin <= 64
     int wvalid;                      // window list (registers or LDS) matches the current configuration and window
     // matrix local-trace path
-    double *ot; int *om, *osst; int nops;            // time-ordered operator list and block sequence (LDS)
+    double *ot; int *om, *osst, *tsst; int nops;     // time-ordered operator list, block sequence, trial block sequence (LDS)
     const int *t_conn, *t_n, *t_off; const double *t_eval, *t_op;   // block-shared tables (LDS); t_op null: operators stay in global memory
     double tr_log, tr_sign;                          // current local trace
     int ms_, mi_;                                    // lane = (outer state ms_, component mi_)
@@ -266,7 +269,7 @@ __device__ __forceinline__ bool pair_ok(double x, double y, double wmin, double 
 // Collect the operators inside the window (wt: tau, wm: f | ca<<8 | slot<<16) and count, for each of them, its partners
 // at later times (wc).  Returns the total = NPairs (Trace.F90:1770-1815); x.nwin = list length.  Up to 64 entries
 // the list lives in registers (lane e = entry e) and is scanned with v_readlane; longer lists stay in LDS.
-__device__ int build_window(Ctx &x)
+__device__ W2DYN_INLINE int build_window(Ctx &x)
 {
     const DevConst &C = x.C;
     int nw = 0;
@@ -332,7 +335,7 @@ __device__ int build_window(Ctx &x)
 }
 
 // integral over (lo,hi) of  eps_f + sum_g U_fg n_g(tau)   for the current configuration (flavour f itself excluded)
-__device__ double level_integral(Ctx &x, int f, double lo, double hi)
+__device__ W2DYN_INLINE double level_integral(Ctx &x, int f, double lo, double hi)
 {
     const DevConst &C = x.C;
     double part = 0.0;
@@ -367,8 +370,8 @@ __device__ __forceinline__ void accpair_add(Ctx &x, int f, double dt)
 // ---------------------------------------------------------------------------------------------------------------
 // pair insertion: CTQMC.F90:3353-3612 (StepAdd), Trace.F90:3657-3698, 2775-2832, MatrixUpdate.F90:392-442
 // ---------------------------------------------------------------------------------------------------------------
-template <bool MAT>
-__device__ void step_add(Ctx &x)
+template <int MAT>
+__device__ W2DYN_INLINE void step_add(Ctx &x)
 {
     const DevConst &C = x.C;
     x.count(C_TRYADD);
@@ -403,9 +406,11 @@ __device__ void step_add(Ctx &x)
         p_lo = mat_lower(x, lo); p_hi = mat_lower(x, hi);
         const int nf2 = 2 * C.nflav;
         const int code_lo = mat_code(f, creator_first ? 1 : 2), code_hi = mat_code(f, creator_first ? 2 : 1);
+        // the walk also records the trial block sequence of the span: tsst[j] = block in front of trial entry j
         int sq = uni(x.osst[p_lo]);
         sq = uni(x.t_conn[sq * nf2 + code_lo]);
-        for (int i = p_lo; i < p_hi && sq >= 0; ++i) sq = uni(x.t_conn[sq * nf2 + uni(x.om[i])]);
+        if (x.lane == 0) x.tsst[p_lo + 1] = sq;
+        for (int i = p_lo; i < p_hi && sq >= 0; ++i) { sq = uni(x.t_conn[sq * nf2 + uni(x.om[i])]); if (x.lane == 0) x.tsst[i + 2] = sq; }
         if (sq >= 0) sq = uni(x.t_conn[sq * nf2 + code_hi]);
         valid = !eq && sq >= 0 && sq == uni(x.osst[p_hi]);
     } else {
@@ -476,8 +481,12 @@ __device__ void step_add(Ctx &x)
     if constexpr (MAT) {
         if (x.nops + 2 > C.wcap) { x.err |= ERR_WCAP; return; }
         const int code_lo = mat_code(f, creator_first ? 1 : 2), code_hi = mat_code(f, creator_first ? 2 : 1);
+        for (int j = x.lane; j <= x.nops + 2; j += 64) {           // blocks outside the span are unchanged
+            if (j <= p_lo) x.tsst[j] = x.osst[j];
+            else if (j >= p_hi + 2) x.tsst[j] = x.osst[j - 2];
+        }
         mat_insert(x, p_lo, lo, code_lo); mat_insert(x, p_hi + 1, hi, code_hi);
-        mat_trace(x, x.outer, -1, -1, tl_new, ts_new);
+        mat_trace_trial<MAT>(x, x.tsst, x.nops, -1, -1, tl_new, ts_new);
         dlogtr = tl_new - x.tr_log;
     } else {
         double I = level_integral(x, f, lo, hi);
@@ -564,7 +573,7 @@ __device__ void step_add(Ctx &x)
     x.det_log += log(fabs(S));
     x.npairs = np_new;
     x.wvalid = 0;
-    if constexpr (MAT) { x.tr_log = tl_new; x.tr_sign = ts_new; mat_walk_sst(x); }
+    if constexpr (MAT) { x.tr_log = tl_new; x.tr_sign = ts_new; mat_commit_sst(x); }
     DBG_STAMP(x, C_DBG7);
     x.count(C_ACCADD);
     accpair_add(x, f, hi - lo);
@@ -573,8 +582,8 @@ __device__ void step_add(Ctx &x)
 // ---------------------------------------------------------------------------------------------------------------
 // pair removal: CTQMC.F90:3892-4150 (StepRem), Trace.F90:4851-4950, 2937-2963, MatrixUpdate.F90:445-482
 // ---------------------------------------------------------------------------------------------------------------
-template <bool MAT>
-__device__ void step_rem(Ctx &x)
+template <int MAT>
+__device__ W2DYN_INLINE void step_rem(Ctx &x)
 {
     const DevConst &C = x.C;
     x.count(C_TRYREM);
@@ -669,8 +678,10 @@ __device__ void step_rem(Ctx &x)
     if constexpr (MAT) {
         i1 = mat_lower(x, t1); i2 = mat_lower(x, t2);
         const int nf2 = 2 * C.nflav;
+        // trial entry j is list entry j (j < i1), j+1 (i1 <= j < i2-1) or j+2; tsst[j] = block in front of it
         int sq = uni(x.osst[i1]);
-        for (int i = i1 + 1; i < i2 && sq >= 0; ++i) sq = uni(x.t_conn[sq * nf2 + uni(x.om[i])]);
+        if (x.lane == 0) x.tsst[i1] = sq;
+        for (int i = i1 + 1; i < i2 && sq >= 0; ++i) { sq = uni(x.t_conn[sq * nf2 + uni(x.om[i])]); if (x.lane == 0 && i < i2 - 1) x.tsst[i] = sq; }
         blocked = !(sq >= 0 && sq == uni(x.osst[i2 + 1]));
     } else if (nw <= 64) {
         blocked = __ballot(x.lane < nw && (x.wr_m & 0xff) == f && x.wr_t > t1 && x.wr_t < t2) != 0ull;
@@ -690,7 +701,12 @@ __device__ void step_rem(Ctx &x)
     bool creator_first = tau_c < tau_a;
     double dlogtr, tl_new = 0.0, ts_new = 1.0;
     if constexpr (MAT) {
-        mat_trace(x, x.outer, i1, i2, tl_new, ts_new);
+        for (int j = x.lane; j <= x.nops - 2; j += 64) {
+            if (j < i1) x.tsst[j] = x.osst[j];
+            else if (j >= i2 - 1) x.tsst[j] = x.osst[j + 2];
+        }
+        wave_sync();
+        mat_trace_trial<MAT>(x, x.tsst, x.nops - 2, i1, i2, tl_new, ts_new);
         dlogtr = tl_new - x.tr_log;
     } else {
         // the pair's own operators sit on the boundary of (t1,t2) and belong to flavour f, which level_integral skips
@@ -755,7 +771,7 @@ __device__ void step_rem(Ctx &x)
     x.det_log += log(fabs(S));
     x.npairs = np - dnp;
     x.wvalid = 0;
-    if constexpr (MAT) { mat_remove(x, i2); mat_remove(x, i1); x.tr_log = tl_new; x.tr_sign = ts_new; mat_walk_sst(x); }
+    if constexpr (MAT) { mat_remove(x, i2); mat_remove(x, i1); x.tr_log = tl_new; x.tr_sign = ts_new; mat_commit_sst(x); }
     x.count(C_ACCREM);
     accpair_add(x, f, t2 - t1);
 }
@@ -763,7 +779,7 @@ __device__ void step_rem(Ctx &x)
 // ---------------------------------------------------------------------------------------------------------------
 // tau-shift: CTQMC.F90:4557-4835, Trace.F90:2355-2457; empty configuration: StepChangeOuter 4570-4638
 // ---------------------------------------------------------------------------------------------------------------
-__device__ void step_change_outer(Ctx &x)
+__device__ W2DYN_INLINE void step_change_outer(Ctx &x)
 {
     const DevConst &C = x.C;
     double r = x.draw();
@@ -778,15 +794,15 @@ __device__ void step_change_outer(Ctx &x)
     x.outer = uni(sel);
 }
 
-template <bool MAT>
-__device__ void step_shift(Ctx &x)
+template <int MAT>
+__device__ W2DYN_INLINE void step_shift(Ctx &x)
 {
     const DevConst &C = x.C;
     int nops = 0;
     for (int f = 0; f < C.nflav; ++f) nops += 2 * x.order(f);
     if (nops == 0) {
         step_change_outer(x);
-        if constexpr (MAT) { mat_walk_sst(x); mat_trace(x, x.outer, -1, -1, x.tr_log, x.tr_sign); }
+        if constexpr (MAT) { mat_walk_sst(x); mat_trace_current<MAT>(x); }
         return;
     }
     double dt = x.draw() * C.beta;
@@ -840,7 +856,7 @@ __device__ void step_shift(Ctx &x)
         x.window_bounds();
     }
     x.npairs = -1; x.wvalid = 0;
-    if constexpr (MAT) { mat_build_list(x); mat_walk_sst(x); mat_trace(x, x.outer, -1, -1, x.tr_log, x.tr_sign); }
+    if constexpr (MAT) { mat_build_list(x); mat_walk_sst(x); mat_trace_current<MAT>(x); }
     x.count(C_ACCSHIFT);
 }
 
@@ -852,7 +868,7 @@ __device__ void step_shift(Ctx &x)
 //   -int_0^beta E(n(tau)) dtau  with  E(n) = sum_f eps_f n_f + sum_{f<g} U_fg n_f n_g
 // n_f(tau) = n_f(0) + #creators before tau - #annihilators before tau.  Pair sums over operators of different
 // flavours are distributed over the lanes.  Creators of flavour f at TCb + f*fstride, annihilators at TAb + f*fstride.
-__device__ double full_logtrace(Ctx &x, const int *Kv, const double *TCb, const double *TAb, int fstride, int outer)
+__device__ W2DYN_INLINE double full_logtrace(Ctx &x, const int *Kv, const double *TCb, const double *TAb, int fstride, int outer)
 {
     const DevConst &C = x.C;
     const double beta = C.beta;
@@ -892,7 +908,7 @@ __device__ double full_logtrace(Ctx &x, const int *Kv, const double *TCb, const 
 // row stride kmax).  Returns log|det F| and its sign in slot order.  What the reference obtains from dgetrf/dgetri
 // (Trace.F90:2279-2333, MatrixUpdate.F90:41-99).  For k <= kgj the whole elimination runs in the wave's LDS scratch
 // (compact stride k); larger matrices are eliminated in place in global memory.
-__device__ void build_and_invert(Ctx &x, int f, int k, const double *tcp, const double *tap, double *A,
+__device__ W2DYN_INLINE void build_and_invert(Ctx &x, int f, int k, const double *tcp, const double *tap, double *A,
                                  double &logdet, double &sgn)
 {
     const DevConst &C = x.C;
@@ -989,14 +1005,14 @@ __device__ void build_and_invert(Ctx &x, int f, int k, const double *tcp, const 
 }
 
 // parity (+1/-1) of the permutation that sorts `t[0..k)` (number of inversions)
-__device__ double sort_parity(Ctx &x, const double *t, int k)
+__device__ W2DYN_INLINE double sort_parity(Ctx &x, const double *t, int k)
 {
     int inv = 0;
     for (int j = x.lane; j < k; j += 64) { double tj = t[j]; for (int i = 0; i < j; ++i) inv += (t[i] > tj) ? 1 : 0; }
     return (wave_sum(inv) & 1) ? -1.0 : 1.0;
 }
 
-__device__ void step_glob(Ctx &x)
+__device__ W2DYN_INLINE void step_glob(Ctx &x)
 {
     const DevConst &C = x.C;
     const int nf = C.nflav, nd = C.nd, kmax = C.kmax;
@@ -1104,8 +1120,8 @@ __device__ __forceinline__ void ctx_setup(Ctx &x, unsigned char *smem)
     x.nops = 0; x.tr_log = 0.0; x.tr_sign = 1.0; x.ms_ = 0; x.mi_ = 0;
     if (C.mat) {
         // per-wave list arrays behind the common slice; block-shared tables at the start of the dynamic LDS
-        x.om = x.K + MAXFLAV; x.osst = x.om + C.wcap;
-        x.ot = (double *)(((size_t)(x.osst + C.wcap + 4) + 7) & ~(size_t)7);
+        x.om = x.K + MAXFLAV; x.osst = x.om + C.wcap; x.tsst = x.osst + C.wcap + 2;
+        x.ot = (double *)(((size_t)(x.tsst + C.wcap + 2) + 7) & ~(size_t)7);
         const int nf2 = 2 * C.nflav;
         int *ti = (int *)smem;
         x.t_conn = ti; x.t_n = ti + C.nsst * nf2; x.t_off = x.t_n + C.nsst;
@@ -1158,8 +1174,7 @@ __device__ __forceinline__ void ctx_load(Ctx &x)
     wave_sync();
     if (C.mat) {      // time-ordered list, block sequence and trace of the stored configuration
         mat_build_list(x);
-        mat_walk_sst(x);
-        mat_trace(x, x.outer, -1, -1, x.tr_log, x.tr_sign);
+        mat_walk_sst(x);                 // the caller evaluates the trace (mat_trace_current<MAT>)
     }
 }
 
@@ -1189,7 +1204,7 @@ __device__ __forceinline__ void ctx_store(Ctx &x)
 #endif
 
 // sweep kernel: nsteps iterations of the Z-space loop (CTQMC.F90:8213-8257 / 8428-8533) for every chain
-template <bool MAT>
+template <int MAT>
 __global__ __launch_bounds__(256) void k_sweep(DevConst C, long long nsteps, int count_sampling)
 {
     extern __shared__ unsigned char smem[];
@@ -1198,6 +1213,7 @@ __global__ __launch_bounds__(256) void k_sweep(DevConst C, long long nsteps, int
     ctx_setup(x, smem);
     if (x.w >= C.nwalkers) return;
     ctx_load(x);
+    if constexpr (MAT != 0) mat_trace_current<MAT>(x);
     const double pg = C.p_glob, ps = C.p_shift;
     // position inside the window-shift period: (TryAdd+TryRem) mod NSlide (CTQMC.F90:8255, 8531)
     unsigned int phase = (unsigned int)((x.cnt[C_TRYADD] + x.cnt[C_TRYREM]) % (unsigned long long)C.nslide);
@@ -1220,7 +1236,7 @@ __global__ __launch_bounds__(256) void k_sweep(DevConst C, long long nsteps, int
             STAMP_KIND(C_CYC_REM); phase += 1; }
         else if (r <= 1.0 - ps) {
 #ifndef W2DYN_NO_GLOB
-            if constexpr (MAT) step_glob_mat(x); else step_glob(x);
+            if constexpr (MAT != 0) step_glob_mat<MAT>(x); else step_glob(x);
 #endif
             STAMP_KIND(C_CYC_GLOB); }
         else {
@@ -1276,7 +1292,7 @@ __global__ __launch_bounds__(256) void k_rebuild(DevConst C)
 //   trace sign   : pairs (i,j) with tau_j < tau_i and Fock bit(f_j) < bit(f_i)          (Operator.F90:158-171)
 //   block sign   : pairs (i,j) with tau_j > tau_i and flavour index f_j < f_i             (Trace.F90:3594-3618)
 //   permaltca    : for every creator, operators of its flavour at later times; +1 if N/2 is odd (3554-3588)
-template <bool MAT>
+template <int MAT>
 __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
 {
     extern __shared__ unsigned char smem[];
@@ -1285,6 +1301,7 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
     ctx_setup(x, smem);
     if (x.w >= C.nwalkers) return;
     ctx_load(x);
+    if constexpr (MAT != 0) mat_trace_current<MAT>(x);
     const int nf = C.nflav, nd = C.nd;
     int par = 0;
     // every lane takes operators (f, type, slot) and scans the operators that can contribute a transposition
@@ -1322,6 +1339,8 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
     if constexpr (MAT) {
         // MeasDensityMatrix_beta_half (CTQMC.F90:3088-3151): kets from 0 to beta/2 through the operators with
         // tau <= beta/2, bras from beta down to beta/2, for all states of the outer block at once
+        if constexpr (MAT >= 2 && MAT <= 4) mat_dm_tree<MAT>(x, cfgsign, bin);
+        else {
         const double b2 = 0.5 * C.beta;
         const int nsm = C.nsm, nout = uni(x.t_n[x.outer]);
         const bool dg = x.lane < nsm * nsm && x.ms_ == x.mi_ && x.ms_ < nout;
@@ -1348,6 +1367,7 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
         for (int j = 0; j < n; ++j) {                    // rho(i1 = bra index, i2 = ket index)
             const double kj = __shfl(ket, x.ms_ * nsm + j, 64);
             if (x.lane < nsm * nsm && x.ms_ < nout && x.mi_ < n && sb == sk) atomicAdd(&dmb[x.mi_ * n + j], bra * fac * kj);
+        }
         }
     } else {
     // state alive at beta/2 (Trace.F90:6334: operators with tau <= beta/2 have acted)

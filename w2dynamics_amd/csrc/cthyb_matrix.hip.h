@@ -14,8 +14,8 @@
 // scale factor (kept as a log), renormalised every few operators.
 #pragma once
 
-__device__ void build_and_invert(Ctx &x, int f, int k, const double *tcp, const double *tap, double *A, double &logdet, double &sgn);
-__device__ double sort_parity(Ctx &x, const double *t, int k);
+__device__ W2DYN_INLINE void build_and_invert(Ctx &x, int f, int k, const double *tcp, const double *tap, double *A, double &logdet, double &sgn);
+__device__ W2DYN_INLINE double sort_parity(Ctx &x, const double *t, int k);
 
 // code of an operator: 2*flavour + (ca - 1), ca 1 = creator, 2 = annihilator
 __device__ __forceinline__ int mat_code(int f, int ca) { return 2 * f + (ca - 1); }
@@ -34,7 +34,7 @@ __device__ __forceinline__ int mat_lower_eq(Ctx &x, double t)
     return c;
 }
 
-__device__ void mat_insert(Ctx &x, int pos, double tau, int code)
+__device__ W2DYN_INLINE void mat_insert(Ctx &x, int pos, double tau, int code)
 {
     for (int base = (x.nops - 1) & ~63; base >= 0 && base + 63 >= pos; base -= 64) {
         int e = base + x.lane;
@@ -49,7 +49,7 @@ __device__ void mat_insert(Ctx &x, int pos, double tau, int code)
     wave_sync();
 }
 
-__device__ void mat_remove(Ctx &x, int pos)
+__device__ W2DYN_INLINE void mat_remove(Ctx &x, int pos)
 {
     for (int base = pos & ~63; base < x.nops; base += 64) {
         int e = base + x.lane;
@@ -63,7 +63,7 @@ __device__ void mat_remove(Ctx &x, int pos)
 }
 
 // time-ordered list from the slot-ordered tau arrays (rank of every operator by counting)
-__device__ void mat_build_list(Ctx &x)
+__device__ W2DYN_INLINE void mat_build_list(Ctx &x)
 {
     const DevConst &C = x.C;
     int n = 0;
@@ -88,20 +88,25 @@ __device__ void mat_build_list(Ctx &x)
     wave_sync();
 }
 
-// block in front of every operator for outer block x.outer; false if the sequence violates the quantum numbers
-__device__ bool mat_walk_sst(Ctx &x)
+// block in front of every operator for outer block `outer`, written to dst[0..nops]; false if the sequence violates
+// the quantum numbers
+__device__ W2DYN_INLINE bool mat_walk_into(Ctx &x, int outer, int *dst)
 {
     const int nf2 = 2 * x.C.nflav;
-    int s = x.outer;
-    bool ok = true;
+    int s = outer;
     for (int i = 0; i < x.nops; ++i) {
-        if (x.lane == 0) x.osst[i] = s;
+        if (x.lane == 0) dst[i] = s;
         if (s >= 0) s = uni(x.t_conn[s * nf2 + uni(x.om[i])]);
     }
-    if (x.lane == 0) x.osst[x.nops] = s;
-    ok = s == x.outer;
+    if (x.lane == 0) dst[x.nops] = s;
     wave_sync();
-    return ok;
+    return s == outer;
+}
+__device__ __forceinline__ bool mat_walk_sst(Ctx &x) { return mat_walk_into(x, x.outer, x.osst); }
+__device__ __forceinline__ void mat_commit_sst(Ctx &x)      // osst <- tsst after an accepted move
+{
+    for (int e = x.lane; e <= x.nops; e += 64) x.osst[e] = x.tsst[e];
+    wave_sync();
 }
 
 // One propagation step of all outer-state vectors: exp(-dt H) inside block sst, then operator `code`
@@ -153,7 +158,7 @@ __device__ __forceinline__ void mat_evolve(Ctx &x, int sst, double dt, double &v
 
 // Local trace of the operator list (entries skip1, skip2 left out) summed over the states of block `outer`.
 // tsign = 0 (and tlog = -inf) when the sequence is forbidden or the trace vanishes.
-__device__ void mat_trace(Ctx &x, int outer, int skip1, int skip2, double &tlog, double &tsign)
+__device__ W2DYN_INLINE void mat_trace(Ctx &x, int outer, int skip1, int skip2, double &tlog, double &tsign)
 {
     const DevConst &C = x.C;
     const int nsm = C.nsm;
@@ -177,9 +182,193 @@ __device__ void mat_trace(Ctx &x, int outer, int skip1, int skip2, double &tlog,
     tlog = lacc + log(fabs(tot)); tsign = tot < 0.0 ? -1.0 : 1.0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Tree evaluation of the trace for NSM <= 4: lane = operator.  With the block in front of every operator known
+// (tsst, maintained incrementally), every operator's transfer matrix  T = Op * diag(exp(-(E - E0) dt))  is built
+// independently, lanes multiply their own short run of matrices and six shuffle steps combine the 64 partial
+// products:  trace = sum_i [ D_end T_{n-1} ... T_1 T_0 ]_ii.  Magnitudes are carried as (matrix scaled by a power
+// of two, integer exponent) per lane plus the sum of the scalar ground-level factors.
+// Entry j of the trial sequence is list entry j with skip1 < skip2 left out (removal proposals); entry n is the final
+// free evolution to beta.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int mat_old_index(int j, int skip1, int skip2)
+{
+    int o = j;
+    if (skip1 >= 0 && o >= skip1) ++o;
+    if (skip2 >= 0 && o >= skip2) ++o;
+    return o;
+}
+
+template <int NSM>
+__device__ __forceinline__ void mat_matmul(const double (&A)[NSM * NSM], const double (&B)[NSM * NSM], double (&Cm)[NSM * NSM])
+{
+#pragma unroll
+    for (int i = 0; i < NSM; ++i)
+#pragma unroll
+        for (int j = 0; j < NSM; ++j) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = 0; k < NSM; ++k) a = fma(A[i * NSM + k], B[k * NSM + j], a);
+            Cm[i * NSM + j] = a;
+        }
+}
+
+template <int NSM>
+__device__ __forceinline__ void mat_normalise(double (&P)[NSM * NSM], int &ex)
+{
+    double m = 0.0;
+#pragma unroll
+    for (int i = 0; i < NSM * NSM; ++i) m = fmax(m, fabs(P[i]));
+    if (m > 0.0) {
+        int e = ilogb(m);
+#pragma unroll
+        for (int i = 0; i < NSM * NSM; ++i) P[i] = ldexp(P[i], -e);
+        ex += e;
+    }
+}
+
+// transfer matrix of trial entry j (j == n: final evolution to tend with the identity as operator).  tbeg is the time
+// the evolution in front of entry `first` starts from (0 for the full trace).
+template <int NSM>
+__device__ __forceinline__ void mat_transfer(Ctx &x, const int *tsst, int j, int n, int skip1, int skip2, int first, double tbeg,
+                                             double tend, double (&T)[NSM * NSM], double &lsum, int &bad)
+{
+    const DevConst &C = x.C;
+    const int nf2 = 2 * C.nflav;
+    int sst = tsst[j];
+    int o = mat_old_index(j, skip1, skip2);
+    // a block index or list position outside its table would address memory outside the wave's LDS slice: flag it
+    // (reported by the host as an internal error) and continue with safe values instead of faulting
+    if ((unsigned)sst >= (unsigned)C.nsst || (unsigned)o > (unsigned)C.wcap || (j != n && (unsigned)x.om[o < C.wcap ? o : 0] >= (unsigned)nf2)) {
+        bad = 1; sst = 0; o = 0;
+    }
+    const double tprev = (j == first) ? tbeg : x.ot[mat_old_index(j - 1, skip1, skip2)];
+    const double tau = (j == n) ? tend : x.ot[o];
+    const double dt = tau - tprev;
+    const int nst = x.t_n[sst], off = x.t_off[sst];
+    const double e0 = x.t_eval[off];
+    double d[NSM];
+#pragma unroll
+    for (int k = 0; k < NSM; ++k) d[k] = (k < nst) ? ((k == 0) ? 1.0 : exp(-(x.t_eval[off + k] - e0) * dt)) : 0.0;
+    lsum -= (e0 - C.egs) * dt;
+    if (j == n) {
+#pragma unroll
+        for (int i = 0; i < NSM; ++i)
+#pragma unroll
+            for (int k = 0; k < NSM; ++k) T[i * NSM + k] = (i == k) ? d[k] : 0.0;
+    } else {
+        const int nsm = C.nsm;                         // the tables are padded to nsm x nsm (nsm <= NSM)
+        const size_t base = (size_t)(sst * nf2 + x.om[o]) * nsm * nsm;
+#pragma unroll
+        for (int i = 0; i < NSM; ++i)
+#pragma unroll
+            for (int k = 0; k < NSM; ++k) {
+                double op = 0.0;
+                if (i < nsm && k < nsm) op = x.t_op ? x.t_op[base + i * nsm + k] : C.opmat[base + i * nsm + k];
+                T[i * NSM + k] = op * d[k];
+            }
+    }
+}
+
+// product of the transfer matrices of trial entries [first, last] (last may be n = final evolution), left in lane 0:
+// P (scaled), binary exponent ex, and the wave-uniform scalar log factor lsum
+template <int NSM>
+__device__ W2DYN_INLINE void mat_tree_product(Ctx &x, const int *tsst, int n, int skip1, int skip2, int first, int last, double tbeg, double tend,
+                                 double (&P)[NSM * NSM], int &ex, double &lsum)
+{
+    const int cnt = last - first + 1;
+    const int per = (cnt + 63) >> 6;
+    ex = 0; lsum = 0.0;
+#pragma unroll
+    for (int i = 0; i < NSM * NSM; ++i) P[i] = ((i / NSM) == (i % NSM)) ? 1.0 : 0.0;
+    const int j0 = first + x.lane * per, j1 = min(j0 + per, last + 1);
+    int bad = 0;
+    for (int j = j0; j < j1; ++j) {
+        double T[NSM * NSM], R[NSM * NSM];
+        mat_transfer<NSM>(x, tsst, j, n, skip1, skip2, first, tbeg, tend, T, lsum, bad);
+        mat_matmul<NSM>(T, P, R);
+#pragma unroll
+        for (int i = 0; i < NSM * NSM; ++i) P[i] = R[i];
+        if (((j - j0) & 3) == 3) mat_normalise<NSM>(P, ex);
+    }
+    mat_normalise<NSM>(P, ex);
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        double Q[NSM * NSM], R[NSM * NSM];
+#pragma unroll
+        for (int i = 0; i < NSM * NSM; ++i) Q[i] = __shfl_down(P[i], s, 64);
+        const int eq = __shfl_down(ex, s, 64);
+        if ((x.lane & (2 * s - 1)) == 0 && x.lane + s < 64) {
+            mat_matmul<NSM>(Q, P, R);                  // later operators act from the left
+#pragma unroll
+            for (int i = 0; i < NSM * NSM; ++i) P[i] = R[i];
+            ex += eq;
+            mat_normalise<NSM>(P, ex);
+        }
+    }
+    lsum = wave_sum(lsum);
+    if (__ballot(bad != 0) != 0ull) x.err |= ERR_BLOCKSEQ;
+}
+
+template <int NSM>
+__device__ W2DYN_INLINE void mat_trace_tree(Ctx &x, const int *tsst, int n, int skip1, int skip2, double &tlog, double &tsign)
+{
+    double P[NSM * NSM]; int ex; double lsum;
+    mat_tree_product<NSM>(x, tsst, n, skip1, skip2, 0, n, 0.0, x.C.beta, P, ex, lsum);
+    double tr = 0.0;
+#pragma unroll
+    for (int i = 0; i < NSM; ++i) tr += P[i * NSM + i];
+    tr = uni(tr); ex = uni(ex);
+    tlog = -HUGE_VAL; tsign = 0.0;
+    if (tr == 0.0 || !(fabs(tr) > 0.0)) return;
+    tlog = lsum + (double)ex * 0.6931471805599453 + log(fabs(tr)); tsign = tr < 0.0 ? -1.0 : 1.0;
+}
+
+// trace of the trial sequence whose block sequence is in tsst: tree for small blocks (MATN = 2, 3, 4 = padded block
+// size the kernel was instantiated for), sequential walk otherwise (MATN = 9)
+template <int MATN>
+__device__ W2DYN_INLINE void mat_trace_trial(Ctx &x, const int *tsst, int n, int skip1, int skip2, double &tlog, double &tsign)
+{
+    if constexpr (MATN >= 2 && MATN <= 4) mat_trace_tree<MATN>(x, tsst, n, skip1, skip2, tlog, tsign);
+    else mat_trace(x, uni(tsst[0]), skip1, skip2, tlog, tsign);
+}
+
+// Density matrix at beta/2 (MeasDensityMatrix_beta_half, CTQMC.F90:3088-3151) from two tree products:
+// K = evolution to beta/2 times the operators with tau <= beta/2, A = the rest up to beta.  Summed over the outer
+// states s, bra_s(i1) ket_s(i2) = A(s,i1) K(i2,s), i.e. rho(i1,i2) += fac * (K A)(i2,i1).
+template <int NSM>
+__device__ W2DYN_INLINE void mat_dm_tree(Ctx &x, double cfgsign, int bin)
+{
+    const DevConst &C = x.C;
+    const double b2 = 0.5 * C.beta;
+    const int nk = mat_lower_eq(x, b2);
+    double K[NSM * NSM], A[NSM * NSM], R[NSM * NSM]; int exk, exa; double lk, la;
+    mat_tree_product<NSM>(x, x.osst, nk, -1, -1, 0, nk, 0.0, b2, K, exk, lk);
+    mat_tree_product<NSM>(x, x.osst, x.nops, -1, -1, nk, x.nops, b2, C.beta, A, exa, la);
+    if (x.lane == 0) {
+        mat_matmul<NSM>(K, A, R);
+        const int sb = x.osst[nk], n = x.t_n[sb];
+        const double fac = -cfgsign * x.tr_sign * exp(lk + la + (double)(exk + exa) * 0.6931471805599453 - x.tr_log);
+        double *dmb = C.acc_dm + (size_t)bin * C.dmsize + C.dmoff[sb];
+#pragma unroll
+        for (int i1 = 0; i1 < NSM; ++i1)
+#pragma unroll
+            for (int i2 = 0; i2 < NSM; ++i2)
+                if (i1 < n && i2 < n) atomicAdd(&dmb[i1 * n + i2], fac * R[i2 * NSM + i1]);
+    }
+}
+
+// trace of the stored configuration (osst must be current)
+template <int MATN>
+__device__ W2DYN_INLINE void mat_trace_current(Ctx &x)
+{
+    if (!(uni(x.osst[x.nops]) == x.outer)) { x.tr_log = -HUGE_VAL; x.tr_sign = 0.0; return; }
+    mat_trace_trial<MATN>(x, x.osst, x.nops, -1, -1, x.tr_log, x.tr_sign);
+}
+
 // check_qn_all_ssts (Trace.F90:1402-1433): number of outer blocks for which the operator sequence is allowed;
 // with select > 0 returns instead the index of the select-th allowed block.
-__device__ int mat_possible(Ctx &x, int select)
+__device__ W2DYN_INLINE int mat_possible(Ctx &x, int select)
 {
     const DevConst &C = x.C;
     const int nf2 = 2 * C.nflav;
@@ -205,7 +394,8 @@ __device__ int mat_possible(Ctx &x, int select)
 
 // global move for the matrix path: CTQMC.F90:4433-4554 with perform_spinflip_check_qn / perform_global_check_qn
 // (Trace.F90:1306-1394).  The times stay where they are, so the sorted list keeps its order and only the codes change.
-__device__ void step_glob_mat(Ctx &x)
+template <int MATN>
+__device__ W2DYN_INLINE void step_glob_mat(Ctx &x)
 {
     const DevConst &C = x.C;
     const int nf = C.nflav, nd = C.nd, kmax = C.kmax;
@@ -276,7 +466,8 @@ __device__ void step_glob_mat(Ctx &x)
         logdet_new += ld; sign_new *= sg;
     }
     double tl, ts;
-    mat_trace(x, outer_new, -1, -1, tl, ts);
+    mat_walk_into(x, outer_new, x.tsst);
+    mat_trace_trial<MATN>(x, x.tsst, x.nops, -1, -1, tl, ts);
     double rnd = x.draw();
     double ratio = (ts == 0.0) ? 0.0 : fabs(exp((tl - x.tr_log) + (logdet_new - x.det_log)) * sst_factor);
     if ((x.err & ERR_SINGULAR) || !(rnd < ratio)) {
@@ -296,7 +487,7 @@ __device__ void step_glob_mat(Ctx &x)
     x.outer = outer_new;
     x.det_log = logdet_new; x.det_sign = sign_new;
     x.tr_log = tl; x.tr_sign = ts;
-    mat_walk_sst(x);
+    mat_commit_sst(x);
     x.npairs = -1;
     x.count(C_ACCGLOB);
 }

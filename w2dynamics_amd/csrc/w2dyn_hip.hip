@@ -157,6 +157,8 @@ Launch walker_launch(const w2dyn_solver *s)
     return l;
 }
 
+int mat_variant(const w2dyn_solver *s) { return !s->mat ? 0 : (s->lp.nsmax <= 2 ? 2 : (s->lp.nsmax <= 4 ? s->lp.nsmax : 9)); }
+
 int time_begin(w2dyn_solver *s) { if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream)); return 0; }
 int time_end(w2dyn_solver *s, const char *name)
 {
@@ -179,6 +181,7 @@ int check_walker_errors(w2dyn_solver *s)
     if (e & ERR_WCAP) return fail(s, W2DYN_EOVERFLOW, "more than %d operators inside the sliding window; reduce TaudiffMax or raise kmax", s->C.wcap);
     if (e & ERR_DETRAT) return fail(s, W2DYN_ENUMERIC, "DetRat too small in removal");
     if (e & ERR_SINGULAR) return fail(s, W2DYN_ENUMERIC, "singular hybridisation matrix in full rebuild");
+    if (e & ERR_BLOCKSEQ) return fail(s, W2DYN_ENUMERIC, "internal error: inconsistent block sequence in the local trace");
     return 0;
 }
 
@@ -480,8 +483,15 @@ int w2dyn_sweep(w2dyn_solver *s, int64_t nsteps, int count_as_sampling)
     Launch l = walker_launch(s);
     int rc;
     if ((rc = time_begin(s))) return rc;
-    if (s->mat) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<true>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps, count_as_sampling);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<false>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps, count_as_sampling);
+    // instantiations: 0 = one-state blocks (closed-form trace); 2, 3, 4 = matrix path with blocks padded to that size
+    // (tree product); 9 = matrix path, sequential propagation (blocks of 5..8 states)
+    switch (mat_variant(s)) {
+    case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<0>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps, count_as_sampling); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<2>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps, count_as_sampling); break;
+    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<3>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps, count_as_sampling); break;
+    case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<4>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps, count_as_sampling); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<9>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps, count_as_sampling); break;
+    }
     HIPCHK(hipGetLastError());
     if ((rc = time_end(s, "sweep"))) return rc;
     s->steps_done += nsteps;
@@ -531,8 +541,13 @@ int w2dyn_measure_once(w2dyn_solver *s)
     Launch l = walker_launch(s);
     int rc;
     if ((rc = time_begin(s))) return rc;
-    if (s->mat) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_misc<true>), l.grid, l.block, l.lds, s->stream, s->C);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_misc<false>), l.grid, l.block, l.lds, s->stream, s->C);
+    switch (mat_variant(s)) {
+    case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_misc<0>), l.grid, l.block, l.lds, s->stream, s->C); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_misc<2>), l.grid, l.block, l.lds, s->stream, s->C); break;
+    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_misc<3>), l.grid, l.block, l.lds, s->stream, s->C); break;
+    case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_misc<4>), l.grid, l.block, l.lds, s->stream, s->C); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_misc<9>), l.grid, l.block, l.lds, s->stream, s->C); break;
+    }
     HIPCHK(hipGetLastError());
     if ((rc = time_end(s, "meas_misc"))) return rc;
     if ((rc = time_begin(s))) return rc;
