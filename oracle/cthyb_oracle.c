@@ -57,6 +57,7 @@ struct ora_walker {
     int64_t *accpair;
     /* accumulators */
     double *gleg, *gtau, *giw, *histo, *dm, *outer_histo;
+    double *g2iw, *g4iw, *g4iwpp;    /* complex interleaved, NULL when not measured */
     double meas_sign; int64_t cnt_sign;
     double mean_sign;
     int aborted;
@@ -902,6 +903,12 @@ ora_walker *ora_create(const ora_params *p, const double *U, const double *ftau_
     w->histo = (double *)calloc((size_t)w->nflav * (p->maxhisto + 1), sizeof(double));
     w->dm = (double *)calloc((size_t)w->nstates, sizeof(double));
     w->outer_histo = (double *)calloc((size_t)w->nstates, sizeof(double));
+    if (p->fourpnt & 4) {                                                           /* CTQMC.F90:552-559, 838-840 */
+        size_t n2 = 2 * (size_t)(p->n4iwf + p->n4iwb), n4 = (size_t)w->nflav * w->nflav * 4 * p->n4iwf * p->n4iwf * (2 * p->n4iwb + 1) * 2;
+        w->g4iw = (double *)calloc(n4, sizeof(double));
+        if (p->meas_g4iwpp) w->g4iwpp = (double *)calloc(n4, sizeof(double));
+        if (p->meas_g2iw) w->g2iw = (double *)calloc((size_t)w->nflav * n2 * n2 * 2, sizeof(double));
+    }
     w->det.log = 0.0; w->det.sign = 1.0;
     w->cfgsign = -1.0;                                                              /* Trace.F90:129 */
     init_window(w, p->taudiffmax);                                                  /* Trace.F90:605 */
@@ -921,7 +928,7 @@ void ora_destroy(ora_walker *w)
     if (!w) return;
     for (int f = 0; f < w->nflav; ++f) free(w->M[f]);
     free(w->ops); free(w->ftab); ora_locprob_free(w->lp); free(w->ptr); free(w->dmblk); free(w->dmoff); free(w->accpair); free(w->gleg); free(w->gtau); free(w->giw);
-    free(w->histo); free(w->dm); free(w->outer_histo); free(w);
+    free(w->histo); free(w->dm); free(w->outer_histo); free(w->g2iw); free(w->g4iw); free(w->g4iwpp); free(w);
 }
 
 void ora_set_taudiffmax(ora_walker *w, double x) { init_window(w, x); }
@@ -937,6 +944,68 @@ void ora_measure_begin(ora_walker *w) { init_counters(w); }
 void ora_sweep(ora_walker *w, int64_t nsteps)
 {
     for (int64_t i = 0; i < nsteps; ++i) { w->cnt_sampling += 1; one_step(w); }
+}
+
+/* measure_g4iw_nfft with the exact-sum transform (CTQMC.F90:2130-2234, Nfft_z.F90:416-453) */
+static void meas_g4iw(ora_walker *w)
+{
+    const int nf = w->nflav, nwf = w->p.n4iwf, nwb = w->p.n4iwb, n2 = 2 * (nwf + nwb), h = n2 / 2;
+    const double beta = w->p.beta;
+    double *g2 = (double *)calloc((size_t)nf * n2 * n2 * 2, sizeof(double));     /* [f][wa][wc] */
+    for (int f = 0; f < nf; ++f) {
+        int k = w->k[f];
+        if (k == 0) continue;
+        double *tc = (double *)malloc(sizeof(double) * k), *ta = (double *)malloc(sizeof(double) * k);
+        int nc = 0, na = 0;
+        for (int i = 0; i < w->nops; ++i) {
+            if (w->ops[i].flav != f) continue;
+            if (w->ops[i].ca == 1) tc[nc++] = w->ops[i].tau; else ta[na++] = w->ops[i].tau;
+        }
+        for (int ifc = 0; ifc < n2; ++ifc) for (int ifa = 0; ifa < n2; ++ifa) {
+            double fc = M_PI / beta * (double)(2 * (ifc + 1) - n2 - 1), fa = M_PI / beta * (double)(2 * (ifa + 1) - n2 - 1);
+            double re = 0.0, im = 0.0;
+            for (int ic = 0; ic < k; ++ic) for (int ia = 0; ia < k; ++ia) {
+                double m = w->M[f][ic * k + ia];
+                double cr = cos(-fc * tc[ic]), ci = sin(-fc * tc[ic]), ar = cos(fa * ta[ia]), ai = sin(fa * ta[ia]);
+                double pr = m * cr, pi = m * ci;
+                re += pr * ar - pi * ai; im += pr * ai + pi * ar;
+            }
+            g2[(((size_t)f * n2 + ifa) * n2 + ifc) * 2] = re; g2[(((size_t)f * n2 + ifa) * n2 + ifc) * 2 + 1] = im;
+        }
+        free(tc); free(ta);
+    }
+    if (w->g2iw) for (size_t i = 0; i < (size_t)nf * n2 * n2 * 2; ++i) w->g2iw[i] += g2[i];
+    /* this_g2iw(o,s,a,c) with frequency indices -n2/2 .. n2/2-1 */
+#define G2(f, a, c) (&g2[(((size_t)(f) * n2 + ((a) + h)) * n2 + ((c) + h)) * 2])
+    const int nb = 2 * nwb + 1, nw = 2 * nwf;
+    for (int f1 = 0; f1 < nf; ++f1) for (int f2 = 0; f2 < nf; ++f2)
+        for (int w1 = -nwf; w1 < nwf; ++w1) for (int w2 = -nwf; w2 < nwf; ++w2) for (int wb = -nwb; wb <= nwb; ++wb) {
+            size_t idx = (((((size_t)f1 * nf + f2) * nw + (w1 + nwf)) * nw + (w2 + nwf)) * nb + (wb + nwb)) * 2;
+            if (w->g4iw) {
+                const double *a, *b;
+                if (w->p.zphconv == 0) { a = G2(f1, w1 + wb, w1); b = G2(f2, w2, w2 + wb); }
+                else { a = G2(f1, w1, w1 - wb); b = G2(f2, w2 - wb, w2); }
+                double re = a[0] * b[0] - a[1] * b[1], im = a[0] * b[1] + a[1] * b[0];
+                if (f1 == f2) {
+                    const double *c, *d;
+                    if (w->p.zphconv == 0) { c = G2(f1, w2, w1); d = G2(f1, w1 + wb, w2 + wb); }
+                    else { c = G2(f1, w1, w2); d = G2(f1, w2 - wb, w1 - wb); }
+                    re -= c[0] * d[0] - c[1] * d[1]; im -= c[0] * d[1] + c[1] * d[0];
+                }
+                w->g4iw[idx] += re; w->g4iw[idx + 1] += im;
+            }
+            if (w->g4iwpp) {
+                const double *a = G2(f1, wb - w2 - 1, w1), *b = G2(f2, w2, wb - w1 - 1);
+                double re = a[0] * b[0] - a[1] * b[1], im = a[0] * b[1] + a[1] * b[0];
+                if (f1 == f2) {
+                    const double *c = G2(f1, w2, w1), *d = G2(f1, wb - w2 - 1, wb - w1 - 1);
+                    re -= c[0] * d[0] - c[1] * d[1]; im -= c[0] * d[1] + c[1] * d[0];
+                }
+                w->g4iwpp[idx] += re; w->g4iwpp[idx + 1] += im;
+            }
+        }
+#undef G2
+    free(g2);
 }
 
 /* MeasDensityMatrix_beta_half, CTQMC.F90:3088-3151 with update_b2_states_eb, Trace.F90:6213-6470: for every state of
@@ -1011,6 +1080,7 @@ void ora_measure_once(ora_walker *w)
                          w->p.meas_giw ? w->giw + (size_t)f * 4 * w->p.niw : NULL);
         free(tc); free(ta);
     }
+    if (w->g4iw || w->g4iwpp) meas_g4iw(w);                             /* CTQMC.F90:8579 */
 }
 
 /* Transform_DensityMatrix_EB_to_OCCB (CTQMC.F90:3163-3179): Evec rho Evec^T per block; keeps the diagonal in w->dm */
@@ -1056,6 +1126,12 @@ void ora_measure_finish(ora_walker *w)
         }
     if (w->p.meas_giw)
         for (size_t i = 0; i < (size_t)nf * 4 * w->p.niw; ++i) w->giw[i] = w->giw[i] * zs / beta;   /* 8815-8817 */
+    {   /* 8790-8800 */
+        size_t n2 = 2 * (size_t)(w->p.n4iwf + w->p.n4iwb), n4 = (size_t)nf * nf * 4 * w->p.n4iwf * w->p.n4iwf * (2 * w->p.n4iwb + 1) * 2;
+        if (w->g4iw) for (size_t i = 0; i < n4; ++i) w->g4iw[i] *= zs / (beta * beta);
+        if (w->g4iwpp) for (size_t i = 0; i < n4; ++i) w->g4iwpp[i] *= zs / (beta * beta);
+        if (w->g2iw) for (size_t i = 0; i < (size_t)nf * n2 * n2 * 2; ++i) w->g2iw[i] *= zs / beta;
+    }
 }
 
 int ora_measure(ora_walker *w)
@@ -1120,6 +1196,19 @@ void ora_get_densitymatrix_diag(const ora_walker *w, double *o) { memcpy(o, w->d
 void ora_get_outer_histo(const ora_walker *w, double *o) { memcpy(o, w->outer_histo, sizeof(double) * (size_t)w->nstates); }
 void ora_get_accpair(const ora_walker *w, int64_t *o) { memcpy(o, w->accpair, sizeof(int64_t) * (size_t)w->nflav * w->p.ntau); }
 void ora_get_energies(const ora_walker *w, double *o) { memcpy(o, w->E, sizeof(double) * (size_t)w->nstates); }
+int ora_get_g2iw(const ora_walker *w, double *o)
+{
+    size_t n2 = 2 * (size_t)(w->p.n4iwf + w->p.n4iwb);
+    if (!w->g2iw) return 0;
+    memcpy(o, w->g2iw, sizeof(double) * (size_t)w->nflav * n2 * n2 * 2); return 1;
+}
+int ora_get_g4iw(const ora_walker *w, double *o, int pp)
+{
+    size_t n4 = (size_t)w->nflav * w->nflav * 4 * w->p.n4iwf * w->p.n4iwf * (2 * w->p.n4iwb + 1) * 2;
+    const double *src = pp ? w->g4iwpp : w->g4iw;
+    if (!src) return 0;
+    memcpy(o, src, sizeof(double) * n4); return 1;
+}
 int ora_nsst(const ora_walker *w) { return w->nsst; }
 int ora_nsmax(const ora_walker *w) { return w->lp->nsmax; }
 void ora_get_blocks(const ora_walker *w, int *n, int *off, int *st)

@@ -41,6 +41,9 @@ typedef struct ora_params {
     int has_szt;            /* "Szt" in QuantumNumbers (CTQMC.F90 glob_has_Szt) */
     char qns[64];           /* QuantumNumbers string (States.F90:164) */
     double epsevec;         /* EPSEVEC (Operator.F90:784) */
+    int fourpnt;            /* module variable fourpnt (impurity.py:515); bit 4 = Matsubara G4 in Z space (CTQMC.F90:226) */
+    int n4iwf, n4iwb;       /* N4iwf, N4iwb */
+    int meas_g2iw, meas_g4iwpp, zphconv;   /* MeasG2iw, MeasG4iwPP, ZPHConvention */
 } ora_params;
 
 typedef struct ora_walker ora_walker;
@@ -77,6 +80,11 @@ void ora_get_gleg(const ora_walker *w, double *out);      /* (Nd,2,NLegMax) */
 void ora_get_gtau(const ora_walker *w, double *out);      /* (Nd,2,Ntau) */
 void ora_get_giw(const ora_walker *w, double *out_reim);  /* (Nd,2,2Niw) complex interleaved */
 void ora_get_histo(const ora_walker *w, double *out);     /* (Nd,2,MaxHisto+1) */
+/* two-particle Z-space estimators (CTQMC.F90:2130-2234), complex interleaved, C order of the reference's axes:
+ * g2iw (Nd,2,n2,n2) with n2 = 2(N4iwf+N4iwb), axes (annihilator frequency, creator frequency);
+ * g4iw / g4iw_pp (Nd,2,Nd,2,2N4iwf,2N4iwf,2N4iwb+1).  Return 0 if the quantity was not measured. */
+int ora_get_g2iw(const ora_walker *w, double *out_reim);
+int ora_get_g4iw(const ora_walker *w, double *out_reim, int pp);
 void ora_get_densitymatrix_diag(const ora_walker *w, double *out);  /* 4^Nd, occupation basis, block order */
 void ora_get_densitymatrix(const ora_walker *w, double *out);       /* (4^Nd)^2 row major, occupation basis, block order
                                                                        (after Transform_DensityMatrix_EB_to_OCCB, CTQMC.F90:3163) */

@@ -18,7 +18,9 @@ class OraParams(C.Structure):
     _fields_ = [("nd", C.c_int), ("beta", C.c_double), ("nftau", C.c_int), ("ntau", C.c_int), ("nlegmax", C.c_int),
                 ("niw", C.c_int), ("meas_giw", C.c_int), ("ncorr", C.c_int), ("nmeas", C.c_int64),
                 ("maxhisto", C.c_int), ("p_glob", C.c_double), ("p_shift", C.c_double), ("taudiffmax", C.c_double),
-                ("has_szt", C.c_int), ("qns", C.c_char * 64), ("epsevec", C.c_double)]
+                ("has_szt", C.c_int), ("qns", C.c_char * 64), ("epsevec", C.c_double),
+                ("fourpnt", C.c_int), ("n4iwf", C.c_int), ("n4iwb", C.c_int), ("meas_g2iw", C.c_int),
+                ("meas_g4iwpp", C.c_int), ("zphconv", C.c_int)]
 
 
 def build():
@@ -63,6 +65,8 @@ def lib():
     L.ora_nsmax.argtypes = [vp]; L.ora_nsmax.restype = C.c_int
     L.ora_get_blocks.argtypes = [vp, ip, ip, ip]
     L.ora_get_occ.argtypes = [vp, dp, dp, C.c_void_p]
+    L.ora_get_g2iw.argtypes = [vp, dp]; L.ora_get_g2iw.restype = C.c_int
+    L.ora_get_g4iw.argtypes = [vp, dp, C.c_int]; L.ora_get_g4iw.restype = C.c_int
     L.ora_get_accpair.argtypes = [vp, lp]
     L.ora_get_counters.argtypes = [vp, dp]
     L.ora_mean_sign.argtypes = [vp]; L.ora_mean_sign.restype = C.c_double
@@ -78,22 +82,24 @@ def lib():
     return L
 
 
-def params_from_pstring(ps, nd, beta):
+def params_from_pstring(ps, nd, beta, fourpnt=0):
     """Pick the keys the oracle needs out of a parsed parameter set (w2dynamics_amd.params.ParameterSet)."""
     return OraParams(nd=nd, beta=beta, nftau=ps.get_int("Nftau"), ntau=ps.get_int("Ntau"),
                      nlegmax=ps.get_int("NLegMax"), niw=ps.get_int("Niw"), meas_giw=ps.get_int("MeasGiw"),
                      ncorr=ps.get_int("NCorr"), nmeas=ps.get_int("Nmeas"), maxhisto=ps.get_int("MaxHisto"),
                      p_glob=ps.get_real("PercentageGlobalMove"), p_shift=ps.get_real("PercentageTauShiftMove"),
                      taudiffmax=ps.get_real("TaudiffMax"), has_szt=int("Szt" in ps.get_str("QuantumNumbers")),
-                     qns=ps.get_str("QuantumNumbers").encode()[:63], epsevec=ps.get_real("EPSEVEC"))
+                     qns=ps.get_str("QuantumNumbers").encode()[:63], epsevec=ps.get_real("EPSEVEC"),
+                     fourpnt=fourpnt, n4iwf=ps.get_int("N4iwf"), n4iwb=ps.get_int("N4iwb"), meas_g2iw=ps.get_int("MeasG2iw"),
+                     meas_g4iwpp=ps.get_int("MeasG4iwPP"), zphconv=int(ps.get_int("ZPHConvention") != 0))
 
 
 class OracleWalker:
     """One chain of the CPU restatement; rng = ("std", seed) or ("philox", seed, walker)."""
 
-    def __init__(self, problem, pset, rng=("std", 0)):
+    def __init__(self, problem, pset, rng=("std", 0), fourpnt=0):
         self.L = lib()
-        self.p = params_from_pstring(pset, problem.nd, problem.beta)
+        self.p = params_from_pstring(pset, problem.nd, problem.beta, fourpnt)
         assert self.p.nftau == problem.nftau, "Nftau in the parameter string must match the F(tau) array"
         if rng[0] == "std":
             self.rng = self.L.ora_rng_std(int(rng[1]))
@@ -156,6 +162,15 @@ class OracleWalker:
         occ = np.zeros((nd, 2, nd, 2)); rho1 = np.zeros((2 * nd, 2 * nd))
         rho2 = np.zeros((2 * nd,) * 4) if nd <= 3 else None
         self.L.ora_get_occ(self.h, occ, rho1, rho2.ctypes.data if rho2 is not None else None)
+        if p.fourpnt & 4:
+            n2 = 2 * (p.n4iwf + p.n4iwb)
+            a = np.zeros((nd, 2, n2, n2, 2))
+            if self.L.ora_get_g2iw(self.h, a):
+                r["g2iw"] = a[..., 0] + 1j * a[..., 1]
+            for key, pp in (("g4iw", 0), ("g4iw_pp", 1)):
+                a = np.zeros((nd, 2, nd, 2, 2 * p.n4iwf, 2 * p.n4iwf, 2 * p.n4iwb + 1, 2))
+                if self.L.ora_get_g4iw(self.h, a, pp):
+                    r[key] = a[..., 0] + 1j * a[..., 1]
         r["occ"] = occ; r["rho1"] = rho1
         if rho2 is not None:
             r["rho2"] = rho2

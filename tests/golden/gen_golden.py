@@ -121,12 +121,44 @@ def gen_stat(only=None):
         print("stat", name, "occ", out["occ_mean"].ravel()[:4], "+-", out["occ_err"].ravel()[:4])
 
 
+G4 = {   # recorded configuration (meas_<cfg>.npz) measured with the Z-space Matsubara two-particle estimators
+    "C1": dict(N4iwf=3, N4iwb=2, MeasG2iw=1, MeasG4iwPP=1, ZPHConvention=0),
+    "C3": dict(N4iwf=3, N4iwb=1, MeasG2iw=1, MeasG4iwPP=1, ZPHConvention=0),
+    "C4S": dict(N4iwf=2, N4iwb=2, MeasG2iw=1, MeasG4iwPP=0, ZPHConvention=1),
+}
+
+
+def gen_g4(only=None):
+    import ast
+    for name, extra in G4.items():
+        if only and name not in only:
+            continue
+        g = np.load(os.path.join(OUT, "meas_%s.npz" % name), allow_pickle=False)
+        over = ast.literal_eval(str(g["overrides"])); over.update(extra)
+        cfg = str(g["config"]); nftau = int(g["nftau"])
+        p, ps = pstring_for(cfg, nftau, over)
+        s = refdrive.RefSolver(p, ps, int(g["seed"]), fourpnt=4)
+        s.set_taudiffmax(over["TaudiffMax"])
+        c = {k: g["cfg_" + k] for k in ("taus", "orbs", "spins", "cas", "hashybs")}
+        c["outer_sst"] = int(g["cfg_outer_sst"]); c["outer_state"] = int(g["cfg_outer_state"])
+        s.set_config(c)
+        s.measure()
+        r = s.results(("g2iw", "g4iw", "g4iw_pp", "gleg", "mean_sign"))
+        s.close()
+        np.savez_compressed(os.path.join(OUT, "g4_%s.npz" % name), config=cfg, nftau=nftau, seed=int(g["seed"]),
+                            overrides=repr(over), **{"cfg_" + k: g["cfg_" + k] for k in ("taus", "orbs", "spins", "cas", "hashybs", "outer_sst", "outer_state")},
+                            **{"res_" + k: v for k, v in r.items()})
+        print("g4", name, {k: v.shape for k, v in r.items()})
+
+
 if __name__ == "__main__":
     if not refdrive.available():
         raise SystemExit("oracle/_ref is not built: run oracle/build_ref.sh in the build container")
-    which = [a for a in sys.argv[1:] if a in ("traj", "stat")] or ["traj", "stat"]
-    only = [a for a in sys.argv[1:] if a not in ("traj", "stat")] or None      # e.g.: gen_golden.py traj C4S C4
+    which = [a for a in sys.argv[1:] if a in ("traj", "stat", "g4")] or ["traj", "stat", "g4"]
+    only = [a for a in sys.argv[1:] if a not in ("traj", "stat", "g4")] or None      # e.g.: gen_golden.py traj C4S C4
     if "traj" in which:
         gen_traj(only)
     if "stat" in which:
         gen_stat(only)
+    if "g4" in which:
+        gen_g4(only)

@@ -115,6 +115,51 @@ def test_recorded_configuration_vs_reference_golden(name):
     q.dest_ctqmc(); q.close()
 
 
+@pytest.mark.parametrize("name", ["C1", "C3", "C4S"])
+def test_two_particle_matsubara_vs_reference_golden(name):
+    """Z-space g2iw / g4iw / g4iw_pp (FourPnt = 4) of a recorded configuration == what the REFERENCE printed."""
+    g = util.load_golden("g4_%s.npz" % name)
+    over = g["overrides"]
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    q = MCTQMC(nwalkers=5, walkers_per_bin=2)
+    q.fourpnt = 4
+    q.init_rnd(int(g["seed"])); q.init_paras(ps)
+    q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+    q.set_taudiffmax(over["TaudiffMax"])
+    c = util.cfg_from(g, "cfg_")
+    q.set_mc_config(len(c["taus"]), c["taus"], c["orbs"], c["spins"], c["cas"], c["hashybs"], c["outer_sst"], c["outer_state"])
+    q.ctqmc_measure(1, 1)
+    for k in ("g2iw", "g4iw", "g4iw_pp"):
+        if "res_" + k in g:
+            assert rel(getattr(q, k), g["res_" + k]) < TOL, k
+            assert rel(getattr(q, k + "_bins").mean(axis=0), g["res_" + k]) < TOL, k      # every chain holds the same configuration
+    assert rel(q.gleg, g["res_gleg"]) < TOL
+    q.dest_ctqmc(); q.close()
+
+
+def test_two_particle_matsubara_chains_vs_oracle():
+    """Sampling run with FourPnt = 4: the mean over chains of g4iw equals the mean of the oracle chains."""
+    over = dict(BASE, Nwarmups=2000, Nmeas=5, NCorr=20, TaudiffMax=4.0, N4iwf=3, N4iwb=2, MeasG2iw=1, MeasG4iwPP=1,
+                PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05)
+    p, ps, pset = util.setup("C3", 501, over)
+    nw = 6
+    q = MCTQMC(nwalkers=nw, walkers_per_bin=1)
+    q.fourpnt = 4
+    q.init_rnd(11); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+    q.set_taudiffmax(4.0); q.ctqmc_warmup(2000); q.ctqmc_measure(1, 1)
+    tot = {"g4iw": 0.0, "g4iw_pp": 0.0, "g2iw": 0.0}
+    for w in range(nw):
+        o = pyoracle.OracleWalker(p, pset, ("philox", 11, w), fourpnt=4)
+        o.set_taudiffmax(4.0); o.warmup(2000); o.measure(); r = o.results()
+        for k in tot:
+            tot[k] = tot[k] + r[k] / nw
+            assert rel(getattr(q, k + "_bins")[w], r[k]) < TOL, (k, w)
+        o.close()
+    for k in tot:
+        assert rel(getattr(q, k), tot[k]) < TOL, k
+    q.dest_ctqmc(); q.close()
+
+
 def test_ragged_and_empty_chains():
     """Empty configurations (k=0 everywhere), chains with very different orders in one launch, walker count not a
     multiple of the block size."""

@@ -132,3 +132,20 @@ def test_legendre_estimator_matches_numpy(oracle_lib):
             ref_l += m * np.array([legendre.legval(x, [0] * l + [1]) for l in range(nleg)])
             ref_t[min(int(d / beta * ntau), ntau - 1)] += m
     assert np.allclose(gl, ref_l, rtol=1e-11, atol=1e-12) and np.allclose(gt, ref_t, rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("name", ["C1", "C3", "C4S"])
+def test_oracle_two_particle_matsubara_estimators(name):
+    """Z-space g2iw / g4iw / g4iw_pp (FourPnt = 4) of a recorded configuration against the reference's output."""
+    g = util.load_golden("g4_%s.npz" % name)
+    over = g["overrides"]
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    w = pyoracle.OracleWalker(p, pset, ("std", int(g["seed"])), fourpnt=4)
+    w.set_taudiffmax(over["TaudiffMax"])
+    assert w.set_config(util.cfg_from(g, "cfg_")) == 0
+    w.measure()
+    r = w.results()
+    for k in ("g2iw", "g4iw", "g4iw_pp"):
+        if "res_" + k in g:
+            assert rel(r[k], g["res_" + k]) < 1e-10, k
+    w.close()

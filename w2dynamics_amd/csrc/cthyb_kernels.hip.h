@@ -1555,4 +1555,120 @@ __global__ __launch_bounds__(64) void k_meas_giw(DevConst C)
     g[0] += re; g[1] += im;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Z-space two-particle Matsubara estimators (measure_g4iw_nfft with the exact-sum transform, CTQMC.F90:2130-2234,
+// Nfft_z.F90:416-453)
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int G2_FC = 32;      // frequency chunk of the two-step transform
+
+// g2(wa, wc) = sum_{ic,ia} exp(-i nu_wc tau_c(ic)) M(ic,ia) exp(+i nu_wa tau_a(ia)) for one chain and flavour, as
+// U(ic,wa) = sum_ia M(ic,ia) Ea(ia,wa) followed by g2(wa,wc) = sum_ic Ec(ic,wc) U(ic,wa): 8 k n2 (k + n2) flop
+// instead of 8 k^2 n2^2.  grid (chains, flavours), 256 threads; LDS 3 * kmax * G2_FC complex.
+// G2 layout [chain][flavour][wa][wc], frequencies nu_n = (2n+1) pi/beta, n = -n2/2 .. n2/2-1.
+__global__ __launch_bounds__(256) void k_meas_g2iw(DevConst C, int n2, double2 *G2)
+{
+    extern __shared__ double2 g2s[];
+    const int w = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, kmax = C.kmax;
+    const int k = C.K[(size_t)w * C.nflav + f];
+    double2 *out = G2 + ((size_t)w * C.nflav + f) * n2 * n2;
+    if (k == 0) { for (int e = tid; e < n2 * n2; e += 256) out[e] = make_double2(0.0, 0.0); return; }
+    double2 *Ea = g2s, *Ec = g2s + (size_t)kmax * G2_FC, *U = Ec + (size_t)kmax * G2_FC;
+    const double *tcp = C.TC + ((size_t)w * C.nflav + f) * kmax, *tap = C.TA + ((size_t)w * C.nflav + f) * kmax;
+    const double *Mf = C.M + ((size_t)w * C.nflav + f) * kmax * kmax;
+    const double pib = M_PI / C.beta;
+    for (int a0 = 0; a0 < n2; a0 += G2_FC) {
+        const int na = min(G2_FC, n2 - a0);
+        for (int e = tid; e < k * na; e += 256) {
+            int ia = e / na, wa = e - ia * na;
+            double sn, cs; sincos(pib * (double)(2 * (a0 + wa + 1) - n2 - 1) * tap[ia], &sn, &cs);
+            Ea[ia * G2_FC + wa] = make_double2(cs, sn);
+        }
+        __syncthreads();
+        for (int e = tid; e < k * na; e += 256) {
+            int ic = e / na, wa = e - ic * na;
+            double re = 0.0, im = 0.0;
+            for (int ia = 0; ia < k; ++ia) { double m = Mf[(size_t)ic * kmax + ia]; double2 z = Ea[ia * G2_FC + wa]; re = fma(m, z.x, re); im = fma(m, z.y, im); }
+            U[ic * G2_FC + wa] = make_double2(re, im);
+        }
+        for (int c0 = 0; c0 < n2; c0 += G2_FC) {
+            const int nc = min(G2_FC, n2 - c0);
+            __syncthreads();
+            for (int e = tid; e < k * nc; e += 256) {
+                int ic = e / nc, wc = e - ic * nc;
+                double sn, cs; sincos(-pib * (double)(2 * (c0 + wc + 1) - n2 - 1) * tcp[ic], &sn, &cs);
+                Ec[ic * G2_FC + wc] = make_double2(cs, sn);
+            }
+            __syncthreads();
+            for (int e = tid; e < na * nc; e += 256) {
+                int wa = e / nc, wc = e - wa * nc;
+                double re = 0.0, im = 0.0;
+                for (int ic = 0; ic < k; ++ic) {
+                    double2 a = Ec[ic * G2_FC + wc], b = U[ic * G2_FC + wa];
+                    re += a.x * b.x - a.y * b.y; im += a.x * b.y + a.y * b.x;
+                }
+                out[(size_t)(a0 + wa) * n2 + (c0 + wc)] = make_double2(re, im);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Assembly of the two-particle Green's function from products of two g2 (CTQMC.F90:2175-2222) and accumulation of g2
+// itself.  One thread per output element and accumulator bin, looping over the chains of the bin: every accumulator
+// element is read and written once per launch (HBM streaming), the g2 values of a chain come from L2.
+// acc4 / acc4pp layout [nb4][f1][f2][w1][w2][wb] (complex), acc2 [nb4][f][wa][wc]; chains of sample bin b go to b % nb4.
+__global__ __launch_bounds__(256) void k_meas_g4iw(DevConst C, int nwf, int nwb, int zph, int nb4, const double2 *G2,
+                                                    double2 *acc4, double2 *acc4pp, double2 *acc2)
+{
+    const int nf = C.nflav, n2 = 2 * (nwf + nwb), h = n2 / 2, nw = 2 * nwf, nb = 2 * nwb + 1;
+    const size_t n4 = (size_t)nf * nf * nw * nw * nb, ng2 = (size_t)nf * n2 * n2;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int b4 = blockIdx.y;
+    if (e < n4) {
+        size_t r = e;
+        const int wb = (int)(r % nb) - nwb; r /= nb;
+        const int w2 = (int)(r % nw) - nwf; r /= nw;
+        const int w1 = (int)(r % nw) - nwf; r /= nw;
+        const int f2 = (int)(r % nf), f1 = (int)(r / nf);
+        int a1, c1, a2, c2, a3, c3, a4, c4;           // (annihilator, creator) frequency indices of the four factors
+        if (zph == 0) { a1 = w1 + wb; c1 = w1; a2 = w2; c2 = w2 + wb; a3 = w2; c3 = w1; a4 = w1 + wb; c4 = w2 + wb; }
+        else { a1 = w1; c1 = w1 - wb; a2 = w2 - wb; c2 = w2; a3 = w1; c3 = w2; a4 = w2 - wb; c4 = w1 - wb; }
+        const int p1a = wb - w2 - 1, p1c = w1, p2a = w2, p2c = wb - w1 - 1, p3a = w2, p3c = w1, p4a = wb - w2 - 1, p4c = wb - w1 - 1;
+        double re = 0.0, im = 0.0, pre = 0.0, pim = 0.0;
+        for (int bin = b4; bin < C.nbins; bin += nb4) {
+            const int w0 = bin * C.walkers_per_bin, w1e = min(w0 + C.walkers_per_bin, C.nwalkers);
+            for (int w = w0; w < w1e; ++w) {
+                const double2 *g1 = G2 + ((size_t)w * nf + f1) * n2 * n2, *g2p = G2 + ((size_t)w * nf + f2) * n2 * n2;
+                if (acc4) {
+                    double2 x = g1[(size_t)(a1 + h) * n2 + (c1 + h)], y = g2p[(size_t)(a2 + h) * n2 + (c2 + h)];
+                    re += x.x * y.x - x.y * y.y; im += x.x * y.y + x.y * y.x;
+                    if (f1 == f2) {
+                        double2 u = g1[(size_t)(a3 + h) * n2 + (c3 + h)], v = g1[(size_t)(a4 + h) * n2 + (c4 + h)];
+                        re -= u.x * v.x - u.y * v.y; im -= u.x * v.y + u.y * v.x;
+                    }
+                }
+                if (acc4pp) {
+                    double2 x = g1[(size_t)(p1a + h) * n2 + (p1c + h)], y = g2p[(size_t)(p2a + h) * n2 + (p2c + h)];
+                    pre += x.x * y.x - x.y * y.y; pim += x.x * y.y + x.y * y.x;
+                    if (f1 == f2) {
+                        double2 u = g1[(size_t)(p3a + h) * n2 + (p3c + h)], v = g1[(size_t)(p4a + h) * n2 + (p4c + h)];
+                        pre -= u.x * v.x - u.y * v.y; pim -= u.x * v.y + u.y * v.x;
+                    }
+                }
+            }
+        }
+        if (acc4) { double2 *d = acc4 + (size_t)b4 * n4 + e; double2 o = *d; o.x += re; o.y += im; *d = o; }
+        if (acc4pp) { double2 *d = acc4pp + (size_t)b4 * n4 + e; double2 o = *d; o.x += pre; o.y += pim; *d = o; }
+    }
+    if (acc2 && e < ng2) {
+        const int f = (int)(e / ((size_t)n2 * n2)); const size_t q = e % ((size_t)n2 * n2);
+        double re = 0.0, im = 0.0;
+        for (int bin = b4; bin < C.nbins; bin += nb4) {
+            const int w0 = bin * C.walkers_per_bin, w1e = min(w0 + C.walkers_per_bin, C.nwalkers);
+            for (int w = w0; w < w1e; ++w) { double2 x = G2[((size_t)w * nf + f) * n2 * n2 + q]; re += x.x; im += x.y; }
+        }
+        double2 *d = acc2 + (size_t)b4 * ng2 + e; double2 o = *d; o.x += re; o.y += im; *d = o;
+    }
+}
+
 }  // namespace w2dyn

@@ -51,6 +51,9 @@ struct w2dyn_solver {
     LocalProblem lp;                 // blocks, eigenbasis and operators of H_loc
     std::vector<int> dmoff;          // offsets of the blocks inside the block-diagonal density matrix
     bool mat = false;                // matrix local-trace path (blocks with more than one state)
+    // Z-space two-particle Matsubara estimators (FourPnt & 4)
+    int n4iwf = 0, n4iwb = 0, meas_g2iw = 0, meas_g4iwpp = 0, zph = 0, nb4 = 0;
+    double2 *G2 = nullptr, *acc4 = nullptr, *acc4pp = nullptr, *acc2 = nullptr;
     DevConst C{};
     std::vector<void *> allocs;
     // accumulators bookkeeping
@@ -274,7 +277,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     // ---- modes this build refuses ----
     struct { const char *key; long long allowed; } zero_int[] = {
         {"segment", 0}, {"offdiag", 0}, {"full_offdiag", 0}, {"statesampling", 0}, {"flavourchange_moves", 0}, {"Phonon", 0},
-        {"Screening", 0}, {"Uw", 0}, {"MeasGtauDetRat", 0}, {"MeasSusz", 0}, {"MeasG2iw", 0}, {"MeasG4iwPP", 0},
+        {"Screening", 0}, {"Uw", 0}, {"MeasGtauDetRat", 0}, {"MeasSusz", 0},
         {"MeasExpResDensityMatrix", 0}, {"MeasSsquare", 0}, {"Gtau_mean_step", 0}, {"Gtau_mid_step", 0}, {"sign_step", 0},
         {"NSymMove", 0}, {"MeasDensityMatrix", 1}, {"Eigenbasis", 1}, {"AccumGtau", 1}};
     for (auto &z : zero_int) {
@@ -288,7 +291,15 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     }
     if (!get_str(s, "EnableOuterTruncation", sv)) return W2DYN_EINVAL;
     if (sv == "YES") return fail(s, W2DYN_EUNSUPPORTED, "EnableOuterTruncation = YES is not supported");
-    if (s->fourpnt != 0) return fail(s, W2DYN_EUNSUPPORTED, "FourPnt = %d is not supported yet", s->fourpnt);
+    if (s->fourpnt != 0 && s->fourpnt != 4)
+        return fail(s, W2DYN_EUNSUPPORTED, "FourPnt = %d is not supported (0, or 4 = Matsubara two-particle Green's function in Z space)", s->fourpnt);
+    if (!get_int(s, "N4iwf", iv)) return W2DYN_EINVAL; s->n4iwf = (int)iv;
+    if (!get_int(s, "N4iwb", iv)) return W2DYN_EINVAL; s->n4iwb = (int)iv;
+    if (!get_int(s, "MeasG2iw", iv)) return W2DYN_EINVAL; s->meas_g2iw = (int)iv;
+    if (!get_int(s, "MeasG4iwPP", iv)) return W2DYN_EINVAL; s->meas_g4iwpp = (int)iv;
+    if (!get_int(s, "ZPHConvention", iv)) return W2DYN_EINVAL; s->zph = iv != 0;
+    if (s->fourpnt == 4 && (s->n4iwf < 1 || s->n4iwb < 0)) return fail(s, W2DYN_EINVAL, "N4iwf=%d N4iwb=%d", s->n4iwf, s->n4iwb);
+    if (s->fourpnt == 4 && s->meas_g4iwpp && s->zph) return fail(s, W2DYN_EUNSUPPORTED, "G4iwPP measurement is not implemented for ZPHConvention != 0 (CTQMC.F90:2220)");
     if (screening) { /* must be zero; checked below once nd is known */ }
 
     if (!get_int(s, "Nd", iv)) return W2DYN_EINVAL; s->nd = (int)iv;
@@ -433,6 +444,19 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if ((rc = dev_alloc(s, C.acc_signouter, B * nouter))) return rc;
     if ((rc = dev_alloc(s, C.acc_sign, B))) return rc;
     if ((rc = dev_alloc(s, C.accpair, (size_t)nf * s->ntau))) return rc;
+    s->G2 = s->acc4 = s->acc4pp = s->acc2 = nullptr; s->nb4 = 0;
+    if (s->fourpnt & 4) {
+        const size_t n2 = 2 * (size_t)(s->n4iwf + s->n4iwb), n4 = (size_t)nf * nf * 4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1), ng2 = (size_t)nf * n2 * n2;
+        const size_t g2bytes = W * ng2 * sizeof(double2);
+        if (g2bytes > ((size_t)32 << 30)) return fail(s, W2DYN_EUNSUPPORTED, "two-particle measurement: %zu bytes of per-chain g2 scratch; use fewer chains or frequencies", g2bytes);
+        const size_t per = (n4 * (1 + (s->meas_g4iwpp ? 1 : 0)) + (s->meas_g2iw ? ng2 : 0)) * sizeof(double2);
+        s->nb4 = (int)std::max<size_t>(1, std::min<size_t>(B, ((size_t)2 << 30) / std::max<size_t>(per, 1)));
+        if ((rc = dev_alloc(s, s->G2, W * ng2))) return rc;
+        if ((rc = dev_alloc(s, s->acc4, (size_t)s->nb4 * n4))) return rc;
+        if (s->meas_g4iwpp) { if ((rc = dev_alloc(s, s->acc4pp, (size_t)s->nb4 * n4))) return rc; }
+        if (s->meas_g2iw) { if ((rc = dev_alloc(s, s->acc2, (size_t)s->nb4 * ng2))) return rc; }
+        if ((size_t)3 * kmax * G2_FC * sizeof(double2) > 160 * 1024) return fail(s, W2DYN_EUNSUPPORTED, "kmax=%d too large for the two-particle transform", kmax);
+    }
     // initial chain state: empty configuration, outer superstate drawn with the chain's first random number
     std::vector<WalkerScalars> ws(W);
     for (size_t w = 0; w < W; ++w) {
@@ -530,6 +554,12 @@ int w2dyn_measure_begin(w2dyn_solver *s)
     HIPCHK(hipMemsetAsync(C.acc_outer, 0, sizeof(double) * B * C.nouter, s->stream));
     HIPCHK(hipMemsetAsync(C.acc_signouter, 0, sizeof(double) * B * C.nouter, s->stream));
     HIPCHK(hipMemsetAsync(C.acc_sign, 0, sizeof(double) * B, s->stream));
+    if (s->fourpnt & 4) {
+        const size_t n2 = 2 * (size_t)(s->n4iwf + s->n4iwb), n4 = (size_t)nf * nf * 4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1), ng2 = (size_t)nf * n2 * n2;
+        HIPCHK(hipMemsetAsync(s->acc4, 0, sizeof(double2) * s->nb4 * n4, s->stream));
+        if (s->acc4pp) HIPCHK(hipMemsetAsync(s->acc4pp, 0, sizeof(double2) * s->nb4 * n4, s->stream));
+        if (s->acc2) HIPCHK(hipMemsetAsync(s->acc2, 0, sizeof(double2) * s->nb4 * ng2, s->stream));
+    }
     s->meas_done = 0; s->time_sim_steps = 0;
     return 0;
 }
@@ -563,6 +593,19 @@ int w2dyn_measure_once(w2dyn_solver *s)
         hipLaunchKernelGGL(k_meas_giw, dim3(s->C.nbins, s->nflav, (s->C.niw2 + 63) / 64), dim3(64), 0, s->stream, s->C);
         HIPCHK(hipGetLastError());
         if ((rc = time_end(s, "meas_giw"))) return rc;
+    }
+    if (s->fourpnt & 4) {           // CTQMC.F90:8579
+        const int n2 = 2 * (s->n4iwf + s->n4iwb);
+        const size_t n4 = (size_t)s->nflav * s->nflav * 4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1), ng2 = (size_t)s->nflav * n2 * n2;
+        if ((rc = time_begin(s))) return rc;
+        hipLaunchKernelGGL(k_meas_g2iw, dim3(s->nwalkers, s->nflav), dim3(256), (size_t)3 * s->C.kmax * G2_FC * sizeof(double2), s->stream, s->C, n2, s->G2);
+        HIPCHK(hipGetLastError());
+        if ((rc = time_end(s, "meas_g2iw"))) return rc;
+        if ((rc = time_begin(s))) return rc;
+        hipLaunchKernelGGL(k_meas_g4iw, dim3((unsigned)((std::max(n4, ng2) + 255) / 256), s->nb4), dim3(256), 0, s->stream, s->C, s->n4iwf, s->n4iwb, s->zph, s->nb4,
+                           s->G2, s->acc4, s->acc4pp, s->acc2);
+        HIPCHK(hipGetLastError());
+        if ((rc = time_end(s, "meas_g4iw"))) return rc;
     }
     s->meas_done += 1;
     return 0;
@@ -705,6 +748,23 @@ int w2dyn_measure_finish(w2dyn_solver *s)
         R["accadd"] = aa; R["accrem"] = ar;
         R["accglob"] = {s->counters[C_ACCGLOB] / s->counters[C_TRYGLOB]};
         R["accshift"] = {s->counters[C_ACCSHIFT] / s->counters[C_TRYSHIFT]};
+    }
+    if (s->fourpnt & 4) {     // CTQMC.F90:8790-8800: G4iw * zScaling / beta^2, G2iw * zScaling / beta, zScaling = -1/(N mean_sign)
+        const size_t n2 = 2 * (size_t)(s->n4iwf + s->n4iwb), n4 = (size_t)nf * nf * 4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1), ng2 = (size_t)nf * n2 * n2;
+        auto reduce4 = [&](const double2 *dev, size_t per, const char *name, double extra) {
+            std::vector<double> raw((size_t)s->nb4 * per * 2), bins((size_t)s->nb4 * per * 2), tot(per * 2, 0.0);
+            (void)hipMemcpy(raw.data(), dev, raw.size() * sizeof(double), hipMemcpyDeviceToHost);
+            for (int b = 0; b < s->nb4; ++b) {
+                double nb = 0.0;
+                for (int bin = b; bin < B; bin += s->nb4) nb += binw(bin);
+                for (size_t i = 0; i < per * 2; ++i) { double v = raw[(size_t)b * per * 2 + i]; tot[i] += v; bins[(size_t)b * per * 2 + i] = v * (-1.0 / (nb * ms)) * extra; }
+            }
+            for (size_t i = 0; i < per * 2; ++i) tot[i] *= (-1.0 / (nmeas_tot * ms)) * extra;
+            R[name] = tot; R[std::string(name) + "_bins"] = bins;
+        };
+        reduce4(s->acc4, n4, "g4iw", 1.0 / (beta * beta));
+        if (s->acc4pp) reduce4(s->acc4pp, n4, "g4iw_pp", 1.0 / (beta * beta));
+        if (s->acc2) reduce4(s->acc2, ng2, "g2iw", 1.0 / beta);
     }
     R["eigenstatesenergies"] = s->energies;
     R["lhisto"] = std::vector<double>(100, 0.0); R["rhisto"] = std::vector<double>(100, 0.0);
@@ -919,6 +979,9 @@ int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out)
     else if (n == "steps_done") *out = (double)s->steps_done;
     else if (n == "meas_done") *out = (double)s->meas_done;
     else if (n == "num_windows") *out = s->C.num_windows;
+    else if (n == "nb4") *out = s->nb4;
+    else if (n == "n4iwf") *out = s->n4iwf;
+    else if (n == "n4iwb") *out = s->n4iwb;
     else if (n == "nsst") *out = s->lp.nsst;
     else if (n == "nsmax") *out = s->lp.nsmax;
     else if (n == "matrix_trace") *out = s->mat ? 1 : 0;

@@ -138,6 +138,7 @@ class MCTQMC:
         self._chk(self._L.w2dyn_set_fourpnt(self._h, int(self.fourpnt)))
         self._chk(self._L.w2dyn_init_solver(self._h, u, f, m, sc, int(iter_no), int(nftau), int(nbands)))
         self._nd = nbands
+        self._n4iwf = int(self.scalar("n4iwf")); self._n4iwb = int(self.scalar("n4iwb"))
 
     def set_taudiffmax(self, x):
         self._chk(self._L.w2dyn_set_taudiffmax(self._h, float(x)))
@@ -235,6 +236,17 @@ class MCTQMC:
         if name == "giw":
             a = self.result("giw").reshape(nd, 2, -1, 2)
             return a[..., 0] + 1j * a[..., 1]
+        if name in ("g4iw", "g4iw_pp", "g2iw", "g4iw_bins", "g4iw_pp_bins", "g2iw_bins"):
+            # Z-space two-particle estimators (FourPnt = 4): axes as the reference's Fortran arrays
+            # g4iw(Nd,2,Nd,2,2*N4iwf,2*N4iwf,2*N4iwb+1), g2iw(Nd,2,n2,n2) [annihilator, creator frequency]
+            a = self.result(name)
+            a = a.reshape(-1, 2); a = a[:, 0] + 1j * a[:, 1]
+            nwf, nwb = self._n4iwf, self._n4iwb
+            lead = (int(self.scalar("nb4")),) if name.endswith("_bins") else ()
+            if name.startswith("g2iw"):
+                n2 = 2 * (nwf + nwb)
+                return a.reshape(lead + (nd, 2, n2, n2))
+            return a.reshape(lead + (nd, 2, nd, 2, 2 * nwf, 2 * nwf, 2 * nwb + 1))
         if name in ("gtau_full", "gleg_full"):
             return self.result(name).reshape(nd, 2, nd, 2, -1)
         if name == "occ":
