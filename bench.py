@@ -27,13 +27,26 @@ import numpy as np  # noqa: E402
 FP64_PEAK_TFLOPS = 78.6     # MI355X fp64 vector == matrix peak (the microarch guide lists no fp64 row)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 
-WORKLOAD = dict(config="C2", nftau=5001,
-                overrides=dict(Nftau=5001, NCorr=200, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Nwarmups=0, Nmeas=1))
+WORKLOADS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on (default)
+    "C2": dict(config="C2", nftau=5001, overrides=dict(Nftau=5001, NCorr=200, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Nwarmups=0, Nmeas=1),
+               text="C2: 1-band Hubbard, Bethe D=1, U=2, beta=100, half filling, TaudiffMax=10, NCorr=200, NLegMax=100, Ntau=1000, Nftau=5001, default move mix"),
+    # the other single-GPU configurations (parity-test cases; selectable with --config for extra bench lines)
+    "C3": dict(config="C3", nftau=5001, overrides=dict(Nftau=5001, NCorr=100, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Nwarmups=0, Nmeas=1),
+               text="C3: 2-orbital density-density, U=2, J=0.25, beta=50, TaudiffMax=10, NCorr=100"),
+    "C4": dict(config="C4", nftau=5001, overrides=dict(Nftau=5001, NCorr=100, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Nwarmups=0, Nmeas=1),
+               text="C4: 3-orbital Kanamori (QNs Nt Szt Qzt, matrix local trace), U=2, J=0.25, beta=50, TaudiffMax=10, NCorr=100"),
+    "C5Z": dict(config="C5Z", nftau=5001, overrides=dict(Nftau=5001, NCorr=100, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Nwarmups=0, Nmeas=1),
+                text="C5 (Z-space part): 5-orbital density-density, U=2, J=0.25, beta=100, TaudiffMax=10, NCorr=100"),
+}
+WORKLOAD = WORKLOADS["C2"]
 
 
 def _cpu_chain(args):
     """One reference (or oracle) chain on one core; returns (mc_steps, seconds, kind)."""
-    seed, nmeas, nwarm = args
+    seed, nmeas, nwarm, wname = args
+    global WORKLOAD
+    WORKLOAD = WORKLOADS[wname]
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from w2dynamics_amd import params, synth
     p = synth.config(WORKLOAD["config"], nftau=WORKLOAD["nftau"])
@@ -59,20 +72,22 @@ def _cpu_chain(args):
         return nmeas * over["NCorr"], dt, "port"
 
 
-def cpu_baseline(cores, nmeas=6000, nwarm=50000):
+def cpu_baseline(cores, wname, nmeas=6000, nwarm=50000):
     import multiprocessing as mp
+    if wname != "C2":
+        nmeas = 3000
     ctx = mp.get_context("spawn")
     with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_chain, [(1000 + i, nmeas, nwarm) for i in range(cores)])
+        res = pool.map(_cpu_chain, [(1000 + i, nmeas, nwarm, wname) for i in range(cores)])
     rate = sum(s / t for s, t, _ in res)
     kind = res[0][2]
     return {"value": rate, "unit": "MC steps/s", "cores": cores, "kind": kind,
-            "meas_per_s": sum((s / WORKLOAD["overrides"]["NCorr"]) / t for s, t, _ in res),
+            "meas_per_s": sum((s / WORKLOADS[wname]["overrides"]["NCorr"]) / t for s, t, _ in res),
             "sample": "%d independent chains (one per core, as the reference's MPI ranks), each %d warm-up steps untimed + "
-                      "%d measurements x NCorr=%d steps timed, same C2 workload" % (cores, nwarm, nmeas, WORKLOAD["overrides"]["NCorr"])}
+                      "%d measurements x NCorr=%d steps timed, same %s workload" % (cores, nwarm, nmeas, WORKLOADS[wname]["overrides"]["NCorr"], wname)}
 
 
-def pmc_traffic(kernel, chains):
+def pmc_traffic(kernel, chains, config):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*_pmc.json, made by
     profiles/collect.sh + pmc_summary.py on the same command); None when no pass exists for this chain count."""
     import glob
@@ -81,7 +96,7 @@ def pmc_traffic(kernel, chains):
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("chains_per_gpu") != chains:
+        if d.get("chains_per_gpu") != chains or d.get("config", "C2") != config:
             continue
         for name, v in d.get("kernels", {}).items():
             if name.startswith(kernel):
@@ -99,7 +114,10 @@ def main():
     ap.add_argument("--thermal", type=int, default=20000, help="untimed thermalisation MC steps per chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cores", type=int, default=0)
+    ap.add_argument("--config", default="C2", choices=sorted(WORKLOADS), help="workload (default: the configuration the metric is quoted on)")
     a = ap.parse_args()
+    global WORKLOAD
+    WORKLOAD = WORKLOADS[a.config]
 
     import torch
     import torch.distributed as dist
@@ -178,14 +196,13 @@ def main():
         flops_gleg = W * prob.nd * 2 * k2 * (5 * over["NLegMax"] + 6)
         ach_tf = flops_gleg / (gleg_ms * 1e-3) / 1e12 if gleg_ms > 0 else 0.0
         value = world * W * ncorr * a.steps / dt
-        tr_sweep, tr_src = pmc_traffic("k_sweep", W)
-        tr_gleg, _ = pmc_traffic("k_meas_gleg", W)
+        tr_sweep, tr_src = pmc_traffic("k_sweep", W, a.config)
+        tr_gleg, _ = pmc_traffic("k_meas_gleg", W, a.config)
         out = {
             "metric": "Metropolis steps/sec (node)", "value": value, "unit": "MC steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C2: 1-band Hubbard, Bethe D=1, U=2, beta=100, half filling, TaudiffMax=10, NCorr=200, "
-                                   "NLegMax=100, Ntau=1000, Nftau=5001, default move mix", "chains_per_gpu": W,
+            "config": {"workload": WORKLOAD["text"], "chains_per_gpu": W,
                        "walkers_per_bin": a.walkers_per_bin, "parallelism": "chains sharded over %d GPU(s), no data-path collective" % world},
             "measurements_per_s": world * W * a.steps / dt,
             "mean_order_per_flavour": k1, "accept_ins": c["accadd"] / max(c["tryadd"], 1), "occ_double": float(oc[0, 0, 0, 1]),
@@ -201,7 +218,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             cores = a.cpu_cores or max(1, min(16, os.cpu_count() or 1))
             try:
-                out["cpu_baseline"] = cpu_baseline(cores)
+                out["cpu_baseline"] = cpu_baseline(cores, a.config)
                 out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
             except Exception as e:  # pragma: no cover
                 out["cpu_baseline"] = {"value": None, "unit": "MC steps/s", "cores": cores, "kind": "port", "sample": "failed: %r" % (e,)}

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs) into per-launch HBM traffic.
 
-usage: pmc_summary.py <dir of FETCH_SIZE pass> <dir of WRITE_SIZE pass> <chains>
+usage: pmc_summary.py <dir of FETCH_SIZE pass> <dir of WRITE_SIZE pass> <chains> [config]
 
 Units and gfx950 correction as MI355X_MICROARCH.md (HBM section) prescribes: both counters are in KiB; on gfx950
 FETCH_SIZE tallies 128-B read requests at 64 B, so the read side is doubled.  The guide calibrates this for 16-B/lane
@@ -40,7 +40,7 @@ def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     chains = int(sys.argv[3]) if len(sys.argv) > 3 else None
-    res = {"chains_per_gpu": chains, "unit": "bytes per launch", "kernels": {}}
+    res = {"chains_per_gpu": chains, "config": sys.argv[4] if len(sys.argv) > 4 else "C2", "unit": "bytes per launch", "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
             continue
