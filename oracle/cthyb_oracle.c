@@ -28,6 +28,7 @@ typedef struct {
     double tau;
     int flav; /* 0-based flavour */
     int ca;   /* 1 creator, 2 annihilator */
+    int wid;  /* 0: hybridising operator (has_hyb); 1..4: worm operator wormContainer(wid) (Trace.F90:123-125) */
 } op_t;
 
 typedef struct { double log, sign; } logval;
@@ -52,6 +53,13 @@ struct ora_walker {
     double taudiff_max, wmin, wmax; int num_windows, wpos;
     int nslide;
     /* counters */
+    /* worm sampling */
+    int sector, isector, icomponent;          /* current sector (1 = Z, 4 = G4), sampled worm sector and component */
+    double eta;
+    double wtry_add, wacc_add, wtry_rem, wacc_rem;                       /* TryAdd/AccAdd/TryRem/AccRem(worm sector) */
+    double try_wadd, acc_wadd, accqn_wadd, try_wrem, acc_wrem, accqn_wrem, try_wrep, acc_wrep;
+    double cnt_sampling_w, cnt_meas_w;
+    double *g4w, *g4wpp;                      /* g4iw_worm, g4iwpp_worm accumulators */
     double try_add, acc_add, accqn_add, try_rem, acc_rem, accqn_rem, try_glob, acc_glob, accqn_glob;
     double try_shift, acc_shift, cnt_sampling, cnt_meas;
     int64_t *accpair;
@@ -267,7 +275,7 @@ static int frank(const ora_walker *w, int idx)
 {
     int r = 0;
     for (int i = 0; i < idx; ++i)
-        if (w->ops[i].flav == w->ops[idx].flav && w->ops[i].ca == w->ops[idx].ca) ++r;
+        if (w->ops[i].wid == 0 && w->ops[i].flav == w->ops[idx].flav && w->ops[i].ca == w->ops[idx].ca) ++r;
     return r;
 }
 
@@ -381,6 +389,7 @@ static double block_sign(const ora_walker *w)
     int tn[MAXFLAV];
     for (int f = 0; f < w->nflav; ++f) tn[f] = 2 * w->k[f];
     for (int i = 0; i < w->nops; ++i) {
+        if (w->ops[i].wid) continue;                         /* only operators with hybridisation lines */
         int f = w->ops[i].flav, orb = f >> 1, spin = f & 1;  /* orb 0-based, spin 0 -> Fortran 1 */
         tn[f] -= 1;
         if (spin == 1) { for (int o = 0; o <= orb; ++o) perm += tn[2 * o + 0]; }
@@ -396,19 +405,35 @@ static double permaltca(const ora_walker *w)
 {
     long perm = 0; int tn[MAXFLAV];
     for (int f = 0; f < w->nflav; ++f) tn[f] = 2 * w->k[f];
+    int nhyb = 0;
     for (int i = 0; i < w->nops; ++i) {
+        if (w->ops[i].wid) continue;
         int f = w->ops[i].flav;
-        tn[f] -= 1;
+        tn[f] -= 1; ++nhyb;
         perm += tn[f] % (3 - w->ops[i].ca);
     }
-    if (((w->nops / 2) % 2) == 1) perm += 1;
+    if (((nhyb / 2) % 2) == 1) perm += 1;
     return (perm & 1) ? -1.0 : 1.0;
 }
 
 /* Trace.F90:3479-3498 (diagonal hybridisation, no worm) */
+/* Trace.F90:3623-3651 get_WormSign */
+static double worm_sign(const ora_walker *w)
+{
+    long perm = 0; double wt[5]; int nw = 0;
+    for (int i = 0; i < w->nops; ++i) if (w->ops[i].wid) { wt[w->ops[i].wid] = w->ops[i].tau; ++nw; }
+    if (nw == 0) return 1.0;
+    for (int i = 0; i < w->nops; ++i) {
+        if (w->ops[i].wid) continue;
+        for (int j = 1; j <= nw; ++j) if (w->ops[i].tau > wt[j]) ++perm;
+    }
+    for (int i = 1; i < nw; ++i) for (int j = i + 1; j <= nw; ++j) if (wt[i] < wt[j]) ++perm;
+    return (perm & 1) ? -1.0 : 1.0;
+}
+
 static double get_sign(const ora_walker *w)
 {
-    return w->tr.sign * w->det.sign * block_sign(w) * permaltca(w);
+    return w->tr.sign * w->det.sign * block_sign(w) * permaltca(w) * worm_sign(w);
 }
 
 /* ------------------------------------------------------------------------------------------------------- */
@@ -457,12 +482,13 @@ static int count_pairs(const ora_walker *w, int pick, int *i1, int *i2)
         const op_t *a = &w->ops[i];
         if (a->tau < w->wmin) continue;
         if (pick == 0 && a->tau > w->wmax) break;
+        if (a->wid) continue;
         for (int j = i + 1; j < w->nops; ++j) {
             const op_t *b = &w->ops[j];
             if (b->flav != a->flav) continue;
             if (b->tau > w->wmax) break;
             if (b->tau > a->tau + w->taudiff_max) break;
-            if (b->ca != a->ca) {
+            if (b->wid == 0 && b->ca != a->ca) {
                 ++n;
                 if (pick > 0 && n == pick) { *i1 = i; *i2 = j; return n; }
             }
@@ -490,7 +516,7 @@ static void accpair_add(ora_walker *w, int f, double dt)
 static void step_add(ora_walker *w)
 {
     const double *ft;
-    w->try_add += 1;
+    if (w->sector == 1) w->try_add += 1; else w->wtry_add += 1;
     /* pair_OperAdd, Trace.F90:3657-3698 */
     double width1 = w->wmax - w->wmin;
     double tau1 = w->wmin + width1 * U01(w);            /* i=1: CA = mod(1,2)+1 = 2 (annihilator) */
@@ -533,7 +559,7 @@ static void step_add(ora_walker *w)
     int iq = 0, ir = 0;
     for (int i = 0; i < w->nops; ++i) {
         const op_t *e = &w->ops[i];
-        if (e->flav != f || i == ia || i == ic) continue;
+        if (e->flav != f || i == ia || i == ic || e->wid) continue;
         if (e->ca == 2) Q[iq++] = ora_hybr(ft, w->p.nftau, w->p.beta, e->tau - tau2);   /* annihilators vs new creator */
         else R[ir++] = ora_hybr(ft, w->p.nftau, w->p.beta, tau1 - e->tau);              /* new annihilator vs creators */
     }
@@ -554,7 +580,7 @@ static void step_add(ora_walker *w)
         w->det.log += detrat.log; w->det.sign *= detrat.sign;
         w->tr = trnew;
         w->cfgsign = -get_sign(w);
-        w->acc_add += 1;
+        if (w->sector == 1) w->acc_add += 1; else w->wacc_add += 1;
         accpair_add(w, f, fabs(tau2 - tau1));
     } else {
         list_remove(w, ia > ic ? ia : ic); list_remove(w, ia > ic ? ic : ia);
@@ -565,7 +591,7 @@ static void step_add(ora_walker *w)
 /* CTQMC.F90:3892-4150 StepRem (change_outer = false) */
 static void step_rem(ora_walker *w)
 {
-    w->try_rem += 1;
+    if (w->sector == 1) w->try_rem += 1; else w->wtry_rem += 1;
     /* gen_OperRemove, Trace.F90:4851-4950 */
     int np = count_pairs(w, 0, NULL, NULL);
     if (np <= 0) { w->accqn_rem += 1; return; }
@@ -603,7 +629,7 @@ static void step_rem(ora_walker *w)
         w->tr = trnew;
         w->cfgsign = -get_sign(w);
         accpair_add(w, f, o2.tau - o1.tau);
-        w->acc_rem += 1;
+        if (w->sector == 1) w->acc_rem += 1; else w->wacc_rem += 1;
     } else {
         list_insert(w, o1); list_insert(w, o2);
     }
@@ -841,24 +867,179 @@ static void step_shift(ora_walker *w)
     free(saved); free(tmp);
 }
 
-/* one iteration of the Z-space loop: CTQMC.F90:8213-8257 (warm-up) == 8434-8488 + 8530-8532 (sampling) */
+/* ------------------------------------------------------------------------------------------------------- */
+/* worm moves, sector 4 (two-particle Green's function): four operators c c+ c c+ without hybridisation lines   */
+/* ------------------------------------------------------------------------------------------------------- */
+
+/* get_Proposal for SectorG4 (CTQMC.F90:5680-5684) */
+static double worm_prefact(const ora_walker *w) { return pow(w->p.beta * (double)w->p.nd, 4.0) * w->eta; }
+
+/* StepWormAdd, CTQMC.F90:4992-5140 */
+static void step_worm_add(ora_walker *w)
+{
+    const int nf = w->nflav;
+    int comp = w->icomponent;
+    if (comp == 0) comp = RINT(w, 1, nf * nf * nf * nf);
+    w->try_wadd += 1;
+    /* set_OperFlavor (Trace.F90:3804-3826): digits of comp-1 in base 2Nd, most significant first; CA = mod(i,2)+1 */
+    op_t o[4]; int rest = comp - 1, base = nf * nf * nf;
+    for (int i = 0; i < 4; ++i) { int bs = rest / base; rest -= bs * base; base /= nf; o[i].flav = bs; o[i].ca = ((i + 1) % 2) + 1; o[i].wid = i + 1; }
+    /* set_OperTime (Trace.F90:3942-3967) */
+    for (int i = 0; i < 4; ++i) {
+        o[i].tau = U01(w) * w->p.beta;
+        if (i > 0 && o[i - 1].tau == o[i].tau) o[i].tau += w->p.beta * 1e-14;
+    }
+    for (int i = 0; i < 4; ++i) list_insert(w, o[i]);
+    double prefact = worm_prefact(w);
+    if (prefact == 0.0 || !sequence_valid(w, w->outer_sst)) {
+        for (int i = w->nops - 1; i >= 0; --i) if (w->ops[i].wid) list_remove(w, i);
+        w->accqn_wadd += 1; w->sector = 1;
+        return;
+    }
+    logval trnew = full_trace(w, w->outer_sst);
+    double rnd = U01(w);
+    if (rnd < fabs(prefact * trnew.sign * w->tr.sign * exp(trnew.log - w->tr.log))) {
+        w->tr = trnew;
+        w->cfgsign = -get_sign(w);
+        w->acc_wadd += 1;
+    } else {
+        for (int i = w->nops - 1; i >= 0; --i) if (w->ops[i].wid) list_remove(w, i);
+        w->sector = 1;
+    }
+}
+
+/* StepWormRem, CTQMC.F90:5144-5249 */
+static void step_worm_rem(ora_walker *w)
+{
+    w->try_wrem += 1;
+    op_t saved[4]; int ns = 0;
+    for (int i = 0; i < w->nops; ++i) if (w->ops[i].wid) saved[ns++] = w->ops[i];
+    for (int i = w->nops - 1; i >= 0; --i) if (w->ops[i].wid) list_remove(w, i);
+    if (!sequence_valid(w, w->outer_sst)) {
+        for (int i = 0; i < ns; ++i) list_insert(w, saved[i]);
+        w->accqn_wrem += 1;
+        return;
+    }
+    logval trnew = full_trace(w, w->outer_sst);
+    double prefact = worm_prefact(w);
+    double rnd = U01(w);
+    if (rnd < fabs(1.0 / prefact * trnew.sign * w->tr.sign * exp(trnew.log - w->tr.log))) {
+        w->tr = trnew;
+        w->cfgsign = -get_sign(w);
+        w->acc_wrem += 1;
+        w->sector = 1;
+    } else {
+        for (int i = 0; i < ns; ++i) list_insert(w, saved[i]);
+    }
+}
+
+/* StepWormReplace for SectorG4 (CTQMC.F90:5809-6297) with propose_WormReplace / do_WormReplace (Trace.F90:3054-3478):
+ * a worm operator and a hybridising operator of the same flavour and type exchange their roles */
+static void step_worm_replace(ora_walker *w)
+{
+    w->try_wrep += 1;
+    int r = RINT(w, 1, 4);
+    int iw = -1;
+    for (int i = 0; i < w->nops; ++i) if (w->ops[i].wid == r) iw = i;
+    const int f = w->ops[iw].flav, ca = w->ops[iw].ca, k = w->k[f];
+    if (k == 0) return;
+    int pos = RINT(w, 1, k);                   /* operPos-th hybridising operator of that flavour and type */
+    int ih = -1, cnt = 0;
+    for (int i = 0; i < w->nops; ++i)
+        if (w->ops[i].wid == 0 && w->ops[i].flav == f && w->ops[i].ca == ca) { if (++cnt == pos) { ih = i; break; } }
+    const double tw = w->ops[iw].tau, th = w->ops[ih].tau;
+    const double *ft = w->ftab + (size_t)f * w->p.nftau;
+    int ncnt = 0;
+    for (int i = 0; i < w->nops; ++i) {
+        const op_t *e = &w->ops[i];
+        if (e->wid == 0 && e->flav == f && e->ca == ca && e->tau > fmin(th, tw) && e->tau < fmax(th, tw)) ++ncnt;
+    }
+    if (tw < th) ncnt = -ncnt;
+    double *u = (double *)calloc((size_t)k, sizeof(double)), *v = (double *)calloc((size_t)k, sizeof(double));
+    double *x = (double *)calloc((size_t)k, sizeof(double)), *y = (double *)calloc((size_t)k, sizeof(double));
+    const double *M = w->M[f];
+    if (ca == 1) {          /* creator: a column of F(tau_a - tau_c) changes */
+        v[pos - 1] = 1.0;
+        int q = 0;
+        for (int i = 0; i < w->nops; ++i) {
+            const op_t *e = &w->ops[i];
+            if (e->wid || e->flav != f || e->ca != 2) continue;
+            u[q++] = -ora_hybr(ft, w->p.nftau, w->p.beta, e->tau - th) + ora_hybr(ft, w->p.nftau, w->p.beta, e->tau - tw);
+        }
+    } else {                /* annihilator: a row changes */
+        u[pos - 1] = 1.0;
+        int q = 0;
+        for (int i = 0; i < w->nops; ++i) {
+            const op_t *e = &w->ops[i];
+            if (e->wid || e->flav != f || e->ca != 1) continue;
+            v[q++] = -ora_hybr(ft, w->p.nftau, w->p.beta, th - e->tau) + ora_hybr(ft, w->p.nftau, w->p.beta, tw - e->tau);
+        }
+    }
+    /* Mat(creator, annihilator): res = Mat u (u over annihilators), detRat = 1 + vdag . res (vdag over creators) */
+    for (int c = 0; c < k; ++c) { double a = 0.0; for (int j = 0; j < k; ++j) a += M[c * k + j] * u[j]; x[c] = a; }
+    double detrat = 1.0;
+    for (int c = 0; c < k; ++c) detrat += v[c] * x[c];
+    double rnd = U01(w);
+    if (rnd < fabs(detrat)) {
+        for (int j = 0; j < k; ++j) { double a = 0.0; for (int c = 0; c < k; ++c) a += M[c * k + j] * v[c]; y[j] = a; }
+        double *Mn = (double *)malloc(sizeof(double) * (size_t)k * k);
+        for (int c = 0; c < k; ++c) for (int j = 0; j < k; ++j) Mn[c * k + j] = M[c * k + j] - x[c] * y[j] / detrat;
+        /* the exchanged operator sits at another rank inside its flavour: move its row (creator) / column (annihilator) */
+        int from = pos - 1, to = pos - 1 + ncnt;
+        if (from != to) {
+            double *T = (double *)malloc(sizeof(double) * (size_t)k * k);
+            for (int c = 0; c < k; ++c) for (int j = 0; j < k; ++j) {
+                int src = (ca == 1) ? c : j, dst;
+                if (src == from) dst = to;
+                else if (from < to) dst = (src > from && src <= to) ? src - 1 : src;
+                else dst = (src >= to && src < from) ? src + 1 : src;
+                if (ca == 1) T[dst * k + j] = Mn[c * k + j]; else T[c * k + dst] = Mn[c * k + j];
+            }
+            free(Mn); Mn = T;
+        }
+        free(w->M[f]); w->M[f] = Mn;
+        w->det.log += log(fabs(detrat));
+        w->det.sign *= (detrat < 0.0 ? -1.0 : 1.0) * ((ncnt & 1) ? -1.0 : 1.0);
+        w->ops[ih].wid = r; w->ops[iw].wid = 0;
+        w->cfgsign = -get_sign(w);
+        w->acc_wrep += 1;
+    }
+    free(u); free(v); free(x); free(y);
+}
+
+/* one iteration of the sampling loop: Z space CTQMC.F90:8431-8488 (== warm-up 8213-8257 without worm insertion),
+ * worm space 8489-8528; window shift 8530-8532 */
 static void one_step(ora_walker *w)
 {
-    double r = U01(w);
-    double pg = w->p.p_glob, ps = w->p.p_shift;
-    if (r < (1.0 - ps - pg) / 2.0) {
-        (void)U01(w);       /* grnd() >= Percentage4OperatorMove (= 0): always the pair move */
-        (void)U01(w);       /* grnd() <  PercentageOuterMove     (= 0): never an outer move  */
-        step_add(w);
-    } else if (r <= 1.0 - ps - pg) {
-        (void)U01(w); (void)U01(w);
-        step_rem(w);
-    } else if (r <= 1.0 - ps) {
-        step_glob(w);
+    if (w->sector == 1) {
+        w->cnt_sampling += 1;
+        double r = U01(w);
+        double pg = w->p.p_glob, ps = w->p.p_shift, pw = (w->isector != 1) ? w->p.p_worm_ins : 0.0;
+        if (r < (1.0 - ps - pg - pw) / 2.0) {
+            (void)U01(w);       /* grnd() >= Percentage4OperatorMove (= 0): always the pair move */
+            (void)U01(w);       /* grnd() <  PercentageOuterMove     (= 0): never an outer move  */
+            step_add(w);
+        } else if (r <= 1.0 - ps - pg - pw) {
+            (void)U01(w); (void)U01(w);
+            step_rem(w);
+        } else if (r <= 1.0 - ps - pg) {
+            w->sector = w->isector;
+            step_worm_add(w);
+        } else if (r <= 1.0 - ps) {
+            step_glob(w);
+        } else {
+            step_shift(w);
+        }
     } else {
-        step_shift(w);
+        w->cnt_sampling_w += 1;
+        double r = U01(w);
+        double prep = w->p.p_worm_rep, pins = w->p.p_worm_ins;
+        if (r < (1.0 - prep - pins) / 2.0) { (void)U01(w); (void)U01(w); step_add(w); }
+        else if (r < 1.0 - prep - pins) { (void)U01(w); (void)U01(w); step_rem(w); }
+        else if (r < 1.0 - pins) step_worm_replace(w);
+        else step_worm_rem(w);
     }
-    long tries = (long)(w->try_add + w->try_rem);
+    long tries = (long)(w->try_add + w->try_rem + w->wtry_add + w->wtry_rem);
     if (tries % w->nslide == 0) shift_window(w);
 }
 
@@ -871,6 +1052,9 @@ static void init_counters(ora_walker *w) /* CTQMC.F90:847-896 */
     w->try_add = w->acc_add = w->accqn_add = w->try_rem = w->acc_rem = w->accqn_rem = 0;
     w->try_glob = w->acc_glob = w->accqn_glob = w->try_shift = w->acc_shift = 0;
     w->cnt_sampling = w->cnt_meas = 0;
+    w->wtry_add = w->wacc_add = w->wtry_rem = w->wacc_rem = 0;
+    w->try_wadd = w->acc_wadd = w->accqn_wadd = w->try_wrem = w->acc_wrem = w->accqn_wrem = w->try_wrep = w->acc_wrep = 0;
+    w->cnt_sampling_w = w->cnt_meas_w = 0;
     memset(w->accpair, 0, sizeof(int64_t) * (size_t)w->nflav * w->p.ntau);
 }
 
@@ -909,6 +1093,12 @@ ora_walker *ora_create(const ora_params *p, const double *U, const double *ftau_
         if (p->meas_g4iwpp) w->g4iwpp = (double *)calloc(n4, sizeof(double));
         if (p->meas_g2iw) w->g2iw = (double *)calloc((size_t)w->nflav * n2 * n2 * 2, sizeof(double));
     }
+    w->sector = w->isector = 1; w->icomponent = 0; w->eta = p->worm_eta;
+    if ((p->fourpnt & 8) && p->worm_meas_g4iw) {                                    /* CTQMC.F90:339-361 */
+        size_t n = (size_t)4 * p->n4iwf * p->n4iwf * (2 * p->n4iwb + 1) * 2;
+        if (p->g4ph) w->g4w = (double *)calloc(n, sizeof(double));
+        if (p->g4pp) w->g4wpp = (double *)calloc(n, sizeof(double));
+    }
     w->det.log = 0.0; w->det.sign = 1.0;
     w->cfgsign = -1.0;                                                              /* Trace.F90:129 */
     init_window(w, p->taudiffmax);                                                  /* Trace.F90:605 */
@@ -928,22 +1118,26 @@ void ora_destroy(ora_walker *w)
     if (!w) return;
     for (int f = 0; f < w->nflav; ++f) free(w->M[f]);
     free(w->ops); free(w->ftab); ora_locprob_free(w->lp); free(w->ptr); free(w->dmblk); free(w->dmoff); free(w->accpair); free(w->gleg); free(w->gtau); free(w->giw);
-    free(w->histo); free(w->dm); free(w->outer_histo); free(w->g2iw); free(w->g4iw); free(w->g4iwpp); free(w);
+    free(w->histo); free(w->dm); free(w->outer_histo); free(w->g2iw); free(w->g4iw); free(w->g4iwpp); free(w->g4w); free(w->g4wpp); free(w);
 }
 
 void ora_set_taudiffmax(ora_walker *w, double x) { init_window(w, x); }
 
 void ora_warmup(ora_walker *w, int64_t n)
 {
+    int isec = w->isector;
     init_counters(w);
+    w->isector = 1;                       /* ctqmc_warmup never inserts worms (CTQMC.F90:8213-8257) */
     for (int64_t i = 0; i < n; ++i) one_step(w);
+    w->cnt_sampling = 0;                  /* the warm-up loop does not count sampling steps */
+    w->isector = isec;
 }
 
 void ora_measure_begin(ora_walker *w) { init_counters(w); }
 
 void ora_sweep(ora_walker *w, int64_t nsteps)
 {
-    for (int64_t i = 0; i < nsteps; ++i) { w->cnt_sampling += 1; one_step(w); }
+    for (int64_t i = 0; i < nsteps; ++i) one_step(w);
 }
 
 /* measure_g4iw_nfft with the exact-sum transform (CTQMC.F90:2130-2234, Nfft_z.F90:416-453) */
@@ -1055,9 +1249,35 @@ static void meas_densitymatrix(ora_walker *w)
     }
 }
 
+/* measure_g4iw_worm with the exact transform (CTQMC.F90:1618-1701, Nfft_worm.F90:94-137): every measurement adds
+ * cfgsign/eta * exp(i[nu1 (t1-t2) + nu2 (t3-t4) + omega (t1-t4)]) (ph; WormPHConvention != 0: omega (t2-t3)) */
+static void meas_g4iw_worm(ora_walker *w)
+{
+    const int nwf = w->p.n4iwf, nwb = w->p.n4iwb, nw = 2 * nwf, nb = 2 * nwb + 1;
+    double t[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < w->nops; ++i) if (w->ops[i].wid) t[w->ops[i].wid] = w->ops[i].tau;
+    const double val = w->cfgsign / w->eta, pib = M_PI / w->p.beta;
+    for (int pp = 0; pp < 2; ++pp) {
+        double *acc = pp ? w->g4wpp : w->g4w;
+        if (!acc) continue;
+        double x1, x2, x3;
+        if (!pp) { x1 = t[1] - t[2]; x2 = t[3] - t[4]; x3 = w->p.wormphconv ? t[2] - t[3] : t[1] - t[4]; }
+        else { x1 = t[1] - t[3]; x2 = t[2] - t[4]; x3 = t[3] - t[2]; }
+        for (int i1 = -nwf; i1 < nwf; ++i1) for (int i2 = -nwf; i2 < nwf; ++i2) for (int i3 = -nwb; i3 <= nwb; ++i3) {
+            double ph = pib * ((double)(2 * i1 + 1) * x1 + (double)(2 * i2 + 1) * x2 + (double)(2 * i3) * x3);
+            size_t idx = ((((size_t)(i1 + nwf)) * nw + (i2 + nwf)) * nb + (i3 + nwb)) * 2;
+            acc[idx] += val * cos(ph); acc[idx + 1] += val * sin(ph);
+        }
+    }
+}
+
 void ora_measure_once(ora_walker *w)
 {
     int nf = w->nflav;
+    if (w->sector != 1) {                                               /* CTQMC.F90:8586-8593 */
+        if (w->g4w || w->g4wpp) { w->cnt_meas_w += 1; meas_g4iw_worm(w); }
+        return;
+    }
     w->cnt_meas += 1;
     w->meas_sign += w->cfgsign; w->cnt_sign += 1;                       /* MeasSign, CTQMC.F90:3343-3350 */
     w->outer_histo[w->outer_sst] += 1.0;                                /* MeasOuterHistograms, 3285-3339 */
@@ -1066,6 +1286,7 @@ void ora_measure_once(ora_walker *w)
         w->histo[(size_t)f * (last + 1) + (k < last ? k : last)] += 1.0;
     }
     meas_densitymatrix(w);
+    if (w->isector != 1) return;                                        /* component sampling: no Z estimators (8554) */
     for (int f = 0; f < nf; ++f) {                                      /* MeasGtauRem + measure_giw_nfft */
         int k = w->k[f];
         if (k == 0) continue;
@@ -1109,7 +1330,7 @@ static void finish_densitymatrix(ora_walker *w)
 void ora_measure_finish(ora_walker *w)
 {
     int nf = w->nflav; double beta = w->p.beta;
-    if (w->cnt_meas == 0) { w->aborted = 2; return; }
+    if (w->cnt_meas == 0 && w->cnt_meas_w == 0) { w->aborted = 2; return; }
     w->mean_sign = w->meas_sign / (double)w->cnt_sign;                                  /* CTQMC.F90:8670 */
     double zs = -1.0 / (w->cnt_meas * w->mean_sign);                                     /* 8697 */
     for (int i = 0; i < w->dmsize; ++i) w->dmblk[i] *= zs;                              /* 8706-8708 */
@@ -1132,6 +1353,41 @@ void ora_measure_finish(ora_walker *w)
         if (w->g4iwpp) for (size_t i = 0; i < n4; ++i) w->g4iwpp[i] *= zs / (beta * beta);
         if (w->g2iw) for (size_t i = 0; i < (size_t)nf * n2 * n2 * 2; ++i) w->g2iw[i] *= zs / beta;
     }
+    if (w->g4w || w->g4wpp) {   /* wormScaling(SectorG4), CTQMC.F90:8833-8849, 8883-8915 */
+        double scal = (w->cnt_meas_w != 0) ? w->cnt_sampling_w / (w->cnt_meas_w * w->cnt_sampling) * 16.0 / (beta * beta) / w->mean_sign : 0.0;
+        size_t n = (size_t)4 * w->p.n4iwf * w->p.n4iwf * (2 * w->p.n4iwb + 1) * 2;
+        if (w->g4w) for (size_t i = 0; i < n; ++i) w->g4w[i] *= scal;
+        if (w->g4wpp) for (size_t i = 0; i < n; ++i) w->g4wpp[i] *= scal;
+    }
+}
+
+int ora_measure_sector(ora_walker *w, int isector, int icomponent)
+{
+    w->isector = isector; w->icomponent = icomponent; w->sector = 1;
+    int rc = ora_measure(w);
+    w->isector = 1;
+    return rc;
+}
+
+void ora_set_wormeta(ora_walker *w, double eta) { w->eta = eta; }
+
+void ora_count_steps(ora_walker *w, int isector, int icomponent, int64_t nfix, int64_t *sw, int64_t *sz)
+{
+    int n = w->nops;
+    op_t *saved = (op_t *)malloc(sizeof(op_t) * (size_t)(n + 1));
+    memcpy(saved, w->ops, sizeof(op_t) * (size_t)n);
+    int outer = w->outer_sst;
+    w->isector = isector; w->icomponent = icomponent; w->sector = 1;
+    for (int64_t j = 0; j < nfix; ++j) one_step(w);
+    *sw = (int64_t)w->cnt_sampling_w; *sz = (int64_t)w->cnt_sampling;
+    w->sector = 1; w->isector = 1;
+    init_counters(w);
+    /* clear_Trace + set_mc_config: back to the configuration the search started from (CTQMC.F90:6436-6440) */
+    double *taus = (double *)malloc(sizeof(double) * (size_t)(n + 1));
+    int *orbs = (int *)malloc(sizeof(int) * (size_t)(n + 1)), *spins = (int *)malloc(sizeof(int) * (size_t)(n + 1)), *cas = (int *)malloc(sizeof(int) * (size_t)(n + 1));
+    for (int i = 0; i < n; ++i) { taus[i] = saved[i].tau; orbs[i] = (saved[i].flav >> 1) + 1; spins[i] = (saved[i].flav & 1) + 1; cas[i] = saved[i].ca; }
+    ora_set_config(w, n, taus, orbs, spins, cas, outer);
+    free(saved); free(taus); free(orbs); free(spins); free(cas);
 }
 
 int ora_measure(ora_walker *w)
@@ -1159,12 +1415,18 @@ void ora_get_config(const ora_walker *w, double *taus, int *orbs, int *spins, in
     *outer_sst = w->outer_sst;
 }
 
+/* hashybs of get_mc_config: -1 = hybridising operator, 0 = worm operator (Trace.F90:6861-6865) */
+void ora_get_hashybs(const ora_walker *w, int *hashybs)
+{
+    for (int i = 0; i < w->nops; ++i) hashybs[i] = w->ops[i].wid ? 0 : -1;
+}
+
 /* Trace.F90:6872-7000 set_mc_config_from_arrays */
 int ora_set_config(ora_walker *w, int n, const double *taus, const int *orbs, const int *spins, const int *cas, int outer_sst)
 {
     ensure_cap(w, n);
     w->nops = n;
-    for (int i = 0; i < n; ++i) { w->ops[i].tau = taus[i]; w->ops[i].flav = 2 * (orbs[i] - 1) + (spins[i] - 1); w->ops[i].ca = cas[i]; }
+    for (int i = 0; i < n; ++i) { w->ops[i].tau = taus[i]; w->ops[i].flav = 2 * (orbs[i] - 1) + (spins[i] - 1); w->ops[i].ca = cas[i]; w->ops[i].wid = 0; }
     w->outer_sst = outer_sst;
     w->wpos = 0; set_window(w);
     w->tr = full_trace(w, outer_sst);
@@ -1208,6 +1470,18 @@ int ora_get_g4iw(const ora_walker *w, double *o, int pp)
     const double *src = pp ? w->g4iwpp : w->g4iw;
     if (!src) return 0;
     memcpy(o, src, sizeof(double) * n4); return 1;
+}
+int ora_get_g4iw_worm(const ora_walker *w, double *o, int pp)
+{
+    const double *src = pp ? w->g4wpp : w->g4w;
+    if (!src) return 0;
+    memcpy(o, src, sizeof(double) * (size_t)4 * w->p.n4iwf * w->p.n4iwf * (2 * w->p.n4iwb + 1) * 2); return 1;
+}
+void ora_get_worm_counters(const ora_walker *w, double *o)
+{
+    o[0] = w->try_wadd; o[1] = w->acc_wadd; o[2] = w->accqn_wadd; o[3] = w->try_wrem; o[4] = w->acc_wrem; o[5] = w->accqn_wrem;
+    o[6] = w->try_wrep; o[7] = w->acc_wrep; o[8] = w->cnt_sampling_w; o[9] = w->cnt_meas_w;
+    o[10] = w->wtry_add; o[11] = w->wacc_add; o[12] = w->wtry_rem; o[13] = w->wacc_rem; o[14] = w->sector;
 }
 int ora_nsst(const ora_walker *w) { return w->nsst; }
 int ora_nsmax(const ora_walker *w) { return w->lp->nsmax; }

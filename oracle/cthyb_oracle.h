@@ -44,6 +44,10 @@ typedef struct ora_params {
     int fourpnt;            /* module variable fourpnt (impurity.py:515); bit 4 = Matsubara G4 in Z space (CTQMC.F90:226) */
     int n4iwf, n4iwb;       /* N4iwf, N4iwb */
     int meas_g2iw, meas_g4iwpp, zphconv;   /* MeasG2iw, MeasG4iwPP, ZPHConvention */
+    /* worm sampling, sector 4 = two-particle Green's function (CTQMC.F90:335-378, 434) */
+    double p_worm_ins, p_worm_rep;         /* PercentageWormInsert, PercentageWormReplace */
+    double worm_eta;                       /* WormEta */
+    int worm_meas_g4iw, g4ph, g4pp, wormphconv;   /* WormMeasG4iw, G4ph, G4pp, WormPHConvention */
 } ora_params;
 
 typedef struct ora_walker ora_walker;
@@ -58,6 +62,16 @@ void ora_destroy(ora_walker *w);
 void ora_set_taudiffmax(ora_walker *w, double x);        /* CTQMC.F90:8180 */
 void ora_warmup(ora_walker *w, int64_t n);               /* CTQMC.F90:8188 */
 int ora_measure(ora_walker *w);                          /* CTQMC.F90:8355 sector Z; returns `aborted` */
+/* ctqmc_measure(isector, icomponent) with isector = 4 (G4 worm) or 1 (CTQMC.F90:8355-8849); returns `aborted` */
+int ora_measure_sector(ora_walker *w, int isector, int icomponent);
+void ora_set_wormeta(ora_walker *w, double eta);         /* module variable wormeta(isector) (impurity.py:719) */
+/* count_steps (CTQMC.F90:6299-6444): nfix steps without measuring, configuration restored afterwards */
+void ora_count_steps(ora_walker *w, int isector, int icomponent, int64_t nfix, int64_t *steps_worm, int64_t *steps_z);
+/* worm results: g4iw_worm / g4iwpp_worm (2N4iwf,2N4iwf,2N4iwb+1) complex interleaved; returns 0 if not measured */
+int ora_get_g4iw_worm(const ora_walker *w, double *out_reim, int pp);
+/* [0]TryWormAdd [1]AccWormAdd [2]AccQNWormAdd [3]TryWormRem [4]AccWormRem [5]AccQNWormRem [6]TryWormRep [7]AccWormRep
+ * [8]CntSampling(worm) [9]CntMeas(worm) [10]TryAdd(worm) [11]AccAdd(worm) [12]TryRem(worm) [13]AccRem(worm) [14]sector now */
+void ora_get_worm_counters(const ora_walker *w, double *out15);
 /* the two halves of ora_measure, for step-by-step checks */
 void ora_measure_begin(ora_walker *w);                   /* init_counters etc. */
 void ora_sweep(ora_walker *w, int64_t nsteps);           /* nsteps Monte Carlo steps of the Z-space loop */
@@ -67,6 +81,7 @@ void ora_measure_finish(ora_walker *w);                  /* normalisation block,
 /* configuration access (CTQMC.F90:9358-9400; Trace.F90:6837-7000) */
 int ora_noper(const ora_walker *w);
 void ora_get_config(const ora_walker *w, double *taus, int *orbs, int *spins, int *cas, int *outer_sst);
+void ora_get_hashybs(const ora_walker *w, int *hashybs);   /* -1 hybridising, 0 worm operator */
 int ora_set_config(ora_walker *w, int n, const double *taus, const int *orbs, const int *spins, const int *cas,
                    int outer_sst);
 /* M block of flavour (orb,spin) [1-based like the reference], time ordered, row=creator, col=annihilator;

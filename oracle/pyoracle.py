@@ -20,7 +20,9 @@ class OraParams(C.Structure):
                 ("maxhisto", C.c_int), ("p_glob", C.c_double), ("p_shift", C.c_double), ("taudiffmax", C.c_double),
                 ("has_szt", C.c_int), ("qns", C.c_char * 64), ("epsevec", C.c_double),
                 ("fourpnt", C.c_int), ("n4iwf", C.c_int), ("n4iwb", C.c_int), ("meas_g2iw", C.c_int),
-                ("meas_g4iwpp", C.c_int), ("zphconv", C.c_int)]
+                ("meas_g4iwpp", C.c_int), ("zphconv", C.c_int),
+                ("p_worm_ins", C.c_double), ("p_worm_rep", C.c_double), ("worm_eta", C.c_double),
+                ("worm_meas_g4iw", C.c_int), ("g4ph", C.c_int), ("g4pp", C.c_int), ("wormphconv", C.c_int)]
 
 
 def build():
@@ -65,6 +67,12 @@ def lib():
     L.ora_nsmax.argtypes = [vp]; L.ora_nsmax.restype = C.c_int
     L.ora_get_blocks.argtypes = [vp, ip, ip, ip]
     L.ora_get_occ.argtypes = [vp, dp, dp, C.c_void_p]
+    L.ora_measure_sector.argtypes = [vp, C.c_int, C.c_int]; L.ora_measure_sector.restype = C.c_int
+    L.ora_set_wormeta.argtypes = [vp, C.c_double]
+    L.ora_count_steps.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.ora_get_g4iw_worm.argtypes = [vp, dp, C.c_int]; L.ora_get_g4iw_worm.restype = C.c_int
+    L.ora_get_worm_counters.argtypes = [vp, dp]
+    L.ora_get_hashybs.argtypes = [vp, ip]
     L.ora_get_g2iw.argtypes = [vp, dp]; L.ora_get_g2iw.restype = C.c_int
     L.ora_get_g4iw.argtypes = [vp, dp, C.c_int]; L.ora_get_g4iw.restype = C.c_int
     L.ora_get_accpair.argtypes = [vp, lp]
@@ -91,7 +99,11 @@ def params_from_pstring(ps, nd, beta, fourpnt=0):
                      taudiffmax=ps.get_real("TaudiffMax"), has_szt=int("Szt" in ps.get_str("QuantumNumbers")),
                      qns=ps.get_str("QuantumNumbers").encode()[:63], epsevec=ps.get_real("EPSEVEC"),
                      fourpnt=fourpnt, n4iwf=ps.get_int("N4iwf"), n4iwb=ps.get_int("N4iwb"), meas_g2iw=ps.get_int("MeasG2iw"),
-                     meas_g4iwpp=ps.get_int("MeasG4iwPP"), zphconv=int(ps.get_int("ZPHConvention") != 0))
+                     meas_g4iwpp=ps.get_int("MeasG4iwPP"), zphconv=int(ps.get_int("ZPHConvention") != 0),
+                     p_worm_ins=ps.get_real("PercentageWormInsert"), p_worm_rep=ps.get_real("PercentageWormReplace"),
+                     worm_eta=ps.get_real("WormEta"), worm_meas_g4iw=ps.get_int("WormMeasG4iw"),
+                     g4ph=int(ps.get_int("G4ph") != 0), g4pp=int(ps.get_int("G4pp") != 0),
+                     wormphconv=int(ps.get_int("WormPHConvention") != 0))
 
 
 class OracleWalker:
@@ -114,6 +126,19 @@ class OracleWalker:
     def set_taudiffmax(self, x): self.L.ora_set_taudiffmax(self.h, float(x))
     def warmup(self, n): self.L.ora_warmup(self.h, int(n))
     def measure(self): return self.L.ora_measure(self.h)
+    def measure_sector(self, isector, icomponent): return self.L.ora_measure_sector(self.h, int(isector), int(icomponent))
+    def set_wormeta(self, eta): self.L.ora_set_wormeta(self.h, float(eta))
+
+    def count_steps(self, isector, icomponent, nfix):
+        a, b = C.c_int64(), C.c_int64()
+        self.L.ora_count_steps(self.h, int(isector), int(icomponent), int(nfix), C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def worm_counters(self):
+        a = np.zeros(15); self.L.ora_get_worm_counters(self.h, a)
+        return dict(zip(("try_wadd", "acc_wadd", "accqn_wadd", "try_wrem", "acc_wrem", "accqn_wrem", "try_wrep", "acc_wrep",
+                         "cnt_sampling_w", "cnt_meas_w", "wtry_add", "wacc_add", "wtry_rem", "wacc_rem", "sector"), a))
+
     def measure_begin(self): self.L.ora_measure_begin(self.h)
     def sweep(self, n): self.L.ora_sweep(self.h, int(n))
     def measure_once(self): self.L.ora_measure_once(self.h)
@@ -124,8 +149,9 @@ class OracleWalker:
         taus = np.zeros(max(n, 1)); orbs = np.zeros(max(n, 1), np.int32); spins = orbs.copy(); cas = orbs.copy()
         o = C.c_int()
         self.L.ora_get_config(self.h, taus, orbs, spins, cas, C.byref(o))
+        hh = np.zeros(max(n, 1), np.int32); self.L.ora_get_hashybs(self.h, hh)
         return dict(taus=taus[:n].copy(), orbs=orbs[:n].copy(), spins=spins[:n].copy(), cas=cas[:n].copy(),
-                    hashybs=-np.ones(n, np.int32), outer_sst=o.value, outer_state=1)
+                    hashybs=hh[:n].copy(), outer_sst=o.value, outer_state=1)
 
     def set_config(self, cfg):
         n = len(cfg["taus"])
@@ -162,6 +188,11 @@ class OracleWalker:
         occ = np.zeros((nd, 2, nd, 2)); rho1 = np.zeros((2 * nd, 2 * nd))
         rho2 = np.zeros((2 * nd,) * 4) if nd <= 3 else None
         self.L.ora_get_occ(self.h, occ, rho1, rho2.ctypes.data if rho2 is not None else None)
+        if p.fourpnt & 8:
+            for key, pp in (("g4iw_worm", 0), ("g4iwpp_worm", 1)):
+                a = np.zeros((2 * p.n4iwf, 2 * p.n4iwf, 2 * p.n4iwb + 1, 2))
+                if self.L.ora_get_g4iw_worm(self.h, a, pp):
+                    r[key] = a[..., 0] + 1j * a[..., 1]
         if p.fourpnt & 4:
             n2 = 2 * (p.n4iwf + p.n4iwb)
             a = np.zeros((nd, 2, n2, n2, 2))

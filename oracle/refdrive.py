@@ -70,9 +70,22 @@ class RefSolver:
         with quiet(self.silent):
             self.q.ctqmc_warmup(int(n))
 
-    def measure(self):
+    def measure(self, isector=1, icomponent=1):
         with quiet(self.silent):
-            self.q.ctqmc_measure(1, 1)
+            self.q.ctqmc_measure(int(isector), int(icomponent))
+
+    def worm_warmup(self, n, isector, icomponent):
+        with quiet(self.silent):
+            self.q.ctqmc_worm_warmup(int(n), int(isector), int(icomponent))
+
+    def set_wormeta(self, eta):
+        self.q.wormeta[:] = float(eta)
+
+    def count_steps(self, isector, icomponent, nfix):
+        sw = np.array(0, dtype=np.int64); sz = np.array(0, dtype=np.int64)
+        with quiet(self.silent):
+            self.q.count_steps(int(isector), int(icomponent), int(nfix), sw, sz)
+        return int(sw), int(sz)
 
     def get_config(self):
         q = self.q

@@ -151,14 +151,51 @@ def gen_g4(only=None):
         print("g4", name, {k: v.shape for k, v in r.items()})
 
 
+WORM = {   # worm sampling in sector 4 (two-particle Green's function), one component each
+    # name: (config, nftau, overrides, seed, component)
+    "C1a": ("C1", 501, dict(Nwarmups=2000, Nmeas=400, NCorr=10, TaudiffMax=3.0, Ntau=50, NLegMax=8, Niw=4, N4iwf=2, N4iwb=1,
+                            PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=0.02, WormMeasG4iw=1,
+                            PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 77, 1),
+    "C1b": ("C1", 501, dict(Nwarmups=2000, Nmeas=600, NCorr=10, TaudiffMax=3.0, Ntau=50, NLegMax=8, Niw=4, N4iwf=2, N4iwb=2,
+                            PercentageWormInsert=0.3, PercentageWormReplace=0.1, WormEta=0.003, WormMeasG4iw=1, G4pp=1,
+                            WormPHConvention=1, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 78, 7),
+    "C3a": ("C3", 501, dict(Nwarmups=3000, Nmeas=500, NCorr=20, TaudiffMax=6.0, Ntau=50, NLegMax=8, Niw=4, N4iwf=2, N4iwb=1,
+                            PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=2e-7, WormMeasG4iw=1,
+                            PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 79, 1 + 0 * 64 + 0 * 16 + 3 * 4 + 3),
+}
+
+
+def gen_worm(only=None):
+    for name, (cfg, nftau, over, seed, comp) in WORM.items():
+        if only and name not in only:
+            continue
+        p, ps = pstring_for(cfg, nftau, over)
+        s = refdrive.RefSolver(p, ps, seed, fourpnt=8)
+        s.set_taudiffmax(over["TaudiffMax"])
+        s.warmup(over["Nwarmups"])
+        steps = s.count_steps(4, comp, 3000)
+        s.worm_warmup(0, 4, comp)
+        s.measure(4, comp)
+        r = s.results(("g4iw_worm", "g4iwpp_worm", "mean_sign", "accwormadd", "accwormrem", "accwormrep", "cntsampling",
+                       "accadd", "accrem", "occ", "histo"))
+        c_end = s.get_config()
+        s.close()
+        np.savez_compressed(os.path.join(OUT, "worm_%s.npz" % name), config=cfg, nftau=nftau, seed=seed, component=comp,
+                            overrides=repr(over), count_steps=np.array(steps), **{"end_" + k: v for k, v in c_end.items()},
+                            **{"res_" + k: v for k, v in r.items()})
+        print("worm", name, "steps(worm, Z) of the eta search", steps, "cntsampling", r["cntsampling"][[0, 3]], "nops", len(c_end["taus"]))
+
+
 if __name__ == "__main__":
     if not refdrive.available():
         raise SystemExit("oracle/_ref is not built: run oracle/build_ref.sh in the build container")
-    which = [a for a in sys.argv[1:] if a in ("traj", "stat", "g4")] or ["traj", "stat", "g4"]
-    only = [a for a in sys.argv[1:] if a not in ("traj", "stat", "g4")] or None      # e.g.: gen_golden.py traj C4S C4
+    which = [a for a in sys.argv[1:] if a in ("traj", "stat", "g4", "worm")] or ["traj", "stat", "g4", "worm"]
+    only = [a for a in sys.argv[1:] if a not in ("traj", "stat", "g4", "worm")] or None      # e.g.: gen_golden.py traj C4S C4
     if "traj" in which:
         gen_traj(only)
     if "stat" in which:
         gen_stat(only)
     if "g4" in which:
         gen_g4(only)
+    if "worm" in which:
+        gen_worm(only)

@@ -149,3 +149,31 @@ def test_oracle_two_particle_matsubara_estimators(name):
         if "res_" + k in g:
             assert rel(r[k], g["res_" + k]) < 1e-10, k
     w.close()
+
+
+@pytest.mark.parametrize("name", ["C1a", "C1b", "C3a"])
+def test_oracle_worm_sampling_retraces_reference(name):
+    """Worm sampling in sector 4 (G4iw): eta-search step counts, sector step counts, acceptance ratios, the final
+    configuration including the worm operators, and the accumulated g4iw_worm agree with the reference run."""
+    g = util.load_golden("worm_%s.npz" % name)
+    over = g["overrides"]; comp = int(g["component"])
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    w = pyoracle.OracleWalker(p, pset, ("std", int(g["seed"])), fourpnt=8)
+    w.set_taudiffmax(over["TaudiffMax"])
+    w.warmup(over["Nwarmups"])
+    assert w.count_steps(4, comp, 3000) == tuple(int(x) for x in g["count_steps"])
+    w.measure_sector(4, comp)
+    r = w.results(); wc = w.worm_counters(); c = w.get_config()
+    assert r["counters"][11] == g["res_cntsampling"][0] and wc["cnt_sampling_w"] == g["res_cntsampling"][3]
+    assert len(c["taus"]) == len(g["end_taus"])
+    if len(c["taus"]):
+        assert np.abs(c["taus"] - g["end_taus"]).max() < 1e-12
+        assert np.array_equal(c["hashybs"], g["end_hashybs"]) and np.array_equal(c["cas"], g["end_cas"])
+    assert wc["acc_wadd"] / wc["try_wadd"] == pytest.approx(float(g["res_accwormadd"][2]), rel=1e-12)
+    assert wc["acc_wrep"] / wc["try_wrep"] == pytest.approx(float(g["res_accwormrep"][2]), rel=1e-12)
+    assert wc["acc_wrem"] / wc["try_wrem"] == pytest.approx(float(g["res_accwormrem"][2]), rel=1e-12)
+    assert rel(r["g4iw_worm"], g["res_g4iw_worm"]) < 1e-10
+    if "res_g4iwpp_worm" in g:
+        assert rel(r["g4iwpp_worm"], g["res_g4iwpp_worm"]) < 1e-10
+    assert rel(r["occ"], g["res_occ"]) < 1e-10
+    w.close()
