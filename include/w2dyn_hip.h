@@ -63,8 +63,21 @@ int w2dyn_set_taudiffmax(w2dyn_solver *s, double taudiffmax);
 int w2dyn_init_counters(w2dyn_solver *s);
 /* ctqmc_warmup(n)                                  CTQMC.F90:8188 */
 int w2dyn_ctqmc_warmup(w2dyn_solver *s, int64_t nwarmups);
-/* ctqmc_measure(isector, icomponent)               CTQMC.F90:8355 (sector 1 = Z this round) */
+/* ctqmc_measure(isector, icomponent)               CTQMC.F90:8355
+ * isector 1 = Z space; isector 4 = worm sampling of the two-particle Green's function component icomponent
+ * (0 = all components), density-density problems only.  Other sectors are refused. */
 int w2dyn_ctqmc_measure(w2dyn_solver *s, int isector, int icomponent);
+/* module variable `wormeta` (impurity.py:719, 755, 784): the same value for every worm sector, CTQMC.F90:194, 434 */
+int w2dyn_set_wormeta(w2dyn_solver *s, double eta);
+int w2dyn_get_wormeta(w2dyn_solver *s, double *eta);
+/* ctqmc_worm_warmup(nwarmups2, isector, icomponent)    CTQMC.F90:8266 (allocates estimator buffers, samples nothing) */
+int w2dyn_ctqmc_worm_warmup(w2dyn_solver *s, int64_t nwarmups2, int isector, int icomponent);
+/* count_steps(isector, icomponent, nfix, steps_worm, steps_z)      CTQMC.F90:6296-6444
+ * nfix steps of the mixed Z / worm loop for every chain, then counters reset and the starting configuration restored
+ * (the random streams move on, as in the reference).  steps_worm / steps_z are the means over the chains of this
+ * context, rounded so that they add up to nfix (what impurity.py:725 checks); the per-chain counts are the result
+ * "steps_worm_chains" (int64, nwalkers). */
+int w2dyn_count_steps(w2dyn_solver *s, int isector, int icomponent, int64_t nfix, int64_t *steps_worm, int64_t *steps_z);
 /* dest_ctqmc()                                     CTQMC.F90:901 */
 int w2dyn_dest_ctqmc(w2dyn_solver *s);
 
@@ -100,7 +113,10 @@ int w2dyn_get_walker_state(w2dyn_solver *s, int walker, double *out6);
  *       "outersuperstatehisto" | "outerstatehisto" | "signhistosuperstates" | "signhistostates" | "tracecontribsuperstates" |
  *       "tracecontribstates" | "statessuperstates" (int32) | "eigenstatesenergies" | "occbasismapping" (4^Nd,Nd,2) int32 |
  *       "accadd" (16) | "accrem" (16) | "accpair" (Nd,2,Ntau) int64 | "cntsampling" (16) int64 | "lhisto" | "rhisto" |
- *       "gtau_full" | "gleg_full" | per-bin: "gleg_bins" (nbins,Nd,2,NLegMax), "gtau_bins", "occ_bins", "giw_bins"
+ *       "gtau_full" | "gleg_full" | per-bin: "gleg_bins" (nbins,Nd,2,NLegMax), "gtau_bins", "occ_bins", "giw_bins" |
+ *       FourPnt & 4: "g4iw", "g4iw_pp" (Nd,2,Nd,2,2N4iwf,2N4iwf,2N4iwb+1) complex, "g2iw" (+ "_bins") |
+ *       worm sampling (FourPnt & 8): "g4iw_worm", "g4iwpp_worm" (2N4iwf,2N4iwf,2N4iwb+1) complex (+ "_bins"),
+ *       "accwormadd" "accwormrem" "accwormrep" (16), "steps_worm_chains" (int64), "worm_counters" per chain
  * Writes min(bytes, size) bytes; *needed (if not NULL) receives the full size. */
 int w2dyn_get_result(w2dyn_solver *s, const char *name, void *out, size_t bytes, size_t *needed);
 /* scalars: "mean_sign" "aborted" "time_warmup" "time_sim" "time_sim_steps" "accglob" "accshift" "accadd4"

@@ -203,7 +203,7 @@ def test_capacity_overflow_is_reported():
 def test_unsupported_modes_are_refused():
     p, _, _ = util.setup("C1", 501, {})
     for over in (dict(segment=1), dict(offdiag=1), dict(statesampling=1), dict(Percentage4OperatorMove=0.1),
-                 dict(PercentageOuterMove=0.1), dict(EnableOuterTruncation="YES"), dict(PercentageWormInsert=0.2)):
+                 dict(PercentageOuterMove=0.1), dict(EnableOuterTruncation="YES")):
         _, ps, _ = util.setup("C1", 501, over)
         q = MCTQMC(nwalkers=4)
         q.init_rnd(1); q.init_paras(ps)
@@ -251,4 +251,112 @@ def test_full_run_statistics_vs_reference(name):
         chi.append((z ** 2).mean())
     assert np.mean(chi) < 2.0, chi
     assert abs(q.accadd[0] - float(g["accadd_mean"][0])) < 5 * float(g["accadd_err"][0]) + 0.003
+    q.dest_ctqmc(); q.close()
+
+
+WORM_CASES = ["C1a", "C1b", "C3a"]
+
+
+def _worm_gpu(g, nw, wpb, seed):
+    over = g["overrides"]
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    q = MCTQMC(nwalkers=nw, walkers_per_bin=wpb)
+    q.fourpnt = 8
+    q.init_rnd(seed); q.init_paras(ps)
+    q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+    q.set_taudiffmax(over["TaudiffMax"])
+    return q, p, pset, over
+
+
+@pytest.mark.parametrize("name", WORM_CASES)
+def test_worm_sampling_chains_vs_oracle(name):
+    """Worm sampling in sector 4 (a-15/a-16): every chain retraces the oracle chain with the same stream through the
+    eta-search step count (count_steps restores the configuration, not the stream), the mixed Z / worm loop and the
+    G4iw worm estimator; the pooled result follows from the per-chain ones."""
+    g = util.load_golden("worm_%s.npz" % name)
+    comp = int(g["component"]); nw = 5
+    q, p, pset, over = _worm_gpu(g, nw, 1, 21)
+    assert q.wormeta[2] == over["WormEta"]
+    q.ctqmc_warmup(over["Nwarmups"])
+    sw, sz = q.count_steps(4, comp, 3000)
+    assert sw + sz == 3000
+    chains_w = q.steps_worm_chains
+    q.ctqmc_worm_warmup(0, 4, comp)
+    q.ctqmc_measure(4, comp)
+    wc = q.worm_counters; bins = q.g4iw_worm_bins
+    keys = ["g4iw_worm"] + (["g4iwpp_worm"] if over.get("G4pp") else [])
+    pooled = {k: 0.0 for k in keys}; cw = cz = mw = 0.0
+    for w in range(nw):
+        o = pyoracle.OracleWalker(p, pset, ("philox", 21, w), fourpnt=8)
+        o.set_taudiffmax(over["TaudiffMax"]); o.warmup(over["Nwarmups"])
+        assert o.count_steps(4, comp, 3000)[0] == chains_w[w], w
+        o.measure_sector(4, comp)
+        r = o.results(); oc = o.worm_counters(); c = o.get_config()
+        got = [r["counters"][11], oc["cnt_sampling_w"], oc["try_wadd"], oc["acc_wadd"], oc["try_wrem"], oc["acc_wrem"], oc["try_wrep"], oc["acc_wrep"]]
+        assert np.array_equal(wc[w], got), (w, wc[w], got)
+        n, osst, _ = q.get_mc_config_scalars(w)
+        assert n == len(c["taus"]) and osst == c["outer_sst"]
+        taus, orbs, spins, cas, hyb, _, _ = q.get_mc_config(n, w)
+        if n:
+            assert np.abs(taus - c["taus"]).max() < 1e-12 and np.array_equal(hyb, c["hashybs"]) and np.array_equal(cas, c["cas"])
+            assert np.array_equal(orbs, c["orbs"]) and np.array_equal(spins, c["spins"])
+        for k in keys:
+            assert rel(getattr(q, k + "_bins")[w], r[k]) < TOL, (k, w)
+            pooled[k] = pooled[k] + r[k] * (oc["cnt_meas_w"] * r["counters"][11] / max(oc["cnt_sampling_w"], 1.0))
+        cw += oc["cnt_sampling_w"]; cz += r["counters"][11]; mw += oc["cnt_meas_w"]
+        assert rel(q.histo_bins[w], r["histo"]) < TOL and rel(q.occ_bins[w], r["occ"]) < TOL
+        o.close()
+    assert mw > 0 and bins.shape[0] == nw
+    for k in keys:
+        assert rel(getattr(q, k), pooled[k] * cw / (mw * cz)) < TOL, k
+    assert q.cntsampling[0] == cz and q.cntsampling[3] == cw
+    q.dest_ctqmc(); q.close()
+
+
+@pytest.mark.parametrize("name", WORM_CASES)
+def test_worm_sampling_vs_reference_statistics(name):
+    """The REFERENCE's g4iw_worm of one short chain (worm_*.npz, mt19937) is one draw from the distribution of the
+    single-chain bins of a GPU run with the same parameters: elementwise within 6 sigma of the GPU bin scatter around
+    the GPU mean (the streams differ, so this is a statistical, not a bit-wise, comparison)."""
+    g = util.load_golden("worm_%s.npz" % name)
+    comp = int(g["component"]); nw = 512
+    q, p, pset, over = _worm_gpu(g, nw, 1, 5)
+    q.ctqmc_warmup(over["Nwarmups"])
+    q.ctqmc_measure(4, comp)
+    for k in ["g4iw_worm"] + (["g4iwpp_worm"] if over.get("G4pp") else []):
+        b = getattr(q, k + "_bins"); m = b.mean(axis=0)
+        sig = np.sqrt(b.real.var(axis=0) + b.imag.var(axis=0))
+        ref = g["res_" + k]
+        assert np.all(np.abs(ref - m) < 6.0 * sig + 1e-12), (k, np.abs(ref - m).max(), sig.max())
+        # the pooled estimate is close to the plain mean of the bins
+        assert np.abs(getattr(q, k) - m).max() < 0.3 * sig.max()
+    assert abs(q.accwormadd[2] - float(g["res_accwormadd"][2])) < 0.05
+    assert abs(q.accwormrep[2] - float(g["res_accwormrep"][2])) < 0.1
+    q.dest_ctqmc(); q.close()
+
+
+def test_worm_modes_refused_or_ignored():
+    """Sectors other than 1 and 4 are refused; worm sampling on the matrix trace path is refused; eta = 0 samples
+    nothing (CTQMC.F90:8409-8418)."""
+    g = util.load_golden("worm_C1a.npz")
+    q, p, pset, over = _worm_gpu(g, 4, 2, 3)
+    with pytest.raises(W2DynError) as e:
+        q.ctqmc_measure(2, 1)
+    assert e.value.code == -2
+    with pytest.raises(W2DynError) as e:
+        q.count_steps(5, 1, 100)
+    assert e.value.code == -2
+    q.wormeta[:] = 0.0
+    q.ctqmc_measure(4, 1)
+    assert q.aborted == 0 and np.all(q.g4iw_worm == 0.0) and q.cntsampling[3] == 0
+    q.dest_ctqmc(); q.close()
+    over = dict(BASE, Nwarmups=10, Nmeas=1, NCorr=5, TaudiffMax=2.0, PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=1.0,
+                WormMeasG4iw=1, N4iwf=2, N4iwb=1)
+    p, ps, pset = util.setup("C4S", 501, over)
+    q = MCTQMC(nwalkers=4, walkers_per_bin=2); q.fourpnt = 8
+    q.init_rnd(1); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+    with pytest.raises(W2DynError) as e:
+        q.ctqmc_measure(4, 1)
+    assert e.value.code == -2
+    q.ctqmc_measure(1, 1)
     q.dest_ctqmc(); q.close()

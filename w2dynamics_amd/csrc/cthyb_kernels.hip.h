@@ -46,6 +46,9 @@ enum Counter { C_TRYADD, C_ACCADD, C_QNADD, C_TRYREM, C_ACCREM, C_QNREM, C_TRYGL
                C_TRYSHIFT, C_ACCSHIFT, C_SAMPLING,
                C_CYC_ADD, C_CYC_REM, C_CYC_GLOB, C_CYC_SHIFT,   // shader cycles per move type (diagnostic build -DW2DYN_STAMPS only)
                C_DBG0, C_DBG1, C_DBG2, C_DBG3, C_DBG4, C_DBG5, C_DBG6, C_DBG7,   // stage stamps (diagnostic build)
+               // worm sampling (sector 4): steps and pair moves inside worm space, worm insert / remove / replace
+               C_W_SAMPLING, C_W_TRYADD, C_W_ACCADD, C_W_TRYREM, C_W_ACCREM,
+               C_TRYWADD, C_ACCWADD, C_QNWADD, C_TRYWREM, C_ACCWREM, C_QNWREM, C_TRYWREP, C_ACCWREP,
                C_NCOUNT };
 
 enum WalkerErr { ERR_NONE = 0, ERR_KMAX = 1, ERR_WCAP = 2, ERR_DETRAT = 4, ERR_SINGULAR = 8, ERR_BLOCKSEQ = 16 };
@@ -59,6 +62,9 @@ struct WalkerScalars {
     double det_sign;            // sign of det F in the reference's time order (Trace%Det%sign)
     double det_log;             // log|det F|
     unsigned long long cnt[C_NCOUNT];
+    // worm sampling: current sector (0/1 = Z, 4 = two-particle worm) and the four worm operators c c+ c c+ in
+    // wormContainer order (Trace.F90:123-125): times and flavours
+    int sector; int wflav[4]; double wtau[4];
 };
 
 struct DevConst {
@@ -93,6 +99,11 @@ struct DevConst {
     const int *sst_n, *sst_off, *conn, *sst_first, *sst_of_state, *dmoff;   // [nsst] [nsst] [nsst][nflav][2] [nsst] [nstates] [nsst+1]
     const double *sst_eval;       // [nstates] eigenvalues in block order
     const double *opmat;          // [nsst][nflav][2][nsm][nsm] operators in the eigenbasis, row = target state, zero padded
+    // worm sampling (CTQMC.F90:335-378, 434; ctqmc_measure arguments)
+    int isector, icomponent, nwf, nwb, wormphconv, g4ph, g4pp;
+    double p_wins, p_wrep, worm_eta;
+    double *acc_g4w, *acc_g4wpp;  // [nbins][2nwf][2nwf][2nwb+1] complex
+    double *acc_nz, *acc_nw;      // [nbins] number of Z / worm measurements (chains measure in the sector they are in)
 };
 
 // bytes of LDS one wave needs (host and device agree through this one function)
@@ -211,6 +222,8 @@ struct Ctx {
     const int *t_conn, *t_n, *t_off; const double *t_eval, *t_op;   // block-shared tables (LDS); t_op null: operators stay in global memory
     double tr_log, tr_sign;                          // current local trace
     int ms_, mi_;                                    // lane = (outer state ms_, component mi_)
+    // worm sampling
+    int sector; double wtau[4]; int wfl[4];
 
     __device__ Ctx(const DevConst &c) : C(c) {}
 
@@ -335,11 +348,24 @@ __device__ W2DYN_INLINE int build_window(Ctx &x)
 }
 
 // integral over (lo,hi) of  eps_f + sum_g U_fg n_g(tau)   for the current configuration (flavour f itself excluded)
+template <bool WORM = false>
 __device__ W2DYN_INLINE double level_integral(Ctx &x, int f, double lo, double hi)
 {
     const DevConst &C = x.C;
     double part = 0.0;
     double base = C.eps[f];
+    if constexpr (WORM) {
+        // worm operators of the other flavours change the occupations too (wormContainer order: c, c+, c, c+)
+        if (x.sector == 4 && x.lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int g = x.wfl[i];
+                if (g == f) continue;
+                const double t = fmin(fmax(x.wtau[i], lo), hi);
+                part += ((i & 1) ? 1.0 : -1.0) * C.udd[f * C.nflav + g] * (hi - t);
+            }
+        }
+    }
     for (int g = 0; g < C.nflav; ++g) {
         if (g == f) continue;
         double u = C.udd[f * C.nflav + g];
@@ -370,11 +396,11 @@ __device__ __forceinline__ void accpair_add(Ctx &x, int f, double dt)
 // ---------------------------------------------------------------------------------------------------------------
 // pair insertion: CTQMC.F90:3353-3612 (StepAdd), Trace.F90:3657-3698, 2775-2832, MatrixUpdate.F90:392-442
 // ---------------------------------------------------------------------------------------------------------------
-template <int MAT>
+template <int MAT, bool WORM = false>
 __device__ W2DYN_INLINE void step_add(Ctx &x)
 {
     const DevConst &C = x.C;
-    x.count(C_TRYADD);
+    if (WORM && x.sector == 4) x.count(C_W_TRYADD); else x.count(C_TRYADD);
     DBG_START(x);
     double width1 = x.wmax - x.wmin;
     double tau1 = x.wmin + width1 * x.draw();                 // annihilator
@@ -421,6 +447,16 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
         double tce = v ? tcp[e] : 2.0 * C.beta, tae = v ? tap[e] : 2.0 * C.beta;
         c_lo += count_pred(tce < lo); a_lo += count_pred(tae < lo);
         blocked |= __ballot((tce >= lo && tce <= hi) || (tae >= lo && tae <= hi)) != 0ull;
+    }
+    if constexpr (WORM) {
+        if (x.sector == 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (x.wfl[i] != f) continue;
+                blocked |= (x.wtau[i] >= lo && x.wtau[i] <= hi);
+                if (x.wtau[i] < lo) { if (i & 1) c_lo += 1; else a_lo += 1; }
+            }
+        }
     }
     int occ_lo = ((x.outer >> flav_bit(f, C.nd)) & 1) + c_lo - a_lo;
     valid = !blocked && occ_lo == (creator_first ? 0 : 1);
@@ -489,7 +525,7 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
         mat_trace_trial<MAT>(x, x.tsst, x.nops, -1, -1, tl_new, ts_new);
         dlogtr = tl_new - x.tr_log;
     } else {
-        double I = level_integral(x, f, lo, hi);
+        double I = level_integral<WORM>(x, f, lo, hi);
         dlogtr = creator_first ? -I : I;
     }
     double rnd = x.draw();
@@ -575,18 +611,18 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
     x.wvalid = 0;
     if constexpr (MAT) { x.tr_log = tl_new; x.tr_sign = ts_new; mat_commit_sst(x); }
     DBG_STAMP(x, C_DBG7);
-    x.count(C_ACCADD);
+    if (WORM && x.sector == 4) x.count(C_W_ACCADD); else x.count(C_ACCADD);
     accpair_add(x, f, hi - lo);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // pair removal: CTQMC.F90:3892-4150 (StepRem), Trace.F90:4851-4950, 2937-2963, MatrixUpdate.F90:445-482
 // ---------------------------------------------------------------------------------------------------------------
-template <int MAT>
+template <int MAT, bool WORM = false>
 __device__ W2DYN_INLINE void step_rem(Ctx &x)
 {
     const DevConst &C = x.C;
-    x.count(C_TRYREM);
+    if (WORM && x.sector == 4) x.count(C_W_TRYREM); else x.count(C_TRYREM);
     DBG_START(x);
     // window list, partner counts and prefix counts are kept until the configuration or the window changes
     if (!x.wvalid || x.npairs < 0) x.npairs = build_window(x);
@@ -695,6 +731,12 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
         }
         blocked = between != 0;
     }
+    if constexpr (WORM) {
+        if (x.sector == 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) blocked |= (x.wfl[i] == f && x.wtau[i] > t1 && x.wtau[i] < t2);
+        }
+    }
     DBG_STAMP(x, C_DBG2);
     if (blocked) { x.count(C_QNREM); return; }
 
@@ -710,7 +752,7 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
         dlogtr = tl_new - x.tr_log;
     } else {
         // the pair's own operators sit on the boundary of (t1,t2) and belong to flavour f, which level_integral skips
-        double I = level_integral(x, f, t1, t2);
+        double I = level_integral<WORM>(x, f, t1, t2);
         dlogtr = creator_first ? I : -I;
     }
     double S = uni(Sv);
@@ -772,7 +814,7 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
     x.npairs = np - dnp;
     x.wvalid = 0;
     if constexpr (MAT) { mat_remove(x, i2); mat_remove(x, i1); x.tr_log = tl_new; x.tr_sign = ts_new; mat_commit_sst(x); }
-    x.count(C_ACCREM);
+    if (WORM && x.sector == 4) x.count(C_W_ACCREM); else x.count(C_ACCREM);
     accpair_add(x, f, t2 - t1);
 }
 
@@ -1158,6 +1200,9 @@ __device__ __forceinline__ void ctx_load(Ctx &x)
     const WalkerScalars &s = C.ws[w];
     x.outer = uni(s.outer); x.npairs = uni(s.npairs); x.wpos = uni(s.wpos); x.err = uni(s.err);
     x.det_sign = uni(s.det_sign); x.det_log = uni(s.det_log);
+    x.sector = uni(s.sector) == 4 ? 4 : 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { x.wtau[i] = uni(s.wtau[i]); x.wfl[i] = uni(s.wflav[i]); }
     unsigned long long nd_ = s.ndraw;
     nd_ = ((unsigned long long)(unsigned)uni((int)(nd_ >> 32)) << 32) | (unsigned long long)(unsigned)uni((int)nd_);
     if (x.lane < C_NCOUNT) x.cnt[x.lane] = s.cnt[x.lane];
@@ -1194,8 +1239,13 @@ __device__ __forceinline__ void ctx_store(Ctx &x)
     if (x.lane == 0) {
         s.ndraw = x.rng_tell(); s.outer = x.outer; s.npairs = x.npairs; s.wpos = x.wpos; s.err = x.err;
         s.det_sign = x.det_sign; s.det_log = x.det_log;
+        s.sector = x.sector;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s.wtau[i] = x.wtau[i]; s.wflav[i] = x.wfl[i]; }
     }
 }
+
+#include "cthyb_worm.hip.h"
 
 #ifdef W2DYN_STAMPS
 #define STAMP_KIND(c) which_ = (c)
@@ -1311,6 +1361,15 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
         for (int li = x.lane; li < 2 * ki; li += 64) {
             bool ci = li < ki;
             double ti = ci ? x.tc(fi)[li] : x.ta(fi)[li - ki];
+            if (!MAT && x.sector == 4) {
+                // worm operators enter the trace sign like any other operator; get_WormSign (Trace.F90:3623-3651) adds the
+                // hybridising operators at later times than each worm operator
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int bw = flav_bit(x.wfl[i], nd); const double tw = x.wtau[i];
+                    par ^= ((tw < ti && bw < biti) ? 1 : 0) ^ ((ti < tw && biti < bw) ? 1 : 0) ^ ((ti > tw) ? 1 : 0);
+                }
+            }
             for (int fj = 0; fj < nf; ++fj) {
                 int kj = x.order(fj);
                 int bitj = flav_bit(fj, nd);
@@ -1330,12 +1389,28 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
     }
     int N = 0;
     for (int f = 0; f < nf; ++f) N += 2 * x.order(f);
+    const bool worm = !MAT && x.sector == 4;
+    if (worm && x.lane == 0) {
+        // worm operators among themselves: trace sign, and the pairs i < j (container order) with tau_i < tau_j
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (x.wtau[j] < x.wtau[i] && flav_bit(x.wfl[j], nd) < flav_bit(x.wfl[i], nd)) par ^= 1;
+                if (i < j && x.wtau[i] < x.wtau[j]) par ^= 1;
+            }
+    }
     par = wave_sum(par) & 1;
     if ((N / 2) & 1) par ^= 1;
     double sign = x.det_sign * (par ? -1.0 : 1.0);
     if constexpr (MAT) sign *= x.tr_sign;            // the trace sign comes with the matrix elements (Trace.F90:3488)
     double cfgsign = -sign;
     const int bin = x.w / C.walkers_per_bin;
+    if (worm) {
+        // a chain in worm space contributes to the worm estimator only (CTQMC.F90:8586-8593); k_meas_g4w picks up its sign
+        if (x.lane == 0) { C.cfgsign[x.w] = cfgsign; atomicAdd(&C.acc_nw[bin], 1.0); }
+        return;
+    }
     if constexpr (MAT) {
         // MeasDensityMatrix_beta_half (CTQMC.F90:3088-3151): kets from 0 to beta/2 through the operators with
         // tau <= beta/2, bras from beta down to beta/2, for all states of the outer block at once
@@ -1385,6 +1460,7 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
     if (x.lane == 0) {
         C.cfgsign[x.w] = cfgsign;
         atomicAdd(&C.acc_sign[bin], cfgsign);
+        atomicAdd(&C.acc_nz[bin], 1.0);
         atomicAdd(&C.acc_outer[(size_t)bin * C.nouter + x.outer], 1.0);
         atomicAdd(&C.acc_signouter[(size_t)bin * C.nouter + x.outer], cfgsign);
     }

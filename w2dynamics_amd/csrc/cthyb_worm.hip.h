@@ -1,0 +1,300 @@
+// Worm sampling in sector 4 (two-particle Green's function) for one-state blocks (density-density problems):
+// StepWormAdd / StepWormRem (CTQMC.F90:4992-5249), StepWormReplace with propose_/do_WormReplace (CTQMC.F90:5809-6297,
+// Trace.F90:3054-3478), the mixed Z / worm-space loop (CTQMC.F90:8428-8533) and the G4iw worm estimator with the exact
+// transform (CTQMC.F90:1618-1701, Nfft_worm.F90:94-137).  Included by cthyb_kernels.hip.h inside namespace w2dyn.
+//
+// The four worm operators c c+ c c+ (wormContainer order, flavours from the component index) carry no hybridisation
+// lines: they enter the local trace and the quantum-number checks but not M.  They are kept as eight wave-uniform
+// scalars (x.wtau, x.wfl); the slot-ordered arrays and M hold hybridising operators only.
+//
+// Trace ratio of inserting the worm into a configuration of hybridising operators (outer state unchanged):
+//   dn_f(tau)  = (# worm creators of flavour f before tau) - (# worm annihilators of f before tau)
+//   -Delta     = sum_f int dn_f (eps_f + sum_{g != f} U_fg n_g) + sum_{f<g} U_fg int dn_f dn_g
+// with n_g the occupations from the hybridising operators alone; the first term is a sum of level integrals over the
+// (at most three) intervals between consecutive worm operators, the second involves the worm times only.
+#pragma once
+
+// sort of the four worm operators by time: ord[m] = container index of the m-th operator in time
+__device__ __forceinline__ void worm_order(const double (&t)[4], int (&ord)[4])
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r += (t[j] < t[i] || (t[j] == t[i] && j < i)) ? 1 : 0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) if (r == m) ord[m] = i;
+    }
+}
+
+// number of hybridising creators / annihilators of flavour f before time t, and whether any lies inside (lo, hi)
+__device__ __forceinline__ void worm_counts(Ctx &x, int f, double t, int &nc, int &na)
+{
+    const int k = x.order(f);
+    const double *tcp = x.tc(f), *tap = x.ta(f);
+    nc = 0; na = 0;
+    for (int base = 0; base < k; base += 64) {
+        const int e = base + x.lane; const bool v = e < k;
+        nc += count_pred(v && tcp[e] < t); na += count_pred(v && tap[e] < t);
+    }
+}
+__device__ __forceinline__ bool worm_any_between(Ctx &x, int f, double lo, double hi)
+{
+    const int k = x.order(f);
+    const double *tcp = x.tc(f), *tap = x.ta(f);
+    bool any = false;
+    for (int base = 0; base < k; base += 64) {
+        const int e = base + x.lane; const bool v = e < k;
+        any |= __ballot(v && ((tcp[e] > lo && tcp[e] < hi) || (tap[e] > lo && tap[e] < hi))) != 0ull;
+    }
+    return any;
+}
+
+// Quantum-number check and log trace ratio (with worm) / (without worm) for worm operators at times t[] with
+// flavours fl[] on top of the present hybridising operators.  At most two distinct flavours can occur in a valid
+// worm (every flavour needs as many worm creators as annihilators).
+__device__ W2DYN_INLINE bool worm_delta(Ctx &x, const double (&t)[4], const int (&fl)[4], double &dlog)
+{
+    const DevConst &C = x.C;
+    int ord[4];
+    worm_order(t, ord);
+    dlog = 0.0;
+    int fa = -1, fb = -1, da = 0, db = 0;
+    bool valid = true;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        int i = 0; double tm = 0.0; int fm = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (ord[m] == q) { i = q; tm = t[q]; fm = fl[q]; }
+        const bool creator = (i & 1) != 0;                 // container order c, c+, c, c+
+        if (fa < 0 || fm == fa) fa = fm;
+        else if (fb < 0 || fm == fb) fb = fm;
+        else valid = false;                                // a third flavour cannot be balanced
+        int nc, na;
+        worm_counts(x, fm, tm, nc, na);
+        const int dcur = (fm == fa) ? da : db;
+        const int occ = ((x.outer >> flav_bit(fm, C.nd)) & 1) + nc - na + dcur;
+        if (occ != (creator ? 0 : 1)) valid = false;
+        if (fm == fa) da += creator ? 1 : -1; else db += creator ? 1 : -1;
+        if (m < 3) {
+            double tn = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (ord[m + 1] == q) tn = t[q];
+            if (valid && da != 0) { if (worm_any_between(x, fa, tm, tn)) valid = false; else dlog -= (double)da * level_integral<false>(x, fa, tm, tn); }
+            if (valid && db != 0) { if (worm_any_between(x, fb, tm, tn)) valid = false; else dlog -= (double)db * level_integral<false>(x, fb, tm, tn); }
+            if (valid && da != 0 && db != 0) dlog -= C.udd[fa * C.nflav + fb] * (double)(da * db) * (tn - tm);
+        }
+    }
+    if (da != 0 || db != 0) valid = false;
+    return valid;
+}
+
+// get_Proposal for SectorG4: (beta Nd)^4 eta (CTQMC.F90:5680-5684)
+__device__ __forceinline__ double worm_prefact(const DevConst &C)
+{
+    const double b = C.beta * (double)C.nd;
+    return b * b * b * b * C.worm_eta;
+}
+
+__device__ W2DYN_INLINE void step_worm_add(Ctx &x)
+{
+    const DevConst &C = x.C;
+    const int nf = C.nflav;
+    int comp = C.icomponent;
+    if (comp == 0) comp = x.randint(1, nf * nf * nf * nf);
+    x.count(C_TRYWADD);
+    double t[4]; int fl[4];
+    int rest = comp - 1, base = nf * nf * nf;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int bs = rest / base; rest -= bs * base; base /= nf; fl[i] = bs; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                      // set_OperTime, Trace.F90:3942-3967
+        t[i] = x.draw() * C.beta;
+        if (i > 0 && t[i - 1] == t[i]) t[i] += C.beta * 1e-14;
+    }
+    double dlog;
+    const bool valid = worm_delta(x, t, fl, dlog);
+    if (worm_prefact(C) == 0.0 || !valid) { x.count(C_QNWADD); x.sector = 1; return; }
+    const double rnd = x.draw();
+    if (rnd < fabs(worm_prefact(C) * exp(dlog))) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x.wtau[i] = t[i]; x.wfl[i] = fl[i]; }
+        x.sector = 4;
+        x.count(C_ACCWADD);
+    } else x.sector = 1;
+}
+
+__device__ W2DYN_INLINE void step_worm_rem(Ctx &x)
+{
+    const DevConst &C = x.C;
+    x.count(C_TRYWREM);
+    double dlog;
+    const bool valid = worm_delta(x, x.wtau, x.wfl, dlog);
+    if (!valid) { x.count(C_QNWREM); return; }
+    const double rnd = x.draw();
+    if (rnd < fabs(exp(-dlog) / worm_prefact(C))) { x.sector = 1; x.count(C_ACCWREM); }
+}
+
+// a worm operator and a hybridising operator of the same flavour and type exchange their roles: one row (creator) or
+// column (annihilator) of the hybridisation matrix changes; Sherman-Morrison on the slot-ordered M, no reordering
+__device__ W2DYN_INLINE void step_worm_replace(Ctx &x)
+{
+    const DevConst &C = x.C;
+    x.count(C_TRYWREP);
+    const int r = x.randint(1, 4) - 1;
+    double tw = 0.0; int f = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i == r) { tw = x.wtau[i]; f = x.wfl[i]; }
+    const bool creator = (r & 1) != 0;
+    const int k = x.order(f), kmax = C.kmax;
+    if (k == 0) return;
+    const int pos = x.randint(1, k);
+    double *tcp = x.tc(f), *tap = x.ta(f), *Mf = x.mat(f);
+    const double *own = creator ? tcp : tap;
+    // slot of the pos-th operator of that flavour and type in time order
+    int slot = -1;
+    for (int base = 0; base < k; base += 64) {
+        const int e = base + x.lane;
+        int rank = 0;
+        if (e < k) { const double te = own[e]; for (int j = 0; j < k; ++j) rank += own[j] < te ? 1 : 0; }
+        const unsigned long long m = __ballot(e < k && rank == pos - 1);
+        if (m) slot = base + __ffsll((long long)m) - 1;
+    }
+    slot = uni(slot);
+    const double th = uni(own[slot]);
+    int ncnt = 0;
+    for (int base = 0; base < k; base += 64) {
+        const int e = base + x.lane;
+        ncnt += count_pred(e < k && own[e] > fmin(th, tw) && own[e] < fmax(th, tw));
+    }
+    const double *ft = C.ftab + (size_t)f * C.nftau;
+    // creator exchanged: u over annihilators, X = M u (per creator), Y = row `slot` of M; detRat = 1 + X[slot]
+    // annihilator exchanged: v over creators, X = column `slot` of M, Y = M^T v; detRat = 1 + v . X
+    for (int e = x.lane; e < k; e += 64) {
+        if (creator) x.Q[e] = -hybr(ft, C.nftau, C.beta, tap[e] - th) + hybr(ft, C.nftau, C.beta, tap[e] - tw);
+        else x.Q[e] = -hybr(ft, C.nftau, C.beta, th - tcp[e]) + hybr(ft, C.nftau, C.beta, tw - tcp[e]);
+    }
+    wave_sync();
+    double part = 0.0;
+    for (int e = x.lane; e < k; e += 64) {
+        double xs = 0.0, ys = 0.0;
+        if (creator) {
+            for (int a = 0; a < k; ++a) xs += Mf[(size_t)e * kmax + a] * x.Q[a];
+            ys = Mf[(size_t)slot * kmax + e];
+        } else {
+            xs = Mf[(size_t)e * kmax + slot];
+            for (int c = 0; c < k; ++c) ys += x.Q[c] * Mf[(size_t)c * kmax + e];
+            part += x.Q[e] * xs;
+        }
+        x.MQ[e] = xs; x.RM[e] = ys;
+    }
+    wave_sync();
+    const double detrat = creator ? 1.0 + uni(x.MQ[slot]) : 1.0 + wave_sum(part);
+    const double rnd = x.draw();
+    if (!(rnd < fabs(detrat))) return;
+    const int kk = k * k;
+    for (int e = x.lane; e < kk; e += 64) {
+        const int c = e / k, a = e - c * k;
+        Mf[(size_t)c * kmax + a] -= x.MQ[c] * x.RM[a] / detrat;
+    }
+    if (x.lane == 0) { if (creator) tcp[slot] = tw; else tap[slot] = tw; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (i == r) x.wtau[i] = th;
+    wave_sync();
+    x.det_log += log(fabs(detrat));
+    x.det_sign *= (detrat < 0.0 ? -1.0 : 1.0) * ((ncnt & 1) ? -1.0 : 1.0);
+    x.npairs = -1; x.wvalid = 0;
+    x.count(C_ACCWREP);
+}
+
+// sweep kernel with worm sampling (scalar trace path): Z space CTQMC.F90:8431-8488, worm space 8489-8528
+__global__ __launch_bounds__(256) void k_sweep_worm(DevConst C, long long nsteps)
+{
+    extern __shared__ unsigned char smem[];
+    Ctx x(C);
+    ctx_setup(x, smem);
+    if (x.w >= C.nwalkers) return;
+    ctx_load(x);
+    const double pg = C.p_glob, ps = C.p_shift, pw = C.p_wins, pr = C.p_wrep;
+    unsigned int phase = (unsigned int)((x.cnt[C_TRYADD] + x.cnt[C_TRYREM] + x.cnt[C_W_TRYADD] + x.cnt[C_W_TRYREM]) % (unsigned long long)C.nslide);
+    phase = (unsigned int)uni((int)phase);
+    for (long long it = 0; it < nsteps; ++it) {
+        if (x.sector != 4) {
+            x.count(C_SAMPLING);
+            const double r = x.draw();
+            if (r < (1.0 - ps - pg - pw) / 2.0) { (void)x.draw(); (void)x.draw(); step_add<0, true>(x); phase += 1; }
+            else if (r <= 1.0 - ps - pg - pw) { (void)x.draw(); (void)x.draw(); step_rem<0, true>(x); phase += 1; }
+            else if (r <= 1.0 - ps - pg) step_worm_add(x);
+            else if (r <= 1.0 - ps) step_glob(x);
+            else step_shift<0>(x);
+        } else {
+            x.count(C_W_SAMPLING);
+            const double r = x.draw();
+            if (r < (1.0 - pr - pw) / 2.0) { (void)x.draw(); (void)x.draw(); step_add<0, true>(x); phase += 1; }
+            else if (r < 1.0 - pr - pw) { (void)x.draw(); (void)x.draw(); step_rem<0, true>(x); phase += 1; }
+            else if (r < 1.0 - pw) step_worm_replace(x);
+            else step_worm_rem(x);
+        }
+        if (phase == (unsigned int)C.nslide) phase = 0;
+        if (phase == 0) {
+            if (C.num_windows > 1) {
+                x.wpos += 1; if (x.wpos == C.num_windows) x.wpos = 0;
+                x.window_bounds(); x.npairs = -1; x.wvalid = 0;
+            } else x.wpos = 0;
+        }
+    }
+    ctx_store(x);
+}
+
+// G4iw worm estimator: every chain that is in worm space adds cfgsign/eta * exp(i[nu1 x1 + nu2 x2 + omega x3]) to its
+// bin, ph: x = (t1-t2, t3-t4, t1-t4 | t2-t3), pp: x = (t1-t3, t2-t4, t3-t2).  One workgroup per bin loops over the
+// bin's chains; the three one-dimensional phase tables of a chain go through LDS, accumulators stay in registers
+// (no HBM traffic per sample), one read-modify-write of the bin's array per launch.
+constexpr int G4W_PER_THREAD = 8;
+__global__ __launch_bounds__(256) void k_meas_g4w(DevConst C, int pp, int nbw)
+{
+    extern __shared__ double2 ph[];              // [2nwf] [2nwf] [2nwb+1]
+    const int nw = 2 * C.nwf, nb = 2 * C.nwb + 1, n = nw * nw * nb, bin = blockIdx.x, tid = threadIdx.x;
+    double *acc = (pp ? C.acc_g4wpp : C.acc_g4w) + (size_t)bin * n * 2;
+    const double pib = M_PI / C.beta;
+    for (int e0 = 0; e0 < n; e0 += 256 * G4W_PER_THREAD) {
+        double re[G4W_PER_THREAD], im[G4W_PER_THREAD];
+#pragma unroll
+        for (int q = 0; q < G4W_PER_THREAD; ++q) { re[q] = 0.0; im[q] = 0.0; }
+        for (int cb = bin; cb < C.nbins; cb += nbw)            // chain bins folded onto this accumulator bin
+        for (int w = cb * C.walkers_per_bin; w < min((cb + 1) * C.walkers_per_bin, C.nwalkers); ++w) {
+            const WalkerScalars &s = C.ws[w];
+            if (s.sector != 4) continue;                     // uniform over the workgroup
+            const double t1 = s.wtau[0], t2 = s.wtau[1], t3 = s.wtau[2], t4 = s.wtau[3];
+            double x1, x2, x3;
+            if (!pp) { x1 = t1 - t2; x2 = t3 - t4; x3 = C.wormphconv ? t2 - t3 : t1 - t4; }
+            else { x1 = t1 - t3; x2 = t2 - t4; x3 = t3 - t2; }
+            const double val = C.cfgsign[w] / C.worm_eta;
+            __syncthreads();
+            for (int i = tid; i < 2 * nw + nb; i += 256) {
+                double a;
+                if (i < nw) a = pib * (double)(2 * (i - C.nwf) + 1) * x1;
+                else if (i < 2 * nw) a = pib * (double)(2 * (i - nw - C.nwf) + 1) * x2;
+                else a = pib * (double)(2 * (i - 2 * nw - C.nwb)) * x3;
+                double sn, cs; sincos(a, &sn, &cs);
+                ph[i] = make_double2(cs, sn);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < G4W_PER_THREAD; ++q) {
+                const int e = e0 + q * 256 + tid;
+                if (e < n) {
+                    const int i3 = e % nb, i2 = (e / nb) % nw, i1 = e / (nb * nw);
+                    const double2 a = ph[i1], b = ph[nw + i2], c = ph[2 * nw + i3];
+                    const double pr = a.x * b.x - a.y * b.y, pi = a.x * b.y + a.y * b.x;
+                    re[q] += val * (pr * c.x - pi * c.y); im[q] += val * (pr * c.y + pi * c.x);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < G4W_PER_THREAD; ++q) {
+            const int e = e0 + q * 256 + tid;
+            if (e < n) { acc[2 * e] += re[q]; acc[2 * e + 1] += im[q]; }
+        }
+    }
+}

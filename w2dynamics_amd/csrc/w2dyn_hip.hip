@@ -54,6 +54,11 @@ struct w2dyn_solver {
     // Z-space two-particle Matsubara estimators (FourPnt & 4)
     int n4iwf = 0, n4iwb = 0, meas_g2iw = 0, meas_g4iwpp = 0, zph = 0, nb4 = 0;
     double2 *G2 = nullptr, *acc4 = nullptr, *acc4pp = nullptr, *acc2 = nullptr;
+    // worm sampling (sector 4): move probabilities, eta, estimator switches, accumulator bins, sector of the running call
+    double p_wins = 0, p_wrep = 0, worm_eta = 0;
+    int worm_meas_g4iw = 0, g4ph = 0, g4pp = 0, wormphconv = 0, nbw = 0, cur_isector = 1;
+    bool no_sampling = false;
+    std::vector<long long> steps_worm_chains;
     DevConst C{};
     std::vector<void *> allocs;
     // accumulators bookkeeping
@@ -284,22 +289,30 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
         if (!get_int(s, z.key, iv)) return W2DYN_EINVAL;
         if (iv != z.allowed) return fail(s, W2DYN_EUNSUPPORTED, "%s = %lld is not supported by the HIP solver (only %lld)", z.key, iv, z.allowed);
     }
-    const char *zero_real[] = {"Percentage4OperatorMove", "PercentageOuterMove", "PercentageWormInsert", "PercentageWormReplace"};
+    const char *zero_real[] = {"Percentage4OperatorMove", "PercentageOuterMove"};
     for (auto key : zero_real) {
         if (!get_real(s, key, rv)) return W2DYN_EINVAL;
         if (rv != 0.0) return fail(s, W2DYN_EUNSUPPORTED, "%s = %g is not supported by the HIP solver (only 0)", key, rv);
     }
     if (!get_str(s, "EnableOuterTruncation", sv)) return W2DYN_EINVAL;
     if (sv == "YES") return fail(s, W2DYN_EUNSUPPORTED, "EnableOuterTruncation = YES is not supported");
-    if (s->fourpnt != 0 && s->fourpnt != 4)
-        return fail(s, W2DYN_EUNSUPPORTED, "FourPnt = %d is not supported (0, or 4 = Matsubara two-particle Green's function in Z space)", s->fourpnt);
+    if (s->fourpnt & ~12)
+        return fail(s, W2DYN_EUNSUPPORTED, "FourPnt = %d is not supported (bits 4 = Matsubara two-particle Green's function in Z space, 8 = worm estimators)", s->fourpnt);
+    if (!get_real(s, "PercentageWormInsert", s->p_wins)) return W2DYN_EINVAL;
+    if (!get_real(s, "PercentageWormReplace", s->p_wrep)) return W2DYN_EINVAL;
+    if (!get_real(s, "WormEta", s->worm_eta)) return W2DYN_EINVAL;                      // CTQMC.F90:434
+    if (!get_int(s, "WormMeasG4iw", iv)) return W2DYN_EINVAL; s->worm_meas_g4iw = iv != 0;
+    if (!get_int(s, "G4ph", iv)) return W2DYN_EINVAL; s->g4ph = iv != 0;
+    if (!get_int(s, "G4pp", iv)) return W2DYN_EINVAL; s->g4pp = iv != 0;
+    if (!get_int(s, "WormPHConvention", iv)) return W2DYN_EINVAL; s->wormphconv = iv != 0;
+    if (!((s->fourpnt & 8) && s->worm_meas_g4iw)) s->g4ph = s->g4pp = 0;                 // CTQMC.F90:339-363
     if (!get_int(s, "N4iwf", iv)) return W2DYN_EINVAL; s->n4iwf = (int)iv;
     if (!get_int(s, "N4iwb", iv)) return W2DYN_EINVAL; s->n4iwb = (int)iv;
     if (!get_int(s, "MeasG2iw", iv)) return W2DYN_EINVAL; s->meas_g2iw = (int)iv;
     if (!get_int(s, "MeasG4iwPP", iv)) return W2DYN_EINVAL; s->meas_g4iwpp = (int)iv;
     if (!get_int(s, "ZPHConvention", iv)) return W2DYN_EINVAL; s->zph = iv != 0;
-    if (s->fourpnt == 4 && (s->n4iwf < 1 || s->n4iwb < 0)) return fail(s, W2DYN_EINVAL, "N4iwf=%d N4iwb=%d", s->n4iwf, s->n4iwb);
-    if (s->fourpnt == 4 && s->meas_g4iwpp && s->zph) return fail(s, W2DYN_EUNSUPPORTED, "G4iwPP measurement is not implemented for ZPHConvention != 0 (CTQMC.F90:2220)");
+    if ((s->fourpnt & 12) && (s->n4iwf < 1 || s->n4iwb < 0)) return fail(s, W2DYN_EINVAL, "N4iwf=%d N4iwb=%d", s->n4iwf, s->n4iwb);
+    if ((s->fourpnt & 4) && s->meas_g4iwpp && s->zph) return fail(s, W2DYN_EUNSUPPORTED, "G4iwPP measurement is not implemented for ZPHConvention != 0 (CTQMC.F90:2220)");
     if (screening) { /* must be zero; checked below once nd is known */ }
 
     if (!get_int(s, "Nd", iv)) return W2DYN_EINVAL; s->nd = (int)iv;
@@ -444,6 +457,19 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if ((rc = dev_alloc(s, C.acc_signouter, B * nouter))) return rc;
     if ((rc = dev_alloc(s, C.acc_sign, B))) return rc;
     if ((rc = dev_alloc(s, C.accpair, (size_t)nf * s->ntau))) return rc;
+    if ((rc = dev_alloc(s, C.acc_nz, B))) return rc;
+    if ((rc = dev_alloc(s, C.acc_nw, B))) return rc;
+    C.nwf = s->n4iwf; C.nwb = s->n4iwb; C.wormphconv = s->wormphconv; C.g4ph = s->g4ph; C.g4pp = s->g4pp;
+    C.p_wins = 0.0; C.p_wrep = s->p_wrep; C.worm_eta = s->worm_eta; C.isector = 1; C.icomponent = 0;
+    s->nbw = 0; s->cur_isector = 1; s->no_sampling = false; s->steps_worm_chains.clear();
+    if (s->g4ph || s->g4pp) {
+        const size_t n = (size_t)4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1) * 2 * ((s->g4ph ? 1 : 0) + (s->g4pp ? 1 : 0));
+        s->nbw = (int)std::max<size_t>(1, std::min<size_t>(B, ((size_t)2 << 30) / (n * sizeof(double))));
+        const size_t one = (size_t)s->nbw * 4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1) * 2;
+        if (s->g4ph) { if ((rc = dev_alloc(s, C.acc_g4w, one))) return rc; }
+        if (s->g4pp) { if ((rc = dev_alloc(s, C.acc_g4wpp, one))) return rc; }
+        if ((size_t)(4 * s->n4iwf + 2 * s->n4iwb + 1) * sizeof(double2) > 64 * 1024) return fail(s, W2DYN_EUNSUPPORTED, "N4iwf=%d N4iwb=%d too large for the worm estimator", s->n4iwf, s->n4iwb);
+    }
     s->G2 = s->acc4 = s->acc4pp = s->acc2 = nullptr; s->nb4 = 0;
     if (s->fourpnt & 4) {
         const size_t n2 = 2 * (size_t)(s->n4iwf + s->n4iwb), n4 = (size_t)nf * nf * 4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1), ng2 = (size_t)nf * n2 * n2;
@@ -509,7 +535,8 @@ int w2dyn_sweep(w2dyn_solver *s, int64_t nsteps, int count_as_sampling)
     if ((rc = time_begin(s))) return rc;
     // instantiations: 0 = one-state blocks (closed-form trace); 2, 3, 4 = matrix path with blocks padded to that size
     // (tree product); 9 = matrix path, sequential propagation (blocks of 5..8 states)
-    switch (mat_variant(s)) {
+    if (s->cur_isector == 4) hipLaunchKernelGGL(k_sweep_worm, l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps);   // counts its own steps
+    else switch (mat_variant(s)) {
     case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<0>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps, count_as_sampling); break;
     case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<2>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps, count_as_sampling); break;
     case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<3>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps, count_as_sampling); break;
@@ -517,7 +544,7 @@ int w2dyn_sweep(w2dyn_solver *s, int64_t nsteps, int count_as_sampling)
     default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<9>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps, count_as_sampling); break;
     }
     HIPCHK(hipGetLastError());
-    if ((rc = time_end(s, "sweep"))) return rc;
+    if ((rc = time_end(s, s->cur_isector == 4 ? "sweep_worm" : "sweep"))) return rc;
     s->steps_done += nsteps;
     return 0;
 }
@@ -554,6 +581,13 @@ int w2dyn_measure_begin(w2dyn_solver *s)
     HIPCHK(hipMemsetAsync(C.acc_outer, 0, sizeof(double) * B * C.nouter, s->stream));
     HIPCHK(hipMemsetAsync(C.acc_signouter, 0, sizeof(double) * B * C.nouter, s->stream));
     HIPCHK(hipMemsetAsync(C.acc_sign, 0, sizeof(double) * B, s->stream));
+    HIPCHK(hipMemsetAsync(C.acc_nz, 0, sizeof(double) * B, s->stream));
+    HIPCHK(hipMemsetAsync(C.acc_nw, 0, sizeof(double) * B, s->stream));
+    {
+        const size_t one = (size_t)s->nbw * 4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1) * 2;
+        if (C.acc_g4w) HIPCHK(hipMemsetAsync(C.acc_g4w, 0, sizeof(double) * one, s->stream));
+        if (C.acc_g4wpp) HIPCHK(hipMemsetAsync(C.acc_g4wpp, 0, sizeof(double) * one, s->stream));
+    }
     if (s->fourpnt & 4) {
         const size_t n2 = 2 * (size_t)(s->n4iwf + s->n4iwb), n4 = (size_t)nf * nf * 4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1), ng2 = (size_t)nf * n2 * n2;
         HIPCHK(hipMemsetAsync(s->acc4, 0, sizeof(double2) * s->nb4 * n4, s->stream));
@@ -580,6 +614,18 @@ int w2dyn_measure_once(w2dyn_solver *s)
     }
     HIPCHK(hipGetLastError());
     if ((rc = time_end(s, "meas_misc"))) return rc;
+    if (s->cur_isector != 1) {      // component sampling: no Z-space Green's function estimators (CTQMC.F90:8554), worm estimator instead
+        if (s->C.acc_g4w || s->C.acc_g4wpp) {
+            if ((rc = time_begin(s))) return rc;
+            const size_t lds = (size_t)(4 * s->n4iwf + 2 * s->n4iwb + 1) * sizeof(double2);
+            if (s->C.acc_g4w) hipLaunchKernelGGL(k_meas_g4w, dim3(s->nbw), dim3(256), lds, s->stream, s->C, 0, s->nbw);
+            if (s->C.acc_g4wpp) hipLaunchKernelGGL(k_meas_g4w, dim3(s->nbw), dim3(256), lds, s->stream, s->C, 1, s->nbw);
+            HIPCHK(hipGetLastError());
+            if ((rc = time_end(s, "meas_g4w"))) return rc;
+        }
+        s->meas_done += 1;
+        return 0;
+    }
     if ((rc = time_begin(s))) return rc;
     if (s->nleg <= 16) launch_gleg<16>(s);
     else if (s->nleg <= 32) launch_gleg<32>(s);
@@ -632,12 +678,15 @@ int w2dyn_measure_finish(w2dyn_solver *s)
     HIPCHK(hipMemcpy(s->res_accpair.data(), C.accpair, s->res_accpair.size() * sizeof(long long), hipMemcpyDeviceToHost));
     s->counters.assign(C_NCOUNT, 0.0);
     for (auto &w : ws) for (int i = 0; i < C_NCOUNT; ++i) s->counters[i] += (double)w.cnt[i];
-    if (s->meas_done == 0) { s->aborted = 2; return 0; }          // CTQMC.F90:8653-8657, 8665
-    const double nmeas_tot = (double)s->meas_done * W;
+    if (s->meas_done == 0 && !s->no_sampling) { s->aborted = 2; return 0; }          // CTQMC.F90:8653-8657, 8665
+    // measurements in Z space per bin: every chain at every measurement in a Z run, the chains found in Z space in a
+    // worm run (CntMeas(SectorZ), CTQMC.F90:8541-8545)
+    std::vector<double> nz = fetch(C.acc_nz, B), nwm = fetch(C.acc_nw, B);
+    double nmeas_tot = 0.0; for (double v : nz) nmeas_tot += v;
     double ssum = 0.0; for (double v : sgn) ssum += v;
     s->mean_sign = ssum / nmeas_tot;                               // CTQMC.F90:8670
     const double ms = s->mean_sign, beta = s->beta;
-    auto binw = [&](int b) { int w0 = b * C.walkers_per_bin, w1 = std::min(w0 + C.walkers_per_bin, W); return (double)(w1 - w0) * (double)s->meas_done; };
+    auto binw = [&](int b) { return nz[b]; };
     auto &R = s->res;
     R.clear();
     // per-bin normalised arrays and their walker-weighted mean
@@ -745,6 +794,13 @@ int w2dyn_measure_finish(w2dyn_solver *s)
     {   // acceptance ratios (CTQMC.F90:8680-8695); 16 sectors, Z = index 0
         std::vector<double> aa(16, 0.0), ar(16, 0.0);
         aa[0] = s->counters[C_ACCADD] / s->counters[C_TRYADD]; ar[0] = s->counters[C_ACCREM] / s->counters[C_TRYREM];
+        std::vector<double> wa(15, 0.0), wr(15, 0.0), wp(15, 0.0);      // AccWormAdd/Rem/Rep(2:NWormSectors), CTQMC.F90:8685-8691
+        if (s->cur_isector == 4) {
+            aa[3] = s->counters[C_W_ACCADD] / s->counters[C_W_TRYADD]; ar[3] = s->counters[C_W_ACCREM] / s->counters[C_W_TRYREM];
+            wa[2] = s->counters[C_ACCWADD] / s->counters[C_TRYWADD]; wr[2] = s->counters[C_ACCWREM] / s->counters[C_TRYWREM];
+            wp[2] = s->counters[C_ACCWREP] / s->counters[C_TRYWREP];
+        }
+        R["accwormadd"] = wa; R["accwormrem"] = wr; R["accwormrep"] = wp;
         R["accadd"] = aa; R["accrem"] = ar;
         R["accglob"] = {s->counters[C_ACCGLOB] / s->counters[C_TRYGLOB]};
         R["accshift"] = {s->counters[C_ACCSHIFT] / s->counters[C_TRYSHIFT]};
@@ -766,6 +822,44 @@ int w2dyn_measure_finish(w2dyn_solver *s)
         if (s->acc4pp) reduce4(s->acc4pp, n4, "g4iw_pp", 1.0 / (beta * beta));
         if (s->acc2) reduce4(s->acc2, ng2, "g2iw", 1.0 / beta);
     }
+    if (s->cur_isector == 4 && (C.acc_g4w || C.acc_g4wpp)) {
+        // wormScaling(SectorG4) = CntSampling(G4) / (CntMeas(G4) CntSampling(Z)) * 16/beta^2 / mean_sign (CTQMC.F90:8825-8849,
+        // 8883-8915); counts are pooled over the chains that share an accumulator bin
+        const size_t n = (size_t)4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1) * 2;
+        const int nbw = s->nbw;
+        std::vector<double> cw(nbw, 0.0), cz(nbw, 0.0), mw(nbw, 0.0);
+        double cwt = 0.0, czt = 0.0, mwt = 0.0;
+        for (int w = 0; w < W; ++w) {
+            const int b = (w / C.walkers_per_bin) % nbw;
+            cw[b] += (double)ws[w].cnt[C_W_SAMPLING]; cz[b] += (double)ws[w].cnt[C_SAMPLING];
+        }
+        for (int b = 0; b < B; ++b) mw[b % nbw] += nwm[b];
+        for (int b = 0; b < nbw; ++b) { cwt += cw[b]; czt += cz[b]; mwt += mw[b]; }
+        auto scal = [&](double c_w, double c_z, double m_w) { return m_w != 0.0 ? c_w / (m_w * c_z) * 16.0 / (beta * beta) / ms : 0.0; };
+        auto reducew = [&](const double *dev, const char *name) {
+            std::vector<double> raw((size_t)nbw * n), tot(n, 0.0);
+            (void)hipMemcpy(raw.data(), dev, raw.size() * sizeof(double), hipMemcpyDeviceToHost);
+            for (int b = 0; b < nbw; ++b) {
+                const double f = scal(cw[b], cz[b], mw[b]);
+                for (size_t i = 0; i < n; ++i) { tot[i] += raw[(size_t)b * n + i]; raw[(size_t)b * n + i] *= f; }
+            }
+            const double f = scal(cwt, czt, mwt);
+            for (size_t i = 0; i < n; ++i) tot[i] *= f;
+            R[name] = tot; R[std::string(name) + "_bins"] = raw;
+        };
+        if (C.acc_g4w) reducew(C.acc_g4w, "g4iw_worm");
+        if (C.acc_g4wpp) reducew(C.acc_g4wpp, "g4iwpp_worm");
+        R["cntmeas_worm"] = {mwt};
+    }
+    {   // per-chain worm counters: steps in Z, steps in worm space, worm insertions tried / accepted, removals, replacements
+        std::vector<double> wc((size_t)W * 8);
+        for (int w = 0; w < W; ++w) {
+            const unsigned long long *c = ws[w].cnt;
+            const int idx[8] = {C_SAMPLING, C_W_SAMPLING, C_TRYWADD, C_ACCWADD, C_TRYWREM, C_ACCWREM, C_TRYWREP, C_ACCWREP};
+            for (int i = 0; i < 8; ++i) wc[(size_t)w * 8 + i] = (double)c[idx[i]];
+        }
+        R["worm_counters"] = wc;
+    }
     R["eigenstatesenergies"] = s->energies;
     R["lhisto"] = std::vector<double>(100, 0.0); R["rhisto"] = std::vector<double>(100, 0.0);
     {   // gtau_full / gleg_full are only filled by the off-diagonal estimators (CTQMC.F90:8752, 8768): zero here
@@ -774,15 +868,38 @@ int w2dyn_measure_finish(w2dyn_solver *s)
     return 0;
 }
 
+// sector bookkeeping shared by ctqmc_measure and count_steps: every chain starts in Z space (CTQMC.F90:6328, 8400)
+static int enter_sector(w2dyn_solver *s, int isector, int icomponent)
+{
+    if (isector != 1 && isector != 4) return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d is not supported (1 = Z, 4 = two-particle Green's function)", isector);
+    if (isector == 4) {
+        const int nf = s->nflav;
+        if (s->mat) return fail(s, W2DYN_EUNSUPPORTED, "worm sampling is only implemented for density-density problems (one-state blocks)");
+        if (icomponent < 0 || icomponent > nf * nf * nf * nf) return fail(s, W2DYN_EINVAL, "component %d out of range", icomponent);
+    }
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    if (isector == 1) s->p_wins = 0.0;                         // CTQMC.F90:8380-8385: a pure Z run switches worm insertion off for good
+    s->cur_isector = isector;
+    s->C.isector = isector; s->C.icomponent = icomponent; s->C.p_wins = isector == 1 ? 0.0 : s->p_wins; s->C.p_wrep = s->p_wrep;
+    s->C.worm_eta = s->worm_eta;
+    std::vector<WalkerScalars> ws(s->nwalkers);
+    HIPCHK(hipMemcpy(ws.data(), s->C.ws, ws.size() * sizeof(WalkerScalars), hipMemcpyDeviceToHost));
+    bool dirty = false;
+    for (auto &w : ws) if (w.sector == 4) { w.sector = 1; dirty = true; }
+    if (dirty) HIPCHK(hipMemcpy(s->C.ws, ws.data(), ws.size() * sizeof(WalkerScalars), hipMemcpyHostToDevice));
+    return 0;
+}
+
 int w2dyn_ctqmc_measure(w2dyn_solver *s, int isector, int icomponent)
 {
-    (void)icomponent;
     if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "ctqmc_measure before init_solver");
-    if (isector != 1) return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d is not supported yet (only Z = 1)", isector);
     int rc;
+    if ((rc = enter_sector(s, isector, icomponent))) return rc;
     if ((rc = w2dyn_measure_begin(s))) return rc;
     double t0 = now_s(), tsteps = 0.0;
-    for (int64_t m = 0; m < s->nmeas; ++m) {
+    s->no_sampling = isector != 1 && s->worm_eta == 0.0;       // CTQMC.F90:8409-8418: nothing is sampled with eta = 0
+    for (int64_t m = 0; m < s->nmeas && !s->no_sampling; ++m) {
         double a = now_s();
         if ((rc = w2dyn_sweep(s, s->ncorr, 1))) return rc;
         if (!s->timing) { /* asynchronous */ }
@@ -791,7 +908,68 @@ int w2dyn_ctqmc_measure(w2dyn_solver *s, int isector, int icomponent)
     }
     if ((rc = w2dyn_sync(s))) return rc;
     s->time_sim = now_s() - t0; s->time_sim_steps = tsteps;
-    return w2dyn_measure_finish(s);
+    rc = w2dyn_measure_finish(s);
+    s->cur_isector = 1; s->C.isector = 1; s->C.p_wins = 0.0;
+    return rc;
+}
+
+int w2dyn_set_wormeta(w2dyn_solver *s, double eta) { if (!s) return W2DYN_EINVAL; s->worm_eta = eta; s->C.worm_eta = eta; return 0; }
+int w2dyn_get_wormeta(w2dyn_solver *s, double *eta) { if (!s || !eta) return W2DYN_EINVAL; *eta = s->worm_eta; return 0; }
+
+int w2dyn_ctqmc_worm_warmup(w2dyn_solver *s, int64_t nwarmups2, int isector, int icomponent)
+{
+    (void)nwarmups2; (void)icomponent;
+    if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "ctqmc_worm_warmup before init_solver");
+    // the reference allocates the buffers of the batched transform here and samples nothing (CTQMC.F90:8266-8348); this
+    // library transforms every measurement on the spot, so only the arguments are checked
+    if (isector != 1 && isector != 4) return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d is not supported (1 = Z, 4 = two-particle Green's function)", isector);
+    if (isector == 4 && s->mat) return fail(s, W2DYN_EUNSUPPORTED, "worm sampling is only implemented for density-density problems (one-state blocks)");
+    return 0;
+}
+
+int w2dyn_count_steps(w2dyn_solver *s, int isector, int icomponent, int64_t nfix, int64_t *steps_worm, int64_t *steps_z)
+{
+    if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "count_steps before init_solver");
+    if (isector != 4) return fail(s, W2DYN_EUNSUPPORTED, "count_steps: worm sector %d is not supported (4 = two-particle Green's function)", isector);
+    if (nfix < 0) return fail(s, W2DYN_EINVAL, "count_steps: nfix = %lld", (long long)nfix);
+    int rc;
+    if ((rc = enter_sector(s, isector, icomponent))) return rc;
+    const DevConst &C = s->C; const size_t W = s->nwalkers, nf = s->nflav, kmax = C.kmax;
+    // starting configuration of every chain (get_mc_config, CTQMC.F90:6322-6325)
+    std::vector<WalkerScalars> ws0(W), ws1(W);
+    std::vector<int> K0(W * nf); std::vector<double> TC0(W * nf * kmax), TA0(W * nf * kmax);
+    HIPCHK(hipMemcpy(ws0.data(), C.ws, W * sizeof(WalkerScalars), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(K0.data(), C.K, K0.size() * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(TC0.data(), C.TC, TC0.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(TA0.data(), C.TA, TA0.size() * sizeof(double), hipMemcpyDeviceToHost));
+    if ((rc = w2dyn_sweep(s, nfix, 1))) return rc;
+    if ((rc = w2dyn_sync(s))) return rc;
+    if ((rc = check_walker_errors(s))) return rc;
+    HIPCHK(hipMemcpy(ws1.data(), C.ws, W * sizeof(WalkerScalars), hipMemcpyDeviceToHost));
+    s->steps_worm_chains.assign(W, 0);
+    double sw = 0.0;
+    for (size_t w = 0; w < W; ++w) { s->steps_worm_chains[w] = (long long)ws1[w].cnt[C_W_SAMPLING]; sw += (double)ws1[w].cnt[C_W_SAMPLING]; }
+    const int64_t mean_w = (int64_t)std::llround(sw / (double)W);
+    if (steps_worm) *steps_worm = mean_w;
+    if (steps_z) *steps_z = nfix - mean_w;
+    // init_counters, clear_Trace, set_mc_config (CTQMC.F90:6434-6438): counters zero, old configuration, window at the
+    // start, M and det rebuilt from scratch; the random streams are not rewound
+    for (size_t w = 0; w < W; ++w) {
+        WalkerScalars &x = ws1[w];
+        memset(x.cnt, 0, sizeof x.cnt);
+        x.outer = ws0[w].outer; x.wpos = 0; x.npairs = -1; x.sector = 1;
+    }
+    HIPCHK(hipMemcpy(C.ws, ws1.data(), W * sizeof(WalkerScalars), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(C.K, K0.data(), K0.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(C.TC, TC0.data(), TC0.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(C.TA, TA0.data(), TA0.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(C.accpair, 0, sizeof(unsigned long long) * s->nflav * s->ntau));
+    s->cur_isector = 1; s->C.isector = 1; s->C.p_wins = 0.0;
+    Launch l = walker_launch(s);
+    hipLaunchKernelGGL(k_rebuild, l.grid, l.block, l.lds, s->stream, s->C);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return check_walker_errors(s);
 }
 
 int w2dyn_dest_ctqmc(w2dyn_solver *s)
@@ -823,6 +1001,7 @@ int w2dyn_get_mc_config_scalars(w2dyn_solver *s, int walker, int *n, int *outer_
     WalkerScalars ws; std::vector<int> K; std::vector<double> TC, TA;
     int rc = fetch_walker(s, walker, ws, K, TC, TA); if (rc) return rc;
     int tot = 0; for (int k : K) tot += 2 * k;
+    if (ws.sector == 4) tot += 4;
     if (n) *n = tot; if (outer_sst) *outer_sst = ws.outer; if (outer_state) *outer_state = 1;
     return 0;
 }
@@ -832,13 +1011,14 @@ int w2dyn_get_mc_config(w2dyn_solver *s, int walker, int n, double *taus, int *o
 {
     WalkerScalars ws; std::vector<int> K; std::vector<double> TC, TA;
     int rc = fetch_walker(s, walker, ws, K, TC, TA); if (rc) return rc;
-    struct Op { double t; int f, ca; };
+    struct Op { double t; int f, ca, hyb; };
     std::vector<Op> ops;
     const int kmax = s->C.kmax;
-    for (int f = 0; f < s->nflav; ++f) for (int e = 0; e < K[f]; ++e) { ops.push_back({TC[(size_t)f * kmax + e], f, 1}); ops.push_back({TA[(size_t)f * kmax + e], f, 2}); }
+    for (int f = 0; f < s->nflav; ++f) for (int e = 0; e < K[f]; ++e) { ops.push_back({TC[(size_t)f * kmax + e], f, 1, -1}); ops.push_back({TA[(size_t)f * kmax + e], f, 2, -1}); }
+    if (ws.sector == 4) for (int i = 0; i < 4; ++i) ops.push_back({ws.wtau[i], ws.wflav[i], (i & 1) ? 1 : 2, 0});     // worm operators: hashyb 0 (Trace.F90:6861-6865)
     if ((int)ops.size() != n) return fail(s, W2DYN_EINVAL, "get_mc_config: n=%d but the chain holds %zu operators", n, ops.size());
     std::sort(ops.begin(), ops.end(), [](const Op &a, const Op &b) { return a.t < b.t; });
-    for (int i = 0; i < n; ++i) { taus[i] = ops[i].t; orbs[i] = (ops[i].f >> 1) + 1; spins[i] = (ops[i].f & 1) + 1; cas[i] = ops[i].ca; hashybs[i] = -1; }
+    for (int i = 0; i < n; ++i) { taus[i] = ops[i].t; orbs[i] = (ops[i].f >> 1) + 1; spins[i] = (ops[i].f & 1) + 1; cas[i] = ops[i].ca; hashybs[i] = ops[i].hyb; }
     if (outer_sst) *outer_sst = ws.outer; if (outer_state) *outer_state = 1;
     return 0;
 }
@@ -878,7 +1058,7 @@ int w2dyn_set_mc_config(w2dyn_solver *s, int walker, int n, const double *taus, 
     for (int w = w0; w < w1; ++w) {
         WalkerScalars ws;
         HIPCHK(hipMemcpy(&ws, C.ws + w, sizeof ws, hipMemcpyDeviceToHost));
-        ws.outer = outer_sst; ws.wpos = 0; ws.npairs = -1;          // Trace.F90:6917-6919, 6973-6975
+        ws.outer = outer_sst; ws.wpos = 0; ws.npairs = -1; ws.sector = 1;          // Trace.F90:6917-6919, 6973-6975
         HIPCHK(hipMemcpy(C.ws + w, &ws, sizeof ws, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(C.K + (size_t)w * nf, K.data(), sizeof(int) * nf, hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(C.TC + (size_t)w * nf * kmax, TC.data(), sizeof(double) * nf * kmax, hipMemcpyHostToDevice));
@@ -948,7 +1128,8 @@ int w2dyn_get_result(w2dyn_solver *s, const char *name, void *out, size_t bytes,
         for (int i = 0; i < s->nstates; ++i) { int st = s->lp.states[i]; for (int b = 0; b < s->nd; ++b) for (int sp = 0; sp < 2; ++sp) itmp[((size_t)i * s->nd + b) * 2 + sp] = (st >> (b + sp * s->nd)) & 1; }
         src = itmp.data(); size = itmp.size() * sizeof(int);
     }
-    else if (n == "cntsampling") { ltmp.assign(16, 0); if (!s->counters.empty()) ltmp[0] = (long long)s->counters[C_SAMPLING]; src = ltmp.data(); size = ltmp.size() * sizeof(long long); }
+    else if (n == "steps_worm_chains") { src = s->steps_worm_chains.data(); size = s->steps_worm_chains.size() * sizeof(long long); }
+    else if (n == "cntsampling") { ltmp.assign(16, 0); if (!s->counters.empty()) { ltmp[0] = (long long)s->counters[C_SAMPLING]; ltmp[3] = (long long)s->counters[C_W_SAMPLING]; } src = ltmp.data(); size = ltmp.size() * sizeof(long long); }
     else if (n == "counters") { src = s->counters.data(); size = s->counters.size() * sizeof(double); }
     else {
         auto it = s->res.find(n);
@@ -980,6 +1161,8 @@ int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out)
     else if (n == "meas_done") *out = (double)s->meas_done;
     else if (n == "num_windows") *out = s->C.num_windows;
     else if (n == "nb4") *out = s->nb4;
+    else if (n == "nbw") *out = s->nbw;
+    else if (n == "wormeta") *out = s->worm_eta;
     else if (n == "n4iwf") *out = s->n4iwf;
     else if (n == "n4iwb") *out = s->n4iwb;
     else if (n == "nsst") *out = s->lp.nsst;

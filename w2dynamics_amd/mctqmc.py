@@ -47,6 +47,10 @@ def load_library(path: str = LIB_PATH):
     L.w2dyn_ctqmc_warmup.argtypes = [vp, C.c_int64]
     L.w2dyn_ctqmc_measure.argtypes = [vp, C.c_int, C.c_int]
     L.w2dyn_dest_ctqmc.argtypes = [vp]
+    L.w2dyn_set_wormeta.argtypes = [vp, C.c_double]
+    L.w2dyn_get_wormeta.argtypes = [vp, C.POINTER(C.c_double)]
+    L.w2dyn_ctqmc_worm_warmup.argtypes = [vp, C.c_int64, C.c_int, C.c_int]
+    L.w2dyn_count_steps.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.w2dyn_measure_begin.argtypes = [vp]
     L.w2dyn_sweep.argtypes = [vp, C.c_int64, C.c_int]
     L.w2dyn_measure_once.argtypes = [vp]
@@ -71,7 +75,7 @@ EXPORTED_SYMBOLS = [
     "w2dyn_ctqmc_warmup", "w2dyn_ctqmc_measure", "w2dyn_dest_ctqmc", "w2dyn_measure_begin", "w2dyn_sweep",
     "w2dyn_measure_once", "w2dyn_measure_finish", "w2dyn_sync", "w2dyn_get_mc_config_scalars", "w2dyn_get_mc_config",
     "w2dyn_set_mc_config", "w2dyn_get_minv", "w2dyn_get_walker_state", "w2dyn_get_result", "w2dyn_get_scalar",
-    "w2dyn_kernel_time",
+    "w2dyn_kernel_time", "w2dyn_set_wormeta", "w2dyn_get_wormeta", "w2dyn_ctqmc_worm_warmup", "w2dyn_count_steps",
 ]
 
 _SCALARS = ("mean_sign", "aborted", "time_warmup", "time_sim", "time_sim_steps", "accglob", "accshift", "accadd4",
@@ -139,6 +143,7 @@ class MCTQMC:
         self._chk(self._L.w2dyn_init_solver(self._h, u, f, m, sc, int(iter_no), int(nftau), int(nbands)))
         self._nd = nbands
         self._n4iwf = int(self.scalar("n4iwf")); self._n4iwb = int(self.scalar("n4iwb"))
+        self.wormeta[:] = self.scalar("wormeta")          # wormEta = WormEta for every sector, CTQMC.F90:434
 
     def set_taudiffmax(self, x):
         self._chk(self._L.w2dyn_set_taudiffmax(self._h, float(x)))
@@ -149,8 +154,29 @@ class MCTQMC:
     def ctqmc_warmup(self, n):
         self._chk(self._L.w2dyn_ctqmc_warmup(self._h, int(n)))
 
+    def _push_wormeta(self, isector):
+        # `wormeta` is a writable module array wormEta(2:NWormSectors) in the reference (impurity.py:719, 755, 784)
+        if int(isector) >= 2:
+            self._chk(self._L.w2dyn_set_wormeta(self._h, float(self.wormeta[int(isector) - 2])))
+
     def ctqmc_measure(self, isector, icomponent):
+        self._push_wormeta(isector)
         self._chk(self._L.w2dyn_ctqmc_measure(self._h, int(isector), int(icomponent)))
+
+    def ctqmc_worm_warmup(self, nwarmups2, isector, icomponent):
+        self._chk(self._L.w2dyn_ctqmc_worm_warmup(self._h, int(nwarmups2), int(isector), int(icomponent)))
+
+    def count_steps(self, isector, icomponent, nfix, steps_worm=None, steps_z=None):
+        """count_steps(isector, icomponent, nfix, steps_worm, steps_z) of the reference (CTQMC.F90:6296): the two
+        0-d integer arrays are filled in place, as f2py does for intent(inout); the pair is returned as well."""
+        self._push_wormeta(isector)
+        a, b = C.c_int64(), C.c_int64()
+        self._chk(self._L.w2dyn_count_steps(self._h, int(isector), int(icomponent), int(nfix), C.byref(a), C.byref(b)))
+        if steps_worm is not None:
+            steps_worm[...] = a.value
+        if steps_z is not None:
+            steps_z[...] = b.value
+        return a.value, b.value
 
     def dest_ctqmc(self):
         self._chk(self._L.w2dyn_dest_ctqmc(self._h))
@@ -247,6 +273,18 @@ class MCTQMC:
                 n2 = 2 * (nwf + nwb)
                 return a.reshape(lead + (nd, 2, n2, n2))
             return a.reshape(lead + (nd, 2, nd, 2, 2 * nwf, 2 * nwf, 2 * nwb + 1))
+        if name in ("g4iw_worm", "g4iwpp_worm", "g4iw_worm_bins", "g4iwpp_worm_bins"):
+            # worm estimator of the sampled component: (2*N4iwf, 2*N4iwf, 2*N4iwb+1), CTQMC.F90:350, 359
+            a = self.result(name).reshape(-1, 2); a = a[:, 0] + 1j * a[:, 1]
+            nwf, nwb = self._n4iwf, self._n4iwb
+            lead = (int(self.scalar("nbw")),) if name.endswith("_bins") else ()
+            return a.reshape(lead + (2 * nwf, 2 * nwf, 2 * nwb + 1))
+        if name in ("accwormadd", "accwormrem", "accwormrep"):
+            return self.result(name)
+        if name == "steps_worm_chains":
+            return self.result(name, np.int64)
+        if name == "worm_counters":
+            return self.result(name).reshape(-1, 8)
         if name in ("gtau_full", "gleg_full"):
             return self.result(name).reshape(nd, 2, nd, 2, -1)
         if name == "occ":
