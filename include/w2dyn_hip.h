@@ -59,6 +59,13 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *u_matrix, const double *fta
                       const double *screening_function, int iter_no, int nftau, int nbands);
 /* set_taudiffmax(x)                                CTQMC.F90:8180 */
 int w2dyn_set_taudiffmax(w2dyn_solver *s, double taudiffmax);
+/* ctqmc_calibrate(list, phase1pairnum, phase2taugrid, phase2pairnum, nprogress)      CTQMC.F90:8088-8178
+ * Window calibration (impurity.py:1150-1172).  list != 0: phase 1, every chain steps until phase1pairnum accepted pair
+ * distances are on its list (tested every min(1000, nprogress) steps); result "accpairtau" (phase1pairnum) is the mean
+ * over the chains of the sorted lists, "accpairtau_chains" (nwalkers, phase1pairnum) the lists themselves.
+ * list == 0: phase 2, histogram "accpair" (Nd,2,phase2taugrid) of accepted pair distances over [0, taudiff_max], summed
+ * over chains; every chain steps until each of its flavours has phase2pairnum accepted pairs.  No window shifts. */
+int w2dyn_ctqmc_calibrate(w2dyn_solver *s, int list, int phase1pairnum, int phase2taugrid, int phase2pairnum, int nprogress);
 /* init_counters()                                  CTQMC.F90:847 */
 int w2dyn_init_counters(w2dyn_solver *s);
 /* ctqmc_warmup(n)                                  CTQMC.F90:8188 */

@@ -63,6 +63,8 @@ struct ora_walker {
     double try_add, acc_add, accqn_add, try_rem, acc_rem, accqn_rem, try_glob, acc_glob, accqn_glob;
     double try_shift, acc_shift, cnt_sampling, cnt_meas;
     int64_t *accpair;
+    int naccpair; double accpair_max;          /* NAccPair, AccPairMax (CTQMC.F90:68-69): Ntau bins over beta outside the calibration */
+    double *accpairtau; int napt, apt_index;   /* AccPairTau list of the window calibration, phase 1 (CTQMC.F90:67, 70) */
     /* accumulators */
     double *gleg, *gtau, *giw, *histo, *dm, *outer_histo;
     double *g2iw, *g4iw, *g4iwpp;    /* complex interleaved, NULL when not measured */
@@ -506,10 +508,11 @@ static inline int RINT(ora_walker *w, int lo, int hi) { return w->rng->randint(w
 
 static void accpair_add(ora_walker *w, int f, double dt)
 {
-    int n = w->p.ntau;
-    int bin = (int)floor(dt / w->p.beta * (double)n) + 1;
+    int n = w->naccpair;
+    int bin = (int)floor(dt / w->accpair_max * (double)n) + 1;
     if (bin > n) bin = n;
     w->accpair[(size_t)f * n + (bin - 1)] += 1;
+    if (w->accpairtau && w->apt_index < w->napt) w->accpairtau[w->apt_index++] = dt;     /* CTQMC.F90:3583-3588, 4123-4128 */
 }
 
 /* CTQMC.F90:3353-3612 StepAdd (change_outer = false, diagonal hybridisation) */
@@ -1055,7 +1058,18 @@ static void init_counters(ora_walker *w) /* CTQMC.F90:847-896 */
     w->wtry_add = w->wacc_add = w->wtry_rem = w->wacc_rem = 0;
     w->try_wadd = w->acc_wadd = w->accqn_wadd = w->try_wrem = w->acc_wrem = w->accqn_wrem = w->try_wrep = w->acc_wrep = 0;
     w->cnt_sampling_w = w->cnt_meas_w = 0;
-    memset(w->accpair, 0, sizeof(int64_t) * (size_t)w->nflav * w->p.ntau);
+    memset(w->accpair, 0, sizeof(int64_t) * (size_t)w->nflav * w->naccpair);
+    w->apt_index = 0;
+}
+
+/* AccPair back to Ntau bins over beta (ctqmc_warmup / ctqmc_measure, CTQMC.F90:8199-8205, 8387-8393) */
+static void accpair_default(ora_walker *w)
+{
+    if (w->naccpair != w->p.ntau) {
+        free(w->accpair);
+        w->accpair = (int64_t *)calloc((size_t)w->nflav * w->p.ntau, sizeof(int64_t));
+    }
+    w->naccpair = w->p.ntau; w->accpair_max = w->p.beta;
 }
 
 ora_walker *ora_create(const ora_params *p, const double *U, const double *ftau_full, const double *mu_full, ora_rng *rng)
@@ -1081,6 +1095,7 @@ ora_walker *ora_create(const ora_params *p, const double *U, const double *ftau_
                ftau_full + ((((size_t)b * 2 + s) * nd + b) * 2 + s) * nft, sizeof(double) * (size_t)nft);
     for (int f = 0; f < w->nflav; ++f) { w->M[f] = (double *)malloc(sizeof(double)); w->k[f] = 0; }
     w->accpair = (int64_t *)calloc((size_t)w->nflav * p->ntau, sizeof(int64_t));
+    w->naccpair = p->ntau; w->accpair_max = p->beta;
     w->gleg = (double *)calloc((size_t)w->nflav * p->nlegmax, sizeof(double));
     w->gtau = (double *)calloc((size_t)w->nflav * p->ntau, sizeof(double));
     w->giw = (double *)calloc((size_t)w->nflav * 2 * p->niw * 2, sizeof(double));
@@ -1117,7 +1132,7 @@ void ora_destroy(ora_walker *w)
 {
     if (!w) return;
     for (int f = 0; f < w->nflav; ++f) free(w->M[f]);
-    free(w->ops); free(w->ftab); ora_locprob_free(w->lp); free(w->ptr); free(w->dmblk); free(w->dmoff); free(w->accpair); free(w->gleg); free(w->gtau); free(w->giw);
+    free(w->ops); free(w->ftab); ora_locprob_free(w->lp); free(w->ptr); free(w->dmblk); free(w->dmoff); free(w->accpair); free(w->accpairtau); free(w->gleg); free(w->gtau); free(w->giw);
     free(w->histo); free(w->dm); free(w->outer_histo); free(w->g2iw); free(w->g4iw); free(w->g4iwpp); free(w->g4w); free(w->g4wpp); free(w);
 }
 
@@ -1126,6 +1141,7 @@ void ora_set_taudiffmax(ora_walker *w, double x) { init_window(w, x); }
 void ora_warmup(ora_walker *w, int64_t n)
 {
     int isec = w->isector;
+    accpair_default(w);
     init_counters(w);
     w->isector = 1;                       /* ctqmc_warmup never inserts worms (CTQMC.F90:8213-8257) */
     for (int64_t i = 0; i < n; ++i) one_step(w);
@@ -1133,7 +1149,52 @@ void ora_warmup(ora_walker *w, int64_t n)
     w->isector = isec;
 }
 
-void ora_measure_begin(ora_walker *w) { init_counters(w); }
+void ora_measure_begin(ora_walker *w) { accpair_default(w); init_counters(w); }
+
+void ora_init_counters(ora_walker *w) { init_counters(w); }
+
+/* ctqmc_calibrate (CTQMC.F90:8088-8178): the Z-space move loop without window shifts and without step counting.
+ * Phase 1 (list != 0) ends at the first multiple of min(1000, nprogress) steps at which phase1pairnum accepted pair
+ * distances are on the list; phase 2 at the first such multiple at which every flavour has phase2pairnum accepted
+ * pairs in the histogram of phase2taugrid bins over [0, taudiff_max].  Returns the number of steps. */
+int64_t ora_calibrate(ora_walker *w, int list, int phase1pairnum, int phase2taugrid, int phase2pairnum, int nprogress)
+{
+    if (list) {
+        if (!w->accpairtau) { w->accpairtau = (double *)calloc((size_t)phase1pairnum, sizeof(double)); w->napt = phase1pairnum; }
+    } else {
+        free(w->accpairtau); w->accpairtau = NULL; w->napt = 0;
+        free(w->accpair);
+        w->accpair = (int64_t *)calloc((size_t)w->nflav * phase2taugrid, sizeof(int64_t));
+        w->naccpair = phase2taugrid; w->accpair_max = w->taudiff_max;
+    }
+    const int chunk = nprogress < 1000 ? nprogress : 1000;
+    const double pg = w->p.p_glob, ps = w->p.p_shift;
+    int64_t i = 0;
+    for (;;) {
+        ++i;
+        double r = U01(w);
+        if (r < (1.0 - ps - pg) / 2.0) { (void)U01(w); (void)U01(w); step_add(w); }
+        else if (r <= 1.0 - ps - pg) { (void)U01(w); (void)U01(w); step_rem(w); }
+        else if (r <= 1.0 - ps) step_glob(w);
+        else step_shift(w);
+        if (i % chunk == 0) {
+            if (list) { if (w->apt_index >= w->napt) break; }
+            else {
+                int done = 1;
+                for (int f = 0; f < w->nflav && done; ++f) {
+                    int64_t sum = 0;
+                    for (int b = 0; b < w->naccpair; ++b) sum += w->accpair[(size_t)f * w->naccpair + b];
+                    if (sum < phase2pairnum) done = 0;
+                }
+                if (done) break;
+            }
+        }
+    }
+    return i;
+}
+
+int ora_get_accpairtau(const ora_walker *w, double *o) { if (!w->accpairtau) return 0; memcpy(o, w->accpairtau, sizeof(double) * (size_t)w->napt); return w->napt; }
+int ora_naccpair(const ora_walker *w) { return w->naccpair; }
 
 void ora_sweep(ora_walker *w, int64_t nsteps)
 {
@@ -1456,7 +1517,7 @@ void ora_get_giw(const ora_walker *w, double *o) { memcpy(o, w->giw, sizeof(doub
 void ora_get_histo(const ora_walker *w, double *o) { memcpy(o, w->histo, sizeof(double) * (size_t)w->nflav * (w->p.maxhisto + 1)); }
 void ora_get_densitymatrix_diag(const ora_walker *w, double *o) { memcpy(o, w->dm, sizeof(double) * (size_t)w->nstates); }
 void ora_get_outer_histo(const ora_walker *w, double *o) { memcpy(o, w->outer_histo, sizeof(double) * (size_t)w->nstates); }
-void ora_get_accpair(const ora_walker *w, int64_t *o) { memcpy(o, w->accpair, sizeof(int64_t) * (size_t)w->nflav * w->p.ntau); }
+void ora_get_accpair(const ora_walker *w, int64_t *o) { memcpy(o, w->accpair, sizeof(int64_t) * (size_t)w->nflav * w->naccpair); }
 void ora_get_energies(const ora_walker *w, double *o) { memcpy(o, w->E, sizeof(double) * (size_t)w->nstates); }
 int ora_get_g2iw(const ora_walker *w, double *o)
 {

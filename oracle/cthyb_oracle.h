@@ -73,6 +73,11 @@ int ora_get_g4iw_worm(const ora_walker *w, double *out_reim, int pp);
  * [8]CntSampling(worm) [9]CntMeas(worm) [10]TryAdd(worm) [11]AccAdd(worm) [12]TryRem(worm) [13]AccRem(worm) [14]sector now */
 void ora_get_worm_counters(const ora_walker *w, double *out15);
 /* the two halves of ora_measure, for step-by-step checks */
+void ora_init_counters(ora_walker *w);                   /* CTQMC.F90:847 */
+/* ctqmc_calibrate(list, phase1pairnum, phase2taugrid, phase2pairnum, nprogress), CTQMC.F90:8088; returns the steps done */
+int64_t ora_calibrate(ora_walker *w, int list, int phase1pairnum, int phase2taugrid, int phase2pairnum, int nprogress);
+int ora_get_accpairtau(const ora_walker *w, double *o);  /* AccPairTau (unsorted), returns its length */
+int ora_naccpair(const ora_walker *w);                   /* current number of AccPair bins */
 void ora_measure_begin(ora_walker *w);                   /* init_counters etc. */
 void ora_sweep(ora_walker *w, int64_t nsteps);           /* nsteps Monte Carlo steps of the Z-space loop */
 void ora_measure_once(ora_walker *w);                    /* one pass of all Z-space estimators */

@@ -69,6 +69,10 @@ def lib():
     L.ora_get_occ.argtypes = [vp, dp, dp, C.c_void_p]
     L.ora_measure_sector.argtypes = [vp, C.c_int, C.c_int]; L.ora_measure_sector.restype = C.c_int
     L.ora_set_wormeta.argtypes = [vp, C.c_double]
+    L.ora_init_counters.argtypes = [vp]
+    L.ora_calibrate.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]; L.ora_calibrate.restype = C.c_int64
+    L.ora_get_accpairtau.argtypes = [vp, dp]; L.ora_get_accpairtau.restype = C.c_int
+    L.ora_naccpair.argtypes = [vp]; L.ora_naccpair.restype = C.c_int
     L.ora_count_steps.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.ora_get_g4iw_worm.argtypes = [vp, dp, C.c_int]; L.ora_get_g4iw_worm.restype = C.c_int
     L.ora_get_worm_counters.argtypes = [vp, dp]
@@ -128,6 +132,18 @@ class OracleWalker:
     def measure(self): return self.L.ora_measure(self.h)
     def measure_sector(self, isector, icomponent): return self.L.ora_measure_sector(self.h, int(isector), int(icomponent))
     def set_wormeta(self, eta): self.L.ora_set_wormeta(self.h, float(eta))
+    def init_counters(self): self.L.ora_init_counters(self.h)
+
+    def calibrate(self, list_, phase1pairnum, phase2taugrid, phase2pairnum, nprogress):
+        return self.L.ora_calibrate(self.h, int(bool(list_)), int(phase1pairnum), int(phase2taugrid), int(phase2pairnum), int(nprogress))
+
+    def accpairtau(self, n):
+        a = np.zeros(int(n)); m = self.L.ora_get_accpairtau(self.h, a)
+        return a[:m]
+
+    def accpair(self):
+        a = np.zeros((self.nd, 2, self.L.ora_naccpair(self.h)), np.int64); self.L.ora_get_accpair(self.h, a)
+        return a
 
     def count_steps(self, isector, icomponent, nfix):
         a, b = C.c_int64(), C.c_int64()
@@ -182,7 +198,7 @@ class OracleWalker:
         a = np.zeros(4 ** nd); self.L.ora_get_densitymatrix_diag(self.h, a); r["dm_diag"] = a
         a = np.zeros(4 ** nd); self.L.ora_get_outer_histo(self.h, a); r["outersuperstatehisto"] = a[:self.nsst].copy()
         a = np.zeros(4 ** nd); self.L.ora_get_energies(self.h, a); r["eigenstatesenergies"] = a
-        a = np.zeros((nd, 2, p.ntau), np.int64); self.L.ora_get_accpair(self.h, a); r["accpair"] = a
+        r["accpair"] = self.accpair()
         a = np.zeros(13); self.L.ora_get_counters(self.h, a); r["counters"] = a
         r["mean_sign"] = self.L.ora_mean_sign(self.h)
         occ = np.zeros((nd, 2, nd, 2)); rho1 = np.zeros((2 * nd, 2 * nd))

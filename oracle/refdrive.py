@@ -81,6 +81,13 @@ class RefSolver:
     def set_wormeta(self, eta):
         self.q.wormeta[:] = float(eta)
 
+    def init_counters(self):
+        self.q.init_counters()
+
+    def calibrate(self, list_, phase1pairnum, phase2taugrid, phase2pairnum, nprogress):
+        with quiet(self.silent):
+            self.q.ctqmc_calibrate(bool(list_), int(phase1pairnum), int(phase2taugrid), int(phase2pairnum), int(nprogress))
+
     def count_steps(self, isector, icomponent, nfix):
         sw = np.array(0, dtype=np.int64); sz = np.array(0, dtype=np.int64)
         with quiet(self.silent):

@@ -186,11 +186,44 @@ def gen_worm(only=None):
         print("worm", name, "steps(worm, Z) of the eta search", steps, "cntsampling", r["cntsampling"][[0, 3]], "nops", len(c_end["taus"]))
 
 
+KINDS = ("traj", "stat", "g4", "worm", "calib")
+
+CALIB = {   # window calibration (ctqmc_calibrate, two phases) from the empty configuration
+    # name: (config, nftau, overrides, seed, (phase1pairnum, phase2taugrid, phase2pairnum, nprogress))
+    "C1": ("C1", 501, dict(TaudiffMax=-1.0, Ntau=50, NLegMax=8, Niw=4, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 311, (300, 20, 150, 100000)),
+    "C3": ("C3", 501, dict(TaudiffMax=-1.0, Ntau=50, NLegMax=8, Niw=4, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 312, (400, 25, 100, 700)),
+    "C4S": ("C4S", 501, dict(TaudiffMax=-1.0, Ntau=50, NLegMax=8, Niw=4, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 313, (300, 20, 100, 100000)),
+}
+
+
+def gen_calib(only=None):
+    for name, (cfg, nftau, over, seed, (n1, grid, n2, nprog)) in CALIB.items():
+        if only and name not in only:
+            continue
+        p, ps = pstring_for(cfg, nftau, over)
+        s = refdrive.RefSolver(p, ps, seed)
+        s.set_taudiffmax(over["TaudiffMax"])
+        s.init_counters()
+        s.calibrate(True, n1, grid, n2, nprog)
+        lst = np.array(s.q.accpairtau).copy()
+        tdm = float(np.sort(lst)[int(0.995 * n1)])           # impurity.py:1159-1163
+        s.set_taudiffmax(tdm)
+        s.init_counters()
+        s.calibrate(False, n1, grid, n2, nprog)
+        acc = np.array(s.q.accpair).copy()
+        c_end = s.get_config()
+        s.close()
+        np.savez_compressed(os.path.join(OUT, "calib_%s.npz" % name), config=cfg, nftau=nftau, seed=seed, overrides=repr(over),
+                            phases=np.array([n1, grid, n2, nprog]), accpairtau=lst, taudiffmax=tdm, accpair=acc,
+                            **{"end_" + k: v for k, v in c_end.items()})
+        print("calib", name, "taudiffmax", tdm, "accpair sums", acc.sum(axis=2).ravel(), "nops", len(c_end["taus"]))
+
+
 if __name__ == "__main__":
     if not refdrive.available():
         raise SystemExit("oracle/_ref is not built: run oracle/build_ref.sh in the build container")
-    which = [a for a in sys.argv[1:] if a in ("traj", "stat", "g4", "worm")] or ["traj", "stat", "g4", "worm"]
-    only = [a for a in sys.argv[1:] if a not in ("traj", "stat", "g4", "worm")] or None      # e.g.: gen_golden.py traj C4S C4
+    which = [a for a in sys.argv[1:] if a in KINDS] or list(KINDS)
+    only = [a for a in sys.argv[1:] if a not in KINDS] or None      # e.g.: gen_golden.py traj C4S C4
     if "traj" in which:
         gen_traj(only)
     if "stat" in which:
@@ -199,3 +232,5 @@ if __name__ == "__main__":
         gen_g4(only)
     if "worm" in which:
         gen_worm(only)
+    if "calib" in which:
+        gen_calib(only)

@@ -360,3 +360,64 @@ def test_worm_modes_refused_or_ignored():
     assert e.value.code == -2
     q.ctqmc_measure(1, 1)
     q.dest_ctqmc(); q.close()
+
+
+@pytest.mark.parametrize("name", ["C1", "C3", "C4S"])
+def test_window_calibration_chains_vs_oracle(name):
+    """ctqmc_calibrate, both phases: every chain owns a list / a completion criterion like a rank of the reference does
+    and retraces the oracle chain with the same stream (scalar and matrix trace path)."""
+    g = util.load_golden("calib_%s.npz" % name)
+    over = g["overrides"]; n1, grid, n2, nprog = (int(x) for x in g["phases"])
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    nw = 5
+    q = make_gpu(p, ps, 17, nw, wpb=1)
+    q.set_taudiffmax(over["TaudiffMax"])
+    q.init_counters()
+    q.ctqmc_calibrate(True, n1, grid, n2, nprog)
+    lists = q.accpairtau_chains
+    assert rel(q.accpairtau, np.sort(lists, axis=1).mean(axis=0)) < 1e-14
+    tdm = float(np.sort(q.accpairtau)[int(0.995 * n1)])
+    q.set_taudiffmax(tdm)
+    q.init_counters()
+    q.ctqmc_calibrate(False, n1, grid, n2, nprog)
+    acc = q.accpair
+    tot = 0
+    for w in range(nw):
+        o = pyoracle.OracleWalker(p, pset, ("philox", 17, w))
+        o.set_taudiffmax(over["TaudiffMax"]); o.init_counters()
+        o.calibrate(True, n1, grid, n2, nprog)
+        assert np.abs(o.accpairtau(n1) - lists[w]).max() < 1e-12, w
+        o.set_taudiffmax(tdm); o.init_counters()
+        o.calibrate(False, n1, grid, n2, nprog)
+        tot = tot + o.accpair()
+        c = o.get_config()
+        n, osst, _ = q.get_mc_config_scalars(w)
+        assert n == len(c["taus"]) and osst == c["outer_sst"]
+        if n:
+            assert np.abs(q.get_mc_config(n, w)[0] - c["taus"]).max() < 1e-12
+        o.close()
+    assert np.array_equal(acc, tot)
+    # the reference's single chain is one draw of the same procedure: its provisional window lies inside the chain scatter
+    t_ch = np.sort(lists, axis=1)[:, int(0.995 * n1)]
+    assert t_ch.min() * 0.5 < float(g["taudiffmax"]) < t_ch.max() * 2.0
+    # a production run after the calibration uses the default histogram again
+    q.ctqmc_warmup(200); q.ctqmc_measure(1, 1)
+    assert q.accpair.shape[-1] == over["Ntau"]
+    q.dest_ctqmc(); q.close()
+
+
+def test_solver_calibrates_window_when_taudiffmax_not_positive():
+    """HipCtHybSolver.solve with TaudiffMax <= 0 runs the two calibration phases (impurity.py:589-591, 1150-1195)."""
+    from w2dynamics_amd.solver import HipCtHybSolver
+    from w2dynamics_amd import synth
+    s = HipCtHybSolver(dict(BASE, Nwarmups=2000, Nmeas=20, NCorr=20, TaudiffMax=-1.0, Nftau=501), seed=5, nwalkers=64, walkers_per_bin=8)
+    s.set_problem(synth.config("C3", nftau=501))
+    q = s.ctqmc
+    p = s.problem
+    q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+    tdm = s.calibrate_taudiff_max(phase1pairnum=300, phase2taugrid=40, phase2pairnum=200)
+    assert 1.0 < tdm < p.beta
+    q.dest_ctqmc()
+    r = s.solve()
+    assert np.allclose(np.abs(np.asarray(r["sign"].mean())), 1.0)
+    assert np.all(np.isfinite(np.asarray(r["gleg"].mean())))

@@ -177,3 +177,27 @@ def test_oracle_worm_sampling_retraces_reference(name):
         assert rel(r["g4iwpp_worm"], g["res_g4iwpp_worm"]) < 1e-10
     assert rel(r["occ"], g["res_occ"]) < 1e-10
     w.close()
+
+
+@pytest.mark.parametrize("name", ["C1", "C3", "C4S"])
+def test_oracle_window_calibration_retraces_reference(name):
+    """ctqmc_calibrate, both phases, from the empty configuration: the list of accepted pair distances, the
+    distance histogram on the calibrated window and the final configuration agree with the reference run."""
+    g = util.load_golden("calib_%s.npz" % name)
+    over = g["overrides"]; n1, grid, n2, nprog = (int(x) for x in g["phases"])
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    w = pyoracle.OracleWalker(p, pset, ("std", int(g["seed"])))
+    w.set_taudiffmax(over["TaudiffMax"])
+    w.init_counters()
+    w.calibrate(True, n1, grid, n2, nprog)
+    lst = w.accpairtau(n1)
+    assert lst.shape == g["accpairtau"].shape and np.abs(lst - g["accpairtau"]).max() < 1e-12
+    tdm = float(np.sort(lst)[int(0.995 * n1)])
+    assert tdm == pytest.approx(float(g["taudiffmax"]), abs=1e-12)
+    w.set_taudiffmax(tdm)
+    w.init_counters()
+    w.calibrate(False, n1, grid, n2, nprog)
+    assert np.array_equal(w.accpair(), g["accpair"])
+    c = w.get_config()
+    assert len(c["taus"]) == len(g["end_taus"]) and np.abs(c["taus"] - g["end_taus"]).max() < 1e-12
+    w.close()

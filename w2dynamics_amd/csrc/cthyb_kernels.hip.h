@@ -104,6 +104,14 @@ struct DevConst {
     double p_wins, p_wrep, worm_eta;
     double *acc_g4w, *acc_g4wpp;  // [nbins][2nwf][2nwf][2nwb+1] complex
     double *acc_nz, *acc_nw;      // [nbins] number of Z / worm measurements (chains measure in the sector they are in)
+    // AccPair histogram (CTQMC.F90:65-70): naccpair bins over [0, accpair_max]; Ntau bins over beta outside the window
+    // calibration.  calib: 0 = off, 1 = phase 1 (per-chain list of accepted pair distances), 2 = phase 2 (histogram on
+    // the calibrated window; per-chain, per-flavour counts decide when a chain is done), CTQMC.F90:8088-8178
+    int naccpair, calib, napt, phase2pairnum;
+    double accpair_max;
+    double *apt_tau;              // [nwalkers][napt]
+    int *apt_cnt;                 // [nwalkers]
+    int *calib_pairs;             // [nwalkers][nflav]
 };
 
 // bytes of LDS one wave needs (host and device agree through this one function)
@@ -381,13 +389,20 @@ __device__ W2DYN_INLINE double level_integral(Ctx &x, int f, double lo, double h
     return base * (hi - lo) + wave_sum(part);
 }
 
+template <bool CALIB>
 __device__ __forceinline__ void accpair_add(Ctx &x, int f, double dt)
 {
     const DevConst &C = x.C;
     if (x.lane == 0) {
-        int bin = (int)floor(dt / C.beta * (double)C.ntau) + 1;
-        if (bin > C.ntau) bin = C.ntau;
-        atomicAdd(&C.accpair[(size_t)f * C.ntau + (bin - 1)], 1ull);
+        int bin = (int)floor(dt / C.accpair_max * (double)C.naccpair) + 1;
+        if (bin > C.naccpair) bin = C.naccpair;
+        atomicAdd(&C.accpair[(size_t)f * C.naccpair + (bin - 1)], 1ull);
+        if constexpr (CALIB) {
+            if (C.calib == 1) {             // AccPairTau, CTQMC.F90:3583-3588, 4123-4128
+                const int i = C.apt_cnt[x.w];
+                if (i < C.napt) { C.apt_tau[(size_t)x.w * C.napt + i] = dt; C.apt_cnt[x.w] = i + 1; }
+            } else C.calib_pairs[(size_t)x.w * C.nflav + f] += 1;
+        }
     }
 }
 
@@ -396,7 +411,7 @@ __device__ __forceinline__ void accpair_add(Ctx &x, int f, double dt)
 // ---------------------------------------------------------------------------------------------------------------
 // pair insertion: CTQMC.F90:3353-3612 (StepAdd), Trace.F90:3657-3698, 2775-2832, MatrixUpdate.F90:392-442
 // ---------------------------------------------------------------------------------------------------------------
-template <int MAT, bool WORM = false>
+template <int MAT, bool WORM = false, bool CALIB = false>
 __device__ W2DYN_INLINE void step_add(Ctx &x)
 {
     const DevConst &C = x.C;
@@ -612,13 +627,13 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
     if constexpr (MAT) { x.tr_log = tl_new; x.tr_sign = ts_new; mat_commit_sst(x); }
     DBG_STAMP(x, C_DBG7);
     if (WORM && x.sector == 4) x.count(C_W_ACCADD); else x.count(C_ACCADD);
-    accpair_add(x, f, hi - lo);
+    accpair_add<CALIB>(x, f, hi - lo);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // pair removal: CTQMC.F90:3892-4150 (StepRem), Trace.F90:4851-4950, 2937-2963, MatrixUpdate.F90:445-482
 // ---------------------------------------------------------------------------------------------------------------
-template <int MAT, bool WORM = false>
+template <int MAT, bool WORM = false, bool CALIB = false>
 __device__ W2DYN_INLINE void step_rem(Ctx &x)
 {
     const DevConst &C = x.C;
@@ -815,7 +830,7 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
     x.wvalid = 0;
     if constexpr (MAT) { mat_remove(x, i2); mat_remove(x, i1); x.tr_log = tl_new; x.tr_sign = ts_new; mat_commit_sst(x); }
     if (WORM && x.sector == 4) x.count(C_W_ACCREM); else x.count(C_ACCREM);
-    accpair_add(x, f, t2 - t1);
+    accpair_add<CALIB>(x, f, t2 - t1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1254,7 +1269,9 @@ __device__ __forceinline__ void ctx_store(Ctx &x)
 #endif
 
 // sweep kernel: nsteps iterations of the Z-space loop (CTQMC.F90:8213-8257 / 8428-8533) for every chain
-template <int MAT>
+// CALIB: the loop of ctqmc_calibrate (CTQMC.F90:8121-8174): same moves, no window shift, no step counting; a chain
+// whose own calibration criterion is met does nothing
+template <int MAT, bool CALIB = false>
 __global__ __launch_bounds__(256) void k_sweep(DevConst C, long long nsteps, int count_sampling)
 {
     extern __shared__ unsigned char smem[];
@@ -1262,6 +1279,15 @@ __global__ __launch_bounds__(256) void k_sweep(DevConst C, long long nsteps, int
     Ctx x(C);
     ctx_setup(x, smem);
     if (x.w >= C.nwalkers) return;
+    if constexpr (CALIB) {
+        bool done;
+        if (C.calib == 1) done = C.apt_cnt[x.w] >= C.napt;
+        else {
+            done = true;
+            for (int f = 0; f < C.nflav; ++f) done = done && C.calib_pairs[(size_t)x.w * C.nflav + f] >= C.phase2pairnum;
+        }
+        if (uni((int)done)) return;
+    }
     ctx_load(x);
     if constexpr (MAT != 0) mat_trace_current<MAT>(x);
     const double pg = C.p_glob, ps = C.p_shift;
@@ -1276,12 +1302,12 @@ __global__ __launch_bounds__(256) void k_sweep(DevConst C, long long nsteps, int
 #endif
         if (r < (1.0 - ps - pg) / 2.0) { (void)x.draw(); (void)x.draw();
 #ifndef W2DYN_NO_ADD
-            step_add<MAT>(x);
+            step_add<MAT, false, CALIB>(x);
 #endif
             STAMP_KIND(C_CYC_ADD); phase += 1; }
         else if (r <= 1.0 - ps - pg) { (void)x.draw(); (void)x.draw();
 #ifndef W2DYN_NO_REM
-            step_rem<MAT>(x);
+            step_rem<MAT, false, CALIB>(x);
 #endif
             STAMP_KIND(C_CYC_REM); phase += 1; }
         else if (r <= 1.0 - ps) {
@@ -1297,6 +1323,7 @@ __global__ __launch_bounds__(256) void k_sweep(DevConst C, long long nsteps, int
 #ifdef W2DYN_STAMPS
         if (x.lane == 0) x.cnt[which_] += __builtin_amdgcn_s_memtime() - t0_;
 #endif
+        if constexpr (CALIB) continue;
         if (phase == (unsigned int)C.nslide) phase = 0;
         if (phase == 0) {                                        // shift_window, Trace.F90:1652-1678
             if (C.num_windows > 1) {

@@ -59,6 +59,9 @@ struct w2dyn_solver {
     int worm_meas_g4iw = 0, g4ph = 0, g4pp = 0, wormphconv = 0, nbw = 0, cur_isector = 1;
     bool no_sampling = false;
     std::vector<long long> steps_worm_chains;
+    // window calibration (ctqmc_calibrate): default AccPair histogram and the one on the calibration grid
+    unsigned long long *accpair_default = nullptr;
+    std::vector<double> accpairtau, accpairtau_chains;
     DevConst C{};
     std::vector<void *> allocs;
     // accumulators bookkeeping
@@ -166,6 +169,17 @@ Launch walker_launch(const w2dyn_solver *s)
 }
 
 int mat_variant(const w2dyn_solver *s) { return !s->mat ? 0 : (s->lp.nsmax <= 2 ? 2 : (s->lp.nsmax <= 4 ? s->lp.nsmax : 9)); }
+
+template <bool CALIB> void launch_sweep(w2dyn_solver *s, const Launch &l, long long nsteps, int count)
+{
+    switch (mat_variant(s)) {
+    case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<0, CALIB>), l.grid, l.block, l.lds, s->stream, s->C, nsteps, count); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<2, CALIB>), l.grid, l.block, l.lds, s->stream, s->C, nsteps, count); break;
+    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<3, CALIB>), l.grid, l.block, l.lds, s->stream, s->C, nsteps, count); break;
+    case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<4, CALIB>), l.grid, l.block, l.lds, s->stream, s->C, nsteps, count); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<9, CALIB>), l.grid, l.block, l.lds, s->stream, s->C, nsteps, count); break;
+    }
+}
 
 int time_begin(w2dyn_solver *s) { if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream)); return 0; }
 int time_end(w2dyn_solver *s, const char *name)
@@ -457,6 +471,8 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if ((rc = dev_alloc(s, C.acc_signouter, B * nouter))) return rc;
     if ((rc = dev_alloc(s, C.acc_sign, B))) return rc;
     if ((rc = dev_alloc(s, C.accpair, (size_t)nf * s->ntau))) return rc;
+    s->accpair_default = C.accpair; C.naccpair = s->ntau; C.accpair_max = s->beta; C.calib = 0;
+    s->accpairtau.clear(); s->accpairtau_chains.clear();
     if ((rc = dev_alloc(s, C.acc_nz, B))) return rc;
     if ((rc = dev_alloc(s, C.acc_nw, B))) return rc;
     C.nwf = s->n4iwf; C.nwb = s->n4iwb; C.wormphconv = s->wormphconv; C.g4ph = s->g4ph; C.g4pp = s->g4pp;
@@ -521,8 +537,16 @@ int w2dyn_init_counters(w2dyn_solver *s)
     HIPCHK(hipMemcpy(ws.data(), s->C.ws, ws.size() * sizeof(WalkerScalars), hipMemcpyDeviceToHost));
     for (auto &w : ws) memset(w.cnt, 0, sizeof w.cnt);
     HIPCHK(hipMemcpy(s->C.ws, ws.data(), ws.size() * sizeof(WalkerScalars), hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(s->C.accpair, 0, sizeof(unsigned long long) * s->nflav * s->ntau));
+    HIPCHK(hipMemset(s->C.accpair, 0, sizeof(unsigned long long) * s->nflav * s->C.naccpair));
+    if (s->C.apt_cnt) HIPCHK(hipMemset(s->C.apt_cnt, 0, sizeof(int) * s->nwalkers));           // apt_index = 1, CTQMC.F90:888
+    if (s->C.calib_pairs) HIPCHK(hipMemset(s->C.calib_pairs, 0, sizeof(int) * s->nwalkers * s->nflav));
     return 0;
+}
+
+// AccPair back to Ntau bins over beta (ctqmc_warmup / ctqmc_measure, CTQMC.F90:8199-8205, 8387-8393)
+static void accpair_to_default(w2dyn_solver *s)
+{
+    s->C.accpair = s->accpair_default; s->C.naccpair = s->ntau; s->C.accpair_max = s->beta; s->C.calib = 0;
 }
 
 int w2dyn_sweep(w2dyn_solver *s, int64_t nsteps, int count_as_sampling)
@@ -536,13 +560,7 @@ int w2dyn_sweep(w2dyn_solver *s, int64_t nsteps, int count_as_sampling)
     // instantiations: 0 = one-state blocks (closed-form trace); 2, 3, 4 = matrix path with blocks padded to that size
     // (tree product); 9 = matrix path, sequential propagation (blocks of 5..8 states)
     if (s->cur_isector == 4) hipLaunchKernelGGL(k_sweep_worm, l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps);   // counts its own steps
-    else switch (mat_variant(s)) {
-    case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<0>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps, count_as_sampling); break;
-    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<2>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps, count_as_sampling); break;
-    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<3>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps, count_as_sampling); break;
-    case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<4>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps, count_as_sampling); break;
-    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<9>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps, count_as_sampling); break;
-    }
+    else launch_sweep<false>(s, l, (long long)nsteps, count_as_sampling);
     HIPCHK(hipGetLastError());
     if ((rc = time_end(s, s->cur_isector == 4 ? "sweep_worm" : "sweep"))) return rc;
     s->steps_done += nsteps;
@@ -557,9 +575,69 @@ int w2dyn_sync(w2dyn_solver *s)
     return 0;
 }
 
+int w2dyn_ctqmc_calibrate(w2dyn_solver *s, int list, int phase1pairnum, int phase2taugrid, int phase2pairnum, int nprogress)
+{
+    if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "ctqmc_calibrate before init_solver");
+    if (phase1pairnum < 1 || phase2taugrid < 1 || phase2pairnum < 0 || nprogress < 1) return fail(s, W2DYN_EINVAL, "ctqmc_calibrate: bad arguments");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    DevConst &C = s->C; const size_t W = s->nwalkers, nf = s->nflav;
+    int rc;
+    if (list) {      // CTQMC.F90:8100-8101: the list is allocated once; the histogram keeps its current shape
+        if (!C.apt_tau || C.napt != phase1pairnum) {
+            if ((rc = dev_alloc(s, C.apt_tau, W * (size_t)phase1pairnum))) return rc;
+            if (!C.apt_cnt) { if ((rc = dev_alloc(s, C.apt_cnt, W))) return rc; }
+            else HIPCHK(hipMemsetAsync(C.apt_cnt, 0, sizeof(int) * W, s->stream));
+            C.napt = phase1pairnum;
+        }
+        C.calib = 1;
+    } else {         // CTQMC.F90:8103-8108
+        unsigned long long *h = nullptr;
+        if ((rc = dev_alloc(s, h, nf * (size_t)phase2taugrid))) return rc;
+        C.accpair = h; C.naccpair = phase2taugrid; C.accpair_max = C.taudiff_max;
+        if (!C.calib_pairs) { if ((rc = dev_alloc(s, C.calib_pairs, W * nf))) return rc; }
+        else HIPCHK(hipMemsetAsync(C.calib_pairs, 0, sizeof(int) * W * nf, s->stream));
+        C.phase2pairnum = phase2pairnum; C.calib = 2;
+    }
+    const long long chunk = std::min(1000, nprogress);          // the completion test runs every min(1000, nprogress) steps
+    Launch l = walker_launch(s);
+    std::vector<int> cnt(list ? W : W * nf);
+    bool done = false;
+    for (long long it = 0; it < 1000000 && !done; ++it) {
+        if ((rc = time_begin(s))) return rc;
+        launch_sweep<true>(s, l, chunk, 0);
+        HIPCHK(hipGetLastError());
+        if ((rc = time_end(s, "sweep_calibrate"))) return rc;
+        HIPCHK(hipMemcpyAsync(cnt.data(), list ? C.apt_cnt : C.calib_pairs, cnt.size() * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipStreamSynchronize(s->stream));
+        done = true;
+        for (int v : cnt) if (v < (list ? phase1pairnum : phase2pairnum)) { done = false; break; }
+        if ((it & 15) == 15 || done) { if ((rc = check_walker_errors(s))) return rc; }
+    }
+    if (!done) return fail(s, W2DYN_ENUMERIC, "ctqmc_calibrate: not every chain completed phase %d within 10^9 steps", list ? 1 : 2);
+    if (list) {
+        // every chain owns a list like every MPI rank of the reference does; `accpairtau` is the mean over chains of the
+        // sorted lists, so that sorted[int(0.995 n)] is the chain average of the percentile (impurity.py:1159-1162)
+        s->accpairtau_chains.resize(W * (size_t)phase1pairnum);
+        HIPCHK(hipMemcpy(s->accpairtau_chains.data(), C.apt_tau, s->accpairtau_chains.size() * sizeof(double), hipMemcpyDeviceToHost));
+        s->accpairtau.assign(phase1pairnum, 0.0);
+        std::vector<double> tmp(phase1pairnum);
+        for (size_t w = 0; w < W; ++w) {
+            std::copy(s->accpairtau_chains.begin() + w * phase1pairnum, s->accpairtau_chains.begin() + (w + 1) * phase1pairnum, tmp.begin());
+            std::sort(tmp.begin(), tmp.end());
+            for (int i = 0; i < phase1pairnum; ++i) s->accpairtau[i] += tmp[i] / (double)W;
+        }
+    }
+    s->res_accpair.resize(nf * (size_t)C.naccpair);
+    HIPCHK(hipMemcpy(s->res_accpair.data(), C.accpair, s->res_accpair.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int w2dyn_ctqmc_warmup(w2dyn_solver *s, int64_t n)
 {
     int rc;
+    if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "ctqmc_warmup before init_solver");
+    accpair_to_default(s);
     if ((rc = w2dyn_init_counters(s))) return rc;
     double t0 = now_s();
     if ((rc = w2dyn_sweep(s, n, 0))) return rc;
@@ -571,6 +649,8 @@ int w2dyn_ctqmc_warmup(w2dyn_solver *s, int64_t n)
 int w2dyn_measure_begin(w2dyn_solver *s)
 {
     int rc;
+    if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "measure before init_solver");
+    accpair_to_default(s);
     if ((rc = w2dyn_init_counters(s))) return rc;
     const DevConst &C = s->C; const size_t B = C.nbins; const int nf = s->nflav;
     HIPCHK(hipMemsetAsync(C.acc_gleg, 0, sizeof(double) * B * nf * s->nleg, s->stream));
@@ -963,7 +1043,7 @@ int w2dyn_count_steps(w2dyn_solver *s, int isector, int icomponent, int64_t nfix
     HIPCHK(hipMemcpy(C.K, K0.data(), K0.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(C.TC, TC0.data(), TC0.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(C.TA, TA0.data(), TA0.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(C.accpair, 0, sizeof(unsigned long long) * s->nflav * s->ntau));
+    HIPCHK(hipMemset(C.accpair, 0, sizeof(unsigned long long) * s->nflav * C.naccpair));
     s->cur_isector = 1; s->C.isector = 1; s->C.p_wins = 0.0;
     Launch l = walker_launch(s);
     hipLaunchKernelGGL(k_rebuild, l.grid, l.block, l.lds, s->stream, s->C);
@@ -1128,6 +1208,8 @@ int w2dyn_get_result(w2dyn_solver *s, const char *name, void *out, size_t bytes,
         for (int i = 0; i < s->nstates; ++i) { int st = s->lp.states[i]; for (int b = 0; b < s->nd; ++b) for (int sp = 0; sp < 2; ++sp) itmp[((size_t)i * s->nd + b) * 2 + sp] = (st >> (b + sp * s->nd)) & 1; }
         src = itmp.data(); size = itmp.size() * sizeof(int);
     }
+    else if (n == "accpairtau") { src = s->accpairtau.data(); size = s->accpairtau.size() * sizeof(double); }
+    else if (n == "accpairtau_chains") { src = s->accpairtau_chains.data(); size = s->accpairtau_chains.size() * sizeof(double); }
     else if (n == "steps_worm_chains") { src = s->steps_worm_chains.data(); size = s->steps_worm_chains.size() * sizeof(long long); }
     else if (n == "cntsampling") { ltmp.assign(16, 0); if (!s->counters.empty()) { ltmp[0] = (long long)s->counters[C_SAMPLING]; ltmp[3] = (long long)s->counters[C_W_SAMPLING]; } src = ltmp.data(); size = ltmp.size() * sizeof(long long); }
     else if (n == "counters") { src = s->counters.data(); size = s->counters.size() * sizeof(double); }

@@ -45,6 +45,7 @@ def load_library(path: str = LIB_PATH):
     L.w2dyn_set_taudiffmax.argtypes = [vp, C.c_double]
     L.w2dyn_init_counters.argtypes = [vp]
     L.w2dyn_ctqmc_warmup.argtypes = [vp, C.c_int64]
+    L.w2dyn_ctqmc_calibrate.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.w2dyn_ctqmc_measure.argtypes = [vp, C.c_int, C.c_int]
     L.w2dyn_dest_ctqmc.argtypes = [vp]
     L.w2dyn_set_wormeta.argtypes = [vp, C.c_double]
@@ -76,6 +77,7 @@ EXPORTED_SYMBOLS = [
     "w2dyn_measure_once", "w2dyn_measure_finish", "w2dyn_sync", "w2dyn_get_mc_config_scalars", "w2dyn_get_mc_config",
     "w2dyn_set_mc_config", "w2dyn_get_minv", "w2dyn_get_walker_state", "w2dyn_get_result", "w2dyn_get_scalar",
     "w2dyn_kernel_time", "w2dyn_set_wormeta", "w2dyn_get_wormeta", "w2dyn_ctqmc_worm_warmup", "w2dyn_count_steps",
+    "w2dyn_ctqmc_calibrate",
 ]
 
 _SCALARS = ("mean_sign", "aborted", "time_warmup", "time_sim", "time_sim_steps", "accglob", "accshift", "accadd4",
@@ -150,6 +152,10 @@ class MCTQMC:
 
     def init_counters(self):
         self._chk(self._L.w2dyn_init_counters(self._h))
+
+    def ctqmc_calibrate(self, list_, phase1pairnum, phase2taugrid, phase2pairnum, nprogress):
+        self._chk(self._L.w2dyn_ctqmc_calibrate(self._h, int(bool(list_)), int(phase1pairnum), int(phase2taugrid),
+                                                int(phase2pairnum), int(nprogress)))
 
     def ctqmc_warmup(self, n):
         self._chk(self._L.w2dyn_ctqmc_warmup(self._h, int(n)))
@@ -281,6 +287,10 @@ class MCTQMC:
             return a.reshape(lead + (2 * nwf, 2 * nwf, 2 * nwb + 1))
         if name in ("accwormadd", "accwormrem", "accwormrep"):
             return self.result(name)
+        if name == "accpairtau":
+            return self.result(name)
+        if name == "accpairtau_chains":
+            return self.result(name).reshape(self.nwalkers, -1)
         if name == "steps_worm_chains":
             return self.result(name, np.int64)
         if name == "worm_counters":

@@ -55,9 +55,7 @@ class HipCtHybSolver:
         p = self.problem
         q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, iter_no + 1)
         tdm = self.qmc["TaudiffMax"]
-        if not tdm > 0.0:
-            raise NotImplementedError("TaudiffMax <= 0 needs the calibration run (impurity.py:1150-1195): next round")
-        q.set_taudiffmax(tdm)
+        q.set_taudiffmax(tdm if tdm > 0.0 else self.calibrate_taudiff_max())       # impurity.py:589-591
         q.ctqmc_warmup(self.qmc["Nwarmups"])
         q.ctqmc_measure(1, 1)
         if q.aborted == 2:
@@ -76,3 +74,33 @@ class HipCtHybSolver:
         q.dest_ctqmc()
         q.dest_paras()
         return result
+
+    def calibrate_taudiff_max(self, phase1pairnum=1000, phase2taugrid=100, phase2pairnum=1000, nprogress=100000):
+        """Two-phase window calibration in the call order of `CtHybSolver.calibrate_taudiff_max`
+        (`impurity.py:1150-1172`): the 99.5th percentile of the accepted pair distances sets a provisional window,
+        then the distance histogram on that window is fitted (`estimate_taudiff_max`)."""
+        q = self.ctqmc
+        q.init_counters()
+        q.ctqmc_calibrate(True, phase1pairnum, phase2taugrid, phase2pairnum, nprogress)
+        acctaulist = q.accpairtau
+        acctaulist.sort()
+        taudiffmax = DistributedSample([np.array((acctaulist[int(0.995 * phase1pairnum)],))], self.comm).mean()
+        taudiffmax = float(np.asarray(taudiffmax).ravel()[0])
+        q.set_taudiffmax(taudiffmax)
+        q.init_counters()
+        q.ctqmc_calibrate(False, phase1pairnum, phase2taugrid, phase2pairnum, nprogress)
+        return self.estimate_taudiff_max(self.comm, q.accpair, taudiffmax, phase2taugrid)
+
+    @staticmethod
+    def estimate_taudiff_max(comm, accept_pair, taudiffmax, phase2taugrid):
+        """Distance at which the fitted exponential decay of the pair acceptance has dropped to 1 %, largest over the
+        flavours (`impurity.py:1174-1195`)."""
+        import scipy.optimize as opt
+        accept_pair = np.asarray(DistributedSample([np.asarray(accept_pair, dtype=np.float64)], comm).mean())
+        taus = (np.arange(phase2taugrid) + 0.5) * taudiffmax / phase2taugrid          # transform.tau_bins(..., "centre")
+        estimates = np.empty(accept_pair.shape[:2])
+        for b in range(accept_pair.shape[0]):
+            for s in range(accept_pair.shape[1]):
+                fit = opt.leastsq(lambda p, t, acc: acc - p[0] * np.exp(p[1] * t), (accept_pair[b, s, 0], -1), (taus, accept_pair[b, s]))
+                estimates[b, s] = np.log(1 - 0.99) / fit[0][1]
+        return float(np.amax(estimates))
