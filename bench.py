@@ -38,15 +38,23 @@ WORKLOADS = {
                text="C4: 3-orbital Kanamori (QNs Nt Szt Qzt, matrix local trace), U=2, J=0.25, beta=50, TaudiffMax=10, NCorr=100"),
     "C5Z": dict(config="C5Z", nftau=5001, overrides=dict(Nftau=5001, NCorr=100, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Nwarmups=0, Nmeas=1),
                 text="C5 (Z-space part): 5-orbital density-density, U=2, J=0.25, beta=100, TaudiffMax=10, NCorr=100"),
+    # BASELINE.json configs[4] on one GPU: worm sampling of one component of the two-particle Green's function (sector 4)
+    "C5": dict(config="C5Z", nftau=5001, worm=dict(component=12, nfix=2000),
+               overrides=dict(Nftau=5001, NCorr=100, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Nwarmups=0, Nmeas=1, N4iwf=10, N4iwb=5,
+                              PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=1.0, WormMeasG4iw=1, G4ph=1, G4pp=0),
+               text="C5: 5-orbital density-density, U=2, J=0.25, beta=100, TaudiffMax=10, NCorr=100, worm sampling in sector 4 (G4iw, "
+                    "component 12 = flavours 0011, N4iwf=10, N4iwb=5, PercentageWormInsert=PercentageWormReplace=0.2, eta balanced by count_steps)"),
 }
 WORKLOAD = WORKLOADS["C2"]
 
 
 def _cpu_chain(args):
     """One reference (or oracle) chain on one core; returns (mc_steps, seconds, kind)."""
-    seed, nmeas, nwarm, wname = args
+    seed, nmeas, nwarm, wname, eta = args
     global WORKLOAD
-    WORKLOAD = WORKLOADS[wname]
+    WORKLOAD = dict(WORKLOADS[wname])
+    if WORKLOAD.get("worm"):
+        WORKLOAD["worm"] = dict(WORKLOAD["worm"], eta=eta)
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from w2dynamics_amd import params, synth
     p = synth.config(WORKLOAD["config"], nftau=WORKLOAD["nftau"])
@@ -56,29 +64,41 @@ def _cpu_chain(args):
         import refdrive
         if not refdrive.available():
             raise ImportError("oracle/_ref not built")
-        s = refdrive.RefSolver(p, ps, seed)
+        worm = WORKLOAD.get("worm")
+        s = refdrive.RefSolver(p, ps, seed, fourpnt=8 if worm else 0)
         s.set_taudiffmax(over["TaudiffMax"])
         s.warmup(nwarm)
-        t0 = time.perf_counter(); s.measure(); dt = time.perf_counter() - t0
+        if worm:
+            s.set_wormeta(worm["eta"])
+            s.worm_warmup(0, 4, worm["component"])
+        t0 = time.perf_counter(); s.measure(*((4, worm["component"]) if worm else (1, 1))); dt = time.perf_counter() - t0
         s.close()
         return nmeas * over["NCorr"], dt, "reference"
     except Exception:
         import pyoracle
-        w = pyoracle.OracleWalker(p, params.ParameterSet(ps), ("std", seed))
+        worm = WORKLOAD.get("worm")
+        w = pyoracle.OracleWalker(p, params.ParameterSet(ps), ("std", seed), fourpnt=8 if worm else 0)
         w.set_taudiffmax(over["TaudiffMax"])
         w.warmup(nwarm)
-        t0 = time.perf_counter(); w.measure(); dt = time.perf_counter() - t0
+        if worm:
+            w.set_wormeta(worm["eta"])
+        t0 = time.perf_counter()
+        if worm:
+            w.measure_sector(4, worm["component"])
+        else:
+            w.measure()
+        dt = time.perf_counter() - t0
         w.close()
         return nmeas * over["NCorr"], dt, "port"
 
 
-def cpu_baseline(cores, wname, nmeas=6000, nwarm=50000):
+def cpu_baseline(cores, wname, nmeas=6000, nwarm=50000, eta=1.0):
     import multiprocessing as mp
     if wname != "C2":
         nmeas = 3000
     ctx = mp.get_context("spawn")
     with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_chain, [(1000 + i, nmeas, nwarm, wname) for i in range(cores)])
+        res = pool.map(_cpu_chain, [(1000 + i, nmeas, nwarm, wname, eta) for i in range(cores)])
     rate = sum(s / t for s, t, _ in res)
     kind = res[0][2]
     return {"value": rate, "unit": "MC steps/s", "cores": cores, "kind": kind,
@@ -137,6 +157,9 @@ def main():
     prob = synth.config(WORKLOAD["config"], nftau=WORKLOAD["nftau"])
     ps = params.make_pstring(over, beta=prob.beta, Nd=prob.nd, Hamiltonian=prob.hamiltonian, QuantumNumbers=prob.quantum_numbers)
     q = MCTQMC(device=local_rank, nwalkers=a.walkers, first_walker=rank * a.walkers, walkers_per_bin=a.walkers_per_bin)
+    worm = WORKLOAD.get("worm")
+    if worm:
+        q.fourpnt = 8
     q.init_rnd(43890); q.init_paras(ps)
     q.init_solver(prob.umatrix, prob.ftau, prob.muimp, prob.screening, 1)
     q.set_taudiffmax(over["TaudiffMax"])
@@ -144,11 +167,27 @@ def main():
     q.ctqmc_warmup(ncorr)                          # thermalise (untimed), in launches of the same size as the timed ones
     for _ in range(max(a.thermal // ncorr - 1, 0)):
         q.sweep(ncorr)
+    eta = 1.0
+    if worm:
+        # eta search of solve_component (impurity.py:717-742): rescale until Z and worm space get equal numbers of steps
+        # starting point: insertion prefactor (beta Nd)^4 eta = 1 (CTQMC.F90:5680-5684)
+        q.wormeta[:] = 1.0 / (prob.beta * prob.nd) ** 4
+        for _ in range(12):
+            sw, sz = q.count_steps(4, worm["component"], worm["nfix"])
+            if sw == 0 or sz == 0 or abs(sw - sz) / float(sw + sz) <= 0.1:
+                break
+            q.wormeta[:] = q.wormeta[:] * float(sz) / float(sw)
+        eta = float(q.wormeta[2])
+        if world > 1:      # all ranks use the mean eta (impurity.py:739-740, 784)
+            t = torch.tensor([eta], dtype=torch.float64, device="cuda"); dist.all_reduce(t); eta = float(t.item()) / world
+            q.wormeta[:] = eta
+        q.set_sector(4, worm["component"])
+    sweep_key = "sweep_worm" if worm else "sweep"
     q.measure_begin()
     for _ in range(a.warmup):
         q.sweep(ncorr); q.measure_once()
     q.sync()
-    for k in ("sweep", "meas_misc", "meas_gleg"):
+    for k in (sweep_key, "meas_misc", "meas_gleg", "meas_g4w"):
         q.kernel_time(k, reset=True)
     if world > 1:
         dist.barrier()
@@ -173,14 +212,17 @@ def main():
     t_reduce = time.perf_counter() - t1
     gl /= world; oc /= world; hi /= world
 
-    sweep_ms, nsweep = q.kernel_time("sweep")
-    gleg_ms, ngleg = q.kernel_time("meas_gleg")
+    sweep_ms, nsweep = q.kernel_time(sweep_key)
+    gleg_ms, ngleg = q.kernel_time("meas_g4w" if worm else "meas_gleg")
     misc_ms, _ = q.kernel_time("meas_misc")
     if rank == 0:
         W = a.walkers
         cnt = q.result("counters")
         names = ["tryadd", "accadd", "qnadd", "tryrem", "accrem", "qnrem", "tryglob", "accglob", "qnglob", "tryshift", "accshift", "sampling"]
         c = dict(zip(names, cnt))
+        if worm:       # pair moves inside worm space and worm replacements touch M the same way (counter order: enum Counter)
+            c["tryadd"] += cnt[25]; c["accadd"] += cnt[26]; c["tryrem"] += cnt[27]; c["accrem"] += cnt[28]
+            c["tryadd"] += cnt[35]; c["accadd"] += cnt[36]
         ks = np.arange(hi.shape[-1])
         k1 = float((hi * ks).sum(-1).mean()); k2 = float((hi * ks ** 2).sum(-1).mean())
         nlaunch_steps = W * ncorr * (a.steps + a.warmup)     # counters cover warm-up rounds too
@@ -194,10 +236,14 @@ def main():
         bytes_sweep = (prop + acc + rem) * scale
         ach_gbs = bytes_sweep / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
         flops_gleg = W * prob.nd * 2 * k2 * (5 * over["NLegMax"] + 6)
+        if worm:       # 8 (2 N4iwf)^2 (2 N4iwb + 1) flop per worm-space measurement
+            nworm_meas = float(q.result("cntmeas_worm")[0]) / max(a.steps + a.warmup, 1)
+            flops_gleg = nworm_meas * 8 * (2 * over["N4iwf"]) ** 2 * (2 * over["N4iwb"] + 1)
         ach_tf = flops_gleg / (gleg_ms * 1e-3) / 1e12 if gleg_ms > 0 else 0.0
         value = world * W * ncorr * a.steps / dt
-        tr_sweep, tr_src = pmc_traffic("k_sweep", W, a.config)
-        tr_gleg, _ = pmc_traffic("k_meas_gleg", W, a.config)
+        kname, mname = ("k_sweep_worm", "k_meas_g4w") if worm else ("k_sweep", "k_meas_gleg")
+        tr_sweep, tr_src = pmc_traffic(kname, W, a.config)
+        tr_gleg, _ = pmc_traffic(mname, W, a.config)
         out = {
             "metric": "Metropolis steps/sec (node)", "value": value, "unit": "MC steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -207,18 +253,21 @@ def main():
             "measurements_per_s": world * W * a.steps / dt,
             "mean_order_per_flavour": k1, "accept_ins": c["accadd"] / max(c["tryadd"], 1), "occ_double": float(oc[0, 0, 0, 1]),
             "allreduce_ms": t_reduce * 1e3,
-            "roofline": {"kernel": "k_sweep", "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": kname, "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": tr_sweep, "traffic_source": tr_src, "avg_launch_ms": sweep_ms, "launches": nsweep,
                          "algorithmic_bytes_per_launch": bytes_sweep},
-            "roofline_meas": {"kernel": "k_meas_gleg", "bound": "mfma", "note": "fp64 vector FMA bound (fp64 vector peak == fp64 MFMA peak on MI355X)",
+            "roofline_meas": {"kernel": mname, "bound": "mfma", "note": "fp64 vector FMA bound (fp64 vector peak == fp64 MFMA peak on MI355X)",
                               "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS,
                               "traffic": tr_gleg, "avg_launch_ms": gleg_ms, "launches": ngleg, "algorithmic_flops_per_launch": flops_gleg},
-            "kernel_ms": {"k_sweep": sweep_ms, "k_meas_gleg": gleg_ms, "k_meas_misc": misc_ms},
+            "kernel_ms": {kname: sweep_ms, mname: gleg_ms, "k_meas_misc": misc_ms},
         }
+        if worm:
+            cs = q.cntsampling
+            out["worm"] = {"eta": eta, "steps_z": int(cs[0]), "steps_worm": int(cs[3]), "component": worm["component"]}
         if world == 1 and not a.no_cpu_baseline:
             cores = a.cpu_cores or max(1, min(16, os.cpu_count() or 1))
             try:
-                out["cpu_baseline"] = cpu_baseline(cores, a.config)
+                out["cpu_baseline"] = cpu_baseline(cores, a.config, eta=eta)
                 out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
             except Exception as e:  # pragma: no cover
                 out["cpu_baseline"] = {"value": None, "unit": "MC steps/s", "cores": cores, "kind": "port", "sample": "failed: %r" % (e,)}

@@ -91,6 +91,9 @@ int w2dyn_dest_ctqmc(w2dyn_solver *s);
 /* the pieces of ctqmc_measure, exposed so that a caller (bench, tests) can time / check them separately:
  * nsteps Monte-Carlo steps for every chain (CTQMC.F90:8428-8533), one pass of the Z-space estimators over every
  * chain (8541-8581), normalisation (8663-8817). */
+/* sector and component of the following w2dyn_sweep / w2dyn_measure_once calls (the first lines of ctqmc_measure,
+ * CTQMC.F90:8380-8400): every chain goes back to Z space; isector 1 or 4 */
+int w2dyn_set_sector(w2dyn_solver *s, int isector, int icomponent);
 int w2dyn_measure_begin(w2dyn_solver *s);
 int w2dyn_sweep(w2dyn_solver *s, int64_t nsteps, int count_as_sampling);
 int w2dyn_measure_once(w2dyn_solver *s);
@@ -132,7 +135,7 @@ int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out);
 
 /* timing of the last w2dyn_sweep / w2dyn_measure_once launches, measured with HIP events on the context's own
  * stream: average kernel duration in ms and number of launches since the last reset (bench.py roofline leg) */
-int w2dyn_kernel_time(w2dyn_solver *s, const char *kernel /* "sweep" | "meas_gleg" | "meas_misc" | "meas_giw" */,
+int w2dyn_kernel_time(w2dyn_solver *s, const char *kernel /* "sweep" | "sweep_worm" | "sweep_calibrate" | "meas_gleg" | "meas_misc" | "meas_giw" | "meas_g2iw" | "meas_g4iw" | "meas_g4w" */,
                       double *avg_ms, int64_t *launches, int reset);
 
 #ifdef __cplusplus

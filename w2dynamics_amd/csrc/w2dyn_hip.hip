@@ -993,6 +993,12 @@ int w2dyn_ctqmc_measure(w2dyn_solver *s, int isector, int icomponent)
     return rc;
 }
 
+int w2dyn_set_sector(w2dyn_solver *s, int isector, int icomponent)
+{
+    if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "set_sector before init_solver");
+    return enter_sector(s, isector, icomponent);
+}
+
 int w2dyn_set_wormeta(w2dyn_solver *s, double eta) { if (!s) return W2DYN_EINVAL; s->worm_eta = eta; s->C.worm_eta = eta; return 0; }
 int w2dyn_get_wormeta(w2dyn_solver *s, double *eta) { if (!s || !eta) return W2DYN_EINVAL; *eta = s->worm_eta; return 0; }
 

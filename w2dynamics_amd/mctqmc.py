@@ -53,6 +53,7 @@ def load_library(path: str = LIB_PATH):
     L.w2dyn_ctqmc_worm_warmup.argtypes = [vp, C.c_int64, C.c_int, C.c_int]
     L.w2dyn_count_steps.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.w2dyn_measure_begin.argtypes = [vp]
+    L.w2dyn_set_sector.argtypes = [vp, C.c_int, C.c_int]
     L.w2dyn_sweep.argtypes = [vp, C.c_int64, C.c_int]
     L.w2dyn_measure_once.argtypes = [vp]
     L.w2dyn_measure_finish.argtypes = [vp]
@@ -77,7 +78,7 @@ EXPORTED_SYMBOLS = [
     "w2dyn_measure_once", "w2dyn_measure_finish", "w2dyn_sync", "w2dyn_get_mc_config_scalars", "w2dyn_get_mc_config",
     "w2dyn_set_mc_config", "w2dyn_get_minv", "w2dyn_get_walker_state", "w2dyn_get_result", "w2dyn_get_scalar",
     "w2dyn_kernel_time", "w2dyn_set_wormeta", "w2dyn_get_wormeta", "w2dyn_ctqmc_worm_warmup", "w2dyn_count_steps",
-    "w2dyn_ctqmc_calibrate",
+    "w2dyn_ctqmc_calibrate", "w2dyn_set_sector",
 ]
 
 _SCALARS = ("mean_sign", "aborted", "time_warmup", "time_sim", "time_sim_steps", "accglob", "accshift", "accadd4",
@@ -189,6 +190,10 @@ class MCTQMC:
 
     # pieces of ctqmc_measure (bench / tests)
     def measure_begin(self): self._chk(self._L.w2dyn_measure_begin(self._h))
+
+    def set_sector(self, isector, icomponent):
+        self._push_wormeta(isector)
+        self._chk(self._L.w2dyn_set_sector(self._h, int(isector), int(icomponent)))
     def sweep(self, nsteps, count_as_sampling=True): self._chk(self._L.w2dyn_sweep(self._h, int(nsteps), int(count_as_sampling)))
     def measure_once(self): self._chk(self._L.w2dyn_measure_once(self._h))
     def measure_finish(self): self._chk(self._L.w2dyn_measure_finish(self._h))

@@ -75,6 +75,88 @@ class HipCtHybSolver:
         q.dest_paras()
         return result
 
+    def solve_component(self, iter_no, isector, icomponent, mc_config_inout=None):
+        """Worm estimator of one component in the call order of `CtHybSolver.solve_component` (`impurity.py:656-892`):
+        init_solver -> (stored configuration | warm-up) -> eta search by count_steps -> ctqmc_worm_warmup ->
+        ctqmc_measure(isector, icomponent) -> result normalised by nflavours^4.  Sector 4 (two-particle Green's
+        function) is the one the HIP library samples."""
+        import scipy.optimize as opt
+        q = self.ctqmc
+        self.comm.Barrier()
+        q.simid = self.rank
+        t0 = time.perf_counter()
+        p = self.problem
+        q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, iter_no + 1)
+        if mc_config_inout:
+            c = mc_config_inout[0]
+            q.set_mc_config(len(c["taus"]), c["taus"], c["orbs"], c["spins"], c["cas"], c["hashybs"], c["outer_sst"], c["outer_state"])
+        tdm = self.qmc["TaudiffMax"]
+        q.set_taudiffmax(tdm if tdm > 0.0 else self.calibrate_taudiff_max())
+        if not mc_config_inout:
+            q.ctqmc_warmup(self.qmc["Nwarmups"])
+            if mc_config_inout is not None:
+                n, osst, ost = q.get_mc_config_scalars()
+                taus, orbs, spins, cas, hyb, osst, ost = q.get_mc_config(n)
+                mc_config_inout.append(dict(taus=taus, orbs=orbs, spins=spins, cas=cas, hashybs=hyb, outer_sst=osst, outer_state=ost))
+        worm_warmups = self.qmc["Nwarmups2Plus"]
+        if worm_warmups < 0:
+            worm_warmups = int(0.1 * self.qmc["Nwarmups"])
+
+        def balance(eta):
+            q.wormeta[:] = eta
+            sw, sz = q.count_steps(isector, icomponent, worm_warmups)
+            if sw + sz != worm_warmups:
+                raise ValueError("%d steps in worm, %d steps in Z, some steps missing!" % (sw, sz))
+            return sw, sz
+
+        search = int(self.qmc["WormSearchEta"])
+        if search == 1:            # rescaling search, impurity.py:717-742
+            q.wormeta[:] = float(self.qmc["WormEta"])
+            for i_try in range(50):
+                sw, sz = balance(q.wormeta[0])
+                if abs(float(sw - sz)) / float(sw + sz) > 0.1:
+                    if i_try == 49 or sw == 0:
+                        q.wormeta[:] = 0.0
+                        break
+                    q.wormeta[:] = q.wormeta[:] * float(sz) / float(sw)
+                else:
+                    break
+            eta = float(q.wormeta[0])
+        elif search == 2:          # root finding, impurity.py:744-779
+            def eta_root(eta):
+                sw, sz = balance(eta)
+                return float(sw - sz) / float(sw + sz)
+            try:
+                eta = opt.brentq(eta_root, 1e-4, 1e2, xtol=0.001, rtol=0.001, maxiter=50, disp=True)
+            except ValueError:
+                try:
+                    eta = opt.brentq(eta_root, 1e-6, 1e4, xtol=0.001, rtol=0.001, maxiter=50, disp=True)
+                except ValueError:
+                    eta = 0.0
+        else:
+            eta = float(self.qmc["WormEta"])
+        eta_stat = DistributedSample([np.array([eta])], self.comm)
+        eta_mean = float(np.asarray(eta_stat.mean()).ravel()[0])
+        q.wormeta[:] = eta_mean
+        q.ctqmc_worm_warmup(worm_warmups, isector, icomponent)
+        q.ctqmc_measure(isector, icomponent)
+        if q.aborted == 2:
+            raise KeyboardInterrupt("CTQMC was interrupted by signal")
+        nfl = 2 * p.nd
+        result = {}
+        if isector == 4:
+            if self.qmc["G4ph"] == 1:
+                result["g4iw-worm/%05d" % icomponent] = DistributedSample(q.g4iw_worm_bins / nfl ** 4, self.comm)
+            if self.qmc["G4pp"] == 1:
+                result["g4iwpp-worm/%05d" % icomponent] = DistributedSample(q.g4iwpp_worm_bins / nfl ** 4, self.comm)
+        result["worm-eta/%05d" % icomponent] = eta_mean
+        result["sign"] = DistributedSample(np.array([q.mean_sign]), self.comm)
+        result["steps-worm-partition/%05d" % icomponent] = np.array(q.cntsampling, dtype=np.double)
+        result["time-qmc"] = time.perf_counter() - t0
+        q.dest_ctqmc()
+        q.dest_paras()
+        return result
+
     def calibrate_taudiff_max(self, phase1pairnum=1000, phase2taugrid=100, phase2pairnum=1000, nprogress=100000):
         """Two-phase window calibration in the call order of `CtHybSolver.calibrate_taudiff_max`
         (`impurity.py:1150-1172`): the 99.5th percentile of the accepted pair distances sets a provisional window,
