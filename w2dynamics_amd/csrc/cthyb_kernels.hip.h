@@ -117,8 +117,12 @@ struct DevConst {
 // bytes of LDS one wave needs (host and device agree through this one function)
 __host__ __device__ inline size_t lds_bytes_per_wave(int nflav, int kmax, int wcap, int kgj, int mat)
 {
-    size_t d = (size_t)2 * nflav * kmax + 4 * (size_t)kmax + wcap + (size_t)kgj * kgj;   // tc, ta, Q, R, MQ, RM, wt, gj
-    size_t i = (size_t)2 * wcap + MAXFLAV;                                     // wm, wc, K
+    // tc, ta, MQ, RM | { Q, R, wt, wm, wc } and the Gauss-Jordan tile gj | counters, K, pivots.  On the scalar trace path
+    // gj lies on top of Q..wc (a full rebuild invalidates the window list anyway); the matrix path keeps data in wm/wc
+    // across the rebuild and gets a tile of its own
+    size_t u1 = ((size_t)2 * kmax + wcap) * sizeof(double) + (size_t)2 * wcap * sizeof(int), u2 = (size_t)kgj * kgj * sizeof(double);
+    size_t d = (size_t)2 * nflav * kmax + 2 * (size_t)kmax + ((mat ? u1 + u2 : (u1 > u2 ? u1 : u2)) + 7) / 8;
+    size_t i = (size_t)MAXFLAV + kmax;                                         // K, piv
     if (mat) { d += wcap + 2; i += (size_t)3 * wcap + 8; }                     // ot; om, osst, tsst
     size_t b = d * sizeof(double) + C_NCOUNT * sizeof(unsigned long long) + i * sizeof(int);
     return (b + 15) & ~(size_t)15;
@@ -212,7 +216,7 @@ struct Ctx {
     double *M;                       // global: this walker's matrices
     // LDS slice of this wave
     double *tc_, *ta_, *Q, *R, *MQ, *RM, *wt, *gj;
-    int *wm, *wc, *K;
+    int *wm, *wc, *K, *piv;
     unsigned long long *cnt;
     // wave-uniform scalars
     unsigned long long chunk;        // index of the 128-draw chunk held in rbuf
@@ -411,6 +415,9 @@ __device__ __forceinline__ void accpair_add(Ctx &x, int f, double dt)
 // ---------------------------------------------------------------------------------------------------------------
 // pair insertion: CTQMC.F90:3353-3612 (StepAdd), Trace.F90:3657-3698, 2775-2832, MatrixUpdate.F90:392-442
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef ADD_UNROLL
+#define ADD_UNROLL 8
+#endif
 template <int MAT, bool WORM = false, bool CALIB = false>
 __device__ W2DYN_INLINE void step_add(Ctx &x)
 {
@@ -580,16 +587,16 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
         int l = l0 + x.lane;
         int lc = l < k ? l : k - 1;
         double rm = 0.0, mq = 0.0;
-        for (int i0 = 0; i0 < k; i0 += 8) {
-            double mc[8], mr[8];
+        for (int i0 = 0; i0 < k; i0 += ADD_UNROLL) {
+            double mc[ADD_UNROLL], mr[ADD_UNROLL];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < ADD_UNROLL; ++u) {
                 int i = i0 + u < k ? i0 + u : k - 1;
                 mc[u] = Mf[(size_t)i * kmax + lc];
                 mr[u] = Mf[(size_t)lc * kmax + i];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < ADD_UNROLL; ++u) {
                 if (i0 + u < k) { rm += x.R[i0 + u] * mc[u]; mq += mr[u] * x.Q[i0 + u]; }
             }
         }
@@ -984,7 +991,7 @@ __device__ W2DYN_INLINE void build_and_invert(Ctx &x, int f, int k, const double
         if (in_lds) x.gj[r * k + c] = v; else A[(size_t)r * kmax + c] = v;
     }
     wave_sync();
-    int *piv = x.wm;                 // k <= kmax <= wcap entries of LDS
+    int *piv = x.piv;                // kmax entries of LDS
     for (int p = 0; p < k; ++p) {
         double best = -1.0; int brow = p;
         for (int r = p + x.lane; r < k; r += 64) {
@@ -1169,15 +1176,19 @@ __device__ __forceinline__ void ctx_setup(Ctx &x, unsigned char *smem)
     x.w = uni((int)(blockIdx.x * (blockDim.x >> 6) + wib));
     unsigned char *base = smem + C.shared_lds + (size_t)wib * C.lds_per_wave;
     x.tc_ = (double *)base; x.ta_ = x.tc_ + C.nflav * C.kmax;
-    x.Q = x.ta_ + C.nflav * C.kmax; x.R = x.Q + C.kmax; x.MQ = x.R + C.kmax; x.RM = x.MQ + C.kmax;
-    x.wt = x.RM + C.kmax;
-    x.gj = x.wt + C.wcap;
-    x.cnt = (unsigned long long *)(x.gj + C.kgj * C.kgj);
-    x.wm = (int *)(x.cnt + C_NCOUNT); x.wc = x.wm + C.wcap; x.K = x.wc + C.wcap;
+    x.MQ = x.ta_ + C.nflav * C.kmax; x.RM = x.MQ + C.kmax;
+    x.Q = x.RM + C.kmax; x.R = x.Q + C.kmax; x.wt = x.R + C.kmax;
+    x.wm = (int *)(x.wt + C.wcap); x.wc = x.wm + C.wcap;
+    {
+        const size_t u1 = ((size_t)2 * C.kmax + C.wcap) * sizeof(double) + (size_t)2 * C.wcap * sizeof(int), u2 = (size_t)C.kgj * C.kgj * sizeof(double);
+        x.gj = C.mat ? x.Q + u1 / 8 : x.Q;                  // scalar path: the tile shares its space with Q, R and the window list
+        x.cnt = (unsigned long long *)(x.Q + ((C.mat ? u1 + u2 : (u1 > u2 ? u1 : u2)) + 7) / 8);
+    }
+    x.K = (int *)(x.cnt + C_NCOUNT); x.piv = x.K + MAXFLAV;
     x.nops = 0; x.tr_log = 0.0; x.tr_sign = 1.0; x.ms_ = 0; x.mi_ = 0;
     if (C.mat) {
         // per-wave list arrays behind the common slice; block-shared tables at the start of the dynamic LDS
-        x.om = x.K + MAXFLAV; x.osst = x.om + C.wcap; x.tsst = x.osst + C.wcap + 2;
+        x.om = x.piv + C.kmax; x.osst = x.om + C.wcap; x.tsst = x.osst + C.wcap + 2;
         x.ot = (double *)(((size_t)(x.tsst + C.wcap + 2) + 7) & ~(size_t)7);
         const int nf2 = 2 * C.nflav;
         int *ti = (int *)smem;
@@ -1271,8 +1282,11 @@ __device__ __forceinline__ void ctx_store(Ctx &x)
 // sweep kernel: nsteps iterations of the Z-space loop (CTQMC.F90:8213-8257 / 8428-8533) for every chain
 // CALIB: the loop of ctqmc_calibrate (CTQMC.F90:8121-8174): same moves, no window shift, no step counting; a chain
 // whose own calibration criterion is met does nothing
+#ifndef W2DYN_WPE
+#define W2DYN_WPE 1
+#endif
 template <int MAT, bool CALIB = false>
-__global__ __launch_bounds__(256) void k_sweep(DevConst C, long long nsteps, int count_sampling)
+__global__ __launch_bounds__(256, (MAT == 0 && !CALIB) ? W2DYN_WPE : 1) void k_sweep(DevConst C, long long nsteps, int count_sampling)
 {
     extern __shared__ unsigned char smem[];
     stage_shared_tables(C, smem);
