@@ -24,15 +24,32 @@
 // evaluating block 64*chunk+i, and handed out with v_readlane - the stream itself is unchanged.
 #pragma once
 #include <hip/hip_runtime.h>
-#ifdef W2DYN_STAMPS
+#if defined(W2DYN_STAMPS) && !defined(W2DYN_STAMPS_GLOB)
 #define DBG_STAMP(x, c) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((x).lane == 0) (x).cnt[c] += t_ - (x).tstamp; (x).tstamp = t_; } while (0)
 #define DBG_START(x) (x).tstamp = __builtin_amdgcn_s_memtime()
 #else
 #define DBG_STAMP(x, c)
 #define DBG_START(x)
 #endif
+#ifdef W2DYN_STAMPS_GLOB      // diagnostic build: the stage stamps time the global move instead of the pair moves
+#define GLOB_STAMP(x, c) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((x).lane == 0) (x).cnt[c] += t_ - (x).tstamp; (x).tstamp = t_; } while (0)
+#define GLOB_START(x) (x).tstamp = __builtin_amdgcn_s_memtime()
+#else
+#define GLOB_STAMP(x, c)
+#define GLOB_START(x)
+#endif
 #include <stdint.h>
 #include "../../include/w2dyn_rng.h"
+
+// minimum waves per SIMD asked of the compiler for the sweep kernels (second __launch_bounds__ argument).  The worm
+// kernel needs 281 registers when left alone, which halves its occupancy; held to 256 it spills 116 bytes that only the
+// rare moves touch and runs 2.4x faster (C5 worm, measured).  The matrix-path kernels gain nothing: LDS bounds them.
+#ifndef W2DYN_WPE_MAT
+#define W2DYN_WPE_MAT 1
+#endif
+#ifndef W2DYN_WPE_WORM
+#define W2DYN_WPE_WORM 2
+#endif
 
 namespace w2dyn {
 
@@ -928,50 +945,17 @@ __device__ W2DYN_INLINE void step_shift(Ctx &x)
 // global moves: CTQMC.F90:4433-4554, Trace.F90:1083-1198, 1306-1433, 2126-2188, 2279-2333
 // ---------------------------------------------------------------------------------------------------------------
 
-// log of the scalar local trace of a configuration, up to the constant Egs*beta:
-//   -int_0^beta E(n(tau)) dtau  with  E(n) = sum_f eps_f n_f + sum_{f<g} U_fg n_f n_g
-// n_f(tau) = n_f(0) + #creators before tau - #annihilators before tau.  Pair sums over operators of different
-// flavours are distributed over the lanes.  Creators of flavour f at TCb + f*fstride, annihilators at TAb + f*fstride.
-__device__ W2DYN_INLINE double full_logtrace(Ctx &x, const int *Kv, const double *TCb, const double *TAb, int fstride, int outer)
-{
-    const DevConst &C = x.C;
-    const double beta = C.beta;
-    double part = 0.0, uni_part = 0.0;
-    for (int f = 0; f < C.nflav; ++f) {
-        int k = Kv[f];
-        double n0 = (double)((outer >> flav_bit(f, C.nd)) & 1);
-        uni_part += C.eps[f] * n0 * beta;
-        const double *cf = TCb + (size_t)f * fstride, *af = TAb + (size_t)f * fstride;
-        for (int e = x.lane; e < k; e += 64) part += C.eps[f] * ((beta - cf[e]) - (beta - af[e]));
-    }
-    for (int f = 0; f < C.nflav; ++f) {
-        for (int g = f + 1; g < C.nflav; ++g) {
-            double u = C.udd[f * C.nflav + g];
-            if (u == 0.0) continue;
-            int kf = Kv[f], kg = Kv[g];
-            double nf0 = (double)((outer >> flav_bit(f, C.nd)) & 1), ng0 = (double)((outer >> flav_bit(g, C.nd)) & 1);
-            uni_part += u * nf0 * ng0 * beta;
-            const double *cf = TCb + (size_t)f * fstride, *af = TAb + (size_t)f * fstride;
-            const double *cg = TCb + (size_t)g * fstride, *ag = TAb + (size_t)g * fstride;
-            for (int e = x.lane; e < kg; e += 64) part += u * nf0 * ((beta - cg[e]) - (beta - ag[e]));
-            for (int e = x.lane; e < kf; e += 64) part += u * ng0 * ((beta - cf[e]) - (beta - af[e]));
-            int nx = 2 * kf, ny = 2 * kg;
-            for (int e = x.lane; e < nx * ny; e += 64) {
-                int ix = e / ny, iy = e - ix * ny;
-                double tx = ix < kf ? cf[ix] : af[ix - kf]; double sx = ix < kf ? 1.0 : -1.0;
-                double ty = iy < kg ? cg[iy] : ag[iy - kg]; double sy = iy < kg ? 1.0 : -1.0;
-                part += u * sx * sy * (beta - fmax(tx, ty));
-            }
-        }
-    }
-    return -(uni_part + wave_sum(part));
-}
-
 // Build F(tau_a_r - tau_c_c) of one flavour (row = annihilator slot, column = creator slot) and invert it by
 // Gauss-Jordan with partial pivoting; the result read as [creator][annihilator] is M and is stored to `A` (global,
 // row stride kmax).  Returns log|det F| and its sign in slot order.  What the reference obtains from dgetrf/dgetri
-// (Trace.F90:2279-2333, MatrixUpdate.F90:41-99).  For k <= kgj the whole elimination runs in the wave's LDS scratch
-// (compact stride k); larger matrices are eliminated in place in global memory.
+// (Trace.F90:2279-2333, MatrixUpdate.F90:41-99).
+// k <= kgj (<= 32): the elimination runs in the wave's LDS tile (compact stride k) with IMPLICIT row pivoting: rows
+// never move, lane r owns row r in the pivot search and remembers the step at which it was eliminated, the row
+// permutation sigma (sigma(p) = row eliminated at step p) is applied once when the result is written out,
+// A^-1[r][c] = W[sigma(r)][sigma^-1(c)].  Pivots, multipliers and updates are those of the row-swapping elimination,
+// so the result is the same to the last bit; what is saved is a row swap per step, the k column swaps at the end and
+// one log per pivot (taken by all lanes at once afterwards).  Larger matrices are eliminated in place in global
+// memory with explicit swaps.
 __device__ W2DYN_INLINE void build_and_invert(Ctx &x, int f, int k, const double *tcp, const double *tap, double *A,
                                  double &logdet, double &sgn)
 {
@@ -981,21 +965,59 @@ __device__ W2DYN_INLINE void build_and_invert(Ctx &x, int f, int k, const double
     logdet = 0.0; sgn = 1.0;
     if (k == 0) return;
     const bool in_lds = k <= C.kgj;
-    double *G = in_lds ? x.gj : A;                 // working matrix and its row stride
-    const int gs = in_lds ? k : kmax;
     const int kk = k * k;
     const unsigned magic = (1u << 24) / (unsigned)k + 1u;
     for (int e = x.lane; e < kk; e += 64) {
         int r = (int)(((unsigned)e * magic) >> 24), c = e - r * k;
         double v = hybr(ft, C.nftau, C.beta, tap[r] - tcp[c]);
-        if (in_lds) x.gj[r * k + c] = v; else A[(size_t)r * kmax + c] = v;
+        if (in_lds) x.gj[e] = v; else A[(size_t)r * kmax + c] = v;
     }
     wave_sync();
     int *piv = x.piv;                // kmax entries of LDS
+    if (in_lds) {
+        const bool lv = x.lane < k;
+        int pstep = -1, sig = 0;     // lane r: step at which row r was eliminated; lane p: sigma(p)
+        double dreg = 1.0;           // lane p: pivot of step p
+        for (int p = 0; p < k; ++p) {
+            const double a = lv ? x.gj[x.lane * k + p] : 0.0;          // column p, lane = row
+            const double v = (lv && pstep < 0) ? fabs(a) : -1.0;
+            const double mx = wave_max(v);
+            if (!(mx > 0.0)) { x.err |= ERR_SINGULAR; return; }
+            const int bi = __ffsll((long long)__ballot(v == mx)) - 1;
+            const double rowv = lv ? x.gj[bi * k + x.lane] : 0.0;      // pivot row, lane = column
+            const double d = readlane_d(a, bi);
+            const double id = 1.0 / d;
+            if (x.lane == bi) pstep = p;
+            if (x.lane == p) { dreg = d; sig = bi; }
+            if (lv) { x.RM[x.lane] = (x.lane == p) ? id : rowv * id; x.MQ[x.lane] = a; }   // scaled pivot row, pivot column
+            wave_sync();
+            for (int e = x.lane; e < kk; e += 64) {
+                int r = (int)(((unsigned)e * magic) >> 24), c = e - r * k;
+                double rp = x.RM[c];
+                x.gj[e] = (r == bi) ? rp : (((c == p) ? 0.0 : x.gj[e]) - x.MQ[r] * rp);
+            }
+            wave_sync();
+        }
+        logdet = wave_sum(lv ? log(fabs(dreg)) : 0.0);
+        int odd = __popcll(__ballot(lv && dreg < 0.0));
+        int inv = 0;                 // inversions of sigma^-1 (same parity as sigma = parity of the row interchanges)
+        for (int i = 0; i < k; ++i) { int pi = __builtin_amdgcn_readlane(pstep, i); inv += (lv && i < x.lane && pi > pstep) ? 1 : 0; }
+        odd += wave_sum(inv);
+        if (odd & 1) sgn = -1.0;
+        if (lv) piv[x.lane] = sig | (pstep << 16);
+        wave_sync();
+        for (int e = x.lane; e < kk; e += 64) {
+            int r = (int)(((unsigned)e * magic) >> 24), c = e - r * k;
+            A[(size_t)r * kmax + c] = x.gj[(piv[r] & 0xffff) * k + (piv[c] >> 16)];
+        }
+        wave_sync();
+        return;
+    }
+    const int gs = kmax;
     for (int p = 0; p < k; ++p) {
         double best = -1.0; int brow = p;
         for (int r = p + x.lane; r < k; r += 64) {
-            double v = fabs(in_lds ? x.gj[r * gs + p] : A[(size_t)r * gs + p]);
+            double v = fabs(A[(size_t)r * gs + p]);
             if (v > best) { best = v; brow = r; }
         }
         double mx = wave_max(best);
@@ -1004,46 +1026,34 @@ __device__ W2DYN_INLINE void build_and_invert(Ctx &x, int f, int k, const double
         int bi = __builtin_amdgcn_readlane(brow, __ffsll((long long)m) - 1);
         if (x.lane == 0) piv[p] = bi;
         if (bi != p) {
-            for (int j = x.lane; j < k; j += 64) {
-                if (in_lds) { double t = x.gj[p * gs + j]; x.gj[p * gs + j] = x.gj[bi * gs + j]; x.gj[bi * gs + j] = t; }
-                else { double t = A[(size_t)p * gs + j]; A[(size_t)p * gs + j] = A[(size_t)bi * gs + j]; A[(size_t)bi * gs + j] = t; }
-            }
+            for (int j = x.lane; j < k; j += 64) { double t = A[(size_t)p * gs + j]; A[(size_t)p * gs + j] = A[(size_t)bi * gs + j]; A[(size_t)bi * gs + j] = t; }
             sgn = -sgn;
             wave_sync();
         }
-        double d = uni(in_lds ? x.gj[p * gs + p] : A[(size_t)p * gs + p]);
+        double d = uni(A[(size_t)p * gs + p]);
         logdet += log(fabs(d)); if (d < 0.0) sgn = -sgn;
         double id = 1.0 / d;
         for (int j = x.lane; j < k; j += 64) {
-            double rv = in_lds ? x.gj[p * gs + j] : A[(size_t)p * gs + j];
-            double cv = in_lds ? x.gj[j * gs + p] : A[(size_t)j * gs + p];
+            double rv = A[(size_t)p * gs + j];
+            double cv = A[(size_t)j * gs + p];
             x.RM[j] = (j == p) ? id : rv * id;            // scaled pivot row
             x.MQ[j] = cv;                                  // pivot column
         }
         wave_sync();
-        if (in_lds) {
-            for (int e = x.lane; e < kk; e += 64) {
-                int r = (int)(((unsigned)e * magic) >> 24), c = e - r * k;
-                double rp = x.RM[c];
-                double v = (r == p) ? rp : (((c == p) ? 0.0 : x.gj[e]) - x.MQ[r] * rp);
-                x.gj[e] = v;
+        for (int e0 = 0; e0 < kk; e0 += 256) {
+            double mv[4]; int rv[4], cv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int e = e0 + u * 64 + x.lane; int ec = e < kk ? e : kk - 1;
+                int r = (int)(((unsigned)ec * magic) >> 24), c = ec - r * k;
+                rv[u] = r; cv[u] = c; mv[u] = A[(size_t)r * kmax + c];
             }
-        } else {
-            for (int e0 = 0; e0 < kk; e0 += 256) {
-                double mv[4]; int rv[4], cv[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    int e = e0 + u * 64 + x.lane; int ec = e < kk ? e : kk - 1;
-                    int r = (int)(((unsigned)ec * magic) >> 24), c = ec - r * k;
-                    rv[u] = r; cv[u] = c; mv[u] = A[(size_t)r * kmax + c];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    int e = e0 + u * 64 + x.lane;
-                    if (e < kk) {
-                        double rp = x.RM[cv[u]];
-                        A[(size_t)rv[u] * kmax + cv[u]] = (rv[u] == p) ? rp : (((cv[u] == p) ? 0.0 : mv[u]) - x.MQ[rv[u]] * rp);
-                    }
+            for (int u = 0; u < 4; ++u) {
+                int e = e0 + u * 64 + x.lane;
+                if (e < kk) {
+                    double rp = x.RM[cv[u]];
+                    A[(size_t)rv[u] * kmax + cv[u]] = (rv[u] == p) ? rp : (((cv[u] == p) ? 0.0 : mv[u]) - x.MQ[rv[u]] * rp);
                 }
             }
         }
@@ -1052,19 +1062,9 @@ __device__ W2DYN_INLINE void build_and_invert(Ctx &x, int f, int k, const double
     for (int p = k - 1; p >= 0; --p) {    // undo the row interchanges as column interchanges
         int bi = uni(piv[p]);
         if (bi != p) {
-            for (int r = x.lane; r < k; r += 64) {
-                if (in_lds) { double t = x.gj[r * gs + p]; x.gj[r * gs + p] = x.gj[r * gs + bi]; x.gj[r * gs + bi] = t; }
-                else { double t = A[(size_t)r * gs + p]; A[(size_t)r * gs + p] = A[(size_t)r * gs + bi]; A[(size_t)r * gs + bi] = t; }
-            }
+            for (int r = x.lane; r < k; r += 64) { double t = A[(size_t)r * gs + p]; A[(size_t)r * gs + p] = A[(size_t)r * gs + bi]; A[(size_t)r * gs + bi] = t; }
             wave_sync();
         }
-    }
-    if (in_lds) {
-        for (int e = x.lane; e < kk; e += 64) {
-            int r = (int)(((unsigned)e * magic) >> 24), c = e - r * k;
-            A[(size_t)r * kmax + c] = x.gj[e];
-        }
-        wave_sync();
     }
 }
 
@@ -1076,11 +1076,71 @@ __device__ W2DYN_INLINE double sort_parity(Ctx &x, const double *t, int k)
     return (wave_sum(inv) & 1) ? -1.0 : 1.0;
 }
 
+// Scalar local trace of the current configuration and of its relabelled image under a global move, both from one pass.
+// log tr = -int_0^beta E(n(tau)) dtau, E(n) = sum_f eps_f n_f + sum_{f<g} U_fg n_f n_g, up to the constant Egs*beta, with
+// n_f(tau) = n_f(0) + #creators before tau - #annihilators before tau:
+//   log tr = -[ sum_f eps_f (n0_f beta + S_f) + sum_{f<g} U_fg (n0_f n0_g beta + n0_f S_g + n0_g S_f + D_fg) ]
+//   S_f  = sum over pairs of f of (ta - tc)                        (occupied length beyond the tau=0 occupation)
+//   D_fg = sum_{x in f, y in g} s_x s_y (beta - max(t_x, t_y))     (s = +1 creator, -1 annihilator)
+// A flavour relabelling f -> gmap[f] only relabels S and D; exchanging creators and annihilators flips the sign of
+// S and leaves D as it is, so D_fg is evaluated once (lane = operator y of g, loop over the operators x of f in LDS)
+// and enters both traces with its own coupling.
+__device__ W2DYN_INLINE void glob_logtraces(Ctx &x, const int *gmap, bool flip, int outer_new, double &ltr_old, double &ltr_new)
+{
+    const DevConst &C = x.C;
+    const int nf = C.nflav, nd = C.nd;
+    const double beta = C.beta;
+    double sreg = 0.0;                               // lane f: S_f
+    for (int f = 0; f < nf; ++f) {
+        const int k = x.order(f);
+        const double *cf = x.tc(f), *af = x.ta(f);
+        double p = 0.0;
+        for (int e = x.lane; e < k; e += 64) p += (beta - cf[e]) - (beta - af[e]);
+        p = wave_sum(p);
+        if (x.lane == f) sreg = p;
+    }
+    double uo = 0.0, un = 0.0, po = 0.0, pn = 0.0;   // wave-uniform parts, per-lane parts (old / new)
+    for (int f = 0; f < nf; ++f) {
+        const int gf = gmap[f];
+        const double sf = readlane_d(sreg, f), sfn = flip ? -sf : sf;
+        const double nf0 = (double)((x.outer >> flav_bit(f, nd)) & 1), nfn = (double)((outer_new >> flav_bit(gf, nd)) & 1);
+        uo += C.eps[f] * (nf0 * beta + sf);
+        un += C.eps[gf] * (nfn * beta + sfn);
+        const int kf = x.order(f);
+        const double *cf = x.tc(f), *af = x.ta(f);
+        for (int g = f + 1; g < nf; ++g) {
+            const int gg = gmap[g];
+            const double u_old = C.udd[f * nf + g], u_new = C.udd[gf * nf + gg];
+            if (u_old == 0.0 && u_new == 0.0) continue;
+            const double sg = readlane_d(sreg, g), sgn_ = flip ? -sg : sg;
+            const double ng0 = (double)((x.outer >> flav_bit(g, nd)) & 1), ngn = (double)((outer_new >> flav_bit(gg, nd)) & 1);
+            uo += u_old * (nf0 * ng0 * beta + nf0 * sg + ng0 * sf);
+            un += u_new * (nfn * ngn * beta + nfn * sgn_ + ngn * sfn);
+            const int kg = x.order(g);
+            if (kf == 0 || kg == 0) continue;
+            const double *cg = x.tc(g), *ag = x.ta(g);
+            for (int base = 0; base < 2 * kg; base += 64) {
+                const int iy = base + x.lane;
+                if (iy < 2 * kg) {
+                    const double ty = iy < kg ? cg[iy] : ag[iy - kg];
+                    double dc = 0.0, da = 0.0;
+                    for (int ix = 0; ix < kf; ++ix) { dc += beta - fmax(cf[ix], ty); da += beta - fmax(af[ix], ty); }
+                    const double t = iy < kg ? dc - da : da - dc;
+                    po += u_old * t; pn += u_new * t;
+                }
+            }
+        }
+    }
+    ltr_old = -(uo + wave_sum(po));
+    ltr_new = -(un + wave_sum(pn));
+}
+
 __device__ W2DYN_INLINE void step_glob(Ctx &x)
 {
     const DevConst &C = x.C;
     const int nf = C.nflav, nd = C.nd, kmax = C.kmax;
     x.count(C_TRYGLOB);
+    GLOB_START(x);
     int nops = 0;
     for (int f = 0; f < nf; ++f) nops += 2 * x.order(f);
     if (nops == 0) return;
@@ -1095,26 +1155,30 @@ __device__ W2DYN_INLINE void step_glob(Ctx &x)
         for (int j = 1; j <= nf; ++j) { int i = x.randint(j, nf); int t = gu[j]; gu[j] = gu[i]; gu[i] = t; }
         gu[0] = x.randint(0, 1);
     }
-    // relabelled copy of the tau arrays in scratch: TS[g][0] = creators, TS[g][1] = annihilators of new flavour g
+    const bool flip = gu[0] != 0;
+    // relabelling: old flavour f becomes gmap[f]; new flavour g comes from fsrc[g].  The new configuration is read from
+    // the old tau arrays in LDS (creators and annihilators exchanged when flip); a copy goes to scratch
+    // (TS[g][0] = creators, TS[g][1] = annihilators of new flavour g) for the installation after acceptance.
     double *TS = C.TS + (size_t)x.w * nf * 2 * kmax;
-    int Kn[MAXFLAV], Ko[MAXFLAV];
+    int gmap[MAXFLAV], fsrc[MAXFLAV];
     for (int f = 0; f < nf; ++f) {
         int num = (f >> 1) + nd * (f & 1) + 1;
         int t = gu[num];
         int g = 2 * ((t - 1) % nd) + (t - 1) / nd;
         int k = x.order(f);
-        Kn[g] = k; Ko[f] = k;
-        const double *srcc = gu[0] ? x.ta(f) : x.tc(f), *srca = gu[0] ? x.tc(f) : x.ta(f);
+        gmap[f] = g; fsrc[g] = f;
+        const double *srcc = flip ? x.ta(f) : x.tc(f), *srca = flip ? x.tc(f) : x.ta(f);
         for (int e = x.lane; e < k; e += 64) { TS[(size_t)(2 * g) * kmax + e] = srcc[e]; TS[(size_t)(2 * g + 1) * kmax + e] = srca[e]; }
     }
-    wave_sync();
     // quantum numbers: occupancy of flavour g at tau=0 is fixed by its first operator, free if it has none
     int fixed = 0, freemask = 0;
     for (int g = 0; g < nf; ++g) {
-        int k = Kn[g];
+        const int f = fsrc[g];
+        int k = x.order(f);
         if (k == 0) { freemask |= 1 << flav_bit(g, nd); continue; }
+        const double *srcc = flip ? x.ta(f) : x.tc(f), *srca = flip ? x.tc(f) : x.ta(f);
         double mc = 1e300, ma = 1e300;
-        for (int e = x.lane; e < k; e += 64) { mc = fmin(mc, TS[(size_t)(2 * g) * kmax + e]); ma = fmin(ma, TS[(size_t)(2 * g + 1) * kmax + e]); }
+        for (int e = x.lane; e < k; e += 64) { mc = fmin(mc, srcc[e]); ma = fmin(ma, srca[e]); }
         mc = wave_min(mc); ma = wave_min(ma);
         if (ma < mc) fixed |= 1 << flav_bit(g, nd);
     }
@@ -1131,37 +1195,57 @@ __device__ W2DYN_INLINE void step_glob(Ctx &x)
         outer_new = fixed;
         for (int b = 0, used = 0; b < 2 * nd; ++b) if ((freemask >> b) & 1) { if ((kk >> used) & 1) outer_new |= 1 << b; ++used; }
     }
+    GLOB_STAMP(x, C_DBG0);
     if (sst_factor == 0.0) { x.count(C_QNGLOB); return; }
 
+    double ltr_old, ltr_new;
+    glob_logtraces(x, gmap, flip, outer_new, ltr_old, ltr_new);
+    GLOB_STAMP(x, C_DBG3);
     // new inverse matrices into the second buffer, determinant in the reference's time order
     double *MBw = C.MB + (size_t)x.w * nf * kmax * kmax;
     double logdet_new = 0.0, sign_new = 1.0;
     for (int g = 0; g < nf; ++g) {
         double ld, sg;
-        const double *tcg = TS + (size_t)(2 * g) * kmax, *tag = TS + (size_t)(2 * g + 1) * kmax;
-        build_and_invert(x, g, Kn[g], tcg, tag, MBw + (size_t)g * kmax * kmax, ld, sg);
-        if (Kn[g] > 0) sg *= sort_parity(x, tcg, Kn[g]) * sort_parity(x, tag, Kn[g]);
+        const int f = fsrc[g], k = x.order(f);
+        const double *tcg = flip ? x.ta(f) : x.tc(f), *tag = flip ? x.tc(f) : x.ta(f);
+        build_and_invert(x, g, k, tcg, tag, MBw + (size_t)g * kmax * kmax, ld, sg);
+        GLOB_STAMP(x, C_DBG1);
+        if (k > 0) sg *= sort_parity(x, tcg, k) * sort_parity(x, tag, k);
+        GLOB_STAMP(x, C_DBG2);
         logdet_new += ld; sign_new *= sg;
     }
-    double ltr_old = full_logtrace(x, Ko, x.tc_, x.ta_, kmax, x.outer);
-    double ltr_new = full_logtrace(x, Kn, TS, TS + kmax, 2 * kmax, outer_new);
     double rnd = x.draw();
     if (x.err & ERR_SINGULAR) return;
     double ratio = fabs(exp((ltr_new - ltr_old) + (logdet_new - x.det_log)) * sst_factor);
     if (!(rnd < ratio)) return;
     // accept: install relabelled taus and new matrices
+    const int kold = x.kreg;         // lane f: order of old flavour f
+    wave_sync();
     for (int g = 0; g < nf; ++g) {
-        int k = Kn[g];
+        const int k = __builtin_amdgcn_readlane(kold, fsrc[g]);
         double *tcp = x.tc(g), *tap = x.ta(g), *Mg = x.mat(g);
         const double *Mn = MBw + (size_t)g * kmax * kmax;
         for (int e = x.lane; e < k; e += 64) { tcp[e] = TS[(size_t)(2 * g) * kmax + e]; tap[e] = TS[(size_t)(2 * g + 1) * kmax + e]; }
-        for (int j0 = 0; j0 < k; j0 += 64) { int j = j0 + x.lane; if (j < k) for (int i = 0; i < k; ++i) Mg[(size_t)i * kmax + j] = Mn[(size_t)i * kmax + j]; }
+        const int kk = k * k;
+        const unsigned magic = k > 0 ? (1u << 24) / (unsigned)k + 1u : 0u;
+        for (int e0 = 0; e0 < kk; e0 += 256) {
+            double mv[4]; int ov[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int e = e0 + u * 64 + x.lane; int ec = e < kk ? e : kk - 1;
+                int i = (int)(((unsigned)ec * magic) >> 24), j = ec - i * k;
+                ov[u] = i * kmax + j; mv[u] = Mn[ov[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { int e = e0 + u * 64 + x.lane; if (e < kk) Mg[ov[u]] = mv[u]; }
+        }
         x.set_order(g, k);
     }
     wave_sync();
     x.outer = outer_new;
     x.det_log = logdet_new; x.det_sign = sign_new;
     x.npairs = -1;
+    GLOB_STAMP(x, C_DBG4);
     x.count(C_ACCGLOB);
 }
 
@@ -1285,8 +1369,9 @@ __device__ __forceinline__ void ctx_store(Ctx &x)
 #ifndef W2DYN_WPE
 #define W2DYN_WPE 1
 #endif
+
 template <int MAT, bool CALIB = false>
-__global__ __launch_bounds__(256, (MAT == 0 && !CALIB) ? W2DYN_WPE : 1) void k_sweep(DevConst C, long long nsteps, int count_sampling)
+__global__ __launch_bounds__(256, (MAT == 0 && !CALIB) ? W2DYN_WPE : (MAT != 0 && !CALIB) ? W2DYN_WPE_MAT : 1) void k_sweep(DevConst C, long long nsteps, int count_sampling)
 {
     extern __shared__ unsigned char smem[];
     stage_shared_tables(C, smem);

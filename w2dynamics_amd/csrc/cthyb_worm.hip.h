@@ -208,7 +208,7 @@ __device__ W2DYN_INLINE void step_worm_replace(Ctx &x)
 }
 
 // sweep kernel with worm sampling (scalar trace path): Z space CTQMC.F90:8431-8488, worm space 8489-8528
-__global__ __launch_bounds__(256) void k_sweep_worm(DevConst C, long long nsteps)
+__global__ __launch_bounds__(256, W2DYN_WPE_WORM) void k_sweep_worm(DevConst C, long long nsteps)
 {
     extern __shared__ unsigned char smem[];
     Ctx x(C);
