@@ -44,6 +44,19 @@ TRAJ = [
                               "C4S-kanamori-allmoves", "C3Q-coarse-blocks-allmoves", "C4-kanamori-default"])
 def test_chains_retrace_oracle(cfg, nftau, over, seed):
     """Every chain: same configuration, M, sign, window and NPairs after warm-up; same estimators after sampling."""
+    _retrace(cfg, nftau, over, seed)
+
+
+@pytest.mark.parametrize("in_lds", ["1", "0"])
+def test_matrix_path_lds_layouts_retrace_oracle(monkeypatch, in_lds):
+    """The matrix path has two LDS layouts (operator matrices staged in LDS at one workgroup per CU, or left in global
+    memory at two workgroups per CU; the host picks by size).  Both must retrace the oracle."""
+    monkeypatch.setenv("W2DYN_MAT_OPS_IN_LDS", in_lds)
+    cfg, nftau, over, seed = TRAJ[5]
+    _retrace(cfg, nftau, over, seed + 1)
+
+
+def _retrace(cfg, nftau, over, seed):
     p, ps, pset = util.setup(cfg, nftau, over)
     nw = 6
     q = make_gpu(p, ps, seed, nw)

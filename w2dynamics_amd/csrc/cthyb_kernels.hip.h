@@ -43,9 +43,10 @@
 
 // minimum waves per SIMD asked of the compiler for the sweep kernels (second __launch_bounds__ argument).  The worm
 // kernel needs 281 registers when left alone, which halves its occupancy; held to 256 it spills 116 bytes that only the
-// rare moves touch and runs 2.4x faster (C5 worm, measured).  The matrix-path kernels gain nothing: LDS bounds them.
+// rare moves touch and runs 2.4x faster (C5 worm, measured).  The matrix-path kernels (264-324 registers when left alone,
+// 36-276 bytes spilled at 256) gain as much once the host picks the LDS layout that lets two workgroups share a CU.
 #ifndef W2DYN_WPE_MAT
-#define W2DYN_WPE_MAT 1
+#define W2DYN_WPE_MAT 2
 #endif
 #ifndef W2DYN_WPE_WORM
 #define W2DYN_WPE_WORM 2

@@ -423,7 +423,14 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
         size_t ints = ((size_t)lp.nsst * nf * 2 + 2 * (size_t)lp.nsst) * sizeof(int);
         ints = (ints + 7) & ~(size_t)7;
         size_t small = ints + (size_t)s->nstates * sizeof(double);
-        C.op_in_lds = (small + nop * sizeof(double) <= 64 * 1024) ? 1 : 0;
+        // Occupancy first: when two workgroups (2 waves per SIMD) fit into the CU's 160 KB with the operator matrices left
+        // in global memory (they are L2 resident) and a 16x16 Gauss-Jordan tile, take that layout: measured 1.55x on the
+        // t2g Kanamori problem against operators staged in LDS at one wave per SIMD.  W2DYN_MAT_OPS_IN_LDS=1/0 overrides.
+        const size_t per_wave16 = lds_bytes_per_wave(nf, kmax, C.wcap, std::min(C.kgj, 16), 1);
+        bool two_groups = ((small + 15) & ~(size_t)15) + 4 * per_wave16 <= 80 * 1024;
+        if (const char *e = getenv("W2DYN_MAT_OPS_IN_LDS")) two_groups = (atoi(e) == 0);
+        if (two_groups) C.kgj = std::min(C.kgj, 16);
+        C.op_in_lds = (!two_groups && small + nop * sizeof(double) <= 64 * 1024) ? 1 : 0;
         C.shared_lds = (int)((small + (C.op_in_lds ? nop * sizeof(double) : 0) + 15) & ~(size_t)15);
     }
     C.lds_per_wave = (int)lds_bytes_per_wave(nf, kmax, C.wcap, C.kgj, C.mat);
