@@ -87,6 +87,7 @@ struct WalkerScalars {
 
 struct DevConst {
     int nd, nflav, nstates, nftau, ntau, nleg, niw2, kmax, nwalkers, num_windows, nslide, has_szt, maxhisto;
+    int lane_shift;          // log2 of the lanes that share one flavour in level_integral: 64 / (nflav rounded up to a power of two)
     int walkers_per_bin, nbins, lds_per_wave, wcap, kgj;   // lds_per_wave in bytes; wcap: window-list capacity; kgj: LDS inversion order limit
     double beta, taudiff_max, p_glob, p_shift, egs;
     unsigned long long seed, first_walker;
@@ -377,38 +378,39 @@ __device__ W2DYN_INLINE int build_window(Ctx &x)
     return total;
 }
 
-// integral over (lo,hi) of  eps_f + sum_g U_fg n_g(tau)   for the current configuration (flavour f itself excluded)
+// integral over (lo,hi) of  eps_f + sum_g U_fg n_g(tau)   for the current configuration (flavour f itself excluded).
+// All other flavours are handled in one pass: the 64 lanes are split into groups of 2^lane_shift lanes, one group per
+// flavour, each lane striding over its flavour's pairs; the coupling U_fg is loaded per lane while the loop runs.
 template <bool WORM = false>
 __device__ W2DYN_INLINE double level_integral(Ctx &x, int f, double lo, double hi)
 {
     const DevConst &C = x.C;
-    double part = 0.0;
-    double base = C.eps[f];
+    const int g = x.lane >> C.lane_shift, sub = x.lane & ((1 << C.lane_shift) - 1);
+    const bool act = g < C.nflav && g != f;
+    const int gc = act ? g : 0;
+    const double u = act ? C.udd[f * C.nflav + gc] : 0.0;
+    const int kall = __builtin_amdgcn_ds_bpermute(gc << 2, x.kreg);     // by all lanes: a masked-off source lane would read as 0
+    const int k = act ? kall : 0;
+    const double *tcp = x.tc_ + gc * C.kmax, *tap = x.ta_ + gc * C.kmax;
+    double acc = (act && sub == 0 && ((x.outer >> flav_bit(gc, C.nd)) & 1)) ? hi - lo : 0.0;
+    for (int e = sub; e < k; e += 1 << C.lane_shift) {
+        double c = fmin(fmax(tcp[e], lo), hi), a = fmin(fmax(tap[e], lo), hi);
+        acc += (hi - c) - (hi - a);
+    }
+    double part = u * acc;
     if constexpr (WORM) {
         // worm operators of the other flavours change the occupations too (wormContainer order: c, c+, c, c+)
         if (x.sector == 4 && x.lane == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int g = x.wfl[i];
-                if (g == f) continue;
+                const int gw = x.wfl[i];
+                if (gw == f) continue;
                 const double t = fmin(fmax(x.wtau[i], lo), hi);
-                part += ((i & 1) ? 1.0 : -1.0) * C.udd[f * C.nflav + g] * (hi - t);
+                part += ((i & 1) ? 1.0 : -1.0) * C.udd[f * C.nflav + gw] * (hi - t);
             }
         }
     }
-    for (int g = 0; g < C.nflav; ++g) {
-        if (g == f) continue;
-        double u = C.udd[f * C.nflav + g];
-        if (u == 0.0) continue;
-        int k = x.order(g);
-        if ((x.outer >> flav_bit(g, C.nd)) & 1) base += u;
-        const double *tcp = x.tc(g), *tap = x.ta(g);
-        for (int e = x.lane; e < k; e += 64) {
-            double c = fmin(fmax(tcp[e], lo), hi), a = fmin(fmax(tap[e], lo), hi);
-            part += u * ((hi - c) - (hi - a));
-        }
-    }
-    return base * (hi - lo) + wave_sum(part);
+    return C.eps[f] * (hi - lo) + wave_sum(part);
 }
 
 template <bool CALIB>

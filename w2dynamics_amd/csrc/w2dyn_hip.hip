@@ -408,6 +408,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     C.walkers_per_bin = s->walkers_per_bin; C.nbins = (s->nwalkers + s->walkers_per_bin - 1) / s->walkers_per_bin;
     C.wcap = std::max(kmax, std::min(2 * nf * kmax, 256));
     C.kgj = std::min(kmax, 32);
+    { int G = 1, sh = 6; while (G < nf) { G <<= 1; --sh; } C.lane_shift = sh; }
     C.nouter = nouter; C.dmsize = s->dmoff[nouter]; C.mat = s->mat ? 1 : 0; C.nsst = lp.nsst; C.nsm = lp.nsmax;
     C.shared_lds = 0; C.op_in_lds = 0;
     std::vector<double> opmat;
