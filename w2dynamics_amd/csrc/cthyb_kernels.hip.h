@@ -378,6 +378,83 @@ __device__ W2DYN_INLINE int build_window(Ctx &x)
     return total;
 }
 
+// Accepted pair moves keep the register-resident window list current instead of invalidating it (a rebuild costs a
+// scan of every flavour plus two passes over the list).  The list order is irrelevant to its users (pairs are enumerated
+// by time), so new operators are appended and removed ones are filled from the tail.  Partner counts c and prefix counts
+// P (pairs whose earlier operator precedes the entry) are corrected by what the two operators change; the result is
+// what build_window computes for the new configuration.  Lists beyond 64 entries (LDS) are still rebuilt.
+__device__ W2DYN_INLINE void window_list_add(Ctx &x, int f, int slot, double tnc, double tna)
+{
+    const int nw = x.nwin;
+    if (!x.wvalid || nw + 2 > 64) { x.wvalid = 0; return; }
+    const double tm = x.C.taudiff_max;
+    const bool live = x.lane < nw;
+    const double te = x.wr_t, thi = te + tm;
+    const int fc = x.wr_m & 0xffff;
+    const bool isa = live && fc == (f | 0x200), isc = live && fc == (f | 0x100);
+    // an entry gains a partner for each new operator of the other type at a later time within taudiff_max
+    const int inc = ((isa && tnc > te && !(tnc > thi)) ? 1 : 0) + ((isc && tna > te && !(tna > thi)) ? 1 : 0);
+    const int cnc = __popcll(__ballot(isa && te > tnc && !(te > tnc + tm))) + ((tna > tnc && !(tna > tnc + tm)) ? 1 : 0);
+    const int cna = __popcll(__ballot(isc && te > tna && !(te > tna + tm))) + ((tnc > tna && !(tnc > tna + tm)) ? 1 : 0);
+    int c = x.wr_c + inc, P = x.wr_p;
+    unsigned long long mk = __ballot(inc != 0);
+    while (mk) {
+        const int q = __ffsll((long long)mk) - 1; mk &= mk - 1ull;
+        const double tq = readlane_d(te, q); const int iq = __builtin_amdgcn_readlane(inc, q);
+        P += (tq < te) ? iq : 0;
+    }
+    P += ((tnc < te) ? cnc : 0) + ((tna < te) ? cna : 0);
+    const int Pnc = wave_sum((live && te < tnc) ? c : 0) + ((tna < tnc) ? cna : 0);
+    const int Pna = wave_sum((live && te < tna) ? c : 0) + ((tnc < tna) ? cnc : 0);
+    if (x.lane == nw) { x.wr_t = tnc; x.wr_m = f | 0x100 | (slot << 16); c = cnc; P = Pnc; }
+    if (x.lane == nw + 1) { x.wr_t = tna; x.wr_m = f | 0x200 | (slot << 16); c = cna; P = Pna; }
+    x.wr_c = c; x.wr_p = P;
+    x.nwin = nw + 2;
+}
+
+// e1, e2: list entries of the removed pair; ic / ia: its creator / annihilator slot; last: slot that moves into the hole
+__device__ W2DYN_INLINE void window_list_rem(Ctx &x, int f, int e1, int e2, int ic, int ia, int last, double tau_c, double tau_a)
+{
+    const int nw = x.nwin;
+    if (!x.wvalid || nw > 64 || e1 < 0 || e2 < 0) { x.wvalid = 0; return; }
+    const double tm = x.C.taudiff_max;
+    const bool live = x.lane < nw && x.lane != e1 && x.lane != e2;
+    double te = x.wr_t; const double thi = te + tm;
+    int me = x.wr_m, c = x.wr_c, P = x.wr_p;
+    const int fc = me & 0xffff;
+    const bool isa = live && fc == (f | 0x200), isc = live && fc == (f | 0x100);
+    const int dec = ((isa && tau_c > te && !(tau_c > thi)) ? 1 : 0) + ((isc && tau_a > te && !(tau_a > thi)) ? 1 : 0);
+    const int c1 = __builtin_amdgcn_readlane(c, e1), c2 = __builtin_amdgcn_readlane(c, e2);
+    const double t1 = readlane_d(te, e1), t2 = readlane_d(te, e2);
+    P -= ((t1 < te) ? c1 : 0) + ((t2 < te) ? c2 : 0);
+    unsigned long long mk = __ballot(dec != 0);
+    while (mk) {
+        const int q = __ffsll((long long)mk) - 1; mk &= mk - 1ull;
+        const double tq = readlane_d(te, q); const int dq = __builtin_amdgcn_readlane(dec, q);
+        P -= (tq < te) ? dq : 0;
+    }
+    c -= dec;
+    // swap-with-last of the slot arrays: the operators that sat in slot `last` now sit in the freed slots
+    if (isc && (me >> 16) == last) me = fc | (ic << 16);
+    if (isa && (me >> 16) == last) me = fc | (ia << 16);
+    // fill the two holes from the tail
+    const int h0 = e1 < e2 ? e1 : e2, h1 = e1 < e2 ? e2 : e1, nn = nw - 2;
+    int d0 = -1, s0 = 0, d1 = -1, s1 = 0;
+    if (h1 < nn) { d0 = h0; s0 = nn; d1 = h1; s1 = nn + 1; }
+    else if (h0 < nn) { d0 = h0; s0 = (h1 == nn) ? nn + 1 : nn; }
+    if (d0 >= 0) {
+        const double tv = readlane_d(te, s0); const int mv = __builtin_amdgcn_readlane(me, s0), cv = __builtin_amdgcn_readlane(c, s0), pv = __builtin_amdgcn_readlane(P, s0);
+        if (x.lane == d0) { te = tv; me = mv; c = cv; P = pv; }
+    }
+    if (d1 >= 0) {
+        const double tv = readlane_d(te, s1); const int mv = __builtin_amdgcn_readlane(me, s1), cv = __builtin_amdgcn_readlane(c, s1), pv = __builtin_amdgcn_readlane(P, s1);
+        if (x.lane == d1) { te = tv; me = mv; c = cv; P = pv; }
+    }
+    if (x.lane >= nn) { te = -1.0; me = -1; c = 0; P = 0; }
+    x.wr_t = te; x.wr_m = me; x.wr_c = c; x.wr_p = P;
+    x.nwin = nn;
+}
+
 // integral over (lo,hi) of  eps_f + sum_g U_fg n_g(tau)   for the current configuration (flavour f itself excluded).
 // All other flavours are handled in one pass: the 64 lanes are split into groups of 2^lane_shift lanes, one group per
 // flavour, each lane striding over its flavour's pairs; the coupling U_fg is loaded per lane while the loop runs.
@@ -650,7 +727,7 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
     x.det_sign *= (S < 0.0 ? -1.0 : 1.0) * sig;
     x.det_log += log(fabs(S));
     x.npairs = np_new;
-    x.wvalid = 0;
+    window_list_add(x, f, k, tau2, tau1);
     if constexpr (MAT) { x.tr_log = tl_new; x.tr_sign = ts_new; mat_commit_sst(x); }
     DBG_STAMP(x, C_DBG7);
     if (WORM && x.sector == 4) x.count(C_W_ACCADD); else x.count(C_ACCADD);
@@ -677,6 +754,7 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
     // first operator of the pick-th pair in the reference's enumeration (time order of the earlier operator),
     // then its rnk-th partner in time order
     double t1, t2; int m1, m2;
+    int e1 = -1, e2 = -1;                                // list entries of the pair (register-resident list only)
     if (nw <= 64) {
         const double te = x.wr_t; const int me = x.wr_m, ce = x.wr_c, P = x.wr_p;
         const bool live = x.lane < nw;
@@ -697,6 +775,7 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
         unsigned long long hm = __ballot(partner && r == rnk - 1);
         int qstar = __ffsll((long long)hm) - 1;
         t2 = readlane_d(te, qstar); m2 = __builtin_amdgcn_readlane(me, qstar);
+        e1 = estar; e2 = qstar;
     } else {
         int estar = -1, rnk = 0;
         for (int base = 0; base < nw; base += 64) {
@@ -854,7 +933,7 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
     x.det_sign *= (S < 0.0 ? -1.0 : 1.0) * sig;
     x.det_log += log(fabs(S));
     x.npairs = np - dnp;
-    x.wvalid = 0;
+    window_list_rem(x, f, e1, e2, ic, ia, last, tau_c, tau_a);
     if constexpr (MAT) { mat_remove(x, i2); mat_remove(x, i1); x.tr_log = tl_new; x.tr_sign = ts_new; mat_commit_sst(x); }
     if (WORM && x.sector == 4) x.count(C_W_ACCREM); else x.count(C_ACCREM);
     accpair_add<CALIB>(x, f, t2 - t1);
