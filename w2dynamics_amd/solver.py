@@ -18,6 +18,7 @@ import time
 import numpy as np
 
 from . import params as _params
+from . import postproc as _postproc
 from .mctqmc import MCTQMC
 from .statistics import DistributedSample, TorchComm
 
@@ -36,6 +37,7 @@ class HipCtHybSolver:
                             kmax=kmax, walkers_per_bin=walkers_per_bin)
         self.ctqmc.init_rnd(seed)
         self.ctqmc.fancy_prog = False
+        self.fttype = "legendre"         # [General] FTType of the reference's configuration (impurity.py:1054)
 
     def set_problem(self, problem, compute_fourpoint=0):
         """problem: w2dynamics_amd.synth.Problem (arrays already in init_solver layout, muimp negated)."""
@@ -70,9 +72,28 @@ class HipCtHybSolver:
         result["accept-rem"] = DistributedSample(np.array([q.accrem]), self.comm)
         result["rho1"] = DistributedSample(np.array([q.rho1]), self.comm)
         result["rho2"] = DistributedSample(np.array([q.rho2]), self.comm)
+        # Green's function for the Dyson equation, (iw, band, spin, band, spin), one sample per accumulator bin
+        # (impurity.py:611-619), and the self-energy moments from rho1 / rho2 (impurity.py:628-640)
+        niw = 2 * int(self.qmc["Niw"])
+        fttype = "none" if (self.fttype == "none" and self.qmc["MeasGiw"]) else "legendre"
+        src = q.giw_bins if fttype == "none" else q.gleg_bins
+        key = "giw-meas" if fttype == "none" else "gleg"
+        result["giw"] = DistributedSample(np.array([_postproc.get_giw({key: b}, niw, fttype) for b in src]), self.comm)
+        nfl = 2 * p.nd
+        result["smom"] = DistributedSample(np.array([_postproc.lattice_convention(
+            _postproc.get_siw_mom(np.asarray(p.umatrix).reshape((nfl,) * 4), q.rho1, q.rho2))]), self.comm)
         result["time-qmc"] = time.perf_counter() - t0
         q.dest_ctqmc()
         q.dest_paras()
+        return result
+
+    def postprocessing(self, result, g0inviw=None):
+        """`ImpurityResult.postprocessing(siw_method="dyson", smom_method="estimate")` (impurity.py:208-225): adds
+        result["siw"] = G0^-1 - G^-1 as jackknife pseudovalues over the accumulator bins of all ranks."""
+        niw = 2 * int(self.qmc["Niw"])
+        if g0inviw is None:
+            g0inviw = self.problem.g0inviw(niw)
+        result["siw"] = _postproc.siw_dyson(result["giw"], g0inviw, diagonal_only=True)
         return result
 
     def solve_component(self, iter_no, isector, icomponent, mc_config_inout=None):

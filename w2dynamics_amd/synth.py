@@ -63,7 +63,7 @@ class Problem:
     """One impurity problem in the layout `init_solver` expects."""
 
     def __init__(self, nd, beta, umatrix, ftau_full, muimp_full_negated, hamiltonian="Density",
-                 quantum_numbers="Nt Szt Azt"):
+                 quantum_numbers="Nt Szt Azt", bath_scale=None, bath_D=1.0):
         self.nd = nd
         self.beta = float(beta)
         self.umatrix = np.ascontiguousarray(umatrix, dtype=np.float64)
@@ -72,6 +72,16 @@ class Problem:
         self.screening = np.zeros_like(self.ftau)
         self.hamiltonian = hamiltonian
         self.quantum_numbers = quantum_numbers
+        self.bath_scale = np.ones(nd) if bath_scale is None else np.asarray(bath_scale, dtype=float)   # F_b = scale_b * F_Bethe
+        self.bath_D = bath_D
+
+    def g0inviw(self, niw):
+        """Inverse Weiss field G0^-1(iw) = iw + mu - Delta(iw) of this problem on `niw` fermionic frequencies, in the
+        caller's layout (iw, band, spin, band, spin) (`ImpurityProblem.g0inviw`, w2dyn/dmft/impurity.py:123)."""
+        from . import postproc
+        fiw = postproc.bethe_fiw(self.beta, niw, self.bath_D)[:, None, None] * self.bath_scale[None, :, None] * np.ones((1, 1, 2))
+        mu = -np.einsum("bsbs->bs", self.muimp)          # init_solver receives -mu
+        return postproc.g0inviw_diagonal(self.beta, niw, mu, fiw)
 
     @property
     def nftau(self):
@@ -92,14 +102,16 @@ def make_problem(nd: int, beta: float, u: float, j: float = 0.0, v: float | None
     f = bethe_ftau(beta, nftau, D)
     ftau = np.zeros((nd, 2, nd, 2, nftau))
     muimp = np.zeros((nd, 2, nd, 2))
+    scale = 1.0 + 0.05 * np.arange(nd)
     for b in range(nd):
         for s in (0, 1):
             ftau[b, s, b, s, :] = f * (1.0 + 0.05 * b)    # mildly orbital dependent: catches flavour mix-ups
             muimp[b, s, b, s] = -(mu + (0.5 - s) * 2.0 * spin_split)
     if kanamori:
         return Problem(nd, beta, kanamori_umatrix(nd, u, v, j), ftau, muimp, hamiltonian="Kanamori",
-                       quantum_numbers=quantum_numbers or "Nt Szt Qzt")
-    return Problem(nd, beta, density_umatrix(nd, u, v, j), ftau, muimp, quantum_numbers=quantum_numbers or "Nt Szt Azt")
+                       quantum_numbers=quantum_numbers or "Nt Szt Qzt", bath_scale=scale, bath_D=D)
+    return Problem(nd, beta, density_umatrix(nd, u, v, j), ftau, muimp, quantum_numbers=quantum_numbers or "Nt Szt Azt",
+                   bath_scale=scale, bath_D=D)
 
 
 # the BASELINE.json configurations (C5's worm part is not covered yet) and small variants for tests
