@@ -72,8 +72,9 @@ def _cpu_chain(args):
             s.set_wormeta(worm["eta"])
             s.worm_warmup(0, 4, worm["component"])
         t0 = time.perf_counter(); s.measure(*((4, worm["component"]) if worm else (1, 1))); dt = time.perf_counter() - t0
+        gl = None if worm else np.array(s.results(("gleg",))["gleg"], dtype=np.float64)
         s.close()
-        return nmeas * over["NCorr"], dt, "reference"
+        return nmeas * over["NCorr"], dt, "reference", gl
     except Exception:
         import pyoracle
         worm = WORKLOAD.get("worm")
@@ -88,8 +89,9 @@ def _cpu_chain(args):
         else:
             w.measure()
         dt = time.perf_counter() - t0
+        gl = None if worm else np.array(w.results()["gleg"], dtype=np.float64)
         w.close()
-        return nmeas * over["NCorr"], dt, "port"
+        return nmeas * over["NCorr"], dt, "port", gl
 
 
 def cpu_baseline(cores, wname, nmeas=6000, nwarm=50000, eta=1.0):
@@ -99,10 +101,15 @@ def cpu_baseline(cores, wname, nmeas=6000, nwarm=50000, eta=1.0):
     ctx = mp.get_context("spawn")
     with ctx.Pool(cores) as pool:
         res = pool.map(_cpu_chain, [(1000 + i, nmeas, nwarm, wname, eta) for i in range(cores)])
-    rate = sum(s / t for s, t, _ in res)
+    rate = sum(s / t for s, t, _, _ in res)
     kind = res[0][2]
-    return {"value": rate, "unit": "MC steps/s", "cores": cores, "kind": kind,
-            "meas_per_s": sum((s / WORKLOADS[wname]["overrides"]["NCorr"]) / t for s, t, _ in res),
+    gerr = None
+    if res[0][3] is not None and cores > 1:      # error of G(l) over the chains (one per core), and the wall time it took
+        gl = np.array([r[3] for r in res])
+        gerr = {"max_stderr_l_lt_20": float((gl.std(axis=0, ddof=1) / np.sqrt(cores))[..., :20].max()),
+                "wall_s": float(max(t for _, t, _, _ in res))}
+    return {"value": rate, "unit": "MC steps/s", "cores": cores, "kind": kind, "gleg_err": gerr,
+            "meas_per_s": sum((s / WORKLOADS[wname]["overrides"]["NCorr"]) / t for s, t, _, _ in res),
             "sample": "%d independent chains (one per core, as the reference's MPI ranks), each %d warm-up steps untimed + "
                       "%d measurements x NCorr=%d steps timed, same %s workload" % (cores, nwarm, nmeas, WORKLOADS[wname]["overrides"]["NCorr"], wname)}
 
@@ -211,6 +218,12 @@ def main():
     gl, gt, oc, hi = comm.allreduce_packed([q.gleg, q.gtau, q.occ, q.histo])
     t_reduce = time.perf_counter() - t1
     gl /= world; oc /= world; hi /= world
+    # G(l) error reached in the timed wall time: standard error over the accumulator bins of all ranks (sum and sum of
+    # squares of the per-bin results through the same all-reduce)
+    gb = np.asarray(q.gleg_bins, dtype=np.float64)
+    s1, s2, nb = comm.allreduce_packed([gb.sum(axis=0), (gb ** 2).sum(axis=0), np.array([float(gb.shape[0])])])
+    nb = float(nb[0])
+    gl_err = np.sqrt(np.maximum(s2 / nb - (s1 / nb) ** 2, 0.0) * nb / max(nb - 1.0, 1.0) / nb)
 
     sweep_ms, nsweep = q.kernel_time(sweep_key)
     gleg_ms, ngleg = q.kernel_time("meas_g4w" if worm else "meas_gleg")
@@ -253,6 +266,9 @@ def main():
             "measurements_per_s": world * W * a.steps / dt,
             "mean_order_per_flavour": k1, "accept_ins": c["accadd"] / max(c["tryadd"], 1), "occ_double": float(oc[0, 0, 0, 1]),
             "allreduce_ms": t_reduce * 1e3,
+            # the warm-up rounds are measured into the same accumulators: the error below belongs to steps+warmup rounds
+            "gleg_err": {"max_stderr_l_lt_20": float(gl_err[..., :20].max()), "bins": int(nb),
+                         "wall_s": dt * (a.steps + a.warmup) / a.steps},
             "roofline": {"kernel": kname, "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": tr_sweep, "traffic_source": tr_src, "avg_launch_ms": sweep_ms, "launches": nsweep,
                          "algorithmic_bytes_per_launch": bytes_sweep},
@@ -269,6 +285,11 @@ def main():
             try:
                 out["cpu_baseline"] = cpu_baseline(cores, a.config, eta=eta)
                 out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+                ce = out["cpu_baseline"].get("gleg_err")
+                if ce:       # Monte-Carlo errors fall as 1/sqrt(time): CPU error scaled to the GPU's wall time
+                    ge = out["gleg_err"]
+                    out["gleg_err_at_fixed_time"] = {"wall_s": ge["wall_s"], "gpu": ge["max_stderr_l_lt_20"],
+                                                     "cpu_same_wall_time": ce["max_stderr_l_lt_20"] * (ce["wall_s"] / ge["wall_s"]) ** 0.5}
             except Exception as e:  # pragma: no cover
                 out["cpu_baseline"] = {"value": None, "unit": "MC steps/s", "cores": cores, "kind": "port", "sample": "failed: %r" % (e,)}
         print(json.dumps(out))

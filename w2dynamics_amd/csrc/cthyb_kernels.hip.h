@@ -237,6 +237,7 @@ struct Ctx {
     double *tc_, *ta_, *Q, *R, *MQ, *RM, *wt, *gj;
     int *wm, *wc, *K, *piv;
     unsigned long long *cnt;
+    unsigned int cntreg;
     // wave-uniform scalars
     unsigned long long chunk;        // index of the 128-draw chunk held in rbuf
     int rpos;                        // next draw inside the chunk (0..128)
@@ -283,6 +284,12 @@ struct Ctx {
         rpos += 1;
         return u;
     }
+    // n draws whose values are not used (the reference draws them, CTQMC.F90:8442-8443): the stream moves on
+    __device__ __forceinline__ void skip(int n)
+    {
+        rpos += n;
+        if (rpos > 128) { chunk += 1; rpos -= 128; rng_fill(); }
+    }
     __device__ __forceinline__ int randint(int lo, int hi)
     {
         int n = hi - lo + 1;
@@ -300,7 +307,8 @@ struct Ctx {
     __device__ __forceinline__ double *mat(int f) const { return M + (size_t)f * C.kmax * C.kmax; }
     __device__ __forceinline__ int order(int f) const { return __builtin_amdgcn_readlane(kreg, f); }
     __device__ __forceinline__ void set_order(int f, int k) { if (lane == f) kreg = k; }
-    __device__ __forceinline__ void count(int c) { if (lane == 0) cnt[c] += 1ull; }
+    // event counters of this launch: lane c holds counter c (no LDS round trip per event); added to cnt[] in ctx_store
+    __device__ __forceinline__ void count(int c) { cntreg += (lane == c) ? 1u : 0u; }
 };
 
 // pair (x,y) of one creator and one annihilator of equal flavour counts as removable (Trace.F90:1794-1814)
@@ -1398,6 +1406,7 @@ __device__ __forceinline__ void ctx_load(Ctx &x)
     unsigned long long nd_ = s.ndraw;
     nd_ = ((unsigned long long)(unsigned)uni((int)(nd_ >> 32)) << 32) | (unsigned long long)(unsigned)uni((int)nd_);
     if (x.lane < C_NCOUNT) x.cnt[x.lane] = s.cnt[x.lane];
+    x.cntreg = 0u;
     x.kreg = (x.lane < nf) ? C.K[(size_t)w * nf + x.lane] : 0;
     wave_sync();
     for (int f = 0; f < nf; ++f) {
@@ -1426,7 +1435,7 @@ __device__ __forceinline__ void ctx_store(Ctx &x)
         for (int e = x.lane; e < k; e += 64) { gc[e] = x.tc(f)[e]; ga[e] = x.ta(f)[e]; }
     }
     WalkerScalars &s = C.ws[w];
-    if (x.lane < C_NCOUNT) s.cnt[x.lane] = x.cnt[x.lane];
+    if (x.lane < C_NCOUNT) s.cnt[x.lane] = x.cnt[x.lane] + (unsigned long long)x.cntreg;
     if (x.lane < nf) C.K[(size_t)w * nf + x.lane] = x.kreg;
     if (x.lane == 0) {
         s.ndraw = x.rng_tell(); s.outer = x.outer; s.npairs = x.npairs; s.wpos = x.wpos; s.err = x.err;
@@ -1449,11 +1458,11 @@ __device__ __forceinline__ void ctx_store(Ctx &x)
 // CALIB: the loop of ctqmc_calibrate (CTQMC.F90:8121-8174): same moves, no window shift, no step counting; a chain
 // whose own calibration criterion is met does nothing
 #ifndef W2DYN_WPE
-#define W2DYN_WPE 1
+#define W2DYN_WPE 2      // the scalar-path kernel sits right at 256 registers: never let it tip over into one wave per SIMD
 #endif
 
 template <int MAT, bool CALIB = false>
-__global__ __launch_bounds__(256, (MAT == 0 && !CALIB) ? W2DYN_WPE : (MAT != 0 && !CALIB) ? W2DYN_WPE_MAT : 1) void k_sweep(DevConst C, long long nsteps, int count_sampling)
+__global__ __launch_bounds__(256, MAT == 0 ? W2DYN_WPE : W2DYN_WPE_MAT) void k_sweep(DevConst C, long long nsteps, int count_sampling)
 {
     extern __shared__ unsigned char smem[];
     stage_shared_tables(C, smem);
@@ -1481,12 +1490,12 @@ __global__ __launch_bounds__(256, (MAT == 0 && !CALIB) ? W2DYN_WPE : (MAT != 0 &
         unsigned long long t0_ = __builtin_amdgcn_s_memtime();
         int which_;
 #endif
-        if (r < (1.0 - ps - pg) / 2.0) { (void)x.draw(); (void)x.draw();
+        if (r < (1.0 - ps - pg) / 2.0) { x.skip(2);
 #ifndef W2DYN_NO_ADD
             step_add<MAT, false, CALIB>(x);
 #endif
             STAMP_KIND(C_CYC_ADD); phase += 1; }
-        else if (r <= 1.0 - ps - pg) { (void)x.draw(); (void)x.draw();
+        else if (r <= 1.0 - ps - pg) { x.skip(2);
 #ifndef W2DYN_NO_REM
             step_rem<MAT, false, CALIB>(x);
 #endif

@@ -222,16 +222,16 @@ __global__ __launch_bounds__(256, W2DYN_WPE_WORM) void k_sweep_worm(DevConst C, 
         if (x.sector != 4) {
             x.count(C_SAMPLING);
             const double r = x.draw();
-            if (r < (1.0 - ps - pg - pw) / 2.0) { (void)x.draw(); (void)x.draw(); step_add<0, true>(x); phase += 1; }
-            else if (r <= 1.0 - ps - pg - pw) { (void)x.draw(); (void)x.draw(); step_rem<0, true>(x); phase += 1; }
+            if (r < (1.0 - ps - pg - pw) / 2.0) { x.skip(2); step_add<0, true>(x); phase += 1; }
+            else if (r <= 1.0 - ps - pg - pw) { x.skip(2); step_rem<0, true>(x); phase += 1; }
             else if (r <= 1.0 - ps - pg) step_worm_add(x);
             else if (r <= 1.0 - ps) step_glob(x);
             else step_shift<0>(x);
         } else {
             x.count(C_W_SAMPLING);
             const double r = x.draw();
-            if (r < (1.0 - pr - pw) / 2.0) { (void)x.draw(); (void)x.draw(); step_add<0, true>(x); phase += 1; }
-            else if (r < 1.0 - pr - pw) { (void)x.draw(); (void)x.draw(); step_rem<0, true>(x); phase += 1; }
+            if (r < (1.0 - pr - pw) / 2.0) { x.skip(2); step_add<0, true>(x); phase += 1; }
+            else if (r < 1.0 - pr - pw) { x.skip(2); step_rem<0, true>(x); phase += 1; }
             else if (r < 1.0 - pw) step_worm_replace(x);
             else step_worm_rem(x);
         }
