@@ -28,6 +28,8 @@ def probe(cfg, nftau, over, nw, kmax=0, rounds=int(os.environ.get('PROBE_ROUNDS'
         if len(c) >= 24:
             print("   rem stages (cycles per rem try): window %.0f pick %.0f between %.0f trace+prob %.0f | add: draws+qn %.0f (per try), detratio %.0f trace/np/prob %.0f (per valid=%d), accept-update %.0f (per acc=%d)" % (
                 c[16] / c[3], c[17] / c[3], c[18] / c[3], c[19] / c[3], c[20] / c[0], c[21] / max(c[0] - c[2], 1), c[22] / max(c[0] - c[2], 1), c[0] - c[2], c[23] / max(c[1], 1), c[1]), flush=True)
+    if os.environ.get("PROBE_PICK") and len(c) >= 24:
+        print("   pick: n=%d, LDS path (nw>64) %.4f, mean nw %.1f, register-path cycles per pick %.0f" % (c[3], c[21] / max(c[3], 1), c[22] / max(c[3], 1), c[23] / max(c[3] - c[21], 1)), flush=True)
     if os.environ.get("PROBE_GLOB") and len(c) >= 24:
         print("   glob stages (cycles per global move): setup+qn %.0f invert %.0f parity %.0f logtrace %.0f install %.0f (acc=%d of %d)" % (
             c[16] / max(c[6], 1), c[17] / max(c[6], 1), c[18] / max(c[6], 1), c[19] / max(c[6], 1), c[20] / max(c[6], 1), c[7], c[6]), flush=True)

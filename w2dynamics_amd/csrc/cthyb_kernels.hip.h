@@ -136,10 +136,10 @@ struct DevConst {
 // bytes of LDS one wave needs (host and device agree through this one function)
 __host__ __device__ inline size_t lds_bytes_per_wave(int nflav, int kmax, int wcap, int kgj, int mat)
 {
-    // tc, ta, MQ, RM | { Q, R, wt, wm, wc } and the Gauss-Jordan tile gj | counters, K, pivots.  On the scalar trace path
+    // tc, ta, MQ, RM | { Q, R, wt, wm, wc, wp } and the Gauss-Jordan tile gj | counters, K, pivots.  On the scalar trace path
     // gj lies on top of Q..wc (a full rebuild invalidates the window list anyway); the matrix path keeps data in wm/wc
     // across the rebuild and gets a tile of its own
-    size_t u1 = ((size_t)2 * kmax + wcap) * sizeof(double) + (size_t)2 * wcap * sizeof(int), u2 = (size_t)kgj * kgj * sizeof(double);
+    size_t u1 = ((size_t)2 * kmax + wcap) * sizeof(double) + (size_t)3 * wcap * sizeof(int), u2 = (size_t)kgj * kgj * sizeof(double);
     size_t d = (size_t)2 * nflav * kmax + 2 * (size_t)kmax + ((mat ? u1 + u2 : (u1 > u2 ? u1 : u2)) + 7) / 8;
     size_t i = (size_t)MAXFLAV + kmax;                                         // K, piv
     if (mat) { d += wcap + 2; i += (size_t)3 * wcap + 8; }                     // ot; om, osst, tsst
@@ -235,7 +235,7 @@ struct Ctx {
     double *M;                       // global: this walker's matrices
     // LDS slice of this wave
     double *tc_, *ta_, *Q, *R, *MQ, *RM, *wt, *gj;
-    int *wm, *wc, *K, *piv;
+    int *wm, *wc, *wp, *K, *piv;
     unsigned long long *cnt;
     unsigned int cntreg;
     // wave-uniform scalars
@@ -380,6 +380,16 @@ __device__ W2DYN_INLINE int build_window(Ctx &x)
             total += c;
         }
         total = wave_sum(total);
+        wave_sync();
+        for (int base = 0; base < nw; base += 64) {      // pairs whose earlier operator precedes entry e in time
+            int e = base + x.lane;
+            if (e < nw) {
+                double te = x.wt[e];
+                int P = 0;
+                for (int q = 0; q < nw; ++q) P += (x.wt[q] < te) ? x.wc[q] : 0;
+                x.wp[e] = P;
+            }
+        }
         wave_sync();
     }
     x.wvalid = 1;
@@ -758,6 +768,12 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
     if (np <= 0) { x.count(C_QNREM); return; }
     int pick = x.randint(1, np);
     const int nw = x.nwin;
+#ifdef W2DYN_STAMPS_PICK
+    if (x.lane == 0) x.cnt[C_DBG4] += 1ull;
+    if (x.lane == 0 && nw > 64) x.cnt[C_DBG5] += 1ull;
+    if (x.lane == 0) x.cnt[C_DBG6] += (unsigned long long)nw;
+    unsigned long long tp0_ = __builtin_amdgcn_s_memtime();
+#endif
 
     // first operator of the pick-th pair in the reference's enumeration (time order of the earlier operator),
     // then its rnk-th partner in time order
@@ -784,16 +800,15 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
         int qstar = __ffsll((long long)hm) - 1;
         t2 = readlane_d(te, qstar); m2 = __builtin_amdgcn_readlane(me, qstar);
         e1 = estar; e2 = qstar;
+#ifdef W2DYN_STAMPS_PICK
+        if (x.lane == 0) x.cnt[C_DBG7] += __builtin_amdgcn_s_memtime() - tp0_;
+#endif
     } else {
         int estar = -1, rnk = 0;
         for (int base = 0; base < nw; base += 64) {
             int e = base + x.lane;
-            int P = 0; bool hit = false;
-            if (e < nw) {
-                double te = x.wt[e];
-                for (int q = 0; q < nw; ++q) P += (x.wt[q] < te) ? x.wc[q] : 0;
-                hit = (P < pick) && (pick <= P + x.wc[e]);
-            }
+            int P = e < nw ? x.wp[e] : 0;
+            bool hit = e < nw && (P < pick) && (pick <= P + x.wc[e]);
             unsigned long long m = __ballot(hit);
             if (m) { int src = __ffsll((long long)m) - 1; estar = base + src; rnk = pick - __shfl(P, src, 64); }
         }
@@ -801,24 +816,23 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
         t1 = x.wt[estar]; m1 = x.wm[estar];
         const int want = (m1 & 0xffff) ^ 0x300;
         const double thi = t1 + C.taudiff_max;
+        // the partner of rank rnk-1 in time: for each partner (a few), count the partners at earlier times
         int qstar = -1;
-        for (int base = 0; base < nw; base += 64) {
-            int q = base + x.lane;
-            bool hit = false;
-            if (q < nw) {
-                double tq = x.wt[q];
-                bool partner = ((x.wm[q] & 0xffff) == want) && (tq > t1) && !(tq > thi);
-                if (partner) {
-                    int r = 0;
-                    for (int p = 0; p < nw; ++p) {
-                        double tp = x.wt[p];
-                        r += (((x.wm[p] & 0xffff) == want) && (tp > t1) && !(tp > thi) && tp < tq) ? 1 : 0;
-                    }
-                    hit = (r == rnk - 1);
+        for (int b1 = 0; b1 < nw && qstar < 0; b1 += 64) {
+            int q = b1 + x.lane;
+            double tq = q < nw ? x.wt[q] : -1.0;
+            unsigned long long pm = __ballot(q < nw && ((x.wm[q < nw ? q : 0] & 0xffff) == want) && (tq > t1) && !(tq > thi));
+            while (pm && qstar < 0) {
+                const int src = __ffsll((long long)pm) - 1; pm &= pm - 1ull;
+                const double tp = x.wt[b1 + src];
+                int less = 0;
+                for (int b2 = 0; b2 < nw; b2 += 64) {
+                    int q2 = b2 + x.lane;
+                    double t2_ = q2 < nw ? x.wt[q2] : -1.0;
+                    less += __popcll(__ballot(q2 < nw && ((x.wm[q2 < nw ? q2 : 0] & 0xffff) == want) && (t2_ > t1) && !(t2_ > thi) && t2_ < tp));
                 }
+                if (less == rnk - 1) qstar = b1 + src;
             }
-            unsigned long long m = __ballot(hit);
-            if (m) qstar = base + __ffsll((long long)m) - 1;
         }
         qstar = uni(qstar);
         t2 = x.wt[qstar]; m2 = x.wm[qstar];
@@ -1352,9 +1366,9 @@ __device__ __forceinline__ void ctx_setup(Ctx &x, unsigned char *smem)
     x.tc_ = (double *)base; x.ta_ = x.tc_ + C.nflav * C.kmax;
     x.MQ = x.ta_ + C.nflav * C.kmax; x.RM = x.MQ + C.kmax;
     x.Q = x.RM + C.kmax; x.R = x.Q + C.kmax; x.wt = x.R + C.kmax;
-    x.wm = (int *)(x.wt + C.wcap); x.wc = x.wm + C.wcap;
+    x.wm = (int *)(x.wt + C.wcap); x.wc = x.wm + C.wcap; x.wp = x.wc + C.wcap;
     {
-        const size_t u1 = ((size_t)2 * C.kmax + C.wcap) * sizeof(double) + (size_t)2 * C.wcap * sizeof(int), u2 = (size_t)C.kgj * C.kgj * sizeof(double);
+        const size_t u1 = ((size_t)2 * C.kmax + C.wcap) * sizeof(double) + (size_t)3 * C.wcap * sizeof(int), u2 = (size_t)C.kgj * C.kgj * sizeof(double);
         x.gj = C.mat ? x.Q + u1 / 8 : x.Q;                  // scalar path: the tile shares its space with Q, R and the window list
         x.cnt = (unsigned long long *)(x.Q + ((C.mat ? u1 + u2 : (u1 > u2 ? u1 : u2)) + 7) / 8);
     }
