@@ -1585,41 +1585,47 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
     if constexpr (MAT != 0) mat_trace_current<MAT>(x);
     const int nf = C.nflav, nd = C.nd;
     int par = 0;
-    // every lane takes operators (f, type, slot) and scans the operators that can contribute a transposition
-    for (int fi = 0; fi < nf; ++fi) {
-        int ki = x.order(fi);
-        int biti = flav_bit(fi, nd);
-        for (int li = x.lane; li < 2 * ki; li += 64) {
-            bool ci = li < ki;
-            double ti = ci ? x.tc(fi)[li] : x.ta(fi)[li - ki];
-            if (!MAT && x.sector == 4) {
-                // worm operators enter the trace sign like any other operator; get_WormSign (Trace.F90:3623-3651) adds the
-                // hybridising operators at later times than each worm operator
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int bw = flav_bit(x.wfl[i], nd); const double tw = x.wtau[i];
-                    par ^= ((tw < ti && bw < biti) ? 1 : 0) ^ ((ti < tw && biti < bw) ? 1 : 0) ^ ((ti > tw) ? 1 : 0);
-                }
-            }
-            for (int fj = 0; fj < nf; ++fj) {
-                int kj = x.order(fj);
-                int bitj = flav_bit(fj, nd);
-                bool wtr = !MAT && bitj < biti, wbl = fj < fi, wsame = (fj == fi) && ci;
-                if (!(wtr || wbl || wsame)) continue;
-                const double *cj = x.tc(fj), *aj = x.ta(fj);
-                int below = 0, above = 0;
-                for (int lj = 0; lj < kj; ++lj) {
-                    double t1 = cj[lj], t2 = aj[lj];
-                    below += (t1 < ti) + (t2 < ti); above += (t1 > ti) + (t2 > ti);
-                }
-                if (wtr) par ^= below & 1;
-                if (wbl) par ^= above & 1;
-                if (wsame) par ^= above & 1;
-            }
-        }
-    }
+    // every lane takes one operator (f, type, slot) of the flat list of all flavours' operators (so the lanes stay busy
+    // whatever the orders of the single flavours are) and scans the operators that can contribute a transposition
     int N = 0;
     for (int f = 0; f < nf; ++f) N += 2 * x.order(f);
+    for (int base = 0; base < N; base += 64) {
+        const int li = base + x.lane;
+        const bool act = li < N;
+        int fi = 0, oi = 0, ki = 0;
+        for (int f = 0, of = 0; f < nf; ++f) {
+            const int k2 = 2 * x.order(f);
+            if (li >= of && li < of + k2) { fi = f; oi = li - of; ki = k2 >> 1; }
+            of += k2;
+        }
+        const int biti = flav_bit(fi, nd);
+        const bool ci = oi < ki;
+        const double ti = !act ? 0.0 : (ci ? x.tc_[fi * C.kmax + oi] : x.ta_[fi * C.kmax + oi - ki]);
+        if (!MAT && x.sector == 4 && act) {
+            // worm operators enter the trace sign like any other operator; get_WormSign (Trace.F90:3623-3651) adds the
+            // hybridising operators at later times than each worm operator
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int bw = flav_bit(x.wfl[i], nd); const double tw = x.wtau[i];
+                par ^= ((tw < ti && bw < biti) ? 1 : 0) ^ ((ti < tw && biti < bw) ? 1 : 0) ^ ((ti > tw) ? 1 : 0);
+            }
+        }
+        for (int fj = 0; fj < nf; ++fj) {
+            const int kj = x.order(fj);
+            const int bitj = flav_bit(fj, nd);
+            const bool wtr = act && !MAT && bitj < biti, wbl = act && fj < fi, wsame = act && (fj == fi) && ci;
+            if (!__ballot(wtr || wbl || wsame)) continue;
+            const double *cj = x.tc(fj), *aj = x.ta(fj);
+            int below = 0, above = 0;
+            for (int lj = 0; lj < kj; ++lj) {
+                double t1 = cj[lj], t2 = aj[lj];
+                below += (t1 < ti) + (t2 < ti); above += (t1 > ti) + (t2 > ti);
+            }
+            if (wtr) par ^= below & 1;
+            if (wbl) par ^= above & 1;
+            if (wsame) par ^= above & 1;
+        }
+    }
     const bool worm = !MAT && x.sector == 4;
     if (worm && x.lane == 0) {
         // worm operators among themselves: trace sign, and the pairs i < j (container order) with tau_i < tau_j
