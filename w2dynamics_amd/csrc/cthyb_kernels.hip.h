@@ -115,6 +115,7 @@ struct DevConst {
     // local problem in block form.  nouter = number of outer blocks (= nstates for one-state blocks); dmsize = doubles of
     // the block-diagonal density matrix; mat != 0 selects the matrix local-trace path (cthyb_matrix.hip.h)
     int nouter, dmsize, mat, nsst, nsm, shared_lds, op_in_lds;
+    const int *shift;             // [nsst][nflav][2] block reached by quantum-number arithmetic (local_problem.hpp)
     const int *sst_n, *sst_off, *conn, *sst_first, *sst_of_state, *dmoff;   // [nsst] [nsst] [nsst][nflav][2] [nsst] [nstates] [nsst+1]
     const double *sst_eval;       // [nstates] eigenvalues in block order
     const double *opmat;          // [nsst][nflav][2][nsm][nsm] operators in the eigenbasis, row = target state, zero padded
@@ -251,7 +252,7 @@ struct Ctx {
     int wvalid;                      // window list (registers or LDS) matches the current configuration and window
     // matrix local-trace path
     double *ot; int *om, *osst, *tsst; int nops;     // time-ordered operator list, block sequence, trial block sequence (LDS)
-    const int *t_conn, *t_n, *t_off; const double *t_eval, *t_op;   // block-shared tables (LDS); t_op null: operators stay in global memory
+    const int *t_conn, *t_shift, *t_n, *t_off; const double *t_eval, *t_op;   // block-shared tables (LDS); t_op null: operators stay in global memory
     double tr_log, tr_sign;                          // current local trace
     int ms_, mi_;                                    // lane = (outer state ms_, component mi_)
     // worm sampling
@@ -569,13 +570,25 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
         p_lo = mat_lower(x, lo); p_hi = mat_lower(x, hi);
         const int nf2 = 2 * C.nflav;
         const int code_lo = mat_code(f, creator_first ? 1 : 2), code_hi = mat_code(f, creator_first ? 2 : 1);
-        // the walk also records the trial block sequence of the span: tsst[j] = block in front of trial entry j
-        int sq = uni(x.osst[p_lo]);
-        sq = uni(x.t_conn[sq * nf2 + code_lo]);
-        if (x.lane == 0) x.tsst[p_lo + 1] = sq;
-        for (int i = p_lo; i < p_hi && sq >= 0; ++i) { sq = uni(x.t_conn[sq * nf2 + uni(x.om[i])]); if (x.lane == 0) x.tsst[i + 2] = sq; }
-        if (sq >= 0) sq = uni(x.t_conn[sq * nf2 + code_hi]);
-        valid = !eq && sq >= 0 && sq == uni(x.osst[p_hi]);
+        // trial block sequence of the span, all entries at once: the block in front of old operator i (p_lo <= i <= p_hi;
+        // i = p_hi: in front of the new later operator) is the old one shifted by the new earlier operator's quantum
+        // numbers; the sequence is allowed iff every link is a connection (tsst[j] = block in front of trial entry j)
+        bool bad = false;
+        for (int base = p_lo; base <= p_hi; base += 64) {
+            const int i = base + x.lane;
+            if (i <= p_hi) {
+                const int ci = x.t_shift[x.osst[i] * nf2 + code_lo];
+                x.tsst[i + 1] = ci;
+                bool ok = ci >= 0;
+                if (ok && i == p_lo) ok = x.t_conn[x.osst[p_lo] * nf2 + code_lo] == ci;
+                if (ok) {
+                    const int nxt = i < p_hi ? x.t_shift[x.osst[i + 1] * nf2 + code_lo] : x.osst[p_hi];
+                    ok = x.t_conn[ci * nf2 + (i < p_hi ? x.om[i] : code_hi)] == nxt;
+                }
+                bad |= !ok;
+            }
+        }
+        valid = !eq && !__ballot(bad);
     } else {
     int c_lo = 0, a_lo = 0; bool blocked = (tau1 == tau2);
     for (int base = 0; base < k; base += 64) {
@@ -857,11 +870,24 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
     if constexpr (MAT) {
         i1 = mat_lower(x, t1); i2 = mat_lower(x, t2);
         const int nf2 = 2 * C.nflav;
-        // trial entry j is list entry j (j < i1), j+1 (i1 <= j < i2-1) or j+2; tsst[j] = block in front of it
-        int sq = uni(x.osst[i1]);
-        if (x.lane == 0) x.tsst[i1] = sq;
-        for (int i = i1 + 1; i < i2 && sq >= 0; ++i) { sq = uni(x.t_conn[sq * nf2 + uni(x.om[i])]); if (x.lane == 0 && i < i2 - 1) x.tsst[i] = sq; }
-        blocked = !(sq >= 0 && sq == uni(x.osst[i2 + 1]));
+        // trial entry j is list entry j (j < i1), j+1 (i1 <= j < i2-1) or j+2; tsst[j] = block in front of it.  Between
+        // the two operators every block is the old one shifted back by the earlier operator's quantum numbers; the pair
+        // may go iff every link of that sequence is a connection (all entries checked at once)
+        const int inv1 = uni(x.om[i1]) ^ 1;
+        bool bad = false;
+        for (int base = i1 + 1; base <= i2; base += 64) {
+            const int i = base + x.lane;
+            if (i <= i2) {
+                const int ci = x.t_shift[x.osst[i] * nf2 + inv1];        // block in front of old operator i in the trial sequence
+                if (i < i2) x.tsst[i - 1] = ci; 
+                bool ok = ci >= 0;
+                if (ok && i < i2) ok = x.t_conn[ci * nf2 + x.om[i]] == x.t_shift[x.osst[i + 1] * nf2 + inv1];
+                if (ok && i == i1 + 1) ok = ci == x.osst[i1];
+                if (ok && i == i2) ok = ci == x.osst[i2 + 1];
+                bad |= !ok;
+            }
+        }
+        blocked = __ballot(bad) != 0ull;
     } else if (nw <= 64) {
         blocked = __ballot(x.lane < nw && (x.wr_m & 0xff) == f && x.wr_t > t1 && x.wr_t < t2) != 0ull;
     } else {
@@ -1380,7 +1406,7 @@ __device__ __forceinline__ void ctx_setup(Ctx &x, unsigned char *smem)
         x.ot = (double *)(((size_t)(x.tsst + C.wcap + 2) + 7) & ~(size_t)7);
         const int nf2 = 2 * C.nflav;
         int *ti = (int *)smem;
-        x.t_conn = ti; x.t_n = ti + C.nsst * nf2; x.t_off = x.t_n + C.nsst;
+        x.t_conn = ti; x.t_shift = ti + C.nsst * nf2; x.t_n = x.t_shift + C.nsst * nf2; x.t_off = x.t_n + C.nsst;
         double *td = (double *)(((size_t)(x.t_off + C.nsst) + 7) & ~(size_t)7);
         x.t_eval = td;
         x.t_op = C.op_in_lds ? td + C.nstates : nullptr;
@@ -1394,9 +1420,9 @@ __device__ __forceinline__ void stage_shared_tables(const DevConst &C, unsigned 
     if (!C.mat) return;
     const int nf2 = 2 * C.nflav;
     int *ti = (int *)smem;
-    int *t_n = ti + C.nsst * nf2, *t_off = t_n + C.nsst;
+    int *t_shift = ti + C.nsst * nf2, *t_n = t_shift + C.nsst * nf2, *t_off = t_n + C.nsst;
     double *td = (double *)(((size_t)(t_off + C.nsst) + 7) & ~(size_t)7);
-    for (int i = threadIdx.x; i < C.nsst * nf2; i += blockDim.x) ti[i] = C.conn[i];
+    for (int i = threadIdx.x; i < C.nsst * nf2; i += blockDim.x) { ti[i] = C.conn[i]; t_shift[i] = C.shift[i]; }
     for (int i = threadIdx.x; i < C.nsst; i += blockDim.x) { t_n[i] = C.sst_n[i]; t_off[i] = C.sst_off[i]; }
     for (int i = threadIdx.x; i < C.nstates; i += blockDim.x) td[i] = C.sst_eval[i];
     if (C.op_in_lds) {

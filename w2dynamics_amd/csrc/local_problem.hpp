@@ -19,6 +19,8 @@ struct LocalProblem {
     std::vector<double> eval;                       // block order, ascending inside a block
     std::vector<std::vector<double>> evec;          // per block, column major n x n: evec[b][j + n*i] = <Fock j|eigen i>
     std::vector<int> conn;                          // [(sst*nflav + f)*2 + (ca-1)]
+    std::vector<int> shift;                         // same index: block whose quantum numbers are those of `sst` changed by the
+                                                    // operator (formal arithmetic, whether or not a state of sst admits it); -1: none
     std::vector<std::vector<double>> op;            // same index: n_target x n_source column major (empty if not connected)
     double egs = 0.0;
     bool identity_blocks = false;                   // every block holds exactly its own Fock state (index == state)
@@ -105,6 +107,35 @@ struct LocalProblem {
         for (int s = 0; s < ns; ++s) for (int f = 0; f < nf; ++f) {
             int t = s ^ (1 << bit(f)), b = sst_of_state[s], tb = sst_of_state[t];
             if (tb != b) conn[((size_t)b * nf + f) * 2 + (t > s ? 0 : 1)] = tb;
+        }
+
+        // Blocks are in one-to-one correspondence with tuples of the (additive) quantum numbers in use, so the block a
+        // sequence passes through after one more operator earlier in time follows from quantum-number arithmetic alone.
+        // The sampler uses this table to propose the whole block sequence of a trial configuration at once and then only
+        // verifies every link against `conn` (check_sst_sequence, Trace.F90:1243-1302, without its serial walk).
+        shift.assign((size_t)nsst * nf * 2, -1);
+        {
+            std::vector<std::vector<double>> qb(nsst, std::vector<double>(6, 0.0));
+            for (int b = 0; b < nsst; ++b) for (int q = 0; q < 6; ++q) qb[b][q] = qn(q, states[sst_off[b]]);
+            for (int b = 0; b < nsst; ++b) for (int f = 0; f < nf; ++f) for (int ca = 1; ca <= 2; ++ca) {
+                const double sg = ca == 1 ? 1.0 : -1.0;
+                const int orb = f >> 1, sp = f & 1, bt = bit(f);
+                double t[6];
+                t[0] = qb[b][0] + sg;
+                t[1] = qb[b][1] + sg * (sp ? 0.5 : -0.5);
+                { const long long v = std::llround(qb[b][2]); const long long p10 = std::llround(std::pow(10.0, orb)); const int dig = (int)((v / p10) % 10); t[2] = qb[b][2] + (dig ? -(double)p10 : (double)p10); }
+                { const long long v = std::llround(qb[b][3]); const long long p10 = std::llround(std::pow(10.0, bt)); const int dig = (int)((v / p10) % 10);
+                  t[3] = ((ca == 1 && dig) || (ca == 2 && !dig)) ? -1.0 : qb[b][3] + sg * (double)p10; }
+                const double dl = (double)(orb + 1) - (double)(nd + 1) / 2.0;
+                t[4] = qb[b][4] + sg * dl;
+                t[5] = t[4] + t[1];
+                if (use[3] && t[3] < 0.0) continue;
+                for (int c = 0; c < nsst; ++c) {
+                    bool same = true;
+                    for (int q = 0; q < 6 && same; ++q) if (use[q] && !(std::fabs(qb[c][q] - t[q]) < 1e-9)) same = false;
+                    if (same) { shift[((size_t)b * nf + f) * 2 + (ca - 1)] = c; break; }
+                }
+            }
         }
 
         std::vector<std::vector<double>> H(nsst);

@@ -421,7 +421,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
             double *dst = &opmat[((size_t)(b * nf + f) * 2 + (ca - 1)) * C.nsm * C.nsm];
             for (int i = 0; i < n2; ++i) for (int j = 0; j < n1; ++j) dst[i * C.nsm + j] = O[i + (size_t)n2 * j];
         }
-        size_t ints = ((size_t)lp.nsst * nf * 2 + 2 * (size_t)lp.nsst) * sizeof(int);
+        size_t ints = ((size_t)lp.nsst * nf * 4 + 2 * (size_t)lp.nsst) * sizeof(int);
         ints = (ints + 7) & ~(size_t)7;
         size_t small = ints + (size_t)s->nstates * sizeof(double);
         // Occupancy first: when two workgroups (2 waves per SIMD) fit into the CU's 160 KB with the operator matrices left
@@ -451,6 +451,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if ((rc = dev_upload(s, C.sst_n, lp.sst_n))) return rc;
     if ((rc = dev_upload(s, C.sst_off, lp.sst_off))) return rc;
     if ((rc = dev_upload(s, C.conn, lp.conn))) return rc;
+    if ((rc = dev_upload(s, C.shift, lp.shift))) return rc;
     if ((rc = dev_upload(s, C.sst_of_state, lp.sst_of_state))) return rc;
     if ((rc = dev_upload(s, C.dmoff, s->dmoff))) return rc;
     if ((rc = dev_upload(s, C.sst_eval, lp.eval))) return rc;
