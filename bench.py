@@ -155,10 +155,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # W2DYN_REHEARSE=1 (not for measurements): all ranks on GPU 0 with the gloo backend, to exercise the N>1 code path on
+    # a one-GPU box; the real thing is one rank per GPU over RCCL
+    rehearse = os.environ.get("W2DYN_REHEARSE", "0") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     comm = TorchComm()
+    red_dev = "cpu" if rehearse else "cuda"
 
     over = WORKLOAD["overrides"]
     prob = synth.config(WORKLOAD["config"], nftau=WORKLOAD["nftau"])
@@ -186,7 +195,7 @@ def main():
             q.wormeta[:] = q.wormeta[:] * float(sz) / float(sw)
         eta = float(q.wormeta[2])
         if world > 1:      # all ranks use the mean eta (impurity.py:739-740, 784)
-            t = torch.tensor([eta], dtype=torch.float64, device="cuda"); dist.all_reduce(t); eta = float(t.item()) / world
+            t = torch.tensor([eta], dtype=torch.float64, device=red_dev); dist.all_reduce(t); eta = float(t.item()) / world
             q.wormeta[:] = eta
         q.set_sector(4, worm["component"])
     sweep_key = "sweep_worm" if worm else "sweep"
@@ -208,7 +217,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # the exchange step of the path: accumulators of all ranks combined by one all-reduce (untimed here, it runs once
