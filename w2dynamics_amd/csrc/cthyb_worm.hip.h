@@ -219,22 +219,31 @@ __global__ __launch_bounds__(256, W2DYN_WPE_WORM) void k_sweep_worm(DevConst C, 
     unsigned int phase = (unsigned int)((x.cnt[C_TRYADD] + x.cnt[C_TRYREM] + x.cnt[C_W_TRYADD] + x.cnt[C_W_TRYREM]) % (unsigned long long)C.nslide);
     phase = (unsigned int)uni((int)phase);
     for (long long it = 0; it < nsteps; ++it) {
+#ifdef W2DYN_STAMPS_WORM      // diagnostic build: shader-clock cycles per move type
+        const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); int kind_;
+#define WORM_KIND(c) kind_ = (c)
+#else
+#define WORM_KIND(c)
+#endif
         if (x.sector != 4) {
             x.count(C_SAMPLING);
             const double r = x.draw();
-            if (r < (1.0 - ps - pg - pw) / 2.0) { x.skip(2); step_add<0, true>(x); phase += 1; }
-            else if (r <= 1.0 - ps - pg - pw) { x.skip(2); step_rem<0, true>(x); phase += 1; }
-            else if (r <= 1.0 - ps - pg) step_worm_add(x);
-            else if (r <= 1.0 - ps) step_glob(x);
-            else step_shift<0>(x);
+            if (r < (1.0 - ps - pg - pw) / 2.0) { x.skip(2); step_add<0, true>(x); phase += 1; WORM_KIND(C_CYC_ADD); }
+            else if (r <= 1.0 - ps - pg - pw) { x.skip(2); step_rem<0, true>(x); phase += 1; WORM_KIND(C_CYC_REM); }
+            else if (r <= 1.0 - ps - pg) { step_worm_add(x); WORM_KIND(C_CYC_GLOB); }
+            else if (r <= 1.0 - ps) { step_glob(x); WORM_KIND(C_CYC_SHIFT); }
+            else { step_shift<0>(x); WORM_KIND(C_CYC_SHIFT); }
         } else {
             x.count(C_W_SAMPLING);
             const double r = x.draw();
-            if (r < (1.0 - pr - pw) / 2.0) { x.skip(2); step_add<0, true>(x); phase += 1; }
-            else if (r < 1.0 - pr - pw) { x.skip(2); step_rem<0, true>(x); phase += 1; }
-            else if (r < 1.0 - pw) step_worm_replace(x);
-            else step_worm_rem(x);
+            if (r < (1.0 - pr - pw) / 2.0) { x.skip(2); step_add<0, true>(x); phase += 1; WORM_KIND(C_DBG5); }
+            else if (r < 1.0 - pr - pw) { x.skip(2); step_rem<0, true>(x); phase += 1; WORM_KIND(C_DBG5); }
+            else if (r < 1.0 - pw) { step_worm_replace(x); WORM_KIND(C_DBG6); }
+            else { step_worm_rem(x); WORM_KIND(C_DBG7); }
         }
+#ifdef W2DYN_STAMPS_WORM
+        if (x.lane == 0) x.cnt[kind_] += __builtin_amdgcn_s_memtime() - t0_;
+#endif
         if (phase == (unsigned int)C.nslide) phase = 0;
         if (phase == 0) {
             if (C.num_windows > 1) {
