@@ -60,6 +60,7 @@ struct ora_walker {
     double try_wadd, acc_wadd, accqn_wadd, try_wrem, acc_wrem, accqn_wrem, try_wrep, acc_wrep;
     double cnt_sampling_w, cnt_meas_w;
     double *g4w, *g4wpp;                      /* g4iw_worm, g4iwpp_worm accumulators */
+    double *giww, *gtauw;                     /* giw_worm (2Niw complex), gtau_worm (Ntau) accumulators (sector 2) */
     double try_add, acc_add, accqn_add, try_rem, acc_rem, accqn_rem, try_glob, acc_glob, accqn_glob;
     double try_shift, acc_shift, cnt_sampling, cnt_meas;
     int64_t *accpair;
@@ -871,28 +872,33 @@ static void step_shift(ora_walker *w)
 }
 
 /* ------------------------------------------------------------------------------------------------------- */
-/* worm moves, sector 4 (two-particle Green's function): four operators c c+ c c+ without hybridisation lines   */
+/* worm moves: sector 4 (two-particle Green's function), four operators c c+ c c+ without hybridisation lines,  */
+/* and sector 2 (one-particle Green's function), two operators c c+ (NOperWorm, CTQMC.F90:5282-5285)             */
 /* ------------------------------------------------------------------------------------------------------- */
 
-/* get_Proposal for SectorG4 (CTQMC.F90:5680-5684) */
-static double worm_prefact(const ora_walker *w) { return pow(w->p.beta * (double)w->p.nd, 4.0) * w->eta; }
+static int worm_nops(const ora_walker *w) { return w->isector == 2 ? 2 : 4; }
+
+/* get_Proposal for SectorG / SectorG4 (CTQMC.F90:5677-5684) */
+static double worm_prefact(const ora_walker *w) { return pow(w->p.beta * (double)w->p.nd, (double)worm_nops(w)) * w->eta; }
 
 /* StepWormAdd, CTQMC.F90:4992-5140 */
 static void step_worm_add(ora_walker *w)
 {
     const int nf = w->nflav;
-    int comp = w->icomponent;
-    if (comp == 0) comp = RINT(w, 1, nf * nf * nf * nf);
+    const int nw = worm_nops(w);
+    int comp = w->icomponent, ncomp = 1;
+    for (int i = 0; i < nw; ++i) ncomp *= nf;
+    if (comp == 0) comp = RINT(w, 1, ncomp);
     w->try_wadd += 1;
     /* set_OperFlavor (Trace.F90:3804-3826): digits of comp-1 in base 2Nd, most significant first; CA = mod(i,2)+1 */
-    op_t o[4]; int rest = comp - 1, base = nf * nf * nf;
-    for (int i = 0; i < 4; ++i) { int bs = rest / base; rest -= bs * base; base /= nf; o[i].flav = bs; o[i].ca = ((i + 1) % 2) + 1; o[i].wid = i + 1; }
+    op_t o[4]; int rest = comp - 1, base = ncomp / nf;
+    for (int i = 0; i < nw; ++i) { int bs = rest / base; rest -= bs * base; base /= nf; o[i].flav = bs; o[i].ca = ((i + 1) % 2) + 1; o[i].wid = i + 1; }
     /* set_OperTime (Trace.F90:3942-3967) */
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < nw; ++i) {
         o[i].tau = U01(w) * w->p.beta;
         if (i > 0 && o[i - 1].tau == o[i].tau) o[i].tau += w->p.beta * 1e-14;
     }
-    for (int i = 0; i < 4; ++i) list_insert(w, o[i]);
+    for (int i = 0; i < nw; ++i) list_insert(w, o[i]);
     double prefact = worm_prefact(w);
     if (prefact == 0.0 || !sequence_valid(w, w->outer_sst)) {
         for (int i = w->nops - 1; i >= 0; --i) if (w->ops[i].wid) list_remove(w, i);
@@ -936,12 +942,12 @@ static void step_worm_rem(ora_walker *w)
     }
 }
 
-/* StepWormReplace for SectorG4 (CTQMC.F90:5809-6297) with propose_WormReplace / do_WormReplace (Trace.F90:3054-3478):
+/* StepWormReplace for SectorG / SectorG4 (CTQMC.F90:5809-6297) with propose_WormReplace / do_WormReplace (Trace.F90:3054-3478):
  * a worm operator and a hybridising operator of the same flavour and type exchange their roles */
 static void step_worm_replace(ora_walker *w)
 {
     w->try_wrep += 1;
-    int r = RINT(w, 1, 4);
+    int r = RINT(w, 1, worm_nops(w));
     int iw = -1;
     for (int i = 0; i < w->nops; ++i) if (w->ops[i].wid == r) iw = i;
     const int f = w->ops[iw].flav, ca = w->ops[iw].ca, k = w->k[f];
@@ -1109,6 +1115,8 @@ ora_walker *ora_create(const ora_params *p, const double *U, const double *ftau_
         if (p->meas_g2iw) w->g2iw = (double *)calloc((size_t)w->nflav * n2 * n2 * 2, sizeof(double));
     }
     w->sector = w->isector = 1; w->icomponent = 0; w->eta = p->worm_eta;
+    if (p->worm_meas_giw) w->giww = (double *)calloc((size_t)4 * p->niw, sizeof(double));      /* CTQMC.F90:597-599 */
+    if (p->worm_meas_gtau) w->gtauw = (double *)calloc((size_t)p->ntau, sizeof(double));        /* CTQMC.F90:609-612 */
     if ((p->fourpnt & 8) && p->worm_meas_g4iw) {                                    /* CTQMC.F90:339-361 */
         size_t n = (size_t)4 * p->n4iwf * p->n4iwf * (2 * p->n4iwb + 1) * 2;
         if (p->g4ph) w->g4w = (double *)calloc(n, sizeof(double));
@@ -1133,7 +1141,7 @@ void ora_destroy(ora_walker *w)
     if (!w) return;
     for (int f = 0; f < w->nflav; ++f) free(w->M[f]);
     free(w->ops); free(w->ftab); ora_locprob_free(w->lp); free(w->ptr); free(w->dmblk); free(w->dmoff); free(w->accpair); free(w->accpairtau); free(w->gleg); free(w->gtau); free(w->giw);
-    free(w->histo); free(w->dm); free(w->outer_histo); free(w->g2iw); free(w->g4iw); free(w->g4iwpp); free(w->g4w); free(w->g4wpp); free(w);
+    free(w->histo); free(w->dm); free(w->outer_histo); free(w->g2iw); free(w->g4iw); free(w->g4iwpp); free(w->g4w); free(w->g4wpp); free(w->giww); free(w->gtauw); free(w);
 }
 
 void ora_set_taudiffmax(ora_walker *w, double x) { init_window(w, x); }
@@ -1332,11 +1340,36 @@ static void meas_g4iw_worm(ora_walker *w)
     }
 }
 
+/* measure_giw_worm / measure_gtau_worm (CTQMC.F90:1061-1120): wormContainer = (c, c+); giw_worm(n) gets
+ * cfgsign/eta * exp(i w_n (t1 - t2)), n = -Niw..Niw-1 (every second entry of the 4Niw-point transform of
+ * x = (t1-t2)/(2 beta), Nfft_worm.F90:94-137); gtau_worm gets +-cfgsign/eta in the bin of t1 - t2 (+ beta, sign -1) */
+static void meas_g_worm(ora_walker *w)
+{
+    double t[3] = {0, 0, 0};
+    for (int i = 0; i < w->nops; ++i) if (w->ops[i].wid) t[w->ops[i].wid] = w->ops[i].tau;
+    const double val = w->cfgsign / w->eta, beta = w->p.beta;
+    if (w->giww) {
+        const int niw = w->p.niw;
+        for (int n = -niw; n < niw; ++n) {
+            double ph = M_PI / beta * (double)(2 * n + 1) * (t[1] - t[2]);
+            w->giww[2 * (n + niw)] += val * cos(ph); w->giww[2 * (n + niw) + 1] += val * sin(ph);
+        }
+    }
+    if (w->gtauw) {
+        double tau = t[1] - t[2], sgn = 1.0;
+        if (tau < 0.0) { tau += beta; sgn = -1.0; }
+        int itau = (int)((double)w->p.ntau * tau / beta) + 1;
+        if (itau > w->p.ntau) itau = w->p.ntau;
+        w->gtauw[itau - 1] += sgn * w->cfgsign / w->eta;
+    }
+}
+
 void ora_measure_once(ora_walker *w)
 {
     int nf = w->nflav;
     if (w->sector != 1) {                                               /* CTQMC.F90:8586-8593 */
-        if (w->g4w || w->g4wpp) { w->cnt_meas_w += 1; meas_g4iw_worm(w); }
+        if (w->sector == 2) { w->cnt_meas_w += 1; meas_g_worm(w); }
+        else if (w->g4w || w->g4wpp) { w->cnt_meas_w += 1; meas_g4iw_worm(w); }
         return;
     }
     w->cnt_meas += 1;
@@ -1414,7 +1447,13 @@ void ora_measure_finish(ora_walker *w)
         if (w->g4iwpp) for (size_t i = 0; i < n4; ++i) w->g4iwpp[i] *= zs / (beta * beta);
         if (w->g2iw) for (size_t i = 0; i < (size_t)nf * n2 * n2 * 2; ++i) w->g2iw[i] *= zs / beta;
     }
-    if (w->g4w || w->g4wpp) {   /* wormScaling(SectorG4), CTQMC.F90:8833-8849, 8883-8915 */
+    if (w->isector == 2 && (w->giww || w->gtauw)) {   /* wormScaling(SectorG), CTQMC.F90:8825, 8843-8876 */
+        double scal = (w->cnt_meas_w != 0) ? w->cnt_sampling_w / (w->cnt_meas_w * w->cnt_sampling) * 4.0 / beta / w->mean_sign : 0.0;
+        double nf2 = (double)nf * (double)nf;
+        if (w->giww) for (int i = 0; i < 4 * w->p.niw; ++i) w->giww[i] = -w->giww[i] * scal / nf2;
+        if (w->gtauw) for (int i = 0; i < w->p.ntau; ++i) w->gtauw[i] = w->gtauw[i] * scal * ((double)w->p.ntau / beta) / nf2;
+    }
+    if (w->isector != 2 && (w->g4w || w->g4wpp)) {   /* wormScaling(SectorG4), CTQMC.F90:8833-8849, 8883-8915 */
         double scal = (w->cnt_meas_w != 0) ? w->cnt_sampling_w / (w->cnt_meas_w * w->cnt_sampling) * 16.0 / (beta * beta) / w->mean_sign : 0.0;
         size_t n = (size_t)4 * w->p.n4iwf * w->p.n4iwf * (2 * w->p.n4iwb + 1) * 2;
         if (w->g4w) for (size_t i = 0; i < n; ++i) w->g4w[i] *= scal;
@@ -1537,6 +1576,18 @@ int ora_get_g4iw_worm(const ora_walker *w, double *o, int pp)
     const double *src = pp ? w->g4wpp : w->g4w;
     if (!src) return 0;
     memcpy(o, src, sizeof(double) * (size_t)4 * w->p.n4iwf * w->p.n4iwf * (2 * w->p.n4iwb + 1) * 2); return 1;
+}
+int ora_get_giw_worm(const ora_walker *w, double *o)
+{
+    if (!w->giww) return 0;
+    memcpy(o, w->giww, sizeof(double) * (size_t)4 * w->p.niw);
+    return 1;
+}
+int ora_get_gtau_worm(const ora_walker *w, double *o)
+{
+    if (!w->gtauw) return 0;
+    memcpy(o, w->gtauw, sizeof(double) * (size_t)w->p.ntau);
+    return 1;
 }
 void ora_get_worm_counters(const ora_walker *w, double *o)
 {

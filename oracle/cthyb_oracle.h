@@ -48,6 +48,8 @@ typedef struct ora_params {
     double p_worm_ins, p_worm_rep;         /* PercentageWormInsert, PercentageWormReplace */
     double worm_eta;                       /* WormEta */
     int worm_meas_g4iw, g4ph, g4pp, wormphconv;   /* WormMeasG4iw, G4ph, G4pp, WormPHConvention */
+    /* worm sampling, sector 2 = one-particle Green's function (CTQMC.F90:597-612) */
+    int worm_meas_giw, worm_meas_gtau;            /* WormMeasGiw, WormMeasGtau */
 } ora_params;
 
 typedef struct ora_walker ora_walker;
@@ -62,13 +64,17 @@ void ora_destroy(ora_walker *w);
 void ora_set_taudiffmax(ora_walker *w, double x);        /* CTQMC.F90:8180 */
 void ora_warmup(ora_walker *w, int64_t n);               /* CTQMC.F90:8188 */
 int ora_measure(ora_walker *w);                          /* CTQMC.F90:8355 sector Z; returns `aborted` */
-/* ctqmc_measure(isector, icomponent) with isector = 4 (G4 worm) or 1 (CTQMC.F90:8355-8849); returns `aborted` */
+/* ctqmc_measure(isector, icomponent) with isector = 2 (G worm), 4 (G4 worm) or 1 (CTQMC.F90:8355-8849); returns `aborted` */
 int ora_measure_sector(ora_walker *w, int isector, int icomponent);
 void ora_set_wormeta(ora_walker *w, double eta);         /* module variable wormeta(isector) (impurity.py:719) */
 /* count_steps (CTQMC.F90:6299-6444): nfix steps without measuring, configuration restored afterwards */
 void ora_count_steps(ora_walker *w, int isector, int icomponent, int64_t nfix, int64_t *steps_worm, int64_t *steps_z);
 /* worm results: g4iw_worm / g4iwpp_worm (2N4iwf,2N4iwf,2N4iwb+1) complex interleaved; returns 0 if not measured */
 int ora_get_g4iw_worm(const ora_walker *w, double *out_reim, int pp);
+/* giw_worm (2Niw) complex interleaved / gtau_worm (Ntau) of the sampled component (CTQMC.F90:1061-1120, 8858-8876);
+ * return 0 if not measured */
+int ora_get_giw_worm(const ora_walker *w, double *out_reim);
+int ora_get_gtau_worm(const ora_walker *w, double *out);
 /* [0]TryWormAdd [1]AccWormAdd [2]AccQNWormAdd [3]TryWormRem [4]AccWormRem [5]AccQNWormRem [6]TryWormRep [7]AccWormRep
  * [8]CntSampling(worm) [9]CntMeas(worm) [10]TryAdd(worm) [11]AccAdd(worm) [12]TryRem(worm) [13]AccRem(worm) [14]sector now */
 void ora_get_worm_counters(const ora_walker *w, double *out15);

@@ -165,25 +165,39 @@ WORM = {   # worm sampling in sector 4 (two-particle Green's function), one comp
 }
 
 
+WORM2 = {  # worm sampling in sector 2 (one-particle Green's function): giw_worm, gtau_worm of one component
+    "C1a": ("C1", 501, dict(Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=50, NLegMax=8, Niw=6,
+                            PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=0.05, WormMeasGiw=1, WormMeasGtau=1,
+                            PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 177, 1),
+    "C1b": ("C1", 501, dict(Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=40, NLegMax=8, Niw=5,
+                            PercentageWormInsert=0.3, PercentageWormReplace=0.1, WormEta=0.1, WormMeasGiw=1, WormMeasGtau=1,
+                            PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 178, 4),
+    "C3a": ("C3", 501, dict(Nwarmups=3000, Nmeas=500, NCorr=20, TaudiffMax=6.0, Ntau=50, NLegMax=8, Niw=8,
+                            PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=2e-3, WormMeasGiw=1, WormMeasGtau=0,
+                            PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 179, 1 + 2 * 4 + 2),
+}
+
+
 def gen_worm(only=None):
-    for name, (cfg, nftau, over, seed, comp) in WORM.items():
+    for sector, table in ((4, WORM), (2, WORM2)):
+      for name, (cfg, nftau, over, seed, comp) in table.items():
         if only and name not in only:
             continue
         p, ps = pstring_for(cfg, nftau, over)
-        s = refdrive.RefSolver(p, ps, seed, fourpnt=8)
+        s = refdrive.RefSolver(p, ps, seed, fourpnt=8 if sector == 4 else 0)
         s.set_taudiffmax(over["TaudiffMax"])
         s.warmup(over["Nwarmups"])
-        steps = s.count_steps(4, comp, 3000)
-        s.worm_warmup(0, 4, comp)
-        s.measure(4, comp)
-        r = s.results(("g4iw_worm", "g4iwpp_worm", "mean_sign", "accwormadd", "accwormrem", "accwormrep", "cntsampling",
+        steps = s.count_steps(sector, comp, 3000)
+        s.worm_warmup(0, sector, comp)
+        s.measure(sector, comp)
+        r = s.results(("g4iw_worm", "g4iwpp_worm", "giw_worm", "gtau_worm", "mean_sign", "accwormadd", "accwormrem", "accwormrep", "cntsampling",
                        "accadd", "accrem", "occ", "histo"))
         c_end = s.get_config()
         s.close()
-        np.savez_compressed(os.path.join(OUT, "worm_%s.npz" % name), config=cfg, nftau=nftau, seed=seed, component=comp,
+        np.savez_compressed(os.path.join(OUT, "worm%s_%s.npz" % ("" if sector == 4 else "2", name)), config=cfg, nftau=nftau, seed=seed, component=comp,
                             overrides=repr(over), count_steps=np.array(steps), **{"end_" + k: v for k, v in c_end.items()},
                             **{"res_" + k: v for k, v in r.items()})
-        print("worm", name, "steps(worm, Z) of the eta search", steps, "cntsampling", r["cntsampling"][[0, 3]], "nops", len(c_end["taus"]))
+        print("worm", name, "steps(worm, Z) of the eta search", steps, "cntsampling", r["cntsampling"][[0, sector - 1]], "nops", len(c_end["taus"]))
 
 
 KINDS = ("traj", "stat", "g4", "worm", "calib")

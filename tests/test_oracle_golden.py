@@ -179,6 +179,33 @@ def test_oracle_worm_sampling_retraces_reference(name):
     w.close()
 
 
+@pytest.mark.parametrize("name", ["C1a", "C1b", "C3a"])
+def test_oracle_g_worm_sampling_retraces_reference(name):
+    """Worm sampling in sector 2 (one-particle Green's function, two worm operators c c+): eta-search step counts,
+    sector step counts, acceptance ratios, final configuration, giw_worm and gtau_worm agree with the reference run."""
+    g = util.load_golden("worm2_%s.npz" % name)
+    over = g["overrides"]; comp = int(g["component"])
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    w = pyoracle.OracleWalker(p, pset, ("std", int(g["seed"])))
+    w.set_taudiffmax(over["TaudiffMax"])
+    w.warmup(over["Nwarmups"])
+    assert w.count_steps(2, comp, 3000) == tuple(int(x) for x in g["count_steps"])
+    w.measure_sector(2, comp)
+    r = w.results(); wc = w.worm_counters(); c = w.get_config()
+    assert r["counters"][11] == g["res_cntsampling"][0] and wc["cnt_sampling_w"] == g["res_cntsampling"][1]
+    assert len(c["taus"]) == len(g["end_taus"])
+    assert np.abs(c["taus"] - g["end_taus"]).max() < 1e-12
+    assert np.array_equal(c["hashybs"], g["end_hashybs"]) and np.array_equal(c["cas"], g["end_cas"])
+    assert wc["acc_wadd"] / wc["try_wadd"] == pytest.approx(float(g["res_accwormadd"][0]), rel=1e-12)
+    assert wc["acc_wrep"] / wc["try_wrep"] == pytest.approx(float(g["res_accwormrep"][0]), rel=1e-12)
+    assert wc["acc_wrem"] / wc["try_wrem"] == pytest.approx(float(g["res_accwormrem"][0]), rel=1e-12)
+    assert rel(r["giw_worm"], g["res_giw_worm"]) < 1e-10
+    if "res_gtau_worm" in g:
+        assert rel(r["gtau_worm"], g["res_gtau_worm"]) < 1e-10
+    assert rel(r["occ"], g["res_occ"]) < 1e-10
+    w.close()
+
+
 @pytest.mark.parametrize("name", ["C1", "C3", "C4S"])
 def test_oracle_window_calibration_retraces_reference(name):
     """ctqmc_calibrate, both phases, from the empty configuration: the list of accepted pair distances, the
