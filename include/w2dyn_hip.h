@@ -71,8 +71,9 @@ int w2dyn_init_counters(w2dyn_solver *s);
 /* ctqmc_warmup(n)                                  CTQMC.F90:8188 */
 int w2dyn_ctqmc_warmup(w2dyn_solver *s, int64_t nwarmups);
 /* ctqmc_measure(isector, icomponent)               CTQMC.F90:8355
- * isector 1 = Z space; isector 4 = worm sampling of the two-particle Green's function component icomponent
- * (0 = all components), density-density problems only.  Other sectors are refused. */
+ * isector 1 = Z space; isector 2 = worm sampling of the one-particle Green's function component icomponent
+ * (giw_worm / gtau_worm, CTQMC.F90:1061-1120); isector 4 = worm sampling of the two-particle Green's function
+ * component icomponent (0 = all components); density-density problems only.  Other sectors are refused. */
 int w2dyn_ctqmc_measure(w2dyn_solver *s, int isector, int icomponent);
 /* module variable `wormeta` (impurity.py:719, 755, 784): the same value for every worm sector, CTQMC.F90:194, 434 */
 int w2dyn_set_wormeta(w2dyn_solver *s, double eta);
@@ -92,7 +93,7 @@ int w2dyn_dest_ctqmc(w2dyn_solver *s);
  * nsteps Monte-Carlo steps for every chain (CTQMC.F90:8428-8533), one pass of the Z-space estimators over every
  * chain (8541-8581), normalisation (8663-8817). */
 /* sector and component of the following w2dyn_sweep / w2dyn_measure_once calls (the first lines of ctqmc_measure,
- * CTQMC.F90:8380-8400): every chain goes back to Z space; isector 1 or 4 */
+ * CTQMC.F90:8380-8400): every chain goes back to Z space; isector 1, 2 or 4 */
 int w2dyn_set_sector(w2dyn_solver *s, int isector, int icomponent);
 int w2dyn_measure_begin(w2dyn_solver *s);
 int w2dyn_sweep(w2dyn_solver *s, int64_t nsteps, int count_as_sampling);
@@ -126,6 +127,7 @@ int w2dyn_get_walker_state(w2dyn_solver *s, int walker, double *out6);
  *       "gtau_full" | "gleg_full" | per-bin: "gleg_bins" (nbins,Nd,2,NLegMax), "gtau_bins", "occ_bins", "giw_bins" |
  *       FourPnt & 4: "g4iw", "g4iw_pp" (Nd,2,Nd,2,2N4iwf,2N4iwf,2N4iwb+1) complex, "g2iw" (+ "_bins") |
  *       worm sampling (FourPnt & 8): "g4iw_worm", "g4iwpp_worm" (2N4iwf,2N4iwf,2N4iwb+1) complex (+ "_bins"),
+ *       worm sector 2 (WormMeasGiw / WormMeasGtau): "giw_worm" (2Niw) complex, "gtau_worm" (Ntau) (+ "_bins": nbins leading),
  *       "accwormadd" "accwormrem" "accwormrep" (16), "steps_worm_chains" (int64), "worm_counters" per chain
  * Writes min(bytes, size) bytes; *needed (if not NULL) receives the full size. */
 int w2dyn_get_result(w2dyn_solver *s, const char *name, void *out, size_t bytes, size_t *needed);
@@ -135,7 +137,7 @@ int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out);
 
 /* timing of the last w2dyn_sweep / w2dyn_measure_once launches, measured with HIP events on the context's own
  * stream: average kernel duration in ms and number of launches since the last reset (bench.py roofline leg) */
-int w2dyn_kernel_time(w2dyn_solver *s, const char *kernel /* "sweep" | "sweep_worm" | "sweep_calibrate" | "meas_gleg" | "meas_misc" | "meas_giw" | "meas_g2iw" | "meas_g4iw" | "meas_g4w" */,
+int w2dyn_kernel_time(w2dyn_solver *s, const char *kernel /* "sweep" | "sweep_worm" | "sweep_calibrate" | "meas_gleg" | "meas_misc" | "meas_giw" | "meas_g2iw" | "meas_g4iw" | "meas_g4w" | "meas_gw" */,
                       double *avg_ms, int64_t *launches, int reset);
 
 #ifdef __cplusplus

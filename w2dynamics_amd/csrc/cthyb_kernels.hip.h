@@ -64,7 +64,7 @@ enum Counter { C_TRYADD, C_ACCADD, C_QNADD, C_TRYREM, C_ACCREM, C_QNREM, C_TRYGL
                C_TRYSHIFT, C_ACCSHIFT, C_SAMPLING,
                C_CYC_ADD, C_CYC_REM, C_CYC_GLOB, C_CYC_SHIFT,   // shader cycles per move type (diagnostic build -DW2DYN_STAMPS only)
                C_DBG0, C_DBG1, C_DBG2, C_DBG3, C_DBG4, C_DBG5, C_DBG6, C_DBG7,   // stage stamps (diagnostic build)
-               // worm sampling (sector 4): steps and pair moves inside worm space, worm insert / remove / replace
+               // worm sampling (sectors 2 and 4): steps and pair moves inside worm space, worm insert / remove / replace
                C_W_SAMPLING, C_W_TRYADD, C_W_ACCADD, C_W_TRYREM, C_W_ACCREM,
                C_TRYWADD, C_ACCWADD, C_QNWADD, C_TRYWREM, C_ACCWREM, C_QNWREM, C_TRYWREP, C_ACCWREP,
                C_NCOUNT };
@@ -80,8 +80,8 @@ struct WalkerScalars {
     double det_sign;            // sign of det F in the reference's time order (Trace%Det%sign)
     double det_log;             // log|det F|
     unsigned long long cnt[C_NCOUNT];
-    // worm sampling: current sector (0/1 = Z, 4 = two-particle worm) and the four worm operators c c+ c c+ in
-    // wormContainer order (Trace.F90:123-125): times and flavours
+    // worm sampling: current sector (0/1 = Z, 2 = one-particle worm c c+, 4 = two-particle worm c c+ c c+) and the
+    // worm operators in wormContainer order (Trace.F90:123-125): times and flavours (the first `sector` entries count)
     int sector; int wflav[4]; double wtau[4];
 };
 
@@ -123,6 +123,7 @@ struct DevConst {
     int isector, icomponent, nwf, nwb, wormphconv, g4ph, g4pp;
     double p_wins, p_wrep, worm_eta;
     double *acc_g4w, *acc_g4wpp;  // [nbins][2nwf][2nwf][2nwb+1] complex
+    double *acc_giww, *acc_gtauw; // [nbins][niw2] complex, [nbins][ntau]: giw_worm / gtau_worm of the sampled component (sector 2)
     double *acc_nz, *acc_nw;      // [nbins] number of Z / worm measurements (chains measure in the sector they are in)
     // AccPair histogram (CTQMC.F90:65-70): naccpair bins over [0, accpair_max]; Ntau bins over beta outside the window
     // calibration.  calib: 0 = off, 1 = phase 1 (per-chain list of accepted pair distances), 2 = phase 2 (histogram on
@@ -477,7 +478,7 @@ __device__ W2DYN_INLINE void window_list_rem(Ctx &x, int f, int e1, int e2, int 
 // integral over (lo,hi) of  eps_f + sum_g U_fg n_g(tau)   for the current configuration (flavour f itself excluded).
 // All other flavours are handled in one pass: the 64 lanes are split into groups of 2^lane_shift lanes, one group per
 // flavour, each lane striding over its flavour's pairs; the coupling U_fg is loaded per lane while the loop runs.
-template <bool WORM = false>
+template <int WORM = 0>      // WORM: number of worm operators of the sampled sector (0 = pure Z-space kernel)
 __device__ W2DYN_INLINE double level_integral(Ctx &x, int f, double lo, double hi)
 {
     const DevConst &C = x.C;
@@ -496,9 +497,9 @@ __device__ W2DYN_INLINE double level_integral(Ctx &x, int f, double lo, double h
     double part = u * acc;
     if constexpr (WORM) {
         // worm operators of the other flavours change the occupations too (wormContainer order: c, c+, c, c+)
-        if (x.sector == 4 && x.lane == 0) {
+        if (x.sector != 1 && x.lane == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < WORM; ++i) {
                 const int gw = x.wfl[i];
                 if (gw == f) continue;
                 const double t = fmin(fmax(x.wtau[i], lo), hi);
@@ -534,11 +535,11 @@ __device__ __forceinline__ void accpair_add(Ctx &x, int f, double dt)
 #ifndef ADD_UNROLL
 #define ADD_UNROLL 8
 #endif
-template <int MAT, bool WORM = false, bool CALIB = false>
+template <int MAT, int WORM = 0, bool CALIB = false>
 __device__ W2DYN_INLINE void step_add(Ctx &x)
 {
     const DevConst &C = x.C;
-    if (WORM && x.sector == 4) x.count(C_W_TRYADD); else x.count(C_TRYADD);
+    if (WORM && x.sector != 1) x.count(C_W_TRYADD); else x.count(C_TRYADD);
     DBG_START(x);
     double width1 = x.wmax - x.wmin;
     double tau1 = x.wmin + width1 * x.draw();                 // annihilator
@@ -599,9 +600,9 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
         blocked |= __ballot((tce >= lo && tce <= hi) || (tae >= lo && tae <= hi)) != 0ull;
     }
     if constexpr (WORM) {
-        if (x.sector == 4) {
+        if (x.sector != 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < WORM; ++i) {
                 if (x.wfl[i] != f) continue;
                 blocked |= (x.wtau[i] >= lo && x.wtau[i] <= hi);
                 if (x.wtau[i] < lo) { if (i & 1) c_lo += 1; else a_lo += 1; }
@@ -761,18 +762,18 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
     window_list_add(x, f, k, tau2, tau1);
     if constexpr (MAT) { x.tr_log = tl_new; x.tr_sign = ts_new; mat_commit_sst(x); }
     DBG_STAMP(x, C_DBG7);
-    if (WORM && x.sector == 4) x.count(C_W_ACCADD); else x.count(C_ACCADD);
+    if (WORM && x.sector != 1) x.count(C_W_ACCADD); else x.count(C_ACCADD);
     accpair_add<CALIB>(x, f, hi - lo);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // pair removal: CTQMC.F90:3892-4150 (StepRem), Trace.F90:4851-4950, 2937-2963, MatrixUpdate.F90:445-482
 // ---------------------------------------------------------------------------------------------------------------
-template <int MAT, bool WORM = false, bool CALIB = false>
+template <int MAT, int WORM = 0, bool CALIB = false>
 __device__ W2DYN_INLINE void step_rem(Ctx &x)
 {
     const DevConst &C = x.C;
-    if (WORM && x.sector == 4) x.count(C_W_TRYREM); else x.count(C_TRYREM);
+    if (WORM && x.sector != 1) x.count(C_W_TRYREM); else x.count(C_TRYREM);
     DBG_START(x);
     // window list, partner counts and prefix counts are kept until the configuration or the window changes
     if (!x.wvalid || x.npairs < 0) x.npairs = build_window(x);
@@ -901,9 +902,9 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
         blocked = between != 0;
     }
     if constexpr (WORM) {
-        if (x.sector == 4) {
+        if (x.sector != 1) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) blocked |= (x.wfl[i] == f && x.wtau[i] > t1 && x.wtau[i] < t2);
+            for (int i = 0; i < WORM; ++i) blocked |= (x.wfl[i] == f && x.wtau[i] > t1 && x.wtau[i] < t2);
         }
     }
     DBG_STAMP(x, C_DBG2);
@@ -983,7 +984,7 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
     x.npairs = np - dnp;
     window_list_rem(x, f, e1, e2, ic, ia, last, tau_c, tau_a);
     if constexpr (MAT) { mat_remove(x, i2); mat_remove(x, i1); x.tr_log = tl_new; x.tr_sign = ts_new; mat_commit_sst(x); }
-    if (WORM && x.sector == 4) x.count(C_W_ACCREM); else x.count(C_ACCREM);
+    if (WORM && x.sector != 1) x.count(C_W_ACCREM); else x.count(C_ACCREM);
     accpair_add<CALIB>(x, f, t2 - t1);
 }
 
@@ -1440,7 +1441,7 @@ __device__ __forceinline__ void ctx_load(Ctx &x)
     const WalkerScalars &s = C.ws[w];
     x.outer = uni(s.outer); x.npairs = uni(s.npairs); x.wpos = uni(s.wpos); x.err = uni(s.err);
     x.det_sign = uni(s.det_sign); x.det_log = uni(s.det_log);
-    x.sector = uni(s.sector) == 4 ? 4 : 1;
+    { const int sec = uni(s.sector); x.sector = (sec == 4 || sec == 2) ? sec : 1; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { x.wtau[i] = uni(s.wtau[i]); x.wfl[i] = uni(s.wflav[i]); }
     unsigned long long nd_ = s.ndraw;
@@ -1627,11 +1628,12 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
         const int biti = flav_bit(fi, nd);
         const bool ci = oi < ki;
         const double ti = !act ? 0.0 : (ci ? x.tc_[fi * C.kmax + oi] : x.ta_[fi * C.kmax + oi - ki]);
-        if (!MAT && x.sector == 4 && act) {
+        if (!MAT && x.sector != 1 && act) {
             // worm operators enter the trace sign like any other operator; get_WormSign (Trace.F90:3623-3651) adds the
             // hybridising operators at later times than each worm operator
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                if (i >= x.sector) continue;                 // two worm operators in sector 2, four in sector 4
                 const int bw = flav_bit(x.wfl[i], nd); const double tw = x.wtau[i];
                 par ^= ((tw < ti && bw < biti) ? 1 : 0) ^ ((ti < tw && biti < bw) ? 1 : 0) ^ ((ti > tw) ? 1 : 0);
             }
@@ -1652,13 +1654,14 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
             if (wsame) par ^= above & 1;
         }
     }
-    const bool worm = !MAT && x.sector == 4;
+    const bool worm = !MAT && x.sector != 1;
     if (worm && x.lane == 0) {
         // worm operators among themselves: trace sign, and the pairs i < j (container order) with tau_i < tau_j
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                if (i >= x.sector || j >= x.sector) continue;
                 if (x.wtau[j] < x.wtau[i] && flav_bit(x.wfl[j], nd) < flav_bit(x.wfl[i], nd)) par ^= 1;
                 if (i < j && x.wtau[i] < x.wtau[j]) par ^= 1;
             }

@@ -1,4 +1,5 @@
-// Worm sampling in sector 4 (two-particle Green's function) for one-state blocks (density-density problems):
+// Worm sampling in sector 4 (two-particle Green's function, NW = 4 worm operators c c+ c c+) and sector 2 (one-particle
+// Green's function, NW = 2 worm operators c c+; NOperWorm, CTQMC.F90:5282-5285) for one-state blocks (density-density problems):
 // StepWormAdd / StepWormRem (CTQMC.F90:4992-5249), StepWormReplace with propose_/do_WormReplace (CTQMC.F90:5809-6297,
 // Trace.F90:3054-3478), the mixed Z / worm-space loop (CTQMC.F90:8428-8533) and the G4iw worm estimator with the exact
 // transform (CTQMC.F90:1618-1701, Nfft_worm.F90:94-137).  Included by cthyb_kernels.hip.h inside namespace w2dyn.
@@ -14,16 +15,17 @@
 // (at most three) intervals between consecutive worm operators, the second involves the worm times only.
 #pragma once
 
-// sort of the four worm operators by time: ord[m] = container index of the m-th operator in time
+// sort of the NW worm operators by time: ord[m] = container index of the m-th operator in time
+template <int NW>
 __device__ __forceinline__ void worm_order(const double (&t)[4], int (&ord)[4])
 {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NW; ++i) {
         int r = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r += (t[j] < t[i] || (t[j] == t[i] && j < i)) ? 1 : 0;
+        for (int j = 0; j < NW; ++j) r += (t[j] < t[i] || (t[j] == t[i] && j < i)) ? 1 : 0;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) if (r == m) ord[m] = i;
+        for (int m = 0; m < NW; ++m) if (r == m) ord[m] = i;
     }
 }
 
@@ -53,19 +55,20 @@ __device__ __forceinline__ bool worm_any_between(Ctx &x, int f, double lo, doubl
 // Quantum-number check and log trace ratio (with worm) / (without worm) for worm operators at times t[] with
 // flavours fl[] on top of the present hybridising operators.  At most two distinct flavours can occur in a valid
 // worm (every flavour needs as many worm creators as annihilators).
+template <int NW>
 __device__ W2DYN_INLINE bool worm_delta(Ctx &x, const double (&t)[4], const int (&fl)[4], double &dlog)
 {
     const DevConst &C = x.C;
-    int ord[4];
-    worm_order(t, ord);
+    int ord[4] = {0, 0, 0, 0};
+    worm_order<NW>(t, ord);
     dlog = 0.0;
     int fa = -1, fb = -1, da = 0, db = 0;
     bool valid = true;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < NW; ++m) {
         int i = 0; double tm = 0.0; int fm = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) if (ord[m] == q) { i = q; tm = t[q]; fm = fl[q]; }
+        for (int q = 0; q < NW; ++q) if (ord[m] == q) { i = q; tm = t[q]; fm = fl[q]; }
         const bool creator = (i & 1) != 0;                 // container order c, c+, c, c+
         if (fa < 0 || fm == fa) fa = fm;
         else if (fb < 0 || fm == fb) fb = fm;
@@ -76,12 +79,12 @@ __device__ W2DYN_INLINE bool worm_delta(Ctx &x, const double (&t)[4], const int 
         const int occ = ((x.outer >> flav_bit(fm, C.nd)) & 1) + nc - na + dcur;
         if (occ != (creator ? 0 : 1)) valid = false;
         if (fm == fa) da += creator ? 1 : -1; else db += creator ? 1 : -1;
-        if (m < 3) {
+        if (m < NW - 1) {
             double tn = 0.0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (ord[m + 1] == q) tn = t[q];
-            if (valid && da != 0) { if (worm_any_between(x, fa, tm, tn)) valid = false; else dlog -= (double)da * level_integral<false>(x, fa, tm, tn); }
-            if (valid && db != 0) { if (worm_any_between(x, fb, tm, tn)) valid = false; else dlog -= (double)db * level_integral<false>(x, fb, tm, tn); }
+            for (int q = 0; q < NW; ++q) if (ord[m + 1] == q) tn = t[q];
+            if (valid && da != 0) { if (worm_any_between(x, fa, tm, tn)) valid = false; else dlog -= (double)da * level_integral<0>(x, fa, tm, tn); }
+            if (valid && db != 0) { if (worm_any_between(x, fb, tm, tn)) valid = false; else dlog -= (double)db * level_integral<0>(x, fb, tm, tn); }
             if (valid && da != 0 && db != 0) dlog -= C.udd[fa * C.nflav + fb] * (double)(da * db) * (tn - tm);
         }
     }
@@ -89,62 +92,67 @@ __device__ W2DYN_INLINE bool worm_delta(Ctx &x, const double (&t)[4], const int 
     return valid;
 }
 
-// get_Proposal for SectorG4: (beta Nd)^4 eta (CTQMC.F90:5680-5684)
+// get_Proposal for SectorG / SectorG4: (beta Nd)^NW eta (CTQMC.F90:5677-5684)
+template <int NW>
 __device__ __forceinline__ double worm_prefact(const DevConst &C)
 {
-    const double b = C.beta * (double)C.nd;
-    return b * b * b * b * C.worm_eta;
+    const double b = C.beta * (double)C.nd, b2 = b * b;
+    return (NW == 4 ? b2 * b2 : b2) * C.worm_eta;
 }
 
+template <int NW>
 __device__ W2DYN_INLINE void step_worm_add(Ctx &x)
 {
     const DevConst &C = x.C;
     const int nf = C.nflav;
+    const int ncomp = NW == 4 ? nf * nf * nf * nf : nf * nf;
     int comp = C.icomponent;
-    if (comp == 0) comp = x.randint(1, nf * nf * nf * nf);
+    if (comp == 0) comp = x.randint(1, ncomp);
     x.count(C_TRYWADD);
-    double t[4]; int fl[4];
-    int rest = comp - 1, base = nf * nf * nf;
+    double t[4] = {0.0, 0.0, 0.0, 0.0}; int fl[4] = {0, 0, 0, 0};
+    int rest = comp - 1, base = ncomp / nf;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int bs = rest / base; rest -= bs * base; base /= nf; fl[i] = bs; }
+    for (int i = 0; i < NW; ++i) { const int bs = rest / base; rest -= bs * base; base /= nf; fl[i] = bs; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {                      // set_OperTime, Trace.F90:3942-3967
+    for (int i = 0; i < NW; ++i) {                     // set_OperTime, Trace.F90:3942-3967
         t[i] = x.draw() * C.beta;
         if (i > 0 && t[i - 1] == t[i]) t[i] += C.beta * 1e-14;
     }
     double dlog;
-    const bool valid = worm_delta(x, t, fl, dlog);
-    if (worm_prefact(C) == 0.0 || !valid) { x.count(C_QNWADD); x.sector = 1; return; }
+    const bool valid = worm_delta<NW>(x, t, fl, dlog);
+    if (worm_prefact<NW>(C) == 0.0 || !valid) { x.count(C_QNWADD); x.sector = 1; return; }
     const double rnd = x.draw();
-    if (rnd < fabs(worm_prefact(C) * exp(dlog))) {
+    if (rnd < fabs(worm_prefact<NW>(C) * exp(dlog))) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { x.wtau[i] = t[i]; x.wfl[i] = fl[i]; }
-        x.sector = 4;
+        for (int i = 0; i < NW; ++i) { x.wtau[i] = t[i]; x.wfl[i] = fl[i]; }
+        x.sector = NW;
         x.count(C_ACCWADD);
     } else x.sector = 1;
 }
 
+template <int NW>
 __device__ W2DYN_INLINE void step_worm_rem(Ctx &x)
 {
     const DevConst &C = x.C;
     x.count(C_TRYWREM);
     double dlog;
-    const bool valid = worm_delta(x, x.wtau, x.wfl, dlog);
+    const bool valid = worm_delta<NW>(x, x.wtau, x.wfl, dlog);
     if (!valid) { x.count(C_QNWREM); return; }
     const double rnd = x.draw();
-    if (rnd < fabs(exp(-dlog) / worm_prefact(C))) { x.sector = 1; x.count(C_ACCWREM); }
+    if (rnd < fabs(exp(-dlog) / worm_prefact<NW>(C))) { x.sector = 1; x.count(C_ACCWREM); }
 }
 
 // a worm operator and a hybridising operator of the same flavour and type exchange their roles: one row (creator) or
 // column (annihilator) of the hybridisation matrix changes; Sherman-Morrison on the slot-ordered M, no reordering
+template <int NW>
 __device__ W2DYN_INLINE void step_worm_replace(Ctx &x)
 {
     const DevConst &C = x.C;
     x.count(C_TRYWREP);
-    const int r = x.randint(1, 4) - 1;
+    const int r = x.randint(1, NW) - 1;
     double tw = 0.0; int f = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) if (i == r) { tw = x.wtau[i]; f = x.wfl[i]; }
+    for (int i = 0; i < NW; ++i) if (i == r) { tw = x.wtau[i]; f = x.wfl[i]; }
     const bool creator = (r & 1) != 0;
     const int k = x.order(f), kmax = C.kmax;
     if (k == 0) return;
@@ -199,7 +207,7 @@ __device__ W2DYN_INLINE void step_worm_replace(Ctx &x)
     }
     if (x.lane == 0) { if (creator) tcp[slot] = tw; else tap[slot] = tw; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) if (i == r) x.wtau[i] = th;
+    for (int i = 0; i < NW; ++i) if (i == r) x.wtau[i] = th;
     wave_sync();
     x.det_log += log(fabs(detrat));
     x.det_sign *= (detrat < 0.0 ? -1.0 : 1.0) * ((ncnt & 1) ? -1.0 : 1.0);
@@ -208,6 +216,7 @@ __device__ W2DYN_INLINE void step_worm_replace(Ctx &x)
 }
 
 // sweep kernel with worm sampling (scalar trace path): Z space CTQMC.F90:8431-8488, worm space 8489-8528
+template <int NW>
 __global__ __launch_bounds__(256, W2DYN_WPE_WORM) void k_sweep_worm(DevConst C, long long nsteps)
 {
     extern __shared__ unsigned char smem[];
@@ -225,21 +234,21 @@ __global__ __launch_bounds__(256, W2DYN_WPE_WORM) void k_sweep_worm(DevConst C, 
 #else
 #define WORM_KIND(c)
 #endif
-        if (x.sector != 4) {
+        if (x.sector == 1) {
             x.count(C_SAMPLING);
             const double r = x.draw();
-            if (r < (1.0 - ps - pg - pw) / 2.0) { x.skip(2); step_add<0, true>(x); phase += 1; WORM_KIND(C_CYC_ADD); }
-            else if (r <= 1.0 - ps - pg - pw) { x.skip(2); step_rem<0, true>(x); phase += 1; WORM_KIND(C_CYC_REM); }
-            else if (r <= 1.0 - ps - pg) { step_worm_add(x); WORM_KIND(C_CYC_GLOB); }
+            if (r < (1.0 - ps - pg - pw) / 2.0) { x.skip(2); step_add<0, NW>(x); phase += 1; WORM_KIND(C_CYC_ADD); }
+            else if (r <= 1.0 - ps - pg - pw) { x.skip(2); step_rem<0, NW>(x); phase += 1; WORM_KIND(C_CYC_REM); }
+            else if (r <= 1.0 - ps - pg) { step_worm_add<NW>(x); WORM_KIND(C_CYC_GLOB); }
             else if (r <= 1.0 - ps) { step_glob(x); WORM_KIND(C_CYC_SHIFT); }
             else { step_shift<0>(x); WORM_KIND(C_CYC_SHIFT); }
         } else {
             x.count(C_W_SAMPLING);
             const double r = x.draw();
-            if (r < (1.0 - pr - pw) / 2.0) { x.skip(2); step_add<0, true>(x); phase += 1; WORM_KIND(C_DBG5); }
-            else if (r < 1.0 - pr - pw) { x.skip(2); step_rem<0, true>(x); phase += 1; WORM_KIND(C_DBG5); }
-            else if (r < 1.0 - pw) { step_worm_replace(x); WORM_KIND(C_DBG6); }
-            else { step_worm_rem(x); WORM_KIND(C_DBG7); }
+            if (r < (1.0 - pr - pw) / 2.0) { x.skip(2); step_add<0, NW>(x); phase += 1; WORM_KIND(C_DBG5); }
+            else if (r < 1.0 - pr - pw) { x.skip(2); step_rem<0, NW>(x); phase += 1; WORM_KIND(C_DBG5); }
+            else if (r < 1.0 - pw) { step_worm_replace<NW>(x); WORM_KIND(C_DBG6); }
+            else { step_worm_rem<NW>(x); WORM_KIND(C_DBG7); }
         }
 #ifdef W2DYN_STAMPS_WORM
         if (x.lane == 0) x.cnt[kind_] += __builtin_amdgcn_s_memtime() - t0_;
@@ -306,4 +315,58 @@ __global__ __launch_bounds__(256) void k_meas_g4w(DevConst C, int pp, int nbw)
             if (e < n) { acc[2 * e] += re[q]; acc[2 * e + 1] += im[q]; }
         }
     }
+}
+
+// One-particle worm estimators (sector 2), measure_giw_worm / measure_gtau_worm (CTQMC.F90:1061-1120): every chain in worm
+// space adds cfgsign/eta * exp(i w_n (t1 - t2)), n = -Niw..Niw-1, to giw_worm of its bin and +-cfgsign/eta to the bin of
+// t1 - t2 (+ beta with sign -1) of gtau_worm.  One workgroup per accumulator bin loops over the bin's chains; thread t
+// owns the frequencies t, t+256, ... and steps from one to the next by a rotation with exp(i 512 pi (t1-t2)/beta) (two
+// sincos per chain and thread); accumulators in registers, the tau histogram in LDS, one read-modify-write per launch.
+constexpr int GW_PER_THREAD = 16;
+__global__ __launch_bounds__(256) void k_meas_gw(DevConst C)
+{
+    extern __shared__ double gth[];              // [ntau]
+    const int bin = blockIdx.x, tid = threadIdx.x, nf2 = C.niw2, niw = C.niw2 / 2;
+    const double pib = M_PI / C.beta;
+    if (C.acc_gtauw) { for (int i = tid; i < C.ntau; i += 256) gth[i] = 0.0; }
+    __syncthreads();
+    const int w0 = bin * C.walkers_per_bin, w1 = min((bin + 1) * C.walkers_per_bin, C.nwalkers);
+    for (int e0 = 0; e0 < nf2 || e0 == 0; e0 += 256 * GW_PER_THREAD) {
+        double re[GW_PER_THREAD], im[GW_PER_THREAD];
+#pragma unroll
+        for (int q = 0; q < GW_PER_THREAD; ++q) { re[q] = 0.0; im[q] = 0.0; }
+        for (int w = w0; w < w1; ++w) {
+            const WalkerScalars &s = C.ws[w];
+            if (s.sector != 2) continue;                     // uniform over the workgroup
+            const double dt = s.wtau[0] - s.wtau[1];
+            const double val = C.cfgsign[w] / C.worm_eta;
+            if (C.acc_giww) {
+                double sn, cs, sr, cr;
+                sincos(pib * (double)(2 * (e0 + tid - niw) + 1) * dt, &sn, &cs);
+                sincos(pib * 512.0 * dt, &sr, &cr);
+#pragma unroll
+                for (int q = 0; q < GW_PER_THREAD; ++q) {
+                    re[q] += val * cs; im[q] += val * sn;
+                    const double c2 = cs * cr - sn * sr; sn = cs * sr + sn * cr; cs = c2;
+                }
+            }
+            if (C.acc_gtauw && e0 == 0 && tid == 0) {
+                double tau = dt, sg = 1.0;
+                if (tau < 0.0) { tau += C.beta; sg = -1.0; }
+                int it = (int)((double)C.ntau * tau / C.beta) + 1;
+                if (it > C.ntau) it = C.ntau;
+                gth[it - 1] += sg * val;
+            }
+        }
+        if (C.acc_giww) {
+            double *acc = C.acc_giww + (size_t)bin * nf2 * 2;
+#pragma unroll
+            for (int q = 0; q < GW_PER_THREAD; ++q) {
+                const int e = e0 + q * 256 + tid;
+                if (e < nf2) { acc[2 * e] += re[q]; acc[2 * e + 1] += im[q]; }
+            }
+        }
+    }
+    __syncthreads();
+    if (C.acc_gtauw) { double *acc = C.acc_gtauw + (size_t)bin * C.ntau; for (int i = tid; i < C.ntau; i += 256) acc[i] += gth[i]; }
 }

@@ -57,6 +57,8 @@ struct w2dyn_solver {
     // worm sampling (sector 4): move probabilities, eta, estimator switches, accumulator bins, sector of the running call
     double p_wins = 0, p_wrep = 0, worm_eta = 0;
     int worm_meas_g4iw = 0, g4ph = 0, g4pp = 0, wormphconv = 0, nbw = 0, cur_isector = 1;
+    int res_isector = 1;                             // sector of the run the result table was made from
+    int worm_meas_giw = 0, worm_meas_gtau = 0;       // sector 2: WormMeasGiw, WormMeasGtau (CTQMC.F90:597-612)
     bool no_sampling = false;
     std::vector<long long> steps_worm_chains;
     // window calibration (ctqmc_calibrate): default AccPair histogram and the one on the calibration grid
@@ -316,6 +318,8 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if (!get_real(s, "PercentageWormReplace", s->p_wrep)) return W2DYN_EINVAL;
     if (!get_real(s, "WormEta", s->worm_eta)) return W2DYN_EINVAL;                      // CTQMC.F90:434
     if (!get_int(s, "WormMeasG4iw", iv)) return W2DYN_EINVAL; s->worm_meas_g4iw = iv != 0;
+    if (!get_int(s, "WormMeasGiw", iv)) return W2DYN_EINVAL; s->worm_meas_giw = iv != 0;
+    if (!get_int(s, "WormMeasGtau", iv)) return W2DYN_EINVAL; s->worm_meas_gtau = iv != 0;
     if (!get_int(s, "G4ph", iv)) return W2DYN_EINVAL; s->g4ph = iv != 0;
     if (!get_int(s, "G4pp", iv)) return W2DYN_EINVAL; s->g4pp = iv != 0;
     if (!get_int(s, "WormPHConvention", iv)) return W2DYN_EINVAL; s->wormphconv = iv != 0;
@@ -487,6 +491,12 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     C.nwf = s->n4iwf; C.nwb = s->n4iwb; C.wormphconv = s->wormphconv; C.g4ph = s->g4ph; C.g4pp = s->g4pp;
     C.p_wins = 0.0; C.p_wrep = s->p_wrep; C.worm_eta = s->worm_eta; C.isector = 1; C.icomponent = 0;
     s->nbw = 0; s->cur_isector = 1; s->no_sampling = false; s->steps_worm_chains.clear();
+    C.acc_giww = C.acc_gtauw = nullptr;
+    if (s->worm_meas_giw) { if ((rc = dev_alloc(s, C.acc_giww, B * (size_t)C.niw2 * 2))) return rc; }
+    if (s->worm_meas_gtau) {
+        if ((rc = dev_alloc(s, C.acc_gtauw, B * (size_t)s->ntau))) return rc;
+        if ((size_t)s->ntau * sizeof(double) > 64 * 1024) return fail(s, W2DYN_EUNSUPPORTED, "Ntau=%d too large for the gtau_worm estimator", s->ntau);
+    }
     if (s->g4ph || s->g4pp) {
         const size_t n = (size_t)4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1) * 2 * ((s->g4ph ? 1 : 0) + (s->g4pp ? 1 : 0));
         s->nbw = (int)std::max<size_t>(1, std::min<size_t>(B, ((size_t)2 << 30) / (n * sizeof(double))));
@@ -568,10 +578,11 @@ int w2dyn_sweep(w2dyn_solver *s, int64_t nsteps, int count_as_sampling)
     if ((rc = time_begin(s))) return rc;
     // instantiations: 0 = one-state blocks (closed-form trace); 2, 3, 4 = matrix path with blocks padded to that size
     // (tree product); 9 = matrix path, sequential propagation (blocks of 5..8 states)
-    if (s->cur_isector == 4) hipLaunchKernelGGL(k_sweep_worm, l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps);   // counts its own steps
+    if (s->cur_isector == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_worm<4>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps);   // counts its own steps
+    else if (s->cur_isector == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_worm<2>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps);
     else launch_sweep<false>(s, l, (long long)nsteps, count_as_sampling);
     HIPCHK(hipGetLastError());
-    if ((rc = time_end(s, s->cur_isector == 4 ? "sweep_worm" : "sweep"))) return rc;
+    if ((rc = time_end(s, s->cur_isector != 1 ? "sweep_worm" : "sweep"))) return rc;
     s->steps_done += nsteps;
     return 0;
 }
@@ -677,6 +688,8 @@ int w2dyn_measure_begin(w2dyn_solver *s)
         if (C.acc_g4w) HIPCHK(hipMemsetAsync(C.acc_g4w, 0, sizeof(double) * one, s->stream));
         if (C.acc_g4wpp) HIPCHK(hipMemsetAsync(C.acc_g4wpp, 0, sizeof(double) * one, s->stream));
     }
+    if (C.acc_giww) HIPCHK(hipMemsetAsync(C.acc_giww, 0, sizeof(double) * B * C.niw2 * 2, s->stream));
+    if (C.acc_gtauw) HIPCHK(hipMemsetAsync(C.acc_gtauw, 0, sizeof(double) * B * s->ntau, s->stream));
     if (s->fourpnt & 4) {
         const size_t n2 = 2 * (size_t)(s->n4iwf + s->n4iwb), n4 = (size_t)nf * nf * 4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1), ng2 = (size_t)nf * n2 * n2;
         HIPCHK(hipMemsetAsync(s->acc4, 0, sizeof(double2) * s->nb4 * n4, s->stream));
@@ -704,7 +717,14 @@ int w2dyn_measure_once(w2dyn_solver *s)
     HIPCHK(hipGetLastError());
     if ((rc = time_end(s, "meas_misc"))) return rc;
     if (s->cur_isector != 1) {      // component sampling: no Z-space Green's function estimators (CTQMC.F90:8554), worm estimator instead
-        if (s->C.acc_g4w || s->C.acc_g4wpp) {
+        if (s->cur_isector == 2) {
+            if (s->C.acc_giww || s->C.acc_gtauw) {
+                if ((rc = time_begin(s))) return rc;
+                hipLaunchKernelGGL(k_meas_gw, dim3(s->C.nbins), dim3(256), (size_t)s->ntau * sizeof(double), s->stream, s->C);
+                HIPCHK(hipGetLastError());
+                if ((rc = time_end(s, "meas_gw"))) return rc;
+            }
+        } else if (s->C.acc_g4w || s->C.acc_g4wpp) {
             if ((rc = time_begin(s))) return rc;
             const size_t lds = (size_t)(4 * s->n4iwf + 2 * s->n4iwb + 1) * sizeof(double2);
             if (s->C.acc_g4w) hipLaunchKernelGGL(k_meas_g4w, dim3(s->nbw), dim3(256), lds, s->stream, s->C, 0, s->nbw);
@@ -880,14 +900,16 @@ int w2dyn_measure_finish(w2dyn_solver *s)
         }
         R["densitymatrix"] = full;
     }
+    s->res_isector = s->cur_isector;
     {   // acceptance ratios (CTQMC.F90:8680-8695); 16 sectors, Z = index 0
         std::vector<double> aa(16, 0.0), ar(16, 0.0);
         aa[0] = s->counters[C_ACCADD] / s->counters[C_TRYADD]; ar[0] = s->counters[C_ACCREM] / s->counters[C_TRYREM];
         std::vector<double> wa(15, 0.0), wr(15, 0.0), wp(15, 0.0);      // AccWormAdd/Rem/Rep(2:NWormSectors), CTQMC.F90:8685-8691
-        if (s->cur_isector == 4) {
-            aa[3] = s->counters[C_W_ACCADD] / s->counters[C_W_TRYADD]; ar[3] = s->counters[C_W_ACCREM] / s->counters[C_W_TRYREM];
-            wa[2] = s->counters[C_ACCWADD] / s->counters[C_TRYWADD]; wr[2] = s->counters[C_ACCWREM] / s->counters[C_TRYWREM];
-            wp[2] = s->counters[C_ACCWREP] / s->counters[C_TRYWREP];
+        if (s->cur_isector == 4 || s->cur_isector == 2) {
+            const int is = s->cur_isector;       // AccAdd(Sector) is indexed from 1, the worm arrays from sector 2
+            aa[is - 1] = s->counters[C_W_ACCADD] / s->counters[C_W_TRYADD]; ar[is - 1] = s->counters[C_W_ACCREM] / s->counters[C_W_TRYREM];
+            wa[is - 2] = s->counters[C_ACCWADD] / s->counters[C_TRYWADD]; wr[is - 2] = s->counters[C_ACCWREM] / s->counters[C_TRYWREM];
+            wp[is - 2] = s->counters[C_ACCWREP] / s->counters[C_TRYWREP];
         }
         R["accwormadd"] = wa; R["accwormrem"] = wr; R["accwormrep"] = wp;
         R["accadd"] = aa; R["accrem"] = ar;
@@ -940,6 +962,29 @@ int w2dyn_measure_finish(w2dyn_solver *s)
         if (C.acc_g4wpp) reducew(C.acc_g4wpp, "g4iwpp_worm");
         R["cntmeas_worm"] = {mwt};
     }
+    if (s->cur_isector == 2 && (C.acc_giww || C.acc_gtauw)) {
+        // wormScaling(SectorG) = CntSampling(G) / (CntMeas(G) CntSampling(Z)) * 4/beta / mean_sign; giw_worm = -sum * scaling
+        // / (2Nd)^2, gtau_worm = sum * scaling * Ntau/beta / (2Nd)^2 (CTQMC.F90:8825, 8843-8876); counts pooled per bin
+        std::vector<double> cw(B, 0.0), cz(B, 0.0);
+        double cwt = 0.0, czt = 0.0, mwt = 0.0;
+        for (int w = 0; w < W; ++w) { const int b = w / C.walkers_per_bin; cw[b] += (double)ws[w].cnt[C_W_SAMPLING]; cz[b] += (double)ws[w].cnt[C_SAMPLING]; }
+        for (int b = 0; b < B; ++b) { cwt += cw[b]; czt += cz[b]; mwt += nwm[b]; }
+        auto scal = [&](double c_w, double c_z, double m_w) { return m_w != 0.0 ? c_w / (m_w * c_z) * 4.0 / beta / ms / ((double)nf * nf) : 0.0; };
+        auto reduceg = [&](const double *dev, size_t n, const char *name, double extra) {
+            std::vector<double> raw((size_t)B * n), tot(n, 0.0);
+            (void)hipMemcpy(raw.data(), dev, raw.size() * sizeof(double), hipMemcpyDeviceToHost);
+            for (int b = 0; b < B; ++b) {
+                const double f = scal(cw[b], cz[b], nwm[b]) * extra;
+                for (size_t i = 0; i < n; ++i) { tot[i] += raw[(size_t)b * n + i]; raw[(size_t)b * n + i] *= f; }
+            }
+            const double f = scal(cwt, czt, mwt) * extra;
+            for (size_t i = 0; i < n; ++i) tot[i] *= f;
+            R[name] = tot; R[std::string(name) + "_bins"] = raw;
+        };
+        if (C.acc_giww) reduceg(C.acc_giww, (size_t)C.niw2 * 2, "giw_worm", -1.0);
+        if (C.acc_gtauw) reduceg(C.acc_gtauw, (size_t)ntau, "gtau_worm", (double)ntau / beta);
+        R["cntmeas_worm"] = {mwt};
+    }
     {   // per-chain worm counters: steps in Z, steps in worm space, worm insertions tried / accepted, removals, replacements
         std::vector<double> wc((size_t)W * 8);
         for (int w = 0; w < W; ++w) {
@@ -960,11 +1005,11 @@ int w2dyn_measure_finish(w2dyn_solver *s)
 // sector bookkeeping shared by ctqmc_measure and count_steps: every chain starts in Z space (CTQMC.F90:6328, 8400)
 static int enter_sector(w2dyn_solver *s, int isector, int icomponent)
 {
-    if (isector != 1 && isector != 4) return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d is not supported (1 = Z, 4 = two-particle Green's function)", isector);
-    if (isector == 4) {
+    if (isector != 1 && isector != 2 && isector != 4) return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d is not supported (1 = Z, 2 = one-particle, 4 = two-particle Green's function)", isector);
+    if (isector != 1) {
         const int nf = s->nflav;
         if (s->mat) return fail(s, W2DYN_EUNSUPPORTED, "worm sampling is only implemented for density-density problems (one-state blocks)");
-        if (icomponent < 0 || icomponent > nf * nf * nf * nf) return fail(s, W2DYN_EINVAL, "component %d out of range", icomponent);
+        if (icomponent < 0 || icomponent > (isector == 4 ? nf * nf * nf * nf : nf * nf)) return fail(s, W2DYN_EINVAL, "component %d out of range", icomponent);
     }
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -975,7 +1020,7 @@ static int enter_sector(w2dyn_solver *s, int isector, int icomponent)
     std::vector<WalkerScalars> ws(s->nwalkers);
     HIPCHK(hipMemcpy(ws.data(), s->C.ws, ws.size() * sizeof(WalkerScalars), hipMemcpyDeviceToHost));
     bool dirty = false;
-    for (auto &w : ws) if (w.sector == 4) { w.sector = 1; dirty = true; }
+    for (auto &w : ws) if (w.sector == 4 || w.sector == 2) { w.sector = 1; dirty = true; }
     if (dirty) HIPCHK(hipMemcpy(s->C.ws, ws.data(), ws.size() * sizeof(WalkerScalars), hipMemcpyHostToDevice));
     return 0;
 }
@@ -1017,15 +1062,15 @@ int w2dyn_ctqmc_worm_warmup(w2dyn_solver *s, int64_t nwarmups2, int isector, int
     if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "ctqmc_worm_warmup before init_solver");
     // the reference allocates the buffers of the batched transform here and samples nothing (CTQMC.F90:8266-8348); this
     // library transforms every measurement on the spot, so only the arguments are checked
-    if (isector != 1 && isector != 4) return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d is not supported (1 = Z, 4 = two-particle Green's function)", isector);
-    if (isector == 4 && s->mat) return fail(s, W2DYN_EUNSUPPORTED, "worm sampling is only implemented for density-density problems (one-state blocks)");
+    if (isector != 1 && isector != 2 && isector != 4) return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d is not supported (1 = Z, 2 = one-particle, 4 = two-particle Green's function)", isector);
+    if (isector != 1 && s->mat) return fail(s, W2DYN_EUNSUPPORTED, "worm sampling is only implemented for density-density problems (one-state blocks)");
     return 0;
 }
 
 int w2dyn_count_steps(w2dyn_solver *s, int isector, int icomponent, int64_t nfix, int64_t *steps_worm, int64_t *steps_z)
 {
     if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "count_steps before init_solver");
-    if (isector != 4) return fail(s, W2DYN_EUNSUPPORTED, "count_steps: worm sector %d is not supported (4 = two-particle Green's function)", isector);
+    if (isector != 4 && isector != 2) return fail(s, W2DYN_EUNSUPPORTED, "count_steps: worm sector %d is not supported (2 = one-particle, 4 = two-particle Green's function)", isector);
     if (nfix < 0) return fail(s, W2DYN_EINVAL, "count_steps: nfix = %lld", (long long)nfix);
     int rc;
     if ((rc = enter_sector(s, isector, icomponent))) return rc;
@@ -1096,7 +1141,7 @@ int w2dyn_get_mc_config_scalars(w2dyn_solver *s, int walker, int *n, int *outer_
     WalkerScalars ws; std::vector<int> K; std::vector<double> TC, TA;
     int rc = fetch_walker(s, walker, ws, K, TC, TA); if (rc) return rc;
     int tot = 0; for (int k : K) tot += 2 * k;
-    if (ws.sector == 4) tot += 4;
+    if (ws.sector == 4 || ws.sector == 2) tot += ws.sector;
     if (n) *n = tot; if (outer_sst) *outer_sst = ws.outer; if (outer_state) *outer_state = 1;
     return 0;
 }
@@ -1110,7 +1155,7 @@ int w2dyn_get_mc_config(w2dyn_solver *s, int walker, int n, double *taus, int *o
     std::vector<Op> ops;
     const int kmax = s->C.kmax;
     for (int f = 0; f < s->nflav; ++f) for (int e = 0; e < K[f]; ++e) { ops.push_back({TC[(size_t)f * kmax + e], f, 1, -1}); ops.push_back({TA[(size_t)f * kmax + e], f, 2, -1}); }
-    if (ws.sector == 4) for (int i = 0; i < 4; ++i) ops.push_back({ws.wtau[i], ws.wflav[i], (i & 1) ? 1 : 2, 0});     // worm operators: hashyb 0 (Trace.F90:6861-6865)
+    if (ws.sector == 4 || ws.sector == 2) for (int i = 0; i < ws.sector; ++i) ops.push_back({ws.wtau[i], ws.wflav[i], (i & 1) ? 1 : 2, 0});     // worm operators: hashyb 0 (Trace.F90:6861-6865)
     if ((int)ops.size() != n) return fail(s, W2DYN_EINVAL, "get_mc_config: n=%d but the chain holds %zu operators", n, ops.size());
     std::sort(ops.begin(), ops.end(), [](const Op &a, const Op &b) { return a.t < b.t; });
     for (int i = 0; i < n; ++i) { taus[i] = ops[i].t; orbs[i] = (ops[i].f >> 1) + 1; spins[i] = (ops[i].f & 1) + 1; cas[i] = ops[i].ca; hashybs[i] = ops[i].hyb; }
@@ -1226,7 +1271,7 @@ int w2dyn_get_result(w2dyn_solver *s, const char *name, void *out, size_t bytes,
     else if (n == "accpairtau") { src = s->accpairtau.data(); size = s->accpairtau.size() * sizeof(double); }
     else if (n == "accpairtau_chains") { src = s->accpairtau_chains.data(); size = s->accpairtau_chains.size() * sizeof(double); }
     else if (n == "steps_worm_chains") { src = s->steps_worm_chains.data(); size = s->steps_worm_chains.size() * sizeof(long long); }
-    else if (n == "cntsampling") { ltmp.assign(16, 0); if (!s->counters.empty()) { ltmp[0] = (long long)s->counters[C_SAMPLING]; ltmp[3] = (long long)s->counters[C_W_SAMPLING]; } src = ltmp.data(); size = ltmp.size() * sizeof(long long); }
+    else if (n == "cntsampling") { ltmp.assign(16, 0); if (!s->counters.empty()) { ltmp[0] = (long long)s->counters[C_SAMPLING]; ltmp[s->res_isector == 2 ? 1 : 3] = (long long)s->counters[C_W_SAMPLING]; } src = ltmp.data(); size = ltmp.size() * sizeof(long long); }
     else if (n == "counters") { src = s->counters.data(); size = s->counters.size() * sizeof(double); }
     else {
         auto it = s->res.find(n);

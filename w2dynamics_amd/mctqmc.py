@@ -290,6 +290,13 @@ class MCTQMC:
             nwf, nwb = self._n4iwf, self._n4iwb
             lead = (int(self.scalar("nbw")),) if name.endswith("_bins") else ()
             return a.reshape(lead + (2 * nwf, 2 * nwf, 2 * nwb + 1))
+        if name in ("giw_worm", "giw_worm_bins"):
+            # one-particle worm estimator of the sampled component: giw_worm(2*Niw), CTQMC.F90:598
+            a = self.result(name).reshape(-1, 2); a = a[:, 0] + 1j * a[:, 1]
+            return a.reshape(int(self.scalar("nbins")), -1) if name.endswith("_bins") else a
+        if name in ("gtau_worm", "gtau_worm_bins"):
+            a = self.result(name)
+            return a.reshape(int(self.scalar("nbins")), -1) if name.endswith("_bins") else a
         if name in ("accwormadd", "accwormrem", "accwormrep"):
             return self.result(name)
         if name == "accpairtau":

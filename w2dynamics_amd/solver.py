@@ -99,8 +99,8 @@ class HipCtHybSolver:
     def solve_component(self, iter_no, isector, icomponent, mc_config_inout=None):
         """Worm estimator of one component in the call order of `CtHybSolver.solve_component` (`impurity.py:656-892`):
         init_solver -> (stored configuration | warm-up) -> eta search by count_steps -> ctqmc_worm_warmup ->
-        ctqmc_measure(isector, icomponent) -> result normalised by nflavours^4.  Sector 4 (two-particle Green's
-        function) is the one the HIP library samples."""
+        ctqmc_measure(isector, icomponent) -> result normalised by nflavours^4.  Sectors 2 (one-particle Green's
+        function: giw-worm, gtau-worm) and 4 (two-particle Green's function) are the ones the HIP library samples."""
         import scipy.optimize as opt
         q = self.ctqmc
         self.comm.Barrier()
@@ -170,12 +170,51 @@ class HipCtHybSolver:
                 result["g4iw-worm/%05d" % icomponent] = DistributedSample(q.g4iw_worm_bins / nfl ** 4, self.comm)
             if self.qmc["G4pp"] == 1:
                 result["g4iwpp-worm/%05d" % icomponent] = DistributedSample(q.g4iwpp_worm_bins / nfl ** 4, self.comm)
+        if isector == 2:          # get_resultset_worm, impurity.py:1312-1315 (already divided by nflavours^2, CTQMC.F90:8871)
+            if self.qmc["WormMeasGiw"] != 0:
+                result["giw-worm/%05d" % icomponent] = DistributedSample(q.giw_worm_bins, self.comm)
+            if self.qmc["WormMeasGtau"] != 0:
+                result["gtau-worm/%05d" % icomponent] = DistributedSample(q.gtau_worm_bins, self.comm)
+        # Z-space quantities are sampled along with every component (impurity.py:966-977)
+        result["occ"] = DistributedSample(q.occ_bins, self.comm)
+        result["rho1"] = DistributedSample(np.array([q.rho1]), self.comm)
+        result["rho2"] = DistributedSample(np.array([q.rho2]), self.comm)
         result["worm-eta/%05d" % icomponent] = eta_mean
         result["sign"] = DistributedSample(np.array([q.mean_sign]), self.comm)
         result["steps-worm-partition/%05d" % icomponent] = np.array(q.cntsampling, dtype=np.double)
         result["time-qmc"] = time.perf_counter() - t0
         q.dest_ctqmc()
         q.dest_paras()
+        return result
+
+    def solve_worm(self, iter_no=0, components=None):
+        """`CtHybSolver.solve_worm` (`impurity.py:906-1010`) for `WormMeasGiw`: every diagonal component of the
+        one-particle Green's function is sampled in worm sector 2 by `solve_component`, the component list is
+        assembled into G(iw) (`get_giw` with FTType `none_worm`, `impurity.py:1066-1072`), the Z-space quantities
+        sampled along with every component are averaged and the self-energy moments follow from rho1 / rho2."""
+        if not self.qmc["WormMeasGiw"]:
+            raise ValueError("solve_worm: WormMeasGiw must be set (the sectors of WormMeasGSigmaiw / WormMeasQQ are not sampled)")
+        p = self.problem
+        nd = p.nd; nfl = 2 * nd; niw = 2 * int(self.qmc["Niw"])
+        if components is None:            # ci.GFComponent(bandspin=(f, f), n_ops=2).index, impurity.py:919-921
+            components = [1 + f * nfl + f for f in range(nfl)]
+        conf, per_comp = [], []
+        for comp in components:
+            self.set_problem(p, self.ctqmc.fourpnt)
+            per_comp.append((comp, self.solve_component(iter_no, 2, comp, conf)))
+        result = {}
+        for comp, r in per_comp:
+            result.update({k: v for k, v in r.items() if k.endswith("/%05d" % comp)})
+        nb = min(np.asarray(r["giw-worm/%05d" % c].local).shape[0] for c, r in per_comp)
+        giw = np.zeros((nb, niw, nd, 2, nd, 2), dtype=complex)
+        for comp, r in per_comp:
+            f1, f2 = divmod(comp - 1, nfl)
+            giw[:, :, f1 // 2, f1 % 2, f2 // 2, f2 % 2] = np.asarray(r["giw-worm/%05d" % comp].local)[:nb]
+        result["giw"] = DistributedSample(giw, self.comm)
+        for key in ("occ", "rho1", "rho2"):
+            result[key] = DistributedSample(np.concatenate([np.asarray(r[key].local) for _, r in per_comp]), self.comm)
+        result["smom"] = DistributedSample(np.array([_postproc.lattice_convention(_postproc.get_siw_mom(
+            np.asarray(p.umatrix).reshape((nfl,) * 4), np.asarray(result["rho1"].mean()), np.asarray(result["rho2"].mean())))]), self.comm)
         return result
 
     def calibrate_taudiff_max(self, phase1pairnum=1000, phase2taugrid=100, phase2pairnum=1000, nprogress=100000):
