@@ -60,6 +60,8 @@ struct ora_walker {
     double try_wadd, acc_wadd, accqn_wadd, try_wrem, acc_wrem, accqn_wrem, try_wrep, acc_wrep;
     double cnt_sampling_w, cnt_meas_w;
     double *g4w, *g4wpp;                      /* g4iw_worm, g4iwpp_worm accumulators */
+    /* AccumGtau = 2: autocorracc (Accumulators.F90:206-362): per-measurement buffer, (spill, mean, sqdiff) per component and level */
+    double *acbuf, *acdat; int aclev; int64_t acn;
     double *giww, *gtauw;                     /* giw_worm (2Niw complex), gtau_worm (Ntau) accumulators (sector 2) */
     double try_add, acc_add, accqn_add, try_rem, acc_rem, accqn_rem, try_glob, acc_glob, accqn_glob;
     double try_shift, acc_shift, cnt_sampling, cnt_meas;
@@ -1115,6 +1117,13 @@ ora_walker *ora_create(const ora_params *p, const double *U, const double *ftau_
         if (p->meas_g2iw) w->g2iw = (double *)calloc((size_t)w->nflav * n2 * n2 * 2, sizeof(double));
     }
     w->sector = w->isector = 1; w->icomponent = 0; w->eta = p->worm_eta;
+    if (p->accum_gtau == 2) {                                                       /* CTQMC.F90:497-500, ilog2 Accumulators.F90:89-101 */
+        int lev = -1; for (int64_t t = p->nmeas; t > 0; t /= 2) ++lev;
+        if (lev < 1) { fprintf(stderr, "oracle: AccumGtau = 2 needs Nmeas >= 2\n"); abort(); }
+        w->aclev = lev; w->acn = 0;
+        w->acbuf = (double *)calloc((size_t)w->nflav * p->ntau, sizeof(double));
+        w->acdat = (double *)calloc((size_t)w->nflav * p->ntau * lev * 3, sizeof(double));
+    }
     if (p->worm_meas_giw) w->giww = (double *)calloc((size_t)4 * p->niw, sizeof(double));      /* CTQMC.F90:597-599 */
     if (p->worm_meas_gtau) w->gtauw = (double *)calloc((size_t)p->ntau, sizeof(double));        /* CTQMC.F90:609-612 */
     if ((p->fourpnt & 8) && p->worm_meas_g4iw) {                                    /* CTQMC.F90:339-361 */
@@ -1141,7 +1150,7 @@ void ora_destroy(ora_walker *w)
     if (!w) return;
     for (int f = 0; f < w->nflav; ++f) free(w->M[f]);
     free(w->ops); free(w->ftab); ora_locprob_free(w->lp); free(w->ptr); free(w->dmblk); free(w->dmoff); free(w->accpair); free(w->accpairtau); free(w->gleg); free(w->gtau); free(w->giw);
-    free(w->histo); free(w->dm); free(w->outer_histo); free(w->g2iw); free(w->g4iw); free(w->g4iwpp); free(w->g4w); free(w->g4wpp); free(w->giww); free(w->gtauw); free(w);
+    free(w->histo); free(w->dm); free(w->outer_histo); free(w->g2iw); free(w->g4iw); free(w->g4iwpp); free(w->g4w); free(w->g4wpp); free(w->giww); free(w->gtauw); free(w->acbuf); free(w->acdat); free(w);
 }
 
 void ora_set_taudiffmax(ora_walker *w, double x) { init_window(w, x); }
@@ -1364,6 +1373,31 @@ static void meas_g_worm(ora_walker *w)
     }
 }
 
+/* autocorracc_add (Accumulators.F90:283-331): Welford update of level 0 with the buffer; whenever the lowest bits of the
+ * count are ones, the mean of the two last lower-level values rolls over into the next level */
+static void autocorr_add(ora_walker *w)
+{
+    const size_t nc = (size_t)w->nflav * w->p.ntau;
+    const int L = w->aclev;
+    for (size_t i = 0; i < nc; ++i) {
+        double *d = w->acdat + i * (size_t)L * 3;        /* [lvl][spill, mean, sqdiff] */
+        int64_t n = w->acn; int lvl = 0;
+        double val = w->acbuf[i];
+        for (;;) {
+            d[lvl * 3] += val;
+            double incr1 = val - d[lvl * 3 + 1];
+            d[lvl * 3 + 1] += incr1 / (double)(n + 1);
+            double incr2 = val - d[lvl * 3 + 1];
+            d[lvl * 3 + 2] += incr1 * incr2;
+            if (!(n & 1) || lvl == L - 1) break;
+            n /= 2; ++lvl;
+            val = d[(lvl - 1) * 3] / 2; d[(lvl - 1) * 3] = 0.0;
+        }
+        w->acbuf[i] = 0.0;
+    }
+    w->acn += 1;
+}
+
 void ora_measure_once(ora_walker *w)
 {
     int nf = w->nflav;
@@ -1390,11 +1424,14 @@ void ora_measure_once(ora_walker *w)
             if (w->ops[i].flav != f) continue;
             if (w->ops[i].ca == 1) tc[nc++] = w->ops[i].tau; else ta[na++] = w->ops[i].tau;
         }
-        ora_meas_flavour(w->M[f], k, tc, ta, w->p.beta, w->cfgsign, w->p.nlegmax, w->gleg + (size_t)f * w->p.nlegmax,
-                         w->p.ntau, w->gtau + (size_t)f * w->p.ntau, 2 * w->p.niw,
+        /* AccumGtau = 0: MeasGtauRem returns at once (CTQMC.F90:2267), neither G(l) nor G(tau); 2: per-measurement buffer */
+        const int acc = w->p.accum_gtau;
+        ora_meas_flavour(w->M[f], k, tc, ta, w->p.beta, w->cfgsign, w->p.nlegmax, acc ? w->gleg + (size_t)f * w->p.nlegmax : NULL,
+                         w->p.ntau, acc == 0 ? NULL : (acc == 2 ? w->acbuf : w->gtau) + (size_t)f * w->p.ntau, 2 * w->p.niw,
                          w->p.meas_giw ? w->giw + (size_t)f * 4 * w->p.niw : NULL);
         free(tc); free(ta);
     }
+    if (w->p.accum_gtau == 2) autocorr_add(w);                          /* gtau_accum%add(), CTQMC.F90:2439 */
     if (w->g4iw || w->g4iwpp) meas_g4iw(w);                             /* CTQMC.F90:8579 */
 }
 
@@ -1429,6 +1466,8 @@ void ora_measure_finish(ora_walker *w)
     double zs = -1.0 / (w->cnt_meas * w->mean_sign);                                     /* 8697 */
     for (int i = 0; i < w->dmsize; ++i) w->dmblk[i] *= zs;                              /* 8706-8708 */
     finish_densitymatrix(w);
+    if (w->p.accum_gtau == 2)                                                           /* autocorracc_mean: level-0 mean */
+        for (size_t i = 0; i < (size_t)nf * w->p.ntau; ++i) w->gtau[i] = w->acdat[i * (size_t)w->aclev * 3 + 1] * w->cnt_meas;
     for (size_t i = 0; i < (size_t)nf * w->p.ntau; ++i)                                 /* 8726-8731 */
         w->gtau[i] = -(w->gtau[i] / w->cnt_meas) / (-w->mean_sign) * (double)w->p.ntau / (beta * beta);
     for (size_t i = 0; i < (size_t)nf * (w->p.maxhisto + 1); ++i) w->histo[i] /= w->cnt_meas;   /* 8755 */
@@ -1576,6 +1615,18 @@ int ora_get_g4iw_worm(const ora_walker *w, double *o, int pp)
     const double *src = pp ? w->g4wpp : w->g4w;
     if (!src) return 0;
     memcpy(o, src, sizeof(double) * (size_t)4 * w->p.n4iwf * w->p.n4iwf * (2 * w->p.n4iwb + 1) * 2); return 1;
+}
+/* autocorracc_blocks (Accumulators.F90:343-361): sqdiff / (n - 1) per level, n halved from level to level;
+ * out (Nd,2,Ntau,nlevels) C order; returns nlevels (0 if AccumGtau != 2); out may be NULL */
+int ora_get_gtau_blocks(const ora_walker *w, double *o)
+{
+    if (!w->acdat) return 0;
+    const size_t nc = (size_t)w->nflav * w->p.ntau; const int L = w->aclev;
+    if (o) for (size_t i = 0; i < nc; ++i) {
+        int64_t n = w->acn;
+        for (int l = 0; l < L; ++l) { o[i * L + l] = w->acdat[(i * L + l) * 3 + 2] / (n > 1 ? (double)(n - 1) : 0.0); n /= 2; }
+    }
+    return L;
 }
 int ora_get_giw_worm(const ora_walker *w, double *o)
 {

@@ -50,6 +50,7 @@ typedef struct ora_params {
     int worm_meas_g4iw, g4ph, g4pp, wormphconv;   /* WormMeasG4iw, G4ph, G4pp, WormPHConvention */
     /* worm sampling, sector 2 = one-particle Green's function (CTQMC.F90:597-612) */
     int worm_meas_giw, worm_meas_gtau;            /* WormMeasGiw, WormMeasGtau */
+    int accum_gtau;         /* AccumGtau: 0 = G(tau)/G(l) not measured, 1 = running mean, 2 = autocorrelation accumulator (CTQMC.F90:492-500) */
 } ora_params;
 
 typedef struct ora_walker ora_walker;
@@ -73,6 +74,7 @@ void ora_count_steps(ora_walker *w, int isector, int icomponent, int64_t nfix, i
 int ora_get_g4iw_worm(const ora_walker *w, double *out_reim, int pp);
 /* giw_worm (2Niw) complex interleaved / gtau_worm (Ntau) of the sampled component (CTQMC.F90:1061-1120, 8858-8876);
  * return 0 if not measured */
+int ora_get_gtau_blocks(const ora_walker *w, double *out);   /* gtau_blocks (Nd,2,Ntau,nlevels), AccumGtau = 2; returns nlevels */
 int ora_get_giw_worm(const ora_walker *w, double *out_reim);
 int ora_get_gtau_worm(const ora_walker *w, double *out);
 /* [0]TryWormAdd [1]AccWormAdd [2]AccQNWormAdd [3]TryWormRem [4]AccWormRem [5]AccQNWormRem [6]TryWormRep [7]AccWormRep

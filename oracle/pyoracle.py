@@ -23,7 +23,7 @@ class OraParams(C.Structure):
                 ("meas_g4iwpp", C.c_int), ("zphconv", C.c_int),
                 ("p_worm_ins", C.c_double), ("p_worm_rep", C.c_double), ("worm_eta", C.c_double),
                 ("worm_meas_g4iw", C.c_int), ("g4ph", C.c_int), ("g4pp", C.c_int), ("wormphconv", C.c_int),
-                ("worm_meas_giw", C.c_int), ("worm_meas_gtau", C.c_int)]
+                ("worm_meas_giw", C.c_int), ("worm_meas_gtau", C.c_int), ("accum_gtau", C.c_int)]
 
 
 def build():
@@ -78,6 +78,7 @@ def lib():
     L.ora_get_g4iw_worm.argtypes = [vp, dp, C.c_int]; L.ora_get_g4iw_worm.restype = C.c_int
     L.ora_get_worm_counters.argtypes = [vp, dp]
     L.ora_get_giw_worm.argtypes = [vp, dp]; L.ora_get_giw_worm.restype = C.c_int
+    L.ora_get_gtau_blocks.argtypes = [vp, C.c_void_p]; L.ora_get_gtau_blocks.restype = C.c_int
     L.ora_get_gtau_worm.argtypes = [vp, dp]; L.ora_get_gtau_worm.restype = C.c_int
     L.ora_get_hashybs.argtypes = [vp, ip]
     L.ora_get_g2iw.argtypes = [vp, dp]; L.ora_get_g2iw.restype = C.c_int
@@ -111,7 +112,8 @@ def params_from_pstring(ps, nd, beta, fourpnt=0):
                      worm_eta=ps.get_real("WormEta"), worm_meas_g4iw=ps.get_int("WormMeasG4iw"),
                      g4ph=int(ps.get_int("G4ph") != 0), g4pp=int(ps.get_int("G4pp") != 0),
                      wormphconv=int(ps.get_int("WormPHConvention") != 0),
-                     worm_meas_giw=int(ps.get_int("WormMeasGiw") != 0), worm_meas_gtau=int(ps.get_int("WormMeasGtau") != 0))
+                     worm_meas_giw=int(ps.get_int("WormMeasGiw") != 0), worm_meas_gtau=int(ps.get_int("WormMeasGtau") != 0),
+                     accum_gtau=ps.get_int("AccumGtau"))
 
 
 class OracleWalker:
@@ -213,6 +215,9 @@ class OracleWalker:
                 a = np.zeros((2 * p.n4iwf, 2 * p.n4iwf, 2 * p.n4iwb + 1, 2))
                 if self.L.ora_get_g4iw_worm(self.h, a, pp):
                     r[key] = a[..., 0] + 1j * a[..., 1]
+        nlev = self.L.ora_get_gtau_blocks(self.h, None)
+        if nlev:
+            a = np.zeros((nd, 2, p.ntau, nlev)); self.L.ora_get_gtau_blocks(self.h, a.ctypes.data); r["gtau_blocks"] = a
         a = np.zeros((2 * p.niw, 2))
         if self.L.ora_get_giw_worm(self.h, a):
             r["giw_worm"] = a[..., 0] + 1j * a[..., 1]

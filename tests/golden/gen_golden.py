@@ -200,7 +200,34 @@ def gen_worm(only=None):
         print("worm", name, "steps(worm, Z) of the eta search", steps, "cntsampling", r["cntsampling"][[0, sector - 1]], "nops", len(c_end["taus"]))
 
 
-KINDS = ("traj", "stat", "g4", "worm", "calib")
+KINDS = ("traj", "stat", "g4", "worm", "calib", "accum")
+
+ACCUM = {   # AccumGtau = 2 (autocorrelation accumulator: gtau_blocks) and 0 (G(tau), G(l) not measured), one seeded chain
+    # name: (config, nftau, overrides, seed)
+    "C1": ("C1", 501, dict(Nwarmups=2000, Nmeas=300, NCorr=10, TaudiffMax=2.0, Ntau=40, NLegMax=8, Niw=4, AccumGtau=2,
+                           PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 411),
+    "C3": ("C3", 501, dict(Nwarmups=3000, Nmeas=130, NCorr=20, TaudiffMax=6.0, Ntau=30, NLegMax=8, Niw=4, AccumGtau=2,
+                           PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 412),
+    "C1off": ("C1", 501, dict(Nwarmups=2000, Nmeas=50, NCorr=10, TaudiffMax=2.0, Ntau=40, NLegMax=8, Niw=4, AccumGtau=0, MeasGiw=1,
+                              NLookup_nfft=0, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 413),
+}
+
+
+def gen_accum(only=None):
+    for name, (cfg, nftau, over, seed) in ACCUM.items():
+        if only and name not in only:
+            continue
+        p, ps = pstring_for(cfg, nftau, over)
+        s = refdrive.RefSolver(p, ps, seed)
+        s.set_taudiffmax(over["TaudiffMax"])
+        s.warmup(over["Nwarmups"])
+        s.measure()
+        r = s.results(("gtau", "gtau_blocks", "gleg", "giw", "occ", "mean_sign"))
+        s.close()
+        np.savez_compressed(os.path.join(OUT, "accum_%s.npz" % name), config=cfg, nftau=nftau, seed=seed, overrides=repr(over),
+                            **{"res_" + k: v for k, v in r.items()})
+        print("accum", name, {k: v.shape for k, v in r.items()})
+
 
 CALIB = {   # window calibration (ctqmc_calibrate, two phases) from the empty configuration
     # name: (config, nftau, overrides, seed, (phase1pairnum, phase2taugrid, phase2pairnum, nprogress))
@@ -248,3 +275,5 @@ if __name__ == "__main__":
         gen_worm(only)
     if "calib" in which:
         gen_calib(only)
+    if "accum" in which:
+        gen_accum(only)

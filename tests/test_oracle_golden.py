@@ -206,6 +206,29 @@ def test_oracle_g_worm_sampling_retraces_reference(name):
     w.close()
 
 
+@pytest.mark.parametrize("name", ["C1", "C3", "C1off"])
+def test_oracle_gtau_accumulator_modes_retrace_reference(name):
+    """AccumGtau = 2 (autocorracc, Accumulators.F90:206-362): G(tau) from the level-0 Welford mean and the log-binned
+    variance stack gtau_blocks agree with the reference run; AccumGtau = 0: neither G(tau) nor G(l) is measured."""
+    g = util.load_golden("accum_%s.npz" % name)
+    over = g["overrides"]
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    w = pyoracle.OracleWalker(p, pset, ("std", int(g["seed"])))
+    w.set_taudiffmax(over["TaudiffMax"])
+    w.warmup(over["Nwarmups"])
+    w.measure()
+    r = w.results()
+    if over["AccumGtau"] == 2:
+        assert rel(r["gtau"], g["res_gtau"]) < 1e-11
+        assert r["gtau_blocks"].shape == g["res_gtau_blocks"].shape and rel(r["gtau_blocks"], g["res_gtau_blocks"]) < 1e-10
+        assert rel(r["gleg"], g["res_gleg"]) < 1e-11
+    else:
+        assert np.all(r["gleg"] == 0.0) and np.all(g["res_gleg"] == 0.0) and np.all(r["gtau"] == 0.0)
+        assert rel(r["giw"], g["res_giw"]) < 1e-11
+    assert rel(r["occ"], g["res_occ"]) < 1e-11
+    w.close()
+
+
 @pytest.mark.parametrize("name", ["C1", "C3", "C4S"])
 def test_oracle_window_calibration_retraces_reference(name):
     """ctqmc_calibrate, both phases, from the empty configuration: the list of accepted pair distances, the
