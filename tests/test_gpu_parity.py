@@ -444,6 +444,42 @@ def test_solver_worm_giw_agrees_with_z_space_estimate():
     assert np.abs(occ_w - occ_z).max() < 0.02
 
 
+@pytest.mark.parametrize("name", ["C1", "C3", "C1off"])
+def test_gtau_accumulator_modes_chains_vs_oracle(name):
+    """a-19: AccumGtau = 2 keeps one autocorrelation accumulator per chain (as the reference keeps one per rank); with
+    one chain per bin gtau_blocks and G(tau) of every chain agree with the oracle chain of the same stream, the pooled
+    gtau_blocks is the chain average.  AccumGtau = 0 measures neither G(tau) nor G(l) (CTQMC.F90:2267)."""
+    g = util.load_golden("accum_%s.npz" % name)
+    over = dict(g["overrides"]); over.setdefault("MeasGiw", 1); over.setdefault("NLookup_nfft", 0)
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    nw = 6
+    q = make_gpu(p, ps, 29, nw, wpb=1)
+    q.set_taudiffmax(over["TaudiffMax"])
+    q.ctqmc_warmup(over["Nwarmups"])
+    q.ctqmc_measure(1, 1)
+    blocks = []
+    for w in range(nw):
+        o = pyoracle.OracleWalker(p, pset, ("philox", 29, w))
+        o.set_taudiffmax(over["TaudiffMax"]); o.warmup(over["Nwarmups"]); o.measure()
+        r = o.results()
+        if over["AccumGtau"] == 2:
+            assert rel(q.gtau_bins[w], r["gtau"]) < TOL and rel(q.gleg_bins[w], r["gleg"]) < TOL
+            assert q.gtau_blocks_bins[w].shape == r["gtau_blocks"].shape == g["res_gtau_blocks"].shape
+            assert rel(q.gtau_blocks_bins[w], r["gtau_blocks"]) < TOL, w
+            blocks.append(r["gtau_blocks"])
+        else:
+            assert np.all(q.gtau_bins[w] == 0.0) and np.all(q.gleg_bins[w] == 0.0)
+            assert rel(q.giw_bins[w], r["giw"]) < TOL
+        assert rel(q.occ_bins[w], r["occ"]) < TOL
+        o.close()
+    if blocks:
+        assert rel(q.gtau_blocks, np.mean(blocks, axis=0)) < TOL
+        # the reference's single chain is one draw: its level-0 variance lies inside the chain scatter (loosely)
+        ref0 = g["res_gtau_blocks"][..., 0]; mine = np.array(blocks)[..., 0]
+        assert np.all(ref0 < 6.0 * mine.max(axis=0) + 1e-12)
+    q.dest_ctqmc(); q.close()
+
+
 def test_worm_modes_refused_or_ignored():
     """Sectors other than 1, 2 and 4 are refused; worm sampling on the matrix trace path is refused; eta = 0 samples
     nothing (CTQMC.F90:8409-8418)."""

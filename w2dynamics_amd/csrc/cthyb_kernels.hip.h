@@ -1865,6 +1865,64 @@ __global__ __launch_bounds__(64) void k_meas_gleg(DevConst C, int lds_hist)
     }
 }
 
+// AccumGtau = 2: autocorrelation accumulator of the G(tau) measurement series (autocorracc_add, Accumulators.F90:283-331),
+// kept per chain like the reference keeps it per rank.  One workgroup per (chain, flavour): this measurement's G(tau)
+// histogram is built in LDS, then thread i folds bin i into the chain's stack of (spill, mean, sqdiff) levels - Welford
+// update of level 0; whenever the low bits of the measurement count n are ones, half the spill of the level below rolls
+// over into the next level.  Streaming read-modify-write of dat[chain][flavour][level][spill|mean|sqdiff][Ntau] (HBM-bound:
+// 48 B per bin for level 0, 96 B amortised over all levels).
+__global__ __launch_bounds__(256) void k_meas_gtau_ac(DevConst C, double *dat, int nlev, long long n)
+{
+    extern __shared__ double hist[];            // [ntau]
+    const int w = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, ntau = C.ntau, kmax = C.kmax;
+    if (C.ws[w].sector > 1) return;             // chains in worm space measure no Z-space estimator
+    for (int i = tid; i < ntau; i += 256) hist[i] = 0.0;
+    __syncthreads();
+    const size_t wf = (size_t)w * C.nflav + f;
+    const int k = C.K[wf];
+    const double cs = C.cfgsign[w];
+    for (int e = tid; e < k * k; e += 256) {
+        const int ic = e / k, ia = e - ic * k;
+        double m = C.M[wf * kmax * kmax + (size_t)ic * kmax + ia], d = C.TA[wf * kmax + ia] - C.TC[wf * kmax + ic];
+        if (!(d > 0.0)) { d = C.beta + C.TA[wf * kmax + ia] - C.TC[wf * kmax + ic]; m = -m; }
+        int idt = (int)(d / C.beta * (double)ntau) + 1;
+        if (idt > ntau) idt = ntau;
+        atomicAdd(&hist[idt - 1], m * cs);
+    }
+    __syncthreads();
+    double *base = dat + wf * (size_t)nlev * 3 * ntau;
+    for (int i = tid; i < ntau; i += 256) {
+        double val = hist[i];
+        long long nn = n;
+        for (int lvl = 0;; ) {
+            double *sp = base + ((size_t)lvl * 3) * ntau + i, *mn = sp + ntau, *sq = mn + ntau;
+            *sp += val;
+            const double incr1 = val - *mn;
+            const double mean = *mn + incr1 / (double)(nn + 1);
+            *mn = mean;
+            *sq += incr1 * (val - mean);
+            if (!(nn & 1) || lvl == nlev - 1) break;
+            nn >>= 1; ++lvl;
+            val = *sp / 2; *sp = 0.0;
+        }
+    }
+}
+
+// autocorracc_blocks (Accumulators.F90:343-361) averaged over the chains of an accumulator bin:
+// out[bin][flavour][level][Ntau] = mean over chains of sqdiff / (n_level - 1), n halved from level to level
+__global__ __launch_bounds__(256) void k_gtau_blocks(DevConst C, const double *dat, int nlev, long long n, double *out)
+{
+    const int bin = blockIdx.x, f = blockIdx.y / nlev, lvl = blockIdx.y % nlev, ntau = C.ntau;
+    long long nl = n >> lvl;
+    const double den = nl > 1 ? (double)(nl - 1) : 0.0;
+    const int w0 = bin * C.walkers_per_bin, w1 = min(w0 + C.walkers_per_bin, C.nwalkers);
+    for (int i = threadIdx.x; i < ntau; i += 256) {
+        double a = 0.0;
+        for (int w = w0; w < w1; ++w) a += dat[((((size_t)w * C.nflav + f) * nlev + lvl) * 3 + 2) * ntau + i] / den;
+        out[(((size_t)bin * C.nflav + f) * nlev + lvl) * ntau + i] = a / (double)(w1 - w0);
+    }
+}
+
 // Matsubara estimator (measure_giw_nfft + naive get_giw, CTQMC.F90:1015-1056, Nfft_z.F90:376-414):
 // giw(n) += sum_ij M(c_j,a_i) exp(-i w_n tau_c_j) exp(+i w_n tau_a_i), no configuration sign.
 // One wave per (bin, flavour, frequency chunk of 64): lane = frequency; the pair loop is wave-uniform, so M and the

@@ -57,6 +57,8 @@ struct w2dyn_solver {
     // worm sampling (sector 4): move probabilities, eta, estimator switches, accumulator bins, sector of the running call
     double p_wins = 0, p_wrep = 0, worm_eta = 0;
     int worm_meas_g4iw = 0, g4ph = 0, g4pp = 0, wormphconv = 0, nbw = 0, cur_isector = 1;
+    // G(tau) accumulator (AccumGtau, CTQMC.F90:492-500): 0 = G(tau)/G(l) not measured, 1 = mean, 2 = per-chain autocorrelation stack
+    int accum_gtau = 1, ac_lev = 0; long long ac_n = 0; double *ac_dat = nullptr, *ac_out = nullptr;
     int res_isector = 1;                             // sector of the run the result table was made from
     int worm_meas_giw = 0, worm_meas_gtau = 0;       // sector 2: WormMeasGiw, WormMeasGtau (CTQMC.F90:597-612)
     bool no_sampling = false;
@@ -300,7 +302,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
         {"segment", 0}, {"offdiag", 0}, {"full_offdiag", 0}, {"statesampling", 0}, {"flavourchange_moves", 0}, {"Phonon", 0},
         {"Screening", 0}, {"Uw", 0}, {"MeasGtauDetRat", 0}, {"MeasSusz", 0},
         {"MeasExpResDensityMatrix", 0}, {"MeasSsquare", 0}, {"Gtau_mean_step", 0}, {"Gtau_mid_step", 0}, {"sign_step", 0},
-        {"NSymMove", 0}, {"MeasDensityMatrix", 1}, {"Eigenbasis", 1}, {"AccumGtau", 1}};
+        {"NSymMove", 0}, {"MeasDensityMatrix", 1}, {"Eigenbasis", 1}};
     for (auto &z : zero_int) {
         if (!get_int(s, z.key, iv)) return W2DYN_EINVAL;
         if (iv != z.allowed) return fail(s, W2DYN_EUNSUPPORTED, "%s = %lld is not supported by the HIP solver (only %lld)", z.key, iv, z.allowed);
@@ -345,6 +347,9 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if (s->meas_giw) { if (!get_int(s, "NLookup_nfft", iv)) return W2DYN_EINVAL; if (iv != 0) return fail(s, W2DYN_EUNSUPPORTED, "MeasGiw needs NLookup_nfft = 0 (exact sums)"); }
     if (!get_int(s, "NCorr", iv)) return W2DYN_EINVAL; s->ncorr = (int)iv;
     if (!get_int(s, "Nmeas", iv)) return W2DYN_EINVAL; s->nmeas = iv;
+    if (!get_int(s, "AccumGtau", iv)) return W2DYN_EINVAL;
+    if (iv < 0 || iv > 2) return fail(s, W2DYN_EINVAL, "invalid value %lld for AccumGtau (0, 1, 2)", iv);     // CTQMC.F90:502
+    s->accum_gtau = (int)iv;
     if (!get_int(s, "MaxHisto", iv)) return W2DYN_EINVAL; s->maxhisto = (int)iv;
     if (!get_real(s, "PercentageGlobalMove", s->p_glob)) return W2DYN_EINVAL;
     if (!get_real(s, "PercentageTauShiftMove", s->p_shift)) return W2DYN_EINVAL;
@@ -491,6 +496,17 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     C.nwf = s->n4iwf; C.nwb = s->n4iwb; C.wormphconv = s->wormphconv; C.g4ph = s->g4ph; C.g4pp = s->g4pp;
     C.p_wins = 0.0; C.p_wrep = s->p_wrep; C.worm_eta = s->worm_eta; C.isector = 1; C.icomponent = 0;
     s->nbw = 0; s->cur_isector = 1; s->no_sampling = false; s->steps_worm_chains.clear();
+    s->ac_dat = s->ac_out = nullptr; s->ac_lev = 0; s->ac_n = 0;
+    if (s->accum_gtau == 2) {        // autocorracc_create(ncomp, ilog2(Nmeas)), CTQMC.F90:497-500, Accumulators.F90:89-101
+        int lev = -1; for (long long t = s->nmeas; t > 0; t /= 2) ++lev;
+        if (lev < 1) return fail(s, W2DYN_EINVAL, "AccumGtau = 2 needs Nmeas >= 2 (Nmeas = %lld)", (long long)s->nmeas);
+        const size_t n = W * (size_t)nf * lev * 3 * s->ntau;
+        if (n * sizeof(double) > ((size_t)64 << 30)) return fail(s, W2DYN_EUNSUPPORTED, "AccumGtau = 2: %zu bytes of per-chain accumulator levels; use fewer chains or tau bins", n * sizeof(double));
+        if ((size_t)s->ntau * sizeof(double) > 64 * 1024) return fail(s, W2DYN_EUNSUPPORTED, "AccumGtau = 2: Ntau = %d too large", s->ntau);
+        s->ac_lev = lev;
+        if ((rc = dev_alloc(s, s->ac_dat, n))) return rc;
+        if ((rc = dev_alloc(s, s->ac_out, B * (size_t)nf * lev * s->ntau))) return rc;
+    }
     C.acc_giww = C.acc_gtauw = nullptr;
     if (s->worm_meas_giw) { if ((rc = dev_alloc(s, C.acc_giww, B * (size_t)C.niw2 * 2))) return rc; }
     if (s->worm_meas_gtau) {
@@ -735,6 +751,7 @@ int w2dyn_measure_once(w2dyn_solver *s)
         s->meas_done += 1;
         return 0;
     }
+    if (s->accum_gtau != 0) {          // AccumGtau = 0: MeasGtauRem returns at once, neither G(l) nor G(tau) (CTQMC.F90:2267)
     if ((rc = time_begin(s))) return rc;
     if (s->nleg <= 16) launch_gleg<16>(s);
     else if (s->nleg <= 32) launch_gleg<32>(s);
@@ -743,6 +760,14 @@ int w2dyn_measure_once(w2dyn_solver *s)
     else launch_gleg<128>(s);
     HIPCHK(hipGetLastError());
     if ((rc = time_end(s, "meas_gleg"))) return rc;
+    }
+    if (s->accum_gtau == 2) {
+        if ((rc = time_begin(s))) return rc;
+        hipLaunchKernelGGL(k_meas_gtau_ac, dim3(s->nwalkers, s->nflav), dim3(256), (size_t)s->ntau * sizeof(double), s->stream, s->C, s->ac_dat, s->ac_lev, s->ac_n);
+        HIPCHK(hipGetLastError());
+        if ((rc = time_end(s, "meas_gtau_ac"))) return rc;
+        s->ac_n += 1;
+    }
     if (s->meas_giw) {
         if ((rc = time_begin(s))) return rc;
         hipLaunchKernelGGL(k_meas_giw, dim3(s->C.nbins, s->nflav, (s->C.niw2 + 63) / 64), dim3(64), 0, s->stream, s->C);
@@ -901,6 +926,22 @@ int w2dyn_measure_finish(w2dyn_solver *s)
         R["densitymatrix"] = full;
     }
     s->res_isector = s->cur_isector;
+    if (s->ac_dat) {     // gtau_blocks (CTQMC.F90:8733-8739, unscaled): per accumulator bin and averaged over the bins' chains
+        const size_t per = (size_t)nf * s->ac_lev * ntau;
+        hipLaunchKernelGGL(k_gtau_blocks, dim3(B, nf * s->ac_lev), dim3(256), 0, s->stream, s->C, s->ac_dat, s->ac_lev, s->ac_n, s->ac_out);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s->stream));
+        std::vector<double> bins((size_t)B * per), tot(per, 0.0);
+        HIPCHK(hipMemcpy(bins.data(), s->ac_out, bins.size() * sizeof(double), hipMemcpyDeviceToHost));
+        double wtot = 0.0;
+        for (int b = 0; b < B; ++b) {
+            const double nch = (double)(std::min<long long>((long long)(b + 1) * C.walkers_per_bin, W) - (long long)b * C.walkers_per_bin);
+            wtot += nch;
+            for (size_t i = 0; i < per; ++i) tot[i] += bins[(size_t)b * per + i] * nch;
+        }
+        for (size_t i = 0; i < per; ++i) tot[i] /= wtot;
+        R["gtau_blocks"] = tot; R["gtau_blocks_bins"] = bins;
+    }
     {   // acceptance ratios (CTQMC.F90:8680-8695); 16 sectors, Z = index 0
         std::vector<double> aa(16, 0.0), ar(16, 0.0);
         aa[0] = s->counters[C_ACCADD] / s->counters[C_TRYADD]; ar[0] = s->counters[C_ACCREM] / s->counters[C_TRYREM];
@@ -1305,6 +1346,7 @@ int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out)
     else if (n == "nb4") *out = s->nb4;
     else if (n == "nbw") *out = s->nbw;
     else if (n == "wormeta") *out = s->worm_eta;
+    else if (n == "ntau") *out = s->ntau;
     else if (n == "n4iwf") *out = s->n4iwf;
     else if (n == "n4iwb") *out = s->n4iwb;
     else if (n == "nsst") *out = s->lp.nsst;

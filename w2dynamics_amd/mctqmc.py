@@ -145,7 +145,7 @@ class MCTQMC:
         self._chk(self._L.w2dyn_set_fourpnt(self._h, int(self.fourpnt)))
         self._chk(self._L.w2dyn_init_solver(self._h, u, f, m, sc, int(iter_no), int(nftau), int(nbands)))
         self._nd = nbands
-        self._n4iwf = int(self.scalar("n4iwf")); self._n4iwb = int(self.scalar("n4iwb"))
+        self._n4iwf = int(self.scalar("n4iwf")); self._n4iwb = int(self.scalar("n4iwb")); self._ntau = int(self.scalar("ntau"))
         self.wormeta[:] = self.scalar("wormeta")          # wormEta = WormEta for every sector, CTQMC.F90:434
 
     def set_taudiffmax(self, x):
@@ -290,6 +290,15 @@ class MCTQMC:
             nwf, nwb = self._n4iwf, self._n4iwb
             lead = (int(self.scalar("nbw")),) if name.endswith("_bins") else ()
             return a.reshape(lead + (2 * nwf, 2 * nwf, 2 * nwb + 1))
+        if name in ("gtau_blocks", "gtau_blocks_bins"):
+            # AccumGtau = 2: gtau_blocks(Nd,2,Ntau,nlevels) (CTQMC.F90:508), mean over the chains (of a bin)
+            a = self.result(name)
+            nb = int(self.scalar("nbins"))
+            if name.endswith("_bins"):
+                a = a.reshape(nb, nd, 2, -1, self._ntau)
+                return np.ascontiguousarray(a.transpose(0, 1, 2, 4, 3))
+            a = a.reshape(nd, 2, -1, self._ntau)
+            return np.ascontiguousarray(a.transpose(0, 1, 3, 2))
         if name in ("giw_worm", "giw_worm_bins"):
             # one-particle worm estimator of the sampled component: giw_worm(2*Niw), CTQMC.F90:598
             a = self.result(name).reshape(-1, 2); a = a[:, 0] + 1j * a[:, 1]
