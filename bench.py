@@ -31,6 +31,10 @@ WORKLOADS = {
     # BASELINE.json configs[1]: the configuration the metric is quoted on (default)
     "C2": dict(config="C2", nftau=5001, overrides=dict(Nftau=5001, NCorr=200, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Nwarmups=0, Nmeas=1),
                text="C2: 1-band Hubbard, Bethe D=1, U=2, beta=100, half filling, TaudiffMax=10, NCorr=200, NLegMax=100, Ntau=1000, Nftau=5001, default move mix"),
+    # C2 with the autocorrelation accumulator of G(tau) (AccumGtau = 2, one stack of log2(Nmeas) levels per chain): adds the
+    # HBM-streaming kernel k_meas_gtau_ac to every step; extra bench line, not the headline
+    "C2A": dict(config="C2", nftau=5001, overrides=dict(Nftau=5001, NCorr=200, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Nwarmups=0, Nmeas=1024, AccumGtau=2),
+                text="C2 + AccumGtau=2 (per-chain autocorrelation accumulator of G(tau), 10 levels)"),
     # the other single-GPU configurations (parity-test cases; selectable with --config for extra bench lines)
     "C3": dict(config="C3", nftau=5001, overrides=dict(Nftau=5001, NCorr=100, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Nwarmups=0, Nmeas=1),
                text="C3: 2-orbital density-density, U=2, J=0.25, beta=50, TaudiffMax=10, NCorr=100"),
@@ -203,7 +207,7 @@ def main():
     for _ in range(a.warmup):
         q.sweep(ncorr); q.measure_once()
     q.sync()
-    for k in (sweep_key, "meas_misc", "meas_gleg", "meas_g4w"):
+    for k in (sweep_key, "meas_misc", "meas_gleg", "meas_g4w", "meas_gtau_ac"):
         q.kernel_time(k, reset=True)
     if world > 1:
         dist.barrier()
@@ -286,6 +290,19 @@ def main():
                               "traffic": tr_gleg, "avg_launch_ms": gleg_ms, "launches": ngleg, "algorithmic_flops_per_launch": flops_gleg},
             "kernel_ms": {kname: sweep_ms, mname: gleg_ms, "k_meas_misc": misc_ms},
         }
+        if over.get("AccumGtau") == 2:
+            # algorithmic bytes of k_meas_gtau_ac: every touched level of every (chain, flavour, tau bin) is one
+            # read-modify-write of (spill, mean, sqdiff) = 48 B; launch number n touches 1 + (trailing one bits of n) levels
+            ac_ms, nac = q.kernel_time("meas_gtau_ac")
+            nlev = int(np.log2(over["Nmeas"]))
+            touched = [min(1 + ((n ^ (n + 1)).bit_length() - 1), nlev) for n in range(a.warmup, a.warmup + a.steps)]
+            ac_bytes = W * prob.nd * 2 * over["Ntau"] * 48.0 * float(np.mean(touched))
+            ac_gbs = ac_bytes / (ac_ms * 1e-3) / 1e9 if ac_ms > 0 else 0.0
+            tr_ac, _ = pmc_traffic("k_meas_gtau_ac", W, a.config)
+            out["roofline_accum"] = {"kernel": "k_meas_gtau_ac", "bound": "hbm", "achieved": ac_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": ac_gbs / HBM_PEAK_GBS, "traffic": tr_ac, "avg_launch_ms": ac_ms, "launches": nac,
+                                     "algorithmic_bytes_per_launch": ac_bytes, "levels": nlev}
+            out["kernel_ms"]["k_meas_gtau_ac"] = ac_ms
         if worm:
             cs = q.cntsampling
             out["worm"] = {"eta": eta, "steps_z": int(cs[0]), "steps_worm": int(cs[3]), "component": worm["component"]}
