@@ -1086,7 +1086,7 @@ ora_walker *ora_create(const ora_params *p, const double *U, const double *ftau_
     w->p = *p; w->rng = rng;
     w->nflav = 2 * p->nd; w->nstates = 1 << (2 * p->nd);
     if (w->nflav > MAXFLAV) { free(w); return NULL; }
-    w->lp = ora_locprob_build(p->nd, U, mu_full, p->qns, p->epsevec);
+    w->lp = ora_locprob_build(p->nd, U, mu_full, p->qns, p->epsevec, p->epsblock);
     if (!w->lp || w->lp->nsmax > 64) { ora_locprob_free(w->lp); free(w); return NULL; }
     w->nsst = w->lp->nsst;
     w->E = w->lp->eval;

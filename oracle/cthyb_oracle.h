@@ -50,6 +50,7 @@ typedef struct ora_params {
     int worm_meas_g4iw, g4ph, g4pp, wormphconv;   /* WormMeasG4iw, G4ph, G4pp, WormPHConvention */
     /* worm sampling, sector 2 = one-particle Green's function (CTQMC.F90:597-612) */
     int worm_meas_giw, worm_meas_gtau;            /* WormMeasGiw, WormMeasGtau */
+    double epsblock;        /* EPSBLOCK: threshold of the automatic block partitioning, QuantumNumbers = All (CTQMC.F90:7972) */
     int accum_gtau;         /* AccumGtau: 0 = G(tau)/G(l) not measured, 1 = running mean, 2 = autocorrelation accumulator (CTQMC.F90:492-500) */
 } ora_params;
 

@@ -76,12 +76,132 @@ static void sym_eig(double *A, int n, double *w, double *V)
     }
 }
 
-ora_locprob *ora_locprob_build(int nd, const double *U, const double *mu_full, const char *qns_in, double epsevec)
+#define BIT(fl) (((fl) >> 1) + nd * ((fl) & 1))
+static double fermi_sign(int state, int bit);
+
+/* dense H_loc in the Fock basis restricted to the blocks of `part` (oneparticle_hamiltonian 482-542, u_hamiltonian
+ * 1042-1107, force_hermitian 1110-1125); H[t * ns + s] = <t|H|s> */
+static double *full_hamiltonian(int nd, const double *U, const double *mu_full, const int *part, int nsst)
+{
+    const int nf = 2 * nd, ns = 1 << nf;
+    double *H = (double *)calloc((size_t)ns * ns, sizeof(double));
+    /* Connect of this partition (init_Psi, Operator.F90:146-178): the last block iSSt2 /= iSSt1 holding a state that the
+     * operator reaches from a state of iSSt1; the Hamiltonian is a sum of block-matrix products along chains of Connect
+     * entries (517-534, 1071-1092), so a term only counts if every step follows Connect */
+    int *conn0 = (int *)malloc(sizeof(int) * (size_t)nsst * nf * 2);
+    for (size_t i = 0; i < (size_t)nsst * nf * 2; ++i) conn0[i] = -1;
+    for (int b = 0; b < nsst; ++b) for (int tb = 0; tb < nsst; ++tb) {
+        if (tb == b) continue;
+        for (int s = 0; s < ns; ++s) {
+            if (part[s] != b) continue;
+            for (int f = 0; f < nf; ++f) { int t = s ^ (1 << BIT(f)); if (part[t] == tb) conn0[(b * nf + f) * 2 + (t > s ? 0 : 1)] = tb; }
+        }
+    }
+#define STEP(cur, next, f, ca) (conn0[(part[cur] * nf + (f)) * 2 + ((ca) - 1)] == part[next])
+    for (int f1 = 0; f1 < nf; ++f1) for (int f2 = 0; f2 < nf; ++f2) {
+        double mu = mu_full[(((f1 >> 1) * 2 + (f1 & 1)) * nd + (f2 >> 1)) * 2 + (f2 & 1)];
+        if (mu == 0.0) continue;
+        for (int s = 0; s < ns; ++s) {
+            if (!(s >> BIT(f2) & 1)) continue;
+            double sg = fermi_sign(s, BIT(f2)); int t = s ^ (1 << BIT(f2));
+            if (!STEP(s, t, f2, 2)) continue;
+            if (t >> BIT(f1) & 1) continue;
+            sg *= fermi_sign(t, BIT(f1));
+            if (!STEP(t, t ^ (1 << BIT(f1)), f1, 1)) continue;
+            t ^= 1 << BIT(f1);
+            if (part[t] == part[s]) H[(size_t)t * ns + s] += mu * sg;
+        }
+    }
+    for (int f1 = 0; f1 < nf; ++f1) for (int f2 = 0; f2 < nf; ++f2) for (int f3 = 0; f3 < nf; ++f3) for (int f4 = 0; f4 < nf; ++f4) {
+        double u = 0.5 * U[((f1 * nf + f2) * nf + f3) * nf + f4];
+        if (u == 0.0) continue;
+        for (int s = 0; s < ns; ++s) {
+            int t = s; double sg = 1.0;
+            if (!(t >> BIT(f3) & 1) || !STEP(t, t ^ (1 << BIT(f3)), f3, 2)) continue;
+            sg *= fermi_sign(t, BIT(f3)); t ^= 1 << BIT(f3);
+            if (!(t >> BIT(f4) & 1) || !STEP(t, t ^ (1 << BIT(f4)), f4, 2)) continue;
+            sg *= fermi_sign(t, BIT(f4)); t ^= 1 << BIT(f4);
+            if ((t >> BIT(f2) & 1) || !STEP(t, t ^ (1 << BIT(f2)), f2, 1)) continue;
+            sg *= fermi_sign(t, BIT(f2)); t ^= 1 << BIT(f2);
+            if ((t >> BIT(f1) & 1) || !STEP(t, t ^ (1 << BIT(f1)), f1, 1)) continue;
+            sg *= fermi_sign(t, BIT(f1)); t ^= 1 << BIT(f1);
+            if (part[t] == part[s]) H[(size_t)t * ns + s] += u * sg;
+        }
+    }
+    for (int i = 0; i < ns; ++i) for (int j = i + 1; j < ns; ++j) {
+        double v = (H[(size_t)i * ns + j] + H[(size_t)j * ns + i]) / 2.0; H[(size_t)i * ns + j] = v; H[(size_t)j * ns + i] = v;
+    }
+#undef STEP
+    free(conn0);
+    return H;
+}
+
+/* analyze_hamiltonian (Operator.F90:303-442), followed literally: nets of connected states inside every block of the
+ * starting partition (303-374), then blocks reached by one operator from the same block are joined, the higher number
+ * becoming the lower and the numbers above moving down, restarting after every join (376-434).
+ * part[state] is refined in place; returns the number of blocks. */
+static int analyze_hamiltonian(int nd, int nsst0, int *part, const double *H, double threshold)
+{
+    const int nf = 2 * nd, ns = 1 << nf;
+    int *s2s = (int *)malloc(sizeof(int) * (size_t)ns), *c2s = (int *)malloc(sizeof(int) * (size_t)ns);
+    int *members = (int *)malloc(sizeof(int) * (size_t)ns), *net = (int *)malloc(sizeof(int) * (size_t)ns);
+    for (int s = 0; s < ns; ++s) s2s[s] = -1;
+    int nsub = -1;
+    for (int b = 0; b < nsst0; ++b) {
+        int n = 0;
+        for (int s = 0; s < ns; ++s) if (part[s] == b) members[n++] = s;      /* block states in ascending order */
+        int start = 0;                                                        /* local index the next net starts from */
+        while (start >= 0) {
+            int len = 1; net[0] = start;
+            nsub += 1; s2s[members[start]] = nsub;
+            for (int node = 0; node < len; ++node)
+                for (int edge = 0; edge < n; ++edge) {
+                    double h = H[(size_t)members[net[node]] * ns + members[edge]];
+                    if (h != 0.0 && fabs(h) > threshold) {
+                        int member = 0;
+                        for (int q = 0; q < len; ++q) if (net[q] == edge) { member = 1; break; }
+                        if (!member) { net[len++] = edge; s2s[members[edge]] = nsub; }
+                    }
+                }
+            start = -1;
+            for (int node = 0; node < n; ++node) if (s2s[members[node]] == -1) { start = node; break; }
+        }
+    }
+    nsub += 1;
+    for (int change = 1; change;) {
+        change = 0;
+        for (int ib = 0; ib < nd && !change; ++ib) for (int is = 0; is < 2 && !change; ++is) for (int ca = 1; ca <= 2 && !change; ++ca) {
+            const int bit = ib + nd * is;
+            for (int s = 0; s < ns; ++s) {
+                c2s[s] = -1;
+                if (ca == 1 && !(s >> bit & 1)) c2s[s] = s2s[s | (1 << bit)];
+                else if (ca == 2 && (s >> bit & 1)) c2s[s] = s2s[s & ~(1 << bit)];
+            }
+            for (int i1 = 0; i1 < ns && !change; ++i1) for (int i2 = i1 + 1; i2 < ns; ++i2) {
+                if (s2s[i1] == s2s[i2] && c2s[i1] != c2s[i2] && c2s[i1] != -1 && c2s[i2] != -1) {
+                    int big = c2s[i1] > c2s[i2] ? c2s[i1] : c2s[i2], small = c2s[i1] > c2s[i2] ? c2s[i2] : c2s[i1];
+                    for (int s = 0; s < ns; ++s) {
+                        if (s2s[s] == big) s2s[s] = small;
+                        if (s2s[s] > big) s2s[s] -= 1;
+                    }
+                    change = 1;
+                    break;
+                }
+            }
+        }
+    }
+    nsub = 0;
+    for (int s = 0; s < ns; ++s) { part[s] = s2s[s]; if (s2s[s] + 1 > nsub) nsub = s2s[s] + 1; }
+    free(s2s); free(c2s); free(members); free(net);
+    return nsub;
+}
+
+ora_locprob *ora_locprob_build(int nd, const double *U, const double *mu_full, const char *qns_in, double epsevec, double epsblock)
 {
     const int nf = 2 * nd, ns = 1 << nf;
     char qns[256];
     strncpy(qns, qns_in ? qns_in : "", sizeof(qns) - 1); qns[sizeof(qns) - 1] = 0;
-    if (strstr(qns, "All")) strcpy(qns, "Nt Szt Azt");
+    const int automatic = strstr(qns, "All") != NULL;
     const int use_nt = strstr(qns, "Nt") != NULL, use_sz = strstr(qns, "Szt") != NULL, use_qz = strstr(qns, "Qzt") != NULL;
     const int use_az = strstr(qns, "Azt") != NULL, use_lz = strstr(qns, "Lzt") != NULL, use_jz = strstr(qns, "Jzt") != NULL;
 
@@ -104,6 +224,14 @@ ora_locprob *ora_locprob_build(int nd, const double *U, const double *mu_full, c
             if (use_jz && !qeq(qn_lzt(nd, s1) + qn_szt(nd, s1), qn_lzt(nd, s2) + qn_szt(nd, s2))) continue;
             lp->sst_of_state[s2] = nsst - 1;
         }
+    }
+    if (automatic) {                                    /* CTQMC.F90:7971-7990 */
+        double big = 0.0;
+        for (int i = 0; i < nf * nf; ++i) if (fabs(mu_full[i]) > big) big = fabs(mu_full[i]);
+        for (int i = 0; i < nf * nf * nf * nf; ++i) if (fabs(U[i]) > big) big = fabs(U[i]);
+        double *Hf = full_hamiltonian(nd, U, mu_full, lp->sst_of_state, nsst);
+        nsst = analyze_hamiltonian(nd, nsst, lp->sst_of_state, Hf, epsblock * big);
+        free(Hf);
     }
     lp->nsst = nsst;
     /* init_substates, States.F90:98-144 */
@@ -138,7 +266,6 @@ ora_locprob *ora_locprob_build(int nd, const double *U, const double *mu_full, c
     /* H_loc per block: oneparticle_hamiltonian (482-542) + u_hamiltonian (1042-1107) + force_hermitian (1110-1125) */
     double **H = (double **)malloc(sizeof(double *) * (size_t)nsst);
     for (int b = 0; b < nsst; ++b) H[b] = (double *)calloc((size_t)lp->sst_n[b] * lp->sst_n[b], sizeof(double));
-#define BIT(fl) (((fl) >> 1) + nd * ((fl) & 1))
     for (int f1 = 0; f1 < nf; ++f1) for (int f2 = 0; f2 < nf; ++f2) {
         int b1 = f1 >> 1, s1 = f1 & 1, b2 = f2 >> 1, s2 = f2 & 1;
         double mu = mu_full[((b1 * 2 + s1) * nd + b2) * 2 + s2];

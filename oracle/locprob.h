@@ -26,9 +26,9 @@ typedef struct ora_locprob {
 } ora_locprob;
 
 /* umatrix (2Nd)^4 with flavour index 2*orb+spin, muimp_full (Nd,2,Nd,2), qns = the QuantumNumbers string
- * ("Nt Szt Qzt", "Nt Szt Azt", ...; "All" is treated as "Nt Szt Azt" and is only right for density-density U),
- * epsevec = EPSEVEC.  Returns NULL on failure. */
-ora_locprob *ora_locprob_build(int nd, const double *umatrix, const double *muimp_full, const char *qns, double epsevec);
+ * ("Nt Szt Qzt", "Nt Szt Azt", ...; "All" = automatic partitioning, analyze_hamiltonian, Operator.F90:303-442, with threshold
+ * epsblock = EPSBLOCK relative to the largest element of U and muimp), epsevec = EPSEVEC.  Returns NULL on failure. */
+ora_locprob *ora_locprob_build(int nd, const double *umatrix, const double *muimp_full, const char *qns, double epsevec, double epsblock);
 void ora_locprob_free(ora_locprob *lp);
 
 static inline int ora_lp_conn(const ora_locprob *lp, int sst, int f, int ca) { return lp->conn[(sst * lp->nflav + f) * 2 + (ca - 1)]; }

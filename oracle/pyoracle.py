@@ -23,7 +23,7 @@ class OraParams(C.Structure):
                 ("meas_g4iwpp", C.c_int), ("zphconv", C.c_int),
                 ("p_worm_ins", C.c_double), ("p_worm_rep", C.c_double), ("worm_eta", C.c_double),
                 ("worm_meas_g4iw", C.c_int), ("g4ph", C.c_int), ("g4pp", C.c_int), ("wormphconv", C.c_int),
-                ("worm_meas_giw", C.c_int), ("worm_meas_gtau", C.c_int), ("accum_gtau", C.c_int)]
+                ("worm_meas_giw", C.c_int), ("worm_meas_gtau", C.c_int), ("epsblock", C.c_double), ("accum_gtau", C.c_int)]
 
 
 def build():
@@ -113,7 +113,7 @@ def params_from_pstring(ps, nd, beta, fourpnt=0):
                      g4ph=int(ps.get_int("G4ph") != 0), g4pp=int(ps.get_int("G4pp") != 0),
                      wormphconv=int(ps.get_int("WormPHConvention") != 0),
                      worm_meas_giw=int(ps.get_int("WormMeasGiw") != 0), worm_meas_gtau=int(ps.get_int("WormMeasGtau") != 0),
-                     accum_gtau=ps.get_int("AccumGtau"))
+                     epsblock=ps.get_real("EPSBLOCK"), accum_gtau=ps.get_int("AccumGtau"))
 
 
 class OracleWalker:

@@ -41,10 +41,21 @@ TRAJ = {
                              NLookup_nfft=0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 99),
     "C4": ("C4", 1001, dict(Nwarmups=10000, Nmeas=100, NCorr=100, TaudiffMax=10.0, Ntau=200, NLegMax=20, Niw=8, MeasGiw=1,
                             NLookup_nfft=0), 31),
+    # automatic block partitioning (QuantumNumbers = All)
+    "C4SA": ("C4SA", 501, dict(Nwarmups=3000, Nmeas=300, NCorr=30, TaudiffMax=3.0, Ntau=100, NLegMax=12, Niw=8, MeasGiw=1,
+                               NLookup_nfft=0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 4243),
+    "C4SX": ("C4SX", 501, dict(Nwarmups=3000, Nmeas=300, NCorr=30, TaudiffMax=3.0, Ntau=100, NLegMax=12, Niw=8, MeasGiw=1,
+                               NLookup_nfft=0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 4244),
+    "C4SQ": ("C4SQ", 501, dict(Nwarmups=2000, Nmeas=100, NCorr=30, TaudiffMax=3.0, Ntau=100, NLegMax=12, Niw=8, MeasGiw=1,
+                               NLookup_nfft=0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 4245),
+    "C4A": ("C4A", 1001, dict(Nwarmups=5000, Nmeas=50, NCorr=100, TaudiffMax=10.0, Ntau=200, NLegMax=20, Niw=8, MeasGiw=1,
+                              NLookup_nfft=0), 32),
+    "C3A": ("C3A", 501, dict(Nwarmups=3000, Nmeas=100, NCorr=30, TaudiffMax=6.0, Ntau=100, NLegMax=12, Niw=8, MeasGiw=1,
+                             NLookup_nfft=0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 78),
 }
 
 KEYS = ("gleg", "gtau", "giw", "histo", "occ", "outersuperstatehisto", "accpair", "mean_sign", "accadd", "accrem",
-        "accglob", "accshift", "eigenstatesenergies", "densitymatrix", "rho1", "rho2")
+        "accglob", "accshift", "eigenstatesenergies", "densitymatrix", "rho1", "rho2", "statessuperstates")
 
 
 def pstring_for(cfgname, nftau, over):

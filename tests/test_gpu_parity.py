@@ -37,11 +37,17 @@ TRAJ = [
     ("C4S", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=3.0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 4242),
     ("C3Q", 501, dict(BASE, Nwarmups=3000, Nmeas=20, NCorr=30, TaudiffMax=5.0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 99),
     ("C4", 1001, dict(BASE, Nwarmups=6000, Nmeas=10, NCorr=100, TaudiffMax=10.0, NLegMax=20, Ntau=200), 31),
+    # QuantumNumbers = All (automatic block partitioning): Kanamori "Nt All", + inter-orbital hopping, "All" alone, 3 orbitals
+    ("C4SA", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=3.0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 4243),
+    ("C4SX", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=3.0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 4244),
+    ("C4SQ", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=3.0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 4245),
+    ("C4A", 1001, dict(BASE, Nwarmups=4000, Nmeas=10, NCorr=100, TaudiffMax=10.0, NLegMax=20, Ntau=200), 32),
 ]
 
 
 @pytest.mark.parametrize("cfg,nftau,over,seed", TRAJ, ids=["C1-addrem", "C1-1window-allmoves", "C3-allmoves", "C2-default", "C5Z-default",
-                              "C4S-kanamori-allmoves", "C3Q-coarse-blocks-allmoves", "C4-kanamori-default"])
+                              "C4S-kanamori-allmoves", "C3Q-coarse-blocks-allmoves", "C4-kanamori-default",
+                              "C4SA-auto-blocks", "C4SX-auto-blocks-hopping", "C4SQ-all-alone", "C4A-auto-blocks-3orb"])
 def test_chains_retrace_oracle(cfg, nftau, over, seed):
     """Every chain: same configuration, M, sign, window and NPairs after warm-up; same estimators after sampling."""
     _retrace(cfg, nftau, over, seed)
@@ -224,10 +230,10 @@ def test_unsupported_modes_are_refused():
             q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
         assert e.value.code == -2, over
         q.close()
-    # automatic block partitioning ("All") is only available for density-density interactions
+    # blocks of more than 8 states are refused: 3-orbital Kanamori with the particle number as the only quantum number
     from w2dynamics_amd import params, synth
-    p2 = synth.config("C4S", 501)
-    ps = params.make_pstring({}, beta=p2.beta, Nd=p2.nd, Hamiltonian="Kanamori", QuantumNumbers="All")
+    p2 = synth.config("C4", 501)
+    ps = params.make_pstring({}, beta=p2.beta, Nd=p2.nd, Hamiltonian="Kanamori", QuantumNumbers="Nt")
     q = MCTQMC(nwalkers=4); q.init_rnd(1); q.init_paras(ps)
     with pytest.raises(W2DynError) as e:
         q.init_solver(p2.umatrix, p2.ftau, p2.muimp, p2.screening, 1)

@@ -18,13 +18,21 @@ def rel(a, b):
     return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300)
 
 
-@pytest.mark.parametrize("name", CASES)
+# QuantumNumbers = All (automatic block partitioning, Operator.F90:303-442): Kanamori with "Nt All" (2 and 3 orbitals),
+# with an inter-orbital hopping that breaks Qzt, "All" on its own (every state alone) and a density-density problem
+AUTO_CASES = ["C4SA", "C4SX", "C4SQ", "C4A", "C3A"]
+
+
+@pytest.mark.parametrize("name", CASES + AUTO_CASES)
 def test_oracle_retraces_reference_chain(name):
     g = util.load_golden("traj_%s.npz" % name)
     over = g["overrides"]
     p, ps, pset = util.setup(g["config"], g["nftau"], over)
     assert abs(p.ftau.sum() - float(g["ftau_sum"])) < 1e-9 * abs(float(g["ftau_sum"]))
     w = pyoracle.OracleWalker(p, pset, ("std", int(g["seed"])))
+    if "res_statessuperstates" in g:      # block of every state, states listed block by block (CTQMC.F90:8053-8055)
+        n, off, st = w.blocks()
+        assert np.array_equal(np.repeat(np.arange(len(n)), n), g["res_statessuperstates"])
     w.set_taudiffmax(over["TaudiffMax"])
     w.warmup(over["Nwarmups"])
     c = w.get_config()

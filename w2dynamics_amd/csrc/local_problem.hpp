@@ -71,12 +71,93 @@ struct LocalProblem {
         }
     }
 
-    // U: (2Nd)^4 with flavour 2*orb+spin; mu_full: (Nd,2,Nd,2) as passed to init_solver; qns: QuantumNumbers string
-    void build(int nd_, const double *U, const double *mu_full, std::string qns, double epsevec)
+    // matrix elements of H_loc = one-particle part + U between Fock states (Operator.F90:482-542, 1042-1107), handed to
+    // `add(source state, target state, value)`.  The reference multiplies block matrices along the chain of `Connect`
+    // entries, so a term only counts if every single operator of it leads from a block into the block `Connect` names
+    // (never into the same block, Operator.F90:150): `step(state before, state after, flavour, ca)` decides that.
+    template <class F, class S> void for_each_h_element(const double *U, const double *mu_full, F add, S step) const
+    {
+        const int nf = nflav, ns = nstates;
+        auto annihilate = [&](int &st, double &sg, int f) { int b = bit(f); if (!(st >> b & 1)) return false; sg *= fsign(st, b); const int t = st ^ (1 << b); if (!step(st, t, f, 2)) return false; st = t; return true; };
+        auto create = [&](int &st, double &sg, int f) { int b = bit(f); if (st >> b & 1) return false; sg *= fsign(st, b); const int t = st ^ (1 << b); if (!step(st, t, f, 1)) return false; st = t; return true; };
+        for (int f1 = 0; f1 < nf; ++f1) for (int f2 = 0; f2 < nf; ++f2) {
+            double mu = mu_full[((size_t)((f1 >> 1) * 2 + (f1 & 1)) * nd + (f2 >> 1)) * 2 + (f2 & 1)];
+            if (mu == 0.0) continue;
+            for (int s = 0; s < ns; ++s) { int t = s; double sg = 1.0; if (annihilate(t, sg, f2) && create(t, sg, f1)) add(s, t, mu * sg); }
+        }
+        for (int f1 = 0; f1 < nf; ++f1) for (int f2 = 0; f2 < nf; ++f2) for (int f3 = 0; f3 < nf; ++f3) for (int f4 = 0; f4 < nf; ++f4) {
+            double u = 0.5 * U[(((size_t)f1 * nf + f2) * nf + f3) * nf + f4];
+            if (u == 0.0) continue;
+            for (int s = 0; s < ns; ++s) {
+                int t = s; double sg = 1.0;
+                if (annihilate(t, sg, f3) && annihilate(t, sg, f4) && create(t, sg, f2) && create(t, sg, f1)) add(s, t, u * sg);
+            }
+        }
+    }
+
+    // QuantumNumbers = All: analyze_hamiltonian (Operator.F90:303-442).  Starting from the partition the named quantum
+    // numbers give (one block if none is named), (i) every block is split into the connected components of H_loc
+    // (elements above `threshold`), numbered block by block by their lowest Fock state, (ii) blocks that one creation or
+    // annihilation operator reaches from the same block are joined until every operator maps a block into one block,
+    // (iii) the joined blocks keep the order of their lowest original number.  Refines sst_of_state / nsst in place.
+    void analyze_hamiltonian(const double *U, const double *mu_full, double threshold)
+    {
+        const int nf = nflav, ns = nstates;
+        std::vector<double> H((size_t)ns * ns, 0.0);
+        // Connect of the starting partition: the last block found that the operator reaches, none for the block itself
+        std::vector<int> conn0((size_t)nsst * nf * 2, -1);
+        for (int b = 0; b < nsst; ++b) for (int tb = 0; tb < nsst; ++tb) {
+            if (tb == b) continue;
+            for (int s = 0; s < ns; ++s) {
+                if (sst_of_state[s] != b) continue;
+                for (int f = 0; f < nf; ++f) { const int t = s ^ (1 << bit(f)); if (sst_of_state[t] == tb) conn0[((size_t)b * nf + f) * 2 + (t > s ? 0 : 1)] = tb; }
+            }
+        }
+        for_each_h_element(U, mu_full, [&](int src, int dst, double v) { if (sst_of_state[src] == sst_of_state[dst]) H[(size_t)dst * ns + src] += v; },
+                           [&](int cur, int next, int f, int ca) { return conn0[((size_t)sst_of_state[cur] * nf + f) * 2 + (ca - 1)] == sst_of_state[next]; });
+        for (int i = 0; i < ns; ++i) for (int j = i + 1; j < ns; ++j) { double v = (H[(size_t)i * ns + j] + H[(size_t)j * ns + i]) / 2.0; H[(size_t)i * ns + j] = H[(size_t)j * ns + i] = v; }
+        std::vector<int> comp(ns, -1), stack;
+        int ncomp = 0;
+        for (int b = 0; b < nsst; ++b) for (int s0 = 0; s0 < ns; ++s0) {
+            if (sst_of_state[s0] != b || comp[s0] != -1) continue;
+            comp[s0] = ncomp; stack.assign(1, s0);
+            while (!stack.empty()) {
+                const int a = stack.back(); stack.pop_back();
+                for (int t = 0; t < ns; ++t) {
+                    const double h = H[(size_t)a * ns + t];
+                    if (h != 0.0 && std::fabs(h) > threshold && sst_of_state[t] == b && comp[t] == -1) { comp[t] = ncomp; stack.push_back(t); }
+                }
+            }
+            ++ncomp;
+        }
+        std::vector<int> parent(ncomp);
+        for (int c = 0; c < ncomp; ++c) parent[c] = c;
+        auto find = [&](int c) { while (parent[c] != c) c = parent[c] = parent[parent[c]]; return c; };
+        for (bool change = true; change;) {
+            change = false;
+            for (int f = 0; f < nf; ++f) for (int ca = 1; ca <= 2; ++ca) {
+                std::vector<int> target(ncomp, -1);
+                for (int s = 0; s < ns; ++s) {
+                    if ((ca == 1) == (bool)(s >> bit(f) & 1)) continue;
+                    const int c = find(comp[s]), t = find(comp[s ^ (1 << bit(f))]);
+                    if (target[c] == -1) target[c] = t;
+                    else if (find(target[c]) != t) { const int r = find(target[c]); parent[std::max(r, t)] = std::min(r, t); target[c] = std::min(r, t); change = true; }
+                }
+            }
+        }
+        std::vector<int> label(ncomp, -1);
+        nsst = 0;
+        for (int c = 0; c < ncomp; ++c) if (find(c) == c) label[c] = nsst++;      // roots are the lowest original numbers
+        for (int s = 0; s < ns; ++s) sst_of_state[s] = label[find(comp[s])];
+    }
+
+    // U: (2Nd)^4 with flavour 2*orb+spin; mu_full: (Nd,2,Nd,2) as passed to init_solver; qns: QuantumNumbers string;
+    // epsblock: EPSBLOCK (only used with QuantumNumbers = All, CTQMC.F90:7971-7975)
+    void build(int nd_, const double *U, const double *mu_full, std::string qns, double epsevec, double epsblock = 1e-13)
     {
         nd = nd_; nflav = 2 * nd; nstates = 1 << nflav;
         const int nf = nflav, ns = nstates;
-        if (qns.find("All") != std::string::npos) qns = "Nt Szt Azt";      // caller guarantees a density-density H here
+        const bool automatic = qns.find("All") != std::string::npos;
         const char *names[6] = {"Nt", "Szt", "Qzt", "Azt", "Lzt", "Jzt"};
         bool use[6];
         for (int q = 0; q < 6; ++q) use[q] = qns.find(names[q]) != std::string::npos;
@@ -91,6 +172,12 @@ struct LocalProblem {
                 for (int q = 0; q < 6 && same; ++q) if (use[q] && !(std::fabs(qn(q, s1) - qn(q, s2)) < 1e-12)) same = false;
                 if (same) sst_of_state[s2] = nsst - 1;
             }
+        }
+        if (automatic) {
+            double big = 0.0;
+            for (size_t i = 0; i < (size_t)nf * nf; ++i) big = std::max(big, std::fabs(mu_full[i]));
+            for (size_t i = 0; i < (size_t)nf * nf * nf * nf; ++i) big = std::max(big, std::fabs(U[i]));
+            analyze_hamiltonian(U, mu_full, epsblock * big);
         }
         sst_n.assign(nsst, 0); sst_off.assign(nsst, 0); states.assign(ns, 0); idx_in_block.assign(ns, 0);
         for (int s = 0; s < ns; ++s) sst_n[sst_of_state[s]] += 1;
@@ -114,7 +201,8 @@ struct LocalProblem {
         // The sampler uses this table to propose the whole block sequence of a trial configuration at once and then only
         // verifies every link against `conn` (check_sst_sequence, Trace.F90:1243-1302, without its serial walk).
         shift.assign((size_t)nsst * nf * 2, -1);
-        {
+        if (automatic) shift = conn;      // after analyze_hamiltonian every operator maps a block into exactly one block (or none)
+        else {
             std::vector<std::vector<double>> qb(nsst, std::vector<double>(6, 0.0));
             for (int b = 0; b < nsst; ++b) for (int q = 0; q < 6; ++q) qb[b][q] = qn(q, states[sst_off[b]]);
             for (int b = 0; b < nsst; ++b) for (int f = 0; f < nf; ++f) for (int ca = 1; ca <= 2; ++ca) {
@@ -145,21 +233,7 @@ struct LocalProblem {
             if (sst_of_state[dst] != b) return;
             H[b][(size_t)idx_in_block[dst] * sst_n[b] + idx_in_block[src]] += v;
         };
-        auto annihilate = [&](int &st, double &sg, int f) { int b = bit(f); if (!(st >> b & 1)) return false; sg *= fsign(st, b); st ^= 1 << b; return true; };
-        auto create = [&](int &st, double &sg, int f) { int b = bit(f); if (st >> b & 1) return false; sg *= fsign(st, b); st ^= 1 << b; return true; };
-        for (int f1 = 0; f1 < nf; ++f1) for (int f2 = 0; f2 < nf; ++f2) {
-            double mu = mu_full[((size_t)((f1 >> 1) * 2 + (f1 & 1)) * nd + (f2 >> 1)) * 2 + (f2 & 1)];
-            if (mu == 0.0) continue;
-            for (int s = 0; s < ns; ++s) { int t = s; double sg = 1.0; if (annihilate(t, sg, f2) && create(t, sg, f1)) add(s, t, mu * sg); }
-        }
-        for (int f1 = 0; f1 < nf; ++f1) for (int f2 = 0; f2 < nf; ++f2) for (int f3 = 0; f3 < nf; ++f3) for (int f4 = 0; f4 < nf; ++f4) {
-            double u = 0.5 * U[(((size_t)f1 * nf + f2) * nf + f3) * nf + f4];
-            if (u == 0.0) continue;
-            for (int s = 0; s < ns; ++s) {
-                int t = s; double sg = 1.0;
-                if (annihilate(t, sg, f3) && annihilate(t, sg, f4) && create(t, sg, f2) && create(t, sg, f1)) add(s, t, u * sg);
-            }
-        }
+        for_each_h_element(U, mu_full, add, [](int, int, int, int) { return true; });
         eval.assign(ns, 0.0); evec.assign(nsst, {});
         for (int b = 0; b < nsst; ++b) {
             const int n = sst_n[b];

@@ -377,11 +377,16 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
         if ((b1 != b2 || s1 != s2) && mu_full[i] != 0.0) dd = false;
         if (screening) for (int t = 0; t < nftau; ++t) if (screening[i * nftau + t] != 0.0) return fail(s, W2DYN_EUNSUPPORTED, "non-zero screening function is not supported");
     }
-    if (!dd && qns.find("All") != std::string::npos)
-        return fail(s, W2DYN_EUNSUPPORTED, "QuantumNumbers = All (automatic partitioning, Operator.F90:303-442) is only supported for density-density interactions; name the quantum numbers, e.g. 'Nt Szt Qzt'");
-    s->lp.build(nd, U, mu_full, qns, epsevec);
+    double epsblock = 1e-13;
+    if (!get_real(s, "EPSBLOCK", epsblock)) return W2DYN_EINVAL;
+    if (qns.find("All") != std::string::npos && nd > 5)
+        return fail(s, W2DYN_EUNSUPPORTED, "QuantumNumbers = All (automatic partitioning) needs the dense 4^Nd x 4^Nd H_loc: Nd = %d > 5", nd);
+    s->lp.build(nd, U, mu_full, qns, epsevec, epsblock);
     const LocalProblem &lp = s->lp;
-    s->mat = !(dd && lp.identity_blocks);
+    // one-state blocks in Fock-state order: only the diagonal of H_loc survives (terms between blocks are dropped,
+    // Operator.F90:521, 1083) and the closed-form trace with eps / udd below is exact, whatever U and muimp hold
+    s->mat = !lp.identity_blocks;
+    (void)dd;
     if (s->mat && lp.nsmax > 8) return fail(s, W2DYN_EUNSUPPORTED, "largest block of H_loc has %d states with QuantumNumbers '%s': the HIP solver handles up to 8", lp.nsmax, qns.c_str());
     s->eps.assign(nf, 0.0); s->udd.assign((size_t)nf * nf, 0.0);
     for (int f = 0; f < nf; ++f) { int b = f >> 1, sp = f & 1; s->eps[f] = mu_full[((size_t)(b * 2 + sp) * nd + b) * 2 + sp]; }

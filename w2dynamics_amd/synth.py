@@ -90,11 +90,12 @@ class Problem:
 
 def make_problem(nd: int, beta: float, u: float, j: float = 0.0, v: float | None = None, mu: float | None = None,
                  D: float = 1.0, nftau: int = 5001, spin_split: float = 0.0, kanamori: bool = False,
-                 quantum_numbers: str | None = None) -> Problem:
+                 quantum_numbers: str | None = None, hop: float = 0.0) -> Problem:
     """Half-filled (by default) density-density problem on a Bethe bath.
 
     mu defaults to U/2 + (Nd-1)(V - J/2) (particle-hole symmetric point for this interaction).
-    `spin_split` adds +-h to the two spin species so that tests can break the symmetry."""
+    `spin_split` adds +-h to the two spin species so that tests can break the symmetry; `hop` adds a spin-conserving
+    hopping between neighbouring orbitals to the local one-particle Hamiltonian (off-diagonal muimp, diagonal bath)."""
     if v is None:
         v = u - 2.0 * j
     if mu is None:
@@ -107,6 +108,9 @@ def make_problem(nd: int, beta: float, u: float, j: float = 0.0, v: float | None
         for s in (0, 1):
             ftau[b, s, b, s, :] = f * (1.0 + 0.05 * b)    # mildly orbital dependent: catches flavour mix-ups
             muimp[b, s, b, s] = -(mu + (0.5 - s) * 2.0 * spin_split)
+    for b in range(nd - 1):
+        for s in (0, 1):
+            muimp[b, s, b + 1, s] = muimp[b + 1, s, b, s] = -hop
     if kanamori:
         return Problem(nd, beta, kanamori_umatrix(nd, u, v, j), ftau, muimp, hamiltonian="Kanamori",
                        quantum_numbers=quantum_numbers or "Nt Szt Qzt", bath_scale=scale, bath_D=D)
@@ -129,6 +133,17 @@ def config(name: str, nftau: int = 5001) -> Problem:
         return make_problem(2, 10.0, 2.0, j=0.25, nftau=nftau, kanamori=True)
     if name == "C3Q":      # density-density U with blocks larger than one state (QNs without Azt): matrix trace path
         return make_problem(2, 20.0, 2.0, j=0.25, nftau=nftau, quantum_numbers="Nt Szt")
+    # automatic block partitioning (QuantumNumbers = All, Operator.F90:303-442)
+    if name == "C4A":
+        return make_problem(3, 50.0, 2.0, j=0.25, nftau=nftau, kanamori=True, quantum_numbers="Nt All")
+    if name == "C4SA":
+        return make_problem(2, 10.0, 2.0, j=0.25, nftau=nftau, kanamori=True, quantum_numbers="Nt All")
+    if name == "C4SX":     # Kanamori + inter-orbital hopping: Qzt is not conserved, the partitioning has to find the blocks
+        return make_problem(2, 10.0, 2.0, j=0.25, nftau=nftau, kanamori=True, quantum_numbers="Nt All", hop=0.3)
+    if name == "C4SQ":     # "All" on its own: the starting partition is one block, whose operators connect nothing
+        return make_problem(2, 10.0, 2.0, j=0.25, nftau=nftau, kanamori=True, quantum_numbers="All")   # (Operator.F90:150): every state ends up alone
+    if name == "C3A":      # density-density: every Fock state is its own block
+        return make_problem(2, 50.0, 2.0, j=0.25, nftau=nftau, quantum_numbers="All")
     if name == "C5Z":
         return make_problem(5, 100.0, 2.0, j=0.25, nftau=nftau)
     raise ValueError("unknown or not-yet-supported configuration %r" % name)
