@@ -41,6 +41,11 @@ TRAJ = {
                              NLookup_nfft=0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 99),
     "C4": ("C4", 1001, dict(Nwarmups=10000, Nmeas=100, NCorr=100, TaudiffMax=10.0, Ntau=200, NLegMax=20, Niw=8, MeasGiw=1,
                             NLookup_nfft=0), 31),
+    # blocks of more than 8 states
+    "C4N": ("C4N", 501, dict(Nwarmups=3000, Nmeas=100, NCorr=30, TaudiffMax=3.0, Ntau=100, NLegMax=12, Niw=8, MeasGiw=1,
+                             NLookup_nfft=0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 4251),
+    "C5K": ("C5K", 501, dict(Nwarmups=3000, Nmeas=50, NCorr=50, TaudiffMax=3.0, Ntau=100, NLegMax=12, Niw=8, MeasGiw=1,
+                             NLookup_nfft=0, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05, MeasDensityMatrix=1), 4252),
     # automatic block partitioning (QuantumNumbers = All)
     "C4SA": ("C4SA", 501, dict(Nwarmups=3000, Nmeas=300, NCorr=30, TaudiffMax=3.0, Ntau=100, NLegMax=12, Niw=8, MeasGiw=1,
                                NLookup_nfft=0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 4243),

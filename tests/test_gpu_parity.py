@@ -42,12 +42,16 @@ TRAJ = [
     ("C4SX", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=3.0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 4244),
     ("C4SQ", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=3.0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 4245),
     ("C4A", 1001, dict(BASE, Nwarmups=4000, Nmeas=10, NCorr=100, TaudiffMax=10.0, NLegMax=20, Ntau=200), 32),
+    # blocks of 9 and 10 states: outer states propagated in batches
+    ("C4N", 501, dict(BASE, Nwarmups=3000, Nmeas=20, NCorr=30, TaudiffMax=3.0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 4251),
+    ("C5K", 501, dict(BASE, Nwarmups=3000, Nmeas=10, NCorr=50, TaudiffMax=3.0, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 4252),
 ]
 
 
 @pytest.mark.parametrize("cfg,nftau,over,seed", TRAJ, ids=["C1-addrem", "C1-1window-allmoves", "C3-allmoves", "C2-default", "C5Z-default",
                               "C4S-kanamori-allmoves", "C3Q-coarse-blocks-allmoves", "C4-kanamori-default",
-                              "C4SA-auto-blocks", "C4SX-auto-blocks-hopping", "C4SQ-all-alone", "C4A-auto-blocks-3orb"])
+                              "C4SA-auto-blocks", "C4SX-auto-blocks-hopping", "C4SQ-all-alone", "C4A-auto-blocks-3orb",
+                              "C4N-9-state-blocks", "C5K-5orb-kanamori-10-state-blocks"])
 def test_chains_retrace_oracle(cfg, nftau, over, seed):
     """Every chain: same configuration, M, sign, window and NPairs after warm-up; same estimators after sampling."""
     _retrace(cfg, nftau, over, seed)

@@ -23,7 +23,10 @@ def rel(a, b):
 AUTO_CASES = ["C4SA", "C4SX", "C4SQ", "C4A", "C3A"]
 
 
-@pytest.mark.parametrize("name", CASES + AUTO_CASES)
+BIG_BLOCK_CASES = ["C4N", "C5K"]      # blocks of 9 (3-orbital Kanamori, Nt Szt) and 10 states (5-orbital Kanamori, Nt Szt Qzt)
+
+
+@pytest.mark.parametrize("name", CASES + AUTO_CASES + BIG_BLOCK_CASES)
 def test_oracle_retraces_reference_chain(name):
     g = util.load_golden("traj_%s.npz" % name)
     over = g["overrides"]

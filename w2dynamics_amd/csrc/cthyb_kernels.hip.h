@@ -255,7 +255,8 @@ struct Ctx {
     double *ot; int *om, *osst, *tsst; int nops;     // time-ordered operator list, block sequence, trial block sequence (LDS)
     const int *t_conn, *t_shift, *t_n, *t_off; const double *t_eval, *t_op;   // block-shared tables (LDS); t_op null: operators stay in global memory
     double tr_log, tr_sign;                          // current local trace
-    int ms_, mi_;                                    // lane = (outer state ms_, component mi_)
+    int ms_, mi_, spb_;                              // lane = (outer state ms_ of the batch, component mi_); spb_ outer states per batch:
+                                                     // all of them (nsm) for blocks of up to 8 states, 64 / nsm beyond (9..16 states)
     // worm sampling
     int sector; double wtau[4]; int wfl[4];
 
@@ -1400,7 +1401,7 @@ __device__ __forceinline__ void ctx_setup(Ctx &x, unsigned char *smem)
         x.cnt = (unsigned long long *)(x.Q + ((C.mat ? u1 + u2 : (u1 > u2 ? u1 : u2)) + 7) / 8);
     }
     x.K = (int *)(x.cnt + C_NCOUNT); x.piv = x.K + MAXFLAV;
-    x.nops = 0; x.tr_log = 0.0; x.tr_sign = 1.0; x.ms_ = 0; x.mi_ = 0;
+    x.nops = 0; x.tr_log = 0.0; x.tr_sign = 1.0; x.ms_ = 0; x.mi_ = 0; x.spb_ = 1;
     if (C.mat) {
         // per-wave list arrays behind the common slice; block-shared tables at the start of the dynamic LDS
         x.om = x.piv + C.kmax; x.osst = x.om + C.wcap; x.tsst = x.osst + C.wcap + 2;
@@ -1411,7 +1412,7 @@ __device__ __forceinline__ void ctx_setup(Ctx &x, unsigned char *smem)
         double *td = (double *)(((size_t)(x.t_off + C.nsst) + 7) & ~(size_t)7);
         x.t_eval = td;
         x.t_op = C.op_in_lds ? td + C.nstates : nullptr;
-        x.ms_ = x.lane / C.nsm; x.mi_ = x.lane - x.ms_ * C.nsm;
+        x.ms_ = x.lane / C.nsm; x.mi_ = x.lane - x.ms_ * C.nsm; x.spb_ = C.nsm <= 8 ? C.nsm : 64 / C.nsm;
     }
 }
 
@@ -1684,8 +1685,9 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
         else {
         const double b2 = 0.5 * C.beta;
         const int nsm = C.nsm, nout = uni(x.t_n[x.outer]);
-        const bool dg = x.lane < nsm * nsm && x.ms_ == x.mi_ && x.ms_ < nout;
         const int nk = mat_lower_eq(x, b2);
+        for (int s0 = 0; s0 < nout; s0 += x.spb_) {            // batches of outer states (one batch for blocks of up to 8 states)
+        const bool dg = x.lane < x.spb_ * nsm && s0 + x.ms_ == x.mi_ && s0 + x.ms_ < nout;
         double ket = dg ? 1.0 : 0.0, lk = 0.0, tp = 0.0;
         int sk = x.outer;
         for (int i = 0; i < nk; ++i) {
@@ -1707,7 +1709,8 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
         double *dmb = C.acc_dm + (size_t)bin * C.dmsize + C.dmoff[sk];
         for (int j = 0; j < n; ++j) {                    // rho(i1 = bra index, i2 = ket index)
             const double kj = __shfl(ket, x.ms_ * nsm + j, 64);
-            if (x.lane < nsm * nsm && x.ms_ < nout && x.mi_ < n && sb == sk) atomicAdd(&dmb[x.mi_ * n + j], bra * fac * kj);
+            if (x.lane < x.spb_ * nsm && s0 + x.ms_ < nout && x.mi_ < n && sb == sk) atomicAdd(&dmb[x.mi_ * n + j], bra * fac * kj);
+        }
         }
         }
     } else {

@@ -11,7 +11,8 @@
 //
 // Trace evaluation: the state vectors of ALL outer states are propagated together, lane = (outer state s, component i)
 // with NSM*NSM <= 64 lanes in use; one operator application is NSM ds_bpermute + FMA per lane.  The vectors share one
-// scale factor (kept as a log), renormalised every few operators.
+// scale factor (kept as a log), renormalised every few operators.  Blocks of 9..16 states (5-orbital Kanamori: 10) take
+// the outer states in batches of 64 / NSM.
 #pragma once
 
 __device__ W2DYN_INLINE void build_and_invert(Ctx &x, int f, int k, const double *tcp, const double *tap, double *A, double &logdet, double &sgn);
@@ -125,7 +126,7 @@ __device__ __forceinline__ int mat_apply(Ctx &x, int sst, int code, double dt, d
     }
     lacc -= (e0 - C.egs) * dt;
     const size_t rowoff = ((size_t)(sst * nf2 + code) * nsm + x.mi_) * nsm;
-    const bool act = x.lane < nsm * nsm;
+    const bool act = x.lane < x.spb_ * nsm;
     double nv = 0.0;
     for (int j = 0; j < n; ++j) {
         const double vj = __shfl(v, x.ms_ * nsm + j, 64);
@@ -163,23 +164,33 @@ __device__ W2DYN_INLINE void mat_trace(Ctx &x, int outer, int skip1, int skip2, 
     const DevConst &C = x.C;
     const int nsm = C.nsm;
     const int nout = uni(x.t_n[outer]);
-    const bool diag = x.lane < nsm * nsm && x.ms_ == x.mi_ && x.ms_ < nout;
-    double v = diag ? 1.0 : 0.0, lacc = 0.0, tprev = 0.0;
-    int sst = outer, cnt = 0;
     tlog = -HUGE_VAL; tsign = 0.0;
-    for (int i = 0; i < x.nops; ++i) {
-        if (i == skip1 || i == skip2) continue;
-        const int code = uni(x.om[i]); const double tau = uni(x.ot[i]);
-        sst = mat_apply(x, sst, code, tau - tprev, v, lacc);
-        if (sst < 0) return;
-        tprev = tau;
-        if ((++cnt & 3) == 0) { if (!mat_rescale(v, lacc)) return; }
+    double sum = 0.0, lref = 0.0;                   // trace = sum * exp(lref), summed over the batches of outer states
+    bool any = false;
+    for (int s0 = 0; s0 < nout; s0 += x.spb_) {
+        const bool diag = x.lane < x.spb_ * nsm && s0 + x.ms_ == x.mi_ && s0 + x.ms_ < nout;
+        double v = diag ? 1.0 : 0.0, lacc = 0.0, tprev = 0.0;
+        int sst = outer, cnt = 0;
+        bool dead = false;
+        for (int i = 0; i < x.nops; ++i) {
+            if (i == skip1 || i == skip2) continue;
+            const int code = uni(x.om[i]); const double tau = uni(x.ot[i]);
+            sst = mat_apply(x, sst, code, tau - tprev, v, lacc);
+            if (sst < 0) return;                     // the quantum-number violation is the same for every batch
+            tprev = tau;
+            if ((++cnt & 3) == 0) { if (!mat_rescale(v, lacc)) { dead = true; break; } }
+        }
+        if (dead) { if (x.spb_ >= nout) return; continue; }
+        if (sst != outer) return;
+        mat_evolve(x, sst, C.beta - tprev, v, lacc);
+        const double tot = wave_sum(diag ? v : 0.0);
+        if (tot == 0.0 || !(fabs(tot) > 0.0)) continue;
+        if (!any) { sum = tot; lref = lacc; any = true; }
+        else if (lacc > lref) { sum = sum * exp(lref - lacc) + tot; lref = lacc; }
+        else sum += tot * exp(lacc - lref);
     }
-    if (sst != outer) return;
-    mat_evolve(x, sst, C.beta - tprev, v, lacc);
-    const double tot = wave_sum(diag ? v : 0.0);
-    if (tot == 0.0 || !(fabs(tot) > 0.0)) return;
-    tlog = lacc + log(fabs(tot)); tsign = tot < 0.0 ? -1.0 : 1.0;
+    if (!any || sum == 0.0 || !(fabs(sum) > 0.0)) return;
+    tlog = lref + log(fabs(sum)); tsign = sum < 0.0 ? -1.0 : 1.0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -387,7 +387,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     // Operator.F90:521, 1083) and the closed-form trace with eps / udd below is exact, whatever U and muimp hold
     s->mat = !lp.identity_blocks;
     (void)dd;
-    if (s->mat && lp.nsmax > 8) return fail(s, W2DYN_EUNSUPPORTED, "largest block of H_loc has %d states with QuantumNumbers '%s': the HIP solver handles up to 8", lp.nsmax, qns.c_str());
+    if (s->mat && lp.nsmax > 16) return fail(s, W2DYN_EUNSUPPORTED, "largest block of H_loc has %d states with QuantumNumbers '%s': the HIP solver handles up to 16", lp.nsmax, qns.c_str());
     s->eps.assign(nf, 0.0); s->udd.assign((size_t)nf * nf, 0.0);
     for (int f = 0; f < nf; ++f) { int b = f >> 1, sp = f & 1; s->eps[f] = mu_full[((size_t)(b * 2 + sp) * nd + b) * 2 + sp]; }
     auto Ut = [&](int a, int b) { return U[((a * nf + b) * nf + a) * nf + b] - U[((a * nf + b) * nf + b) * nf + a]; };

@@ -133,6 +133,11 @@ def config(name: str, nftau: int = 5001) -> Problem:
         return make_problem(2, 10.0, 2.0, j=0.25, nftau=nftau, kanamori=True)
     if name == "C3Q":      # density-density U with blocks larger than one state (QNs without Azt): matrix trace path
         return make_problem(2, 20.0, 2.0, j=0.25, nftau=nftau, quantum_numbers="Nt Szt")
+    # blocks of 9..16 states (outer states taken in batches on the GPU)
+    if name == "C4N":      # 3-orbital Kanamori with Nt, Szt only: largest block 9 states
+        return make_problem(3, 10.0, 2.0, j=0.25, nftau=nftau, kanamori=True, quantum_numbers="Nt Szt")
+    if name == "C5K":      # 5-orbital Kanamori (d shell): 1024 states, largest block 10 states
+        return make_problem(5, 10.0, 2.0, j=0.25, nftau=nftau, kanamori=True)
     # automatic block partitioning (QuantumNumbers = All, Operator.F90:303-442)
     if name == "C4A":
         return make_problem(3, 50.0, 2.0, j=0.25, nftau=nftau, kanamori=True, quantum_numbers="Nt All")
