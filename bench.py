@@ -42,6 +42,8 @@ WORKLOADS = {
                text="C4: 3-orbital Kanamori (QNs Nt Szt Qzt, matrix local trace), U=2, J=0.25, beta=50, TaudiffMax=10, NCorr=100"),
     "C5Z": dict(config="C5Z", nftau=5001, overrides=dict(Nftau=5001, NCorr=100, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Nwarmups=0, Nmeas=1),
                 text="C5 (Z-space part): 5-orbital density-density, U=2, J=0.25, beta=100, TaudiffMax=10, NCorr=100"),
+    "C5K": dict(config="C5KB", nftau=5001, overrides=dict(Nftau=5001, NCorr=100, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Nwarmups=0, Nmeas=1),
+                text="C5K: 5-orbital Kanamori (d shell, QNs Nt Szt Qzt: 352 blocks of up to 10 states, matrix local trace), U=2, J=0.25, beta=50, TaudiffMax=10, NCorr=100"),
     # BASELINE.json configs[4] on one GPU: worm sampling of one component of the two-particle Green's function (sector 4)
     "C5": dict(config="C5Z", nftau=5001, worm=dict(component=12, nfix=2000),
                overrides=dict(Nftau=5001, NCorr=100, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Nwarmups=0, Nmeas=1, N4iwf=10, N4iwb=5,

@@ -145,6 +145,7 @@ __host__ __device__ inline size_t lds_bytes_per_wave(int nflav, int kmax, int wc
     size_t d = (size_t)2 * nflav * kmax + 2 * (size_t)kmax + ((mat ? u1 + u2 : (u1 > u2 ? u1 : u2)) + 7) / 8;
     size_t i = (size_t)MAXFLAV + kmax;                                         // K, piv
     if (mat) { d += wcap + 2; i += (size_t)3 * wcap + 8; }                     // ot; om, osst, tsst
+    if (mat > 4) { const size_t nt = mat <= 8 ? 8 : (mat <= 10 ? 10 : 16); d += 5 * nt * nt; }   // stage of MAT_CH operator matrices + vector tile (sequential trace, mat = block size)
     size_t b = d * sizeof(double) + C_NCOUNT * sizeof(unsigned long long) + i * sizeof(int);
     return (b + 15) & ~(size_t)15;
 }
@@ -252,8 +253,10 @@ struct Ctx {
     double wr_t; int wr_m, wr_c, wr_p;  // lane e: window-list entry e (tau, f|ca<<8|slot<<16, partner count, pairs before e) when nwin <= 64
     int wvalid;                      // window list (registers or LDS) matches the current configuration and window
     // matrix local-trace path
+    double *opbuf;                                   // stage of MAT_CH operator matrices (blocks of more than 4 states)
     double *ot; int *om, *osst, *tsst; int nops;     // time-ordered operator list, block sequence, trial block sequence (LDS)
-    const int *t_conn, *t_shift, *t_n, *t_off; const double *t_eval, *t_op;   // block-shared tables (LDS); t_op null: operators stay in global memory
+    const short *t_conn, *t_shift;                   // 16-bit block numbers: the two tables are the bulk of the shared LDS (5 orbitals: 352 blocks x 20 operators)
+    const int *t_n, *t_off; const double *t_eval, *t_op;   // block-shared tables (LDS); t_op null: operators stay in global memory
     double tr_log, tr_sign;                          // current local trace
     int ms_, mi_, spb_;                              // lane = (outer state ms_ of the batch, component mi_); spb_ outer states per batch:
                                                      // all of them (nsm) for blocks of up to 8 states, 64 / nsm beyond (9..16 states)
@@ -1406,9 +1409,10 @@ __device__ __forceinline__ void ctx_setup(Ctx &x, unsigned char *smem)
         // per-wave list arrays behind the common slice; block-shared tables at the start of the dynamic LDS
         x.om = x.piv + C.kmax; x.osst = x.om + C.wcap; x.tsst = x.osst + C.wcap + 2;
         x.ot = (double *)(((size_t)(x.tsst + C.wcap + 2) + 7) & ~(size_t)7);
+        x.opbuf = x.ot + C.wcap + 2;
         const int nf2 = 2 * C.nflav;
-        int *ti = (int *)smem;
-        x.t_conn = ti; x.t_shift = ti + C.nsst * nf2; x.t_n = x.t_shift + C.nsst * nf2; x.t_off = x.t_n + C.nsst;
+        short *ti = (short *)smem;
+        x.t_conn = ti; x.t_shift = ti + C.nsst * nf2; x.t_n = (const int *)(ti + 2 * C.nsst * nf2); x.t_off = x.t_n + C.nsst;
         double *td = (double *)(((size_t)(x.t_off + C.nsst) + 7) & ~(size_t)7);
         x.t_eval = td;
         x.t_op = C.op_in_lds ? td + C.nstates : nullptr;
@@ -1421,10 +1425,10 @@ __device__ __forceinline__ void stage_shared_tables(const DevConst &C, unsigned 
 {
     if (!C.mat) return;
     const int nf2 = 2 * C.nflav;
-    int *ti = (int *)smem;
-    int *t_shift = ti + C.nsst * nf2, *t_n = t_shift + C.nsst * nf2, *t_off = t_n + C.nsst;
+    short *ti = (short *)smem;
+    short *t_shift = ti + C.nsst * nf2; int *t_n = (int *)(ti + 2 * C.nsst * nf2), *t_off = t_n + C.nsst;
     double *td = (double *)(((size_t)(t_off + C.nsst) + 7) & ~(size_t)7);
-    for (int i = threadIdx.x; i < C.nsst * nf2; i += blockDim.x) { ti[i] = C.conn[i]; t_shift[i] = C.shift[i]; }
+    for (int i = threadIdx.x; i < C.nsst * nf2; i += blockDim.x) { ti[i] = (short)C.conn[i]; t_shift[i] = (short)C.shift[i]; }
     for (int i = threadIdx.x; i < C.nsst; i += blockDim.x) { t_n[i] = C.sst_n[i]; t_off[i] = C.sst_off[i]; }
     for (int i = threadIdx.x; i < C.nstates; i += blockDim.x) td[i] = C.sst_eval[i];
     if (C.op_in_lds) {

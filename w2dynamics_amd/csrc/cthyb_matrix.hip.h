@@ -335,13 +335,197 @@ __device__ W2DYN_INLINE void mat_trace_tree(Ctx &x, const int *tsst, int n, int 
     tlog = lsum + (double)ex * 0.6931471805599453 + log(fabs(tr)); tsign = tr < 0.0 ? -1.0 : 1.0;
 }
 
+// Sequential evaluation of the trace of a trial sequence whose block sequence tsst is known (blocks of 5..16 states):
+// lane = (outer state of the batch, component), all batches of outer states advance together on one common scale and
+// share the operator rows.  The operator matrices live in global memory (L2): with the block sequence known their
+// addresses are known up front, so they are fetched MAT_CH operators ahead - all 64 lanes load the next chunk into
+// registers while the current chunk is applied out of the wave's LDS stage (one memory latency per chunk instead of one
+// per operator and batch).
+constexpr int MAT_CH = 4, MAT_NB = 4;
+
+// Everything the evaluator needs, by value: LDS locations as byte offsets into the dynamic LDS (so that the out-of-line
+// function below addresses LDS as LDS, not through generic pointers) and plain numbers.  The function is a REAL call on
+// purpose: inlined into the sweep kernel its loop shares the register file with the whole step logic and the
+// allocator spills loop-carried values to scratch (measured: ~5000 cycles per operator, 0.5 M cycles per trace); as a
+// call the caller's state is saved once per trace and the loop runs out of registers.
+struct MatSeqArgs {
+    unsigned tsst, om, ot, conn, tn, toff, teval, opbuf, top;      // byte offsets; top = 0xffffffff: operators in global memory
+    const double *opmat;
+    int n, skip1, skip2, nsm, spb, nf2, nsst;
+    double beta, egs;
+};
+
+// padded block size the evaluator is instantiated for (stage and vector exchange use this stride)
+__host__ __device__ inline int mat_seq_pad(int nsm) { return nsm <= 8 ? 8 : (nsm <= 10 ? 10 : 16); }
+
+// NT: padded block size.  The lane's vector components v[b] (one per batch of outer states) stay in registers; for the
+// matrix-vector product they are exchanged through a small LDS tile (V[state][component], stride NT), so that one
+// operator costs a handful of wide LDS reads issued back to back instead of NT dependent cross-lane shuffles per batch.
+template <int NT>
+__device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
+{
+    extern __shared__ unsigned char lds_base[];
+    const int lane = (int)__lane_id();
+    const int *tsst = (const int *)(lds_base + uni((int)a.tsst)), *om = (const int *)(lds_base + uni((int)a.om));
+    const double *ot = (const double *)(lds_base + uni((int)a.ot));
+    const short *t_conn = (const short *)(lds_base + uni((int)a.conn));
+    const int *t_n = (const int *)(lds_base + uni((int)a.tn)), *t_off = (const int *)(lds_base + uni((int)a.toff));
+    const double *t_eval = (const double *)(lds_base + uni((int)a.teval));
+    double *opbuf = (double *)(lds_base + uni((int)a.opbuf)), *vbuf = opbuf + MAT_CH * NT * NT;
+    const bool ops_lds = uni((int)a.top) != -1;
+    const double *ops_l = (const double *)(lds_base + (ops_lds ? uni((int)a.top) : 0));
+    const double *ops_g = (const double *)(((unsigned long long)(unsigned)uni((int)((unsigned long long)a.opmat >> 32)) << 32) | (unsigned long long)(unsigned)uni((int)(unsigned long long)a.opmat));
+    const int n = uni(a.n), skip1 = uni(a.skip1), skip2 = uni(a.skip2), nsm = uni(a.nsm), spb = uni(a.spb), nf2 = uni(a.nf2), nsst = uni(a.nsst);
+    const double beta = uni(a.beta), egs = uni(a.egs);
+    const int nsq = nsm * nsm, ms = lane / nsm, mi = lane - ms * nsm;
+    double2 res = make_double2(-HUGE_VAL, 0.0);
+    const int outer = uni(tsst[0]);
+    if ((unsigned)outer >= (unsigned)nsst || uni(tsst[n]) != outer) return res;
+    const int nout = uni(t_n[outer]);
+    const bool act = lane < spb * nsm;
+    bool diag[MAT_NB], valid[MAT_NB]; double v[MAT_NB];
+#pragma unroll
+    for (int b = 0; b < MAT_NB; ++b) {
+        const int st = b * spb + ms;
+        valid[b] = act && st < nout;
+        diag[b] = valid[b] && st == mi;
+        v[b] = diag[b] ? 1.0 : 0.0;
+    }
+    for (int e = lane; e < NT * NT; e += 64) vbuf[e] = 0.0;      // the padding of the vector tile stays zero from here on
+    constexpr int NREG = (MAT_CH * NT * NT + 63) / 64;
+    double reg[NREG];
+    auto fetch = [&](int c) {                       // operators c*MAT_CH .. of the trial sequence into registers
+#pragma unroll
+        for (int q = 0; q < NREG; ++q) {
+            const int e = q * 64 + lane;
+            reg[q] = 0.0;
+            if (e < MAT_CH * NT * NT) {              // stage layout (operator, row, column) with the padded stride NT: constant divisors
+                const int jo = e / (NT * NT), r = e - jo * (NT * NT), i = r / NT, k = r - i * NT, j = c * MAT_CH + jo;
+                if (j < n && i < nsm && k < nsm) {
+                    const int sst = tsst[j], code = om[mat_old_index(j, skip1, skip2)];
+                    if ((unsigned)sst < (unsigned)nsst && (unsigned)code < (unsigned)nf2) {
+                        const size_t idx = (size_t)(sst * nf2 + code) * nsq + i * nsm + k;
+                        reg[q] = ops_lds ? ops_l[idx] : ops_g[idx];
+                    }
+                }
+            }
+        }
+    };
+    // Everything about operator j that is the same for all lanes (time step, block size and offset, scalar decay) is
+    // worked out for 64 operators at once, lane jj for operator base + jj, and handed to the sequential loop with
+    // v_readlane: the loop itself then waits for LDS only twice per operator (vector tile, eigenvalue of the lane's state).
+    double lacc = 0.0, tlast = 0.0;
+    int iexp = 0;                                   // common binary exponent taken out of the vectors
+    fetch(0);
+    for (int base = 0; base < n; base += 64) {
+        const int jm = base + lane;
+        double my_dt = 0.0, my_sc = 0.0; int my_on = 0; bool my_bad = false;
+        if (jm < n) {
+            const int sst = tsst[jm], o = mat_old_index(jm, skip1, skip2);
+            const double tau = ot[o], tp = jm == 0 ? 0.0 : ot[mat_old_index(jm - 1, skip1, skip2)];
+            my_dt = tau - tp;
+            if ((unsigned)sst >= (unsigned)nsst) my_bad = true;
+            else {
+                const int code = om[o];
+                my_bad = (unsigned)code >= (unsigned)nf2 || t_conn[sst * nf2 + code] < 0;
+                const int off = t_off[sst];
+                my_on = off | (t_n[sst] << 16);
+                my_sc = (t_eval[off] - egs) * my_dt;
+            }
+            if (jm == n - 1) tlast = tau;
+        }
+        if (__ballot(my_bad) != 0ull) return res;
+        lacc -= wave_sum(my_sc);
+        const int cnt = min(64, n - base);
+        // eigenvalue difference of the lane's state in the block of the first operator of this group (prefetched one ahead)
+        int on = __builtin_amdgcn_readlane(my_on, 0);
+        double de = ((on >> 16) > 1 && mi < (on >> 16)) ? t_eval[(on & 0xffff) + mi] - t_eval[on & 0xffff] : 0.0;
+        for (int jj = 0; jj < cnt; ++jj) {
+            const int j = base + jj;
+            if ((j % MAT_CH) == 0) {                 // stage the next MAT_CH operator matrices
+                wave_sync();
+#pragma unroll
+                for (int q = 0; q < NREG; ++q) { const int e = q * 64 + lane; if (e < MAT_CH * NT * NT) opbuf[e] = reg[q]; }
+                wave_sync();
+                if (j + MAT_CH < n) fetch(j / MAT_CH + 1);
+            }
+            const int jo = j % MAT_CH;
+            const int dlo = __builtin_amdgcn_readlane((int)__double2loint(my_dt), jj), dhi = __builtin_amdgcn_readlane(__double2hiint(my_dt), jj);
+            const double dt = __hiloint2double(dhi, dlo);
+            const double fdec = exp(-de * dt);
+            if (jj + 1 < cnt) {                      // next operator's eigenvalue difference: in flight during this product
+                on = __builtin_amdgcn_readlane(my_on, jj + 1);
+                de = ((on >> 16) > 1 && mi < (on >> 16)) ? t_eval[(on & 0xffff) + mi] - t_eval[on & 0xffff] : 0.0;
+            }
+#pragma unroll
+            for (int b = 0; b < MAT_NB; ++b) if (valid[b]) vbuf[(b * spb + ms) * NT + mi] = v[b] * fdec;
+            wave_sync();
+            const double *row = opbuf + (jo * NT + (act ? mi : 0)) * NT;
+#pragma unroll
+            for (int b = 0; b < MAT_NB; ++b) {
+                if (b * spb < nout) {                // uniform
+                    const double *vr = vbuf + (valid[b] ? (b * spb + ms) : 0) * NT;
+                    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NT; k += 2) { acc0 = fma(row[k], vr[k], acc0); acc1 = fma(row[k + 1], vr[k + 1], acc1); }
+                    v[b] = valid[b] ? acc0 + acc1 : 0.0;
+                }
+            }
+            wave_sync();
+            if ((j & 3) == 3) {                      // keep the vectors near one: take out a power of two (exact)
+                double m = 0.0;
+#pragma unroll
+                for (int b = 0; b < MAT_NB; ++b) m = fmax(m, fabs(v[b]));
+                m = wave_max(m);
+                if (!(m > 0.0)) return res;
+                const int e2 = ilogb(m);
+#pragma unroll
+                for (int b = 0; b < MAT_NB; ++b) v[b] = ldexp(v[b], -e2);
+                iexp += e2;
+            }
+        }
+    }
+    const double tprev = uni(wave_max(tlast));
+    lacc += (double)iexp * 0.6931471805599453;
+    {   // free evolution to beta inside the outer block
+        const int off = uni(t_off[outer]);
+        const double e0 = uni(t_eval[off]), dt = beta - tprev;
+        lacc -= (e0 - egs) * dt;
+        const double fdec = (nout > 1 && mi < nout) ? exp(-(t_eval[off + mi] - e0) * dt) : 1.0;
+        double part = 0.0;
+#pragma unroll
+        for (int b = 0; b < MAT_NB; ++b) part += diag[b] ? v[b] * fdec : 0.0;
+        const double tot = wave_sum(part);
+        if (tot == 0.0 || !(fabs(tot) > 0.0)) return res;
+        res.x = lacc + log(fabs(tot)); res.y = tot < 0.0 ? -1.0 : 1.0;
+    }
+    return res;
+}
+
+__device__ __forceinline__ void mat_trace_seq(Ctx &x, const int *tsst, int n, int skip1, int skip2, double &tlog, double &tsign)
+{
+    extern __shared__ unsigned char lds_base[];
+    const DevConst &C = x.C;
+    auto off = [&](const void *p) { return (unsigned)((const unsigned char *)p - lds_base); };
+    MatSeqArgs a;
+    a.tsst = off(tsst); a.om = off(x.om); a.ot = off(x.ot); a.conn = off(x.t_conn); a.tn = off(x.t_n); a.toff = off(x.t_off);
+    a.teval = off(x.t_eval); a.opbuf = off(x.opbuf); a.top = x.t_op ? off(x.t_op) : 0xffffffffu;
+    a.opmat = C.opmat;
+    a.n = n; a.skip1 = skip1; a.skip2 = skip2; a.nsm = C.nsm; a.spb = x.spb_; a.nf2 = 2 * C.nflav; a.nsst = C.nsst;
+    a.beta = C.beta; a.egs = C.egs;
+    wave_sync();
+    const int nt = mat_seq_pad(C.nsm);
+    const double2 r = nt == 8 ? mat_trace_seq_core<8>(a) : (nt == 10 ? mat_trace_seq_core<10>(a) : mat_trace_seq_core<16>(a));
+    tlog = uni(r.x); tsign = uni(r.y);
+}
+
 // trace of the trial sequence whose block sequence is in tsst: tree for small blocks (MATN = 2, 3, 4 = padded block
 // size the kernel was instantiated for), sequential walk otherwise (MATN = 9)
 template <int MATN>
 __device__ W2DYN_INLINE void mat_trace_trial(Ctx &x, const int *tsst, int n, int skip1, int skip2, double &tlog, double &tsign)
 {
     if constexpr (MATN >= 2 && MATN <= 4) mat_trace_tree<MATN>(x, tsst, n, skip1, skip2, tlog, tsign);
-    else mat_trace(x, uni(tsst[0]), skip1, skip2, tlog, tsign);
+    else mat_trace_seq(x, tsst, n, skip1, skip2, tlog, tsign);
 }
 
 // Density matrix at beta/2 (MeasDensityMatrix_beta_half, CTQMC.F90:3088-3151) from two tree products:

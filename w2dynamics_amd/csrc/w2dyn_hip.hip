@@ -435,21 +435,22 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
             double *dst = &opmat[((size_t)(b * nf + f) * 2 + (ca - 1)) * C.nsm * C.nsm];
             for (int i = 0; i < n2; ++i) for (int j = 0; j < n1; ++j) dst[i * C.nsm + j] = O[i + (size_t)n2 * j];
         }
-        size_t ints = ((size_t)lp.nsst * nf * 4 + 2 * (size_t)lp.nsst) * sizeof(int);
+        if (lp.nsst > 32767) return fail(s, W2DYN_EUNSUPPORTED, "%d blocks: more than the 16-bit block tables hold", lp.nsst);
+        size_t ints = (size_t)lp.nsst * nf * 4 * sizeof(short) + 2 * (size_t)lp.nsst * sizeof(int);
         ints = (ints + 7) & ~(size_t)7;
         size_t small = ints + (size_t)s->nstates * sizeof(double);
         // Occupancy first: when two workgroups (2 waves per SIMD) fit into the CU's 160 KB with the operator matrices left
         // in global memory (they are L2 resident) and a 16x16 Gauss-Jordan tile, take that layout: measured 1.55x on the
         // t2g Kanamori problem against operators staged in LDS at one wave per SIMD.  W2DYN_MAT_OPS_IN_LDS=1/0 overrides.
-        const size_t per_wave16 = lds_bytes_per_wave(nf, kmax, C.wcap, std::min(C.kgj, 16), 1);
+        const size_t per_wave16 = lds_bytes_per_wave(nf, kmax, C.wcap, std::min(C.kgj, 16), C.nsm);
         bool two_groups = ((small + 15) & ~(size_t)15) + 4 * per_wave16 <= 80 * 1024;
         if (const char *e = getenv("W2DYN_MAT_OPS_IN_LDS")) two_groups = (atoi(e) == 0);
         if (two_groups) C.kgj = std::min(C.kgj, 16);
         C.op_in_lds = (!two_groups && small + nop * sizeof(double) <= 64 * 1024) ? 1 : 0;
         C.shared_lds = (int)((small + (C.op_in_lds ? nop * sizeof(double) : 0) + 15) & ~(size_t)15);
     }
-    C.lds_per_wave = (int)lds_bytes_per_wave(nf, kmax, C.wcap, C.kgj, C.mat);
-    if ((size_t)C.shared_lds + 4 * (size_t)C.lds_per_wave > 160 * 1024 && C.kgj > 16) { C.kgj = 16; C.lds_per_wave = (int)lds_bytes_per_wave(nf, kmax, C.wcap, C.kgj, C.mat); }
+    C.lds_per_wave = (int)lds_bytes_per_wave(nf, kmax, C.wcap, C.kgj, C.mat ? C.nsm : 0);
+    if ((size_t)C.shared_lds + 4 * (size_t)C.lds_per_wave > 160 * 1024 && C.kgj > 16) { C.kgj = 16; C.lds_per_wave = (int)lds_bytes_per_wave(nf, kmax, C.wcap, C.kgj, C.mat ? C.nsm : 0); }
     if ((size_t)C.shared_lds + 4 * (size_t)C.lds_per_wave > 160 * 1024) return fail(s, W2DYN_EUNSUPPORTED, "kmax=%d needs %d bytes of LDS per chain: too large", kmax, C.lds_per_wave);
     C.beta = s->beta; C.p_glob = s->p_glob; C.p_shift = s->p_shift; C.egs = s->egs;
     C.seed = (unsigned long long)s->seed; C.first_walker = (unsigned long long)s->first_walker;

@@ -138,6 +138,8 @@ def config(name: str, nftau: int = 5001) -> Problem:
         return make_problem(3, 10.0, 2.0, j=0.25, nftau=nftau, kanamori=True, quantum_numbers="Nt Szt")
     if name == "C5K":      # 5-orbital Kanamori (d shell): 1024 states, largest block 10 states
         return make_problem(5, 10.0, 2.0, j=0.25, nftau=nftau, kanamori=True)
+    if name == "C5KB":     # the same at the temperature of BASELINE.json's 5-orbital configuration
+        return make_problem(5, 50.0, 2.0, j=0.25, nftau=nftau, kanamori=True)
     # automatic block partitioning (QuantumNumbers = All, Operator.F90:303-442)
     if name == "C4A":
         return make_problem(3, 50.0, 2.0, j=0.25, nftau=nftau, kanamori=True, quantum_numbers="Nt All")
