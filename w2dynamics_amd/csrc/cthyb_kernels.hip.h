@@ -153,6 +153,14 @@ __host__ __device__ inline size_t lds_bytes_per_wave(int nflav, int kmax, int wc
 // ---------------------------------------------------------------------------------------------------------------
 // wave helpers
 // ---------------------------------------------------------------------------------------------------------------
+// hand-off through LDS only: orders and drains the wave's LDS operations (s_waitcnt lgkmcnt(0)) and leaves global loads
+// in flight - wave_sync() below also waits for every outstanding global access (vmcnt(0)), which undoes a prefetch
+__device__ __forceinline__ void lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 __device__ __forceinline__ void wave_sync()
 {
     // cross-lane hand-off through LDS / global memory inside ONE wave: order the memory operations for the

@@ -443,10 +443,10 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
         for (int jj = 0; jj < cnt; ++jj) {
             const int j = base + jj;
             if ((j % MAT_CH) == 0) {                 // stage the next MAT_CH operator matrices
-                wave_sync();
+                lds_sync();
 #pragma unroll
                 for (int q = 0; q < NREG; ++q) { const int e = q * 64 + lane; if (e < MAT_CH * NT * NT) opbuf[e] = reg[q]; }
-                wave_sync();
+                lds_sync();
                 if (j + MAT_CH < n) fetch(j / MAT_CH + 1);
             }
             const int jo = j % MAT_CH;
@@ -459,7 +459,7 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
             }
 #pragma unroll
             for (int b = 0; b < MAT_NB; ++b) if (valid[b]) vbuf[(b * spb + ms) * NT + mi] = v[b] * fdec;
-            wave_sync();
+            lds_sync();
             const double *row = opbuf + (jo * NT + (act ? mi : 0)) * NT;
 #pragma unroll
             for (int b = 0; b < MAT_NB; ++b) {
@@ -471,7 +471,7 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
                     v[b] = valid[b] ? acc0 + acc1 : 0.0;
                 }
             }
-            wave_sync();
+            lds_sync();
             if ((j & 3) == 3) {                      // keep the vectors near one: take out a power of two (exact)
                 double m = 0.0;
 #pragma unroll
