@@ -1906,6 +1906,29 @@ __global__ __launch_bounds__(256) void k_meas_gtau_ac(DevConst C, double *dat, i
     }
     __syncthreads();
     double *base = dat + wf * (size_t)nlev * 3 * ntau;
+    // two tau bins per thread as 16-byte accesses when the rows are 16-byte aligned (Ntau even), one otherwise
+    if ((ntau & 1) == 0) {
+        for (int i = 2 * tid; i < ntau; i += 512) {
+            double2 val = make_double2(hist[i], hist[i + 1]);
+            long long nn = n;
+            for (int lvl = 0;; ) {
+                double2 *sp = (double2 *)(base + ((size_t)lvl * 3) * ntau + i), *mn = (double2 *)((double *)sp + ntau), *sq = (double2 *)((double *)mn + ntau);
+                double2 s_ = *sp, m_ = *mn, q_ = *sq;
+                const double rn = (double)(nn + 1);
+                const double i1x = val.x - m_.x, i1y = val.y - m_.y;
+                s_.x += val.x; s_.y += val.y;
+                m_.x += i1x / rn; m_.y += i1y / rn;
+                q_.x += i1x * (val.x - m_.x); q_.y += i1y * (val.y - m_.y);
+                const bool roll = (nn & 1) && lvl != nlev - 1;
+                val = make_double2(s_.x / 2, s_.y / 2);
+                if (roll) s_ = make_double2(0.0, 0.0);
+                *sp = s_; *mn = m_; *sq = q_;
+                if (!roll) break;
+                nn >>= 1; ++lvl;
+            }
+        }
+        return;
+    }
     for (int i = tid; i < ntau; i += 256) {
         double val = hist[i];
         long long nn = n;
