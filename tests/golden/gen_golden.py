@@ -178,6 +178,10 @@ WORM = {   # worm sampling in sector 4 (two-particle Green's function), one comp
     "C3a": ("C3", 501, dict(Nwarmups=3000, Nmeas=500, NCorr=20, TaudiffMax=6.0, Ntau=50, NLegMax=8, Niw=4, N4iwf=2, N4iwb=1,
                             PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=2e-7, WormMeasG4iw=1,
                             PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 79, 1 + 0 * 64 + 0 * 16 + 3 * 4 + 3),
+    # matrix local-trace path (2-orbital Kanamori): a spin-flip component, flavours (0, 1, 3, 2) = c_0 c+_1 c_3 c+_2
+    "C4Sa": ("C4S", 501, dict(Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=50, NLegMax=8, Niw=4, N4iwf=2, N4iwb=1,
+                              PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=1e-4, WormMeasG4iw=1,
+                              PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 80, 1 + 0 * 64 + 1 * 16 + 3 * 4 + 2),
 }
 
 
@@ -191,6 +195,10 @@ WORM2 = {  # worm sampling in sector 2 (one-particle Green's function): giw_worm
     "C3a": ("C3", 501, dict(Nwarmups=3000, Nmeas=500, NCorr=20, TaudiffMax=6.0, Ntau=50, NLegMax=8, Niw=8,
                             PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=2e-3, WormMeasGiw=1, WormMeasGtau=0,
                             PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 179, 1 + 2 * 4 + 2),
+    # matrix local-trace path (2-orbital Kanamori)
+    "C4Sa": ("C4S", 501, dict(Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=50, NLegMax=8, Niw=6,
+                              PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=0.02, WormMeasGiw=1, WormMeasGtau=1,
+                              PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 180, 1 + 3 * 4 + 3),
 }
 
 

@@ -162,7 +162,7 @@ def test_oracle_two_particle_matsubara_estimators(name):
     w.close()
 
 
-@pytest.mark.parametrize("name", ["C1a", "C1b", "C3a"])
+@pytest.mark.parametrize("name", ["C1a", "C1b", "C3a", "C4Sa"])
 def test_oracle_worm_sampling_retraces_reference(name):
     """Worm sampling in sector 4 (G4iw): eta-search step counts, sector step counts, acceptance ratios, the final
     configuration including the worm operators, and the accumulated g4iw_worm agree with the reference run."""
@@ -190,7 +190,7 @@ def test_oracle_worm_sampling_retraces_reference(name):
     w.close()
 
 
-@pytest.mark.parametrize("name", ["C1a", "C1b", "C3a"])
+@pytest.mark.parametrize("name", ["C1a", "C1b", "C3a", "C4Sa"])
 def test_oracle_g_worm_sampling_retraces_reference(name):
     """Worm sampling in sector 2 (one-particle Green's function, two worm operators c c+): eta-search step counts,
     sector step counts, acceptance ratios, final configuration, giw_worm and gtau_worm agree with the reference run."""
