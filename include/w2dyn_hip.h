@@ -73,7 +73,7 @@ int w2dyn_ctqmc_warmup(w2dyn_solver *s, int64_t nwarmups);
 /* ctqmc_measure(isector, icomponent)               CTQMC.F90:8355
  * isector 1 = Z space; isector 2 = worm sampling of the one-particle Green's function component icomponent
  * (giw_worm / gtau_worm, CTQMC.F90:1061-1120); isector 4 = worm sampling of the two-particle Green's function
- * component icomponent (0 = all components); density-density problems only.  Other sectors are refused. */
+ * component icomponent (0 = all components); both trace paths.  Other sectors are refused. */
 int w2dyn_ctqmc_measure(w2dyn_solver *s, int isector, int icomponent);
 /* module variable `wormeta` (impurity.py:719, 755, 784): the same value for every worm sector, CTQMC.F90:194, 434 */
 int w2dyn_set_wormeta(w2dyn_solver *s, double eta);

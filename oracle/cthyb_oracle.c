@@ -1509,6 +1509,8 @@ int ora_measure_sector(ora_walker *w, int isector, int icomponent)
 }
 
 void ora_set_wormeta(ora_walker *w, double eta) { w->eta = eta; }
+/* sector and component of the following ora_sweep calls (step-by-step checks); every chain starts in Z space */
+void ora_set_sector(ora_walker *w, int isector, int icomponent) { w->isector = isector; w->icomponent = icomponent; }
 
 void ora_count_steps(ora_walker *w, int isector, int icomponent, int64_t nfix, int64_t *sw, int64_t *sz)
 {

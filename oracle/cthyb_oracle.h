@@ -68,7 +68,8 @@ void ora_warmup(ora_walker *w, int64_t n);               /* CTQMC.F90:8188 */
 int ora_measure(ora_walker *w);                          /* CTQMC.F90:8355 sector Z; returns `aborted` */
 /* ctqmc_measure(isector, icomponent) with isector = 2 (G worm), 4 (G4 worm) or 1 (CTQMC.F90:8355-8849); returns `aborted` */
 int ora_measure_sector(ora_walker *w, int isector, int icomponent);
-void ora_set_wormeta(ora_walker *w, double eta);         /* module variable wormeta(isector) (impurity.py:719) */
+void ora_set_wormeta(ora_walker *w, double eta);
+void ora_set_sector(ora_walker *w, int isector, int icomponent);   /* sector of the following ora_sweep calls */         /* module variable wormeta(isector) (impurity.py:719) */
 /* count_steps (CTQMC.F90:6299-6444): nfix steps without measuring, configuration restored afterwards */
 void ora_count_steps(ora_walker *w, int isector, int icomponent, int64_t nfix, int64_t *steps_worm, int64_t *steps_z);
 /* worm results: g4iw_worm / g4iwpp_worm (2N4iwf,2N4iwf,2N4iwb+1) complex interleaved; returns 0 if not measured */

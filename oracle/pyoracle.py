@@ -70,6 +70,7 @@ def lib():
     L.ora_get_occ.argtypes = [vp, dp, dp, C.c_void_p]
     L.ora_measure_sector.argtypes = [vp, C.c_int, C.c_int]; L.ora_measure_sector.restype = C.c_int
     L.ora_set_wormeta.argtypes = [vp, C.c_double]
+    L.ora_set_sector.argtypes = [vp, C.c_int, C.c_int]
     L.ora_init_counters.argtypes = [vp]
     L.ora_calibrate.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]; L.ora_calibrate.restype = C.c_int64
     L.ora_get_accpairtau.argtypes = [vp, dp]; L.ora_get_accpairtau.restype = C.c_int
@@ -138,6 +139,7 @@ class OracleWalker:
     def measure(self): return self.L.ora_measure(self.h)
     def measure_sector(self, isector, icomponent): return self.L.ora_measure_sector(self.h, int(isector), int(icomponent))
     def set_wormeta(self, eta): self.L.ora_set_wormeta(self.h, float(eta))
+    def set_sector(self, isector, icomponent): self.L.ora_set_sector(self.h, int(isector), int(icomponent))
     def init_counters(self): self.L.ora_init_counters(self.h)
 
     def calibrate(self, list_, phase1pairnum, phase2taugrid, phase2pairnum, nprogress):

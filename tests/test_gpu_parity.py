@@ -277,7 +277,7 @@ def test_full_run_statistics_vs_reference(name):
     q.dest_ctqmc(); q.close()
 
 
-WORM_CASES = ["C1a", "C1b", "C3a"]
+WORM_CASES = ["C1a", "C1b", "C3a", "C4Sa"]      # C4Sa: matrix trace path (2-orbital Kanamori)
 
 
 def _worm_gpu(g, nw, wpb, seed):
@@ -491,8 +491,7 @@ def test_gtau_accumulator_modes_chains_vs_oracle(name):
 
 
 def test_worm_modes_refused_or_ignored():
-    """Sectors other than 1, 2 and 4 are refused; worm sampling on the matrix trace path is refused; eta = 0 samples
-    nothing (CTQMC.F90:8409-8418)."""
+    """Sectors other than 1, 2 and 4 are refused; eta = 0 samples nothing (CTQMC.F90:8409-8418)."""
     g = util.load_golden("worm_C1a.npz")
     q, p, pset, over = _worm_gpu(g, 4, 2, 3)
     with pytest.raises(W2DynError) as e:
@@ -504,16 +503,6 @@ def test_worm_modes_refused_or_ignored():
     q.wormeta[:] = 0.0
     q.ctqmc_measure(4, 1)
     assert q.aborted == 0 and np.all(q.g4iw_worm == 0.0) and q.cntsampling[3] == 0
-    q.dest_ctqmc(); q.close()
-    over = dict(BASE, Nwarmups=10, Nmeas=1, NCorr=5, TaudiffMax=2.0, PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=1.0,
-                WormMeasG4iw=1, N4iwf=2, N4iwb=1)
-    p, ps, pset = util.setup("C4S", 501, over)
-    q = MCTQMC(nwalkers=4, walkers_per_bin=2); q.fourpnt = 8
-    q.init_rnd(1); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
-    with pytest.raises(W2DynError) as e:
-        q.ctqmc_measure(4, 1)
-    assert e.value.code == -2
-    q.ctqmc_measure(1, 1)
     q.dest_ctqmc(); q.close()
 
 

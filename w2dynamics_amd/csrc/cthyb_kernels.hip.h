@@ -913,8 +913,8 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
         }
         blocked = between != 0;
     }
-    if constexpr (WORM) {
-        if (x.sector != 1) {
+    if constexpr (WORM != 0 && MAT == 0) {        // one-state blocks: a worm operator of the pair's flavour between its operators blocks the removal
+        if (x.sector != 1) {                      // (with larger blocks the list walk above has seen the worm operators already)
 #pragma unroll
             for (int i = 0; i < WORM; ++i) blocked |= (x.wfl[i] == f && x.wtau[i] > t1 && x.wtau[i] < t2);
         }
@@ -1474,6 +1474,11 @@ __device__ __forceinline__ void ctx_load(Ctx &x)
     wave_sync();
     if (C.mat) {      // time-ordered list, block sequence and trace of the stored configuration
         mat_build_list(x);
+        if (x.sector != 1) {                         // worm operators are list entries like any other (no hybridisation lines: not in M)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < x.sector) mat_insert(x, mat_lower(x, x.wtau[i]), x.wtau[i], mat_code(x.wfl[i], (i & 1) ? 1 : 2));
+        }
         mat_walk_sst(x);                 // the caller evaluates the trace (mat_trace_current<MAT>)
     }
 }
@@ -1641,14 +1646,15 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
         const int biti = flav_bit(fi, nd);
         const bool ci = oi < ki;
         const double ti = !act ? 0.0 : (ci ? x.tc_[fi * C.kmax + oi] : x.ta_[fi * C.kmax + oi - ki]);
-        if (!MAT && x.sector != 1 && act) {
+        if (x.sector != 1 && act) {
             // worm operators enter the trace sign like any other operator; get_WormSign (Trace.F90:3623-3651) adds the
             // hybridising operators at later times than each worm operator
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (i >= x.sector) continue;                 // two worm operators in sector 2, four in sector 4
                 const int bw = flav_bit(x.wfl[i], nd); const double tw = x.wtau[i];
-                par ^= ((tw < ti && bw < biti) ? 1 : 0) ^ ((ti < tw && biti < bw) ? 1 : 0) ^ ((ti > tw) ? 1 : 0);
+                if (!MAT) par ^= ((tw < ti && bw < biti) ? 1 : 0) ^ ((ti < tw && biti < bw) ? 1 : 0);   // trace sign (scalar path only)
+                par ^= (ti > tw) ? 1 : 0;
             }
         }
         for (int fj = 0; fj < nf; ++fj) {
@@ -1667,7 +1673,7 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
             if (wsame) par ^= above & 1;
         }
     }
-    const bool worm = !MAT && x.sector != 1;
+    const bool worm = x.sector != 1;
     if (worm && x.lane == 0) {
         // worm operators among themselves: trace sign, and the pairs i < j (container order) with tau_i < tau_j
 #pragma unroll
@@ -1675,7 +1681,7 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (i >= x.sector || j >= x.sector) continue;
-                if (x.wtau[j] < x.wtau[i] && flav_bit(x.wfl[j], nd) < flav_bit(x.wfl[i], nd)) par ^= 1;
+                if (!MAT && x.wtau[j] < x.wtau[i] && flav_bit(x.wfl[j], nd) < flav_bit(x.wfl[i], nd)) par ^= 1;
                 if (i < j && x.wtau[i] < x.wtau[j]) par ^= 1;
             }
     }

@@ -215,15 +215,84 @@ __device__ W2DYN_INLINE void step_worm_replace(Ctx &x)
     x.count(C_ACCWREP);
 }
 
-// sweep kernel with worm sampling (scalar trace path): Z space CTQMC.F90:8431-8488, worm space 8489-8528
-template <int NW>
+// Matrix trace path: the worm operators are entries of the time-ordered operator list (they take part in the block
+// sequence and in the trace like any operator, but not in M).  Insertion: put the NW operators into the list, walk the
+// block sequence from the outer block (this IS the quantum-number check, check_sst_sequence), evaluate the trace.
+template <int NW, int MAT>
+__device__ W2DYN_INLINE void step_worm_add_mat(Ctx &x)
+{
+    const DevConst &C = x.C;
+    const int nf = C.nflav;
+    const int ncomp = NW == 4 ? nf * nf * nf * nf : nf * nf;
+    int comp = C.icomponent;
+    if (comp == 0) comp = x.randint(1, ncomp);
+    x.count(C_TRYWADD);
+    double t[4] = {0.0, 0.0, 0.0, 0.0}; int fl[4] = {0, 0, 0, 0};
+    int rest = comp - 1, base = ncomp / nf;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { const int bs = rest / base; rest -= bs * base; base /= nf; fl[i] = bs; }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {                     // set_OperTime, Trace.F90:3942-3967
+        t[i] = x.draw() * C.beta;
+        if (i > 0 && t[i - 1] == t[i]) t[i] += C.beta * 1e-14;
+    }
+    if (x.nops + NW > C.wcap) { x.err |= ERR_WCAP; x.count(C_QNWADD); x.sector = 1; return; }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) mat_insert(x, mat_lower(x, t[i]), t[i], mat_code(fl[i], (i & 1) ? 1 : 2));
+    auto take_out = [&]() {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) mat_remove(x, mat_lower(x, t[i]));
+        wave_sync();
+    };
+    const bool valid = mat_walk_into(x, x.outer, x.tsst);
+    if (worm_prefact<NW>(C) == 0.0 || !valid) { take_out(); x.count(C_QNWADD); x.sector = 1; return; }
+    double tl, ts;
+    mat_trace_trial<MAT>(x, x.tsst, x.nops, -1, -1, tl, ts);
+    const double rnd = x.draw();
+    if (ts != 0.0 && rnd < fabs(worm_prefact<NW>(C) * exp(tl - x.tr_log))) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) { x.wtau[i] = t[i]; x.wfl[i] = fl[i]; }
+        x.tr_log = tl; x.tr_sign = ts; mat_commit_sst(x);
+        x.sector = NW;
+        x.count(C_ACCWADD);
+    } else { take_out(); x.sector = 1; }
+}
+
+template <int NW, int MAT>
+__device__ W2DYN_INLINE void step_worm_rem_mat(Ctx &x)
+{
+    const DevConst &C = x.C;
+    x.count(C_TRYWREM);
+#pragma unroll
+    for (int i = 0; i < NW; ++i) mat_remove(x, mat_lower(x, x.wtau[i]));
+    wave_sync();
+    auto put_back = [&]() {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) mat_insert(x, mat_lower(x, x.wtau[i]), x.wtau[i], mat_code(x.wfl[i], (i & 1) ? 1 : 2));
+    };
+    const bool valid = mat_walk_into(x, x.outer, x.tsst);
+    if (!valid) { put_back(); x.count(C_QNWREM); return; }
+    double tl, ts;
+    mat_trace_trial<MAT>(x, x.tsst, x.nops, -1, -1, tl, ts);
+    const double rnd = x.draw();
+    if (ts != 0.0 && rnd < fabs(exp(tl - x.tr_log) / worm_prefact<NW>(C))) {
+        x.tr_log = tl; x.tr_sign = ts; mat_commit_sst(x);
+        x.sector = 1; x.count(C_ACCWREM);
+    } else put_back();
+}
+
+// sweep kernel with worm sampling: Z space CTQMC.F90:8431-8488, worm space 8489-8528.  MAT = 0: scalar trace path,
+// otherwise the matrix trace path instantiation (2, 3, 4, 9 as in k_sweep)
+template <int NW, int MAT>
 __global__ __launch_bounds__(256, W2DYN_WPE_WORM) void k_sweep_worm(DevConst C, long long nsteps)
 {
     extern __shared__ unsigned char smem[];
+    stage_shared_tables(C, smem);
     Ctx x(C);
     ctx_setup(x, smem);
     if (x.w >= C.nwalkers) return;
     ctx_load(x);
+    if constexpr (MAT != 0) mat_trace_current<MAT>(x);
     const double pg = C.p_glob, ps = C.p_shift, pw = C.p_wins, pr = C.p_wrep;
     unsigned int phase = (unsigned int)((x.cnt[C_TRYADD] + x.cnt[C_TRYREM] + x.cnt[C_W_TRYADD] + x.cnt[C_W_TRYREM]) % (unsigned long long)C.nslide);
     phase = (unsigned int)uni((int)phase);
@@ -237,18 +306,18 @@ __global__ __launch_bounds__(256, W2DYN_WPE_WORM) void k_sweep_worm(DevConst C, 
         if (x.sector == 1) {
             x.count(C_SAMPLING);
             const double r = x.draw();
-            if (r < (1.0 - ps - pg - pw) / 2.0) { x.skip(2); step_add<0, NW>(x); phase += 1; WORM_KIND(C_CYC_ADD); }
-            else if (r <= 1.0 - ps - pg - pw) { x.skip(2); step_rem<0, NW>(x); phase += 1; WORM_KIND(C_CYC_REM); }
-            else if (r <= 1.0 - ps - pg) { step_worm_add<NW>(x); WORM_KIND(C_CYC_GLOB); }
-            else if (r <= 1.0 - ps) { step_glob(x); WORM_KIND(C_CYC_SHIFT); }
-            else { step_shift<0>(x); WORM_KIND(C_CYC_SHIFT); }
+            if (r < (1.0 - ps - pg - pw) / 2.0) { x.skip(2); step_add<MAT, NW>(x); phase += 1; WORM_KIND(C_CYC_ADD); }
+            else if (r <= 1.0 - ps - pg - pw) { x.skip(2); step_rem<MAT, NW>(x); phase += 1; WORM_KIND(C_CYC_REM); }
+            else if (r <= 1.0 - ps - pg) { if constexpr (MAT != 0) step_worm_add_mat<NW, MAT>(x); else step_worm_add<NW>(x); WORM_KIND(C_CYC_GLOB); }
+            else if (r <= 1.0 - ps) { if constexpr (MAT != 0) step_glob_mat<MAT>(x); else step_glob(x); WORM_KIND(C_CYC_SHIFT); }
+            else { step_shift<MAT>(x); WORM_KIND(C_CYC_SHIFT); }
         } else {
             x.count(C_W_SAMPLING);
             const double r = x.draw();
-            if (r < (1.0 - pr - pw) / 2.0) { x.skip(2); step_add<0, NW>(x); phase += 1; WORM_KIND(C_DBG5); }
-            else if (r < 1.0 - pr - pw) { x.skip(2); step_rem<0, NW>(x); phase += 1; WORM_KIND(C_DBG5); }
+            if (r < (1.0 - pr - pw) / 2.0) { x.skip(2); step_add<MAT, NW>(x); phase += 1; WORM_KIND(C_DBG5); }
+            else if (r < 1.0 - pr - pw) { x.skip(2); step_rem<MAT, NW>(x); phase += 1; WORM_KIND(C_DBG5); }
             else if (r < 1.0 - pw) { step_worm_replace<NW>(x); WORM_KIND(C_DBG6); }
-            else { step_worm_rem<NW>(x); WORM_KIND(C_DBG7); }
+            else { if constexpr (MAT != 0) step_worm_rem_mat<NW, MAT>(x); else step_worm_rem<NW>(x); WORM_KIND(C_DBG7); }
         }
 #ifdef W2DYN_STAMPS_WORM
         if (x.lane == 0) x.cnt[kind_] += __builtin_amdgcn_s_memtime() - t0_;

@@ -185,6 +185,17 @@ template <bool CALIB> void launch_sweep(w2dyn_solver *s, const Launch &l, long l
     }
 }
 
+template <int NW> void launch_sweep_worm(w2dyn_solver *s, const Launch &l, long long nsteps)
+{
+    switch (mat_variant(s)) {
+    case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_worm<NW, 0>), l.grid, l.block, l.lds, s->stream, s->C, nsteps); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_worm<NW, 2>), l.grid, l.block, l.lds, s->stream, s->C, nsteps); break;
+    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_worm<NW, 3>), l.grid, l.block, l.lds, s->stream, s->C, nsteps); break;
+    case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_worm<NW, 4>), l.grid, l.block, l.lds, s->stream, s->C, nsteps); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_worm<NW, 9>), l.grid, l.block, l.lds, s->stream, s->C, nsteps); break;
+    }
+}
+
 int time_begin(w2dyn_solver *s) { if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream)); return 0; }
 int time_end(w2dyn_solver *s, const char *name)
 {
@@ -600,8 +611,8 @@ int w2dyn_sweep(w2dyn_solver *s, int64_t nsteps, int count_as_sampling)
     if ((rc = time_begin(s))) return rc;
     // instantiations: 0 = one-state blocks (closed-form trace); 2, 3, 4 = matrix path with blocks padded to that size
     // (tree product); 9 = matrix path, sequential propagation (blocks of 5..8 states)
-    if (s->cur_isector == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_worm<4>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps);   // counts its own steps
-    else if (s->cur_isector == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_worm<2>), l.grid, l.block, l.lds, s->stream, s->C, (long long)nsteps);
+    if (s->cur_isector == 4) launch_sweep_worm<4>(s, l, (long long)nsteps);   // counts its own steps
+    else if (s->cur_isector == 2) launch_sweep_worm<2>(s, l, (long long)nsteps);
     else launch_sweep<false>(s, l, (long long)nsteps, count_as_sampling);
     HIPCHK(hipGetLastError());
     if ((rc = time_end(s, s->cur_isector != 1 ? "sweep_worm" : "sweep"))) return rc;
@@ -1055,7 +1066,6 @@ static int enter_sector(w2dyn_solver *s, int isector, int icomponent)
     if (isector != 1 && isector != 2 && isector != 4) return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d is not supported (1 = Z, 2 = one-particle, 4 = two-particle Green's function)", isector);
     if (isector != 1) {
         const int nf = s->nflav;
-        if (s->mat) return fail(s, W2DYN_EUNSUPPORTED, "worm sampling is only implemented for density-density problems (one-state blocks)");
         if (icomponent < 0 || icomponent > (isector == 4 ? nf * nf * nf * nf : nf * nf)) return fail(s, W2DYN_EINVAL, "component %d out of range", icomponent);
     }
     HIPCHK(hipSetDevice(s->device));
@@ -1110,7 +1120,6 @@ int w2dyn_ctqmc_worm_warmup(w2dyn_solver *s, int64_t nwarmups2, int isector, int
     // the reference allocates the buffers of the batched transform here and samples nothing (CTQMC.F90:8266-8348); this
     // library transforms every measurement on the spot, so only the arguments are checked
     if (isector != 1 && isector != 2 && isector != 4) return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d is not supported (1 = Z, 2 = one-particle, 4 = two-particle Green's function)", isector);
-    if (isector != 1 && s->mat) return fail(s, W2DYN_EUNSUPPORTED, "worm sampling is only implemented for density-density problems (one-state blocks)");
     return 0;
 }
 
