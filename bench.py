@@ -44,6 +44,12 @@ WORKLOADS = {
                 text="C5 (Z-space part): 5-orbital density-density, U=2, J=0.25, beta=100, TaudiffMax=10, NCorr=100"),
     "C5K": dict(config="C5KB", nftau=5001, overrides=dict(Nftau=5001, NCorr=100, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Nwarmups=0, Nmeas=1),
                 text="C5K: 5-orbital Kanamori (d shell, QNs Nt Szt Qzt: 352 blocks of up to 10 states, matrix local trace), U=2, J=0.25, beta=50, TaudiffMax=10, NCorr=100"),
+    # worm sampling on the matrix trace path: 3-orbital Kanamori, component 8 = flavours 0011
+    "C4W": dict(config="C4", nftau=5001, worm=dict(component=8, nfix=2000),
+                overrides=dict(Nftau=5001, NCorr=100, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Nwarmups=0, Nmeas=1, N4iwf=10, N4iwb=5,
+                               PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=1.0, WormMeasG4iw=1, G4ph=1, G4pp=0),
+                text="C4W: 3-orbital Kanamori (matrix local trace), beta=50, worm sampling in sector 4 (G4iw, component 8 = flavours 0011, "
+                     "N4iwf=10, N4iwb=5, PercentageWormInsert=PercentageWormReplace=0.2, eta balanced by count_steps)"),
     # BASELINE.json configs[4] on one GPU: worm sampling of one component of the two-particle Green's function (sector 4)
     "C5": dict(config="C5Z", nftau=5001, worm=dict(component=12, nfix=2000),
                overrides=dict(Nftau=5001, NCorr=100, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Nwarmups=0, Nmeas=1, N4iwf=10, N4iwb=5,

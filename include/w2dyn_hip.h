@@ -107,6 +107,12 @@ int w2dyn_get_mc_config_scalars(w2dyn_solver *s, int walker, int *n, int *outer_
 /* get_mc_config(n) -> taus, orbs, spins, cas, hashybs (time ordered; hashybs -1 = hybridising, Trace.F90:6861) */
 int w2dyn_get_mc_config(w2dyn_solver *s, int walker, int n, double *taus, int *orbs, int *spins, int *cas,
                         int *hashybs, int *outer_sst, int *outer_state);
+/* All chains at once: what CtHybConfig.get_from_ctqmc / set_to_ctqmc (impurity.py:699-709, w2dyn/dmft/impurity.py CtHybConfig)
+ * do for the one chain of a rank between the component runs of solve_worm / solve_component.  save keeps every chain's
+ * configuration (and its position in its random stream) on the host inside the context, across init_solver calls;
+ * restore puts them back (same number of chains, flavours and order capacity) and rebuilds M. */
+int w2dyn_save_mc_configs(w2dyn_solver *s);
+int w2dyn_restore_mc_configs(w2dyn_solver *s);
 /* set_mc_config(n, taus, ...) / set_empty_mc_config                 CTQMC.F90:9378, 9391; Trace.F90:6872-7000 */
 int w2dyn_set_mc_config(w2dyn_solver *s, int walker, int n, const double *taus, const int *orbs, const int *spins,
                         const int *cas, const int *hashybs, int outer_sst, int outer_state);

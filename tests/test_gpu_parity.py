@@ -490,6 +490,31 @@ def test_gtau_accumulator_modes_chains_vs_oracle(name):
     q.dest_ctqmc(); q.close()
 
 
+def test_solver_worm_giw_kanamori_agrees_with_z_space_estimate():
+    """solve_worm on the matrix trace path (2-orbital Kanamori): G(iw) from the sector-2 worm components agrees with the
+    Z-space Legendre estimate within the error bars of the two runs."""
+    from w2dynamics_amd.solver import HipCtHybSolver
+    from w2dynamics_amd import synth
+    base = dict(BASE, Nwarmups=3000, Nwarmups2Plus=3000, Nmeas=300, NCorr=20, TaudiffMax=3.0, Nftau=501, Niw=10, NLegMax=30, NLegOrder=30,
+                PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=0.01, WormMeasGiw=1, WormSearchEta=1)
+    s = HipCtHybSolver(base, seed=12, nwalkers=512, walkers_per_bin=16)
+    s.set_problem(synth.config("C4S", nftau=501))
+    rw = s.solve_worm()
+    gw = np.asarray(rw["giw"].mean()); ew = np.asarray(rw["giw"].stderr())
+    s.set_problem(synth.config("C4S", nftau=501))
+    rz = s.solve()
+    gz = np.asarray(rz["giw"].mean()); ez = np.asarray(rz["giw"].stderr())
+    for b in range(2):
+        for sp in range(2):
+            d = np.abs(gw[:, b, sp, b, sp] - gz[:, b, sp, b, sp]); e = np.sqrt(ew[:, b, sp, b, sp] ** 2 + ez[:, b, sp, b, sp] ** 2)
+            assert np.all(d < 5.0 * e + 2e-3), (b, sp, d.max(), e.max())
+    assert np.all(gw[10:, 0, 0, 0, 0].imag < 0)
+    do = np.abs(np.asarray(rw["occ"].mean()) - np.asarray(rz["occ"].mean()))
+    eo = np.sqrt(np.asarray(rw["occ"].stderr()) ** 2 + np.asarray(rz["occ"].stderr()) ** 2)
+    print("occ: largest difference", do.max(), "in units of the combined error", (do / (eo + 1e-12)).max())
+    assert np.all(do < 5.0 * eo + 0.01), (do.max(), eo.max())
+
+
 def test_worm_modes_refused_or_ignored():
     """Sectors other than 1, 2 and 4 are refused; eta = 0 samples nothing (CTQMC.F90:8409-8418)."""
     g = util.load_golden("worm_C1a.npz")

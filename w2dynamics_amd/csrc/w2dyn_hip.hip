@@ -63,6 +63,8 @@ struct w2dyn_solver {
     int worm_meas_giw = 0, worm_meas_gtau = 0;       // sector 2: WormMeasGiw, WormMeasGtau (CTQMC.F90:597-612)
     bool no_sampling = false;
     std::vector<long long> steps_worm_chains;
+    // configurations of all chains kept on the host across init_solver calls (w2dyn_save_mc_configs / w2dyn_restore_mc_configs)
+    std::vector<WalkerScalars> snap_ws; std::vector<int> snap_K; std::vector<double> snap_TC, snap_TA; int snap_nf = 0, snap_kmax = 0;
     // window calibration (ctqmc_calibrate): default AccPair histogram and the one on the calibration grid
     unsigned long long *accpair_default = nullptr;
     std::vector<double> accpairtau, accpairtau_chains;
@@ -1261,6 +1263,48 @@ int w2dyn_set_mc_config(w2dyn_solver *s, int walker, int n, const double *taus, 
         HIPCHK(hipMemcpy(C.TA + (size_t)w * nf * kmax, TA.data(), sizeof(double) * nf * kmax, hipMemcpyHostToDevice));
     }
     // M, det and NPairs of every chain rebuilt on the device (Trace.F90:6990-6999)
+    Launch l = walker_launch(s);
+    hipLaunchKernelGGL(k_rebuild, l.grid, l.block, l.lds, s->stream, s->C);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));
+    return check_walker_errors(s);
+}
+
+int w2dyn_save_mc_configs(w2dyn_solver *s)
+{
+    if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "save_mc_configs before init_solver");
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    const DevConst &C = s->C; const size_t W = s->nwalkers, nf = s->nflav, kmax = C.kmax;
+    s->snap_ws.resize(W); s->snap_K.resize(W * nf); s->snap_TC.resize(W * nf * kmax); s->snap_TA.resize(W * nf * kmax);
+    HIPCHK(hipMemcpy(s->snap_ws.data(), C.ws, W * sizeof(WalkerScalars), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(s->snap_K.data(), C.K, W * nf * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(s->snap_TC.data(), C.TC, W * nf * kmax * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(s->snap_TA.data(), C.TA, W * nf * kmax * sizeof(double), hipMemcpyDeviceToHost));
+    for (auto &w : s->snap_ws) if (w.sector == 2 || w.sector == 4) return fail(s, W2DYN_EINVAL, "save_mc_configs: a chain is in worm space");
+    s->snap_nf = (int)nf; s->snap_kmax = (int)kmax;
+    return 0;
+}
+
+int w2dyn_restore_mc_configs(w2dyn_solver *s)
+{
+    if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "restore_mc_configs before init_solver");
+    const DevConst &C = s->C; const size_t W = s->nwalkers, nf = s->nflav, kmax = C.kmax;
+    if (s->snap_ws.size() != W || s->snap_nf != (int)nf || s->snap_kmax != (int)kmax)
+        return fail(s, W2DYN_EINVAL, "restore_mc_configs: no saved configurations of this shape (chains %zu/%zu, flavours %d/%zu, kmax %d/%zu)",
+                    s->snap_ws.size(), W, s->snap_nf, nf, s->snap_kmax, kmax);
+    HIPCHK(hipSetDevice(s->device));
+    HIPCHK(hipStreamSynchronize(s->stream));
+    std::vector<WalkerScalars> ws(W);
+    HIPCHK(hipMemcpy(ws.data(), C.ws, W * sizeof(WalkerScalars), hipMemcpyDeviceToHost));
+    for (size_t w = 0; w < W; ++w) {       // configuration and position in the chain's random stream; counters and window start afresh
+        ws[w].outer = s->snap_ws[w].outer; ws[w].ndraw = s->snap_ws[w].ndraw;
+        ws[w].wpos = 0; ws[w].npairs = -1; ws[w].sector = 1;                   // Trace.F90:6917-6919, 6973-6975
+    }
+    HIPCHK(hipMemcpy(C.ws, ws.data(), W * sizeof(WalkerScalars), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(C.K, s->snap_K.data(), W * nf * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(C.TC, s->snap_TC.data(), W * nf * kmax * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(C.TA, s->snap_TA.data(), W * nf * kmax * sizeof(double), hipMemcpyHostToDevice));
     Launch l = walker_launch(s);
     hipLaunchKernelGGL(k_rebuild, l.grid, l.block, l.lds, s->stream, s->C);
     HIPCHK(hipGetLastError());

@@ -54,6 +54,8 @@ def load_library(path: str = LIB_PATH):
     L.w2dyn_count_steps.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.w2dyn_measure_begin.argtypes = [vp]
     L.w2dyn_set_sector.argtypes = [vp, C.c_int, C.c_int]
+    L.w2dyn_save_mc_configs.argtypes = [vp]
+    L.w2dyn_restore_mc_configs.argtypes = [vp]
     L.w2dyn_sweep.argtypes = [vp, C.c_int64, C.c_int]
     L.w2dyn_measure_once.argtypes = [vp]
     L.w2dyn_measure_finish.argtypes = [vp]
@@ -78,7 +80,7 @@ EXPORTED_SYMBOLS = [
     "w2dyn_measure_once", "w2dyn_measure_finish", "w2dyn_sync", "w2dyn_get_mc_config_scalars", "w2dyn_get_mc_config",
     "w2dyn_set_mc_config", "w2dyn_get_minv", "w2dyn_get_walker_state", "w2dyn_get_result", "w2dyn_get_scalar",
     "w2dyn_kernel_time", "w2dyn_set_wormeta", "w2dyn_get_wormeta", "w2dyn_ctqmc_worm_warmup", "w2dyn_count_steps",
-    "w2dyn_ctqmc_calibrate", "w2dyn_set_sector",
+    "w2dyn_ctqmc_calibrate", "w2dyn_set_sector", "w2dyn_save_mc_configs", "w2dyn_restore_mc_configs",
 ]
 
 _SCALARS = ("mean_sign", "aborted", "time_warmup", "time_sim", "time_sim_steps", "accglob", "accshift", "accadd4",
@@ -222,6 +224,13 @@ class MCTQMC:
         self._chk(self._L.w2dyn_set_mc_config(self._h, int(walker), int(n), f(taus, np.float64), f(orbs, np.int32),
                                               f(spins, np.int32), f(cas, np.int32), f(hashybs, np.int32),
                                               int(outer_sst), int(outer_state)))
+
+    def save_mc_configs(self):
+        """Every chain's configuration kept inside the context across init_solver calls (CtHybConfig.get_from_ctqmc for all chains)."""
+        self._chk(self._L.w2dyn_save_mc_configs(self._h))
+
+    def restore_mc_configs(self):
+        self._chk(self._L.w2dyn_restore_mc_configs(self._h))
 
     def set_empty_mc_config(self, outer_sst, outer_state, walker=-1):
         self.set_mc_config(0, [], [], [], [], [], outer_sst, outer_state, walker)

@@ -110,7 +110,10 @@ class HipCtHybSolver:
         q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, iter_no + 1)
         if mc_config_inout:
             c = mc_config_inout[0]
-            q.set_mc_config(len(c["taus"]), c["taus"], c["orbs"], c["spins"], c["cas"], c["hashybs"], c["outer_sst"], c["outer_state"])
+            if c.get("all_chains_saved"):      # every chain goes on from its own configuration, as every rank of the reference does
+                q.restore_mc_configs()
+            else:
+                q.set_mc_config(len(c["taus"]), c["taus"], c["orbs"], c["spins"], c["cas"], c["hashybs"], c["outer_sst"], c["outer_state"])
         tdm = self.qmc["TaudiffMax"]
         q.set_taudiffmax(tdm if tdm > 0.0 else self.calibrate_taudiff_max())
         if not mc_config_inout:
@@ -118,7 +121,9 @@ class HipCtHybSolver:
             if mc_config_inout is not None:
                 n, osst, ost = q.get_mc_config_scalars()
                 taus, orbs, spins, cas, hyb, osst, ost = q.get_mc_config(n)
-                mc_config_inout.append(dict(taus=taus, orbs=orbs, spins=spins, cas=cas, hashybs=hyb, outer_sst=osst, outer_state=ost))
+                q.save_mc_configs()
+                mc_config_inout.append(dict(taus=taus, orbs=orbs, spins=spins, cas=cas, hashybs=hyb, outer_sst=osst, outer_state=ost,
+                                            all_chains_saved=True))
         worm_warmups = self.qmc["Nwarmups2Plus"]
         if worm_warmups < 0:
             worm_warmups = int(0.1 * self.qmc["Nwarmups"])
