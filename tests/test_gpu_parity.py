@@ -57,6 +57,48 @@ def test_chains_retrace_oracle(cfg, nftau, over, seed):
     _retrace(cfg, nftau, over, seed)
 
 
+def test_full_size_run_properties():
+    """BASELINE.json's bench configuration at full size (C2, 16384 chains, NCorr = 200, Ntau = 1000, NLegMax = 100,
+    Nftau = 5001) through size-independent properties: a chain's trajectory depends on (seed, chain number) only - the
+    same chains come out of a 64-chain context at the right offset and of the CPU oracle; the pooled results are the
+    means of the bins; histograms are normalised; half filling and the sign come out right."""
+    over = dict(Nwarmups=2000, Nmeas=3, NCorr=200, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Niw=8, Nftau=5001)
+    p, ps, pset = util.setup("C2", 5001, over)
+    W = 16384
+
+    def run(nw, first):
+        q = MCTQMC(nwalkers=nw, first_walker=first, walkers_per_bin=8)
+        q.init_rnd(977); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+        q.set_taudiffmax(over["TaudiffMax"]); q.ctqmc_warmup(over["Nwarmups"]); q.ctqmc_measure(1, 1)
+        return q
+
+    big = run(W, 0)
+    gl, glb, hi = big.gleg, big.gleg_bins, big.histo
+    assert glb.shape == (W // 8, 1, 2, 100)
+    assert rel(gl, glb.mean(axis=0)) < 1e-12 and rel(big.gtau, big.gtau_bins.mean(axis=0)) < 1e-12
+    assert np.abs(hi.sum(axis=-1) - 1.0).max() < 1e-12 and big.mean_sign == -1.0
+    occ = big.occ
+    assert abs(occ[0, 0, 0, 0] - 0.5) < 0.01 and abs(occ[0, 1, 0, 1] - 0.5) < 0.01 and 0.0 < occ[0, 0, 0, 1] < 0.25
+    assert np.all(big.gtau[..., 1:-1] > 0.0)
+    for first in (0, W - 64):
+        small = run(64, first)
+        assert rel(small.gleg_bins, glb[first // 8: first // 8 + 8]) < 1e-12
+        for w in (0, 63):
+            n, osst, _ = small.get_mc_config_scalars(w)
+            nb, osb, _ = big.get_mc_config_scalars(first + w)
+            assert n == nb and osst == osb and n > 0
+            assert np.array_equal(small.get_mc_config(n, w)[0], big.get_mc_config(n, first + w)[0])
+        small.dest_ctqmc(); small.close()
+    w = W - 1                                          # the last chain of the full-size run against the CPU oracle
+    o = pyoracle.OracleWalker(p, pset, ("philox", 977, w))
+    o.set_taudiffmax(over["TaudiffMax"]); o.warmup(over["Nwarmups"]); o.measure()
+    c = o.get_config()
+    n, osst, _ = big.get_mc_config_scalars(w)
+    assert n == len(c["taus"]) and osst == c["outer_sst"] and np.abs(big.get_mc_config(n, w)[0] - c["taus"]).max() < 1e-10
+    o.close()
+    big.dest_ctqmc(); big.close()
+
+
 @pytest.mark.parametrize("in_lds", ["1", "0"])
 def test_matrix_path_lds_layouts_retrace_oracle(monkeypatch, in_lds):
     """The matrix path has two LDS layouts (operator matrices staged in LDS at one workgroup per CU, or left in global
