@@ -62,6 +62,7 @@ struct ora_walker {
     double *g4w, *g4wpp;                      /* g4iw_worm, g4iwpp_worm accumulators */
     /* AccumGtau = 2: autocorracc (Accumulators.F90:206-362): per-measurement buffer, (spill, mean, sqdiff) per component and level */
     double *acbuf, *acdat; int aclev; int64_t acn;
+    double *g4tau, *g4leg;                    /* FourPnt & 1: G4tau (Nd,2,Nd,2,N4tau^3); FourPnt & 2: G4leg (Nd,2,Nd,2,N4tau,N4tau,2N4iwb+1) complex */
     double *giww, *gtauw;                     /* giw_worm (2Niw complex), gtau_worm (Ntau) accumulators (sector 2) */
     double try_add, acc_add, accqn_add, try_rem, acc_rem, accqn_rem, try_glob, acc_glob, accqn_glob;
     double try_shift, acc_shift, cnt_sampling, cnt_meas;
@@ -423,6 +424,15 @@ static double permaltca(const ora_walker *w)
 
 /* Trace.F90:3479-3498 (diagonal hybridisation, no worm) */
 /* Trace.F90:3623-3651 get_WormSign */
+/* legendrep, LegendrePoly.F90:21-46: P_0..P_{n-1} at x by Bonnet's forward recursion */
+static void legendre_p(double x, int n, double *pl)
+{
+    if (x == 1.0) { for (int i = 0; i < n; ++i) pl[i] = 1.0; return; }
+    if (x == -1.0) { for (int i = 0; i < n; ++i) pl[i] = (i & 1) ? -1.0 : 1.0; return; }
+    pl[0] = 1.0; if (n > 1) pl[1] = x;
+    for (int i = 2; i < n; ++i) pl[i] = ((2 * i - 1) * x * pl[i - 1] - (i - 1) * pl[i - 2]) / i;
+}
+
 static double worm_sign(const ora_walker *w)
 {
     long perm = 0; double wt[5]; int nw = 0;
@@ -1124,6 +1134,11 @@ ora_walker *ora_create(const ora_params *p, const double *U, const double *ftau_
         w->acbuf = (double *)calloc((size_t)w->nflav * p->ntau, sizeof(double));
         w->acdat = (double *)calloc((size_t)w->nflav * p->ntau * lev * 3, sizeof(double));
     }
+    if (p->fourpnt & 1) w->g4tau = (double *)calloc((size_t)w->nflav * w->nflav * p->n4tau * p->n4tau * p->n4tau, sizeof(double));   /* CTQMC.F90:544-547 */
+    if (p->fourpnt & 2) {                                                           /* 548-551: allocated with N4tau, filled up to N4leg */
+        if (p->n4leg > p->n4tau || p->n4leg < 2) { fprintf(stderr, "oracle: FourPnt & 2 needs 2 <= N4leg <= N4tau\n"); abort(); }
+        w->g4leg = (double *)calloc((size_t)w->nflav * w->nflav * p->n4tau * p->n4tau * (2 * p->n4iwb + 1) * 2, sizeof(double));
+    }
     if (p->worm_meas_giw) w->giww = (double *)calloc((size_t)4 * p->niw, sizeof(double));      /* CTQMC.F90:597-599 */
     if (p->worm_meas_gtau) w->gtauw = (double *)calloc((size_t)p->ntau, sizeof(double));        /* CTQMC.F90:609-612 */
     if ((p->fourpnt & 8) && p->worm_meas_g4iw) {                                    /* CTQMC.F90:339-361 */
@@ -1150,7 +1165,7 @@ void ora_destroy(ora_walker *w)
     if (!w) return;
     for (int f = 0; f < w->nflav; ++f) free(w->M[f]);
     free(w->ops); free(w->ftab); ora_locprob_free(w->lp); free(w->ptr); free(w->dmblk); free(w->dmoff); free(w->accpair); free(w->accpairtau); free(w->gleg); free(w->gtau); free(w->giw);
-    free(w->histo); free(w->dm); free(w->outer_histo); free(w->g2iw); free(w->g4iw); free(w->g4iwpp); free(w->g4w); free(w->g4wpp); free(w->giww); free(w->gtauw); free(w->acbuf); free(w->acdat); free(w);
+    free(w->histo); free(w->dm); free(w->outer_histo); free(w->g2iw); free(w->g4iw); free(w->g4iwpp); free(w->g4w); free(w->g4wpp); free(w->g4tau); free(w->g4leg); free(w->giww); free(w->gtauw); free(w->acbuf); free(w->acdat); free(w);
 }
 
 void ora_set_taudiffmax(ora_walker *w, double x) { init_window(w, x); }
@@ -1327,6 +1342,62 @@ static void meas_densitymatrix(ora_walker *w)
     }
 }
 
+/* MeasGtau4PntLeg (CTQMC.F90:2609-2763): for every annihilator a1 and creator c1 of one flavour and every creator c2 and
+ * annihilator a2 of a (possibly different) flavour, M = M1(c1,a1) M2(c2,a2) - [same flavour] M(c2,a1) M(c1,a2) with the
+ * fermionic sign of the two time differences goes to the tau bin (tau12, tau34, tau14) and, times P_l(x12) P_l'(x34)
+ * exp(i w_m tau14), to the mixed Legendre / Matsubara representation (Boehnke 2011).  No configuration sign. */
+static void meas_g4leg(ora_walker *w)
+{
+    const int nf = w->nflav, nt = w->p.n4tau, nl = w->p.n4leg, nwb = w->p.n4iwb, nw = 2 * nwb + 1;
+    const double beta = w->p.beta;
+    double *tc[MAXFLAV], *ta[MAXFLAV];
+    for (int f = 0; f < nf; ++f) {
+        int k = w->k[f], nc = 0, na = 0;
+        tc[f] = (double *)malloc(sizeof(double) * (size_t)(k + 1)); ta[f] = (double *)malloc(sizeof(double) * (size_t)(k + 1));
+        for (int i = 0; i < w->nops; ++i) {
+            if (w->ops[i].flav != f || w->ops[i].wid) continue;
+            if (w->ops[i].ca == 1) tc[f][nc++] = w->ops[i].tau; else ta[f][na++] = w->ops[i].tau;
+        }
+    }
+    double *leg12 = (double *)malloc(sizeof(double) * (size_t)(nl + 2)), *leg34 = (double *)malloc(sizeof(double) * (size_t)(nl + 2));
+    for (int f1 = 0; f1 < nf; ++f1) for (int f2 = 0; f2 < nf; ++f2) {
+        const int k1 = w->k[f1], k2 = w->k[f2];
+        const double *M1 = w->M[f1], *M2 = w->M[f2];
+        for (int a1 = 0; a1 < k1; ++a1) for (int c1 = 0; c1 < k1; ++c1) {
+            double tau12 = ta[f1][a1] - tc[f1][c1];
+            const double sgn12 = tau12 < 0.0 ? -1.0 : 1.0;
+            if (tau12 < 0.0) tau12 += beta;
+            if (w->g4leg) legendre_p(2.0 / beta * tau12 - 1.0, nl, leg12);
+            for (int c2 = 0; c2 < k2; ++c2) {
+                double tau14 = ta[f1][a1] - tc[f2][c2];
+                if (tau14 < 0.0) tau14 += beta;
+                for (int a2 = 0; a2 < k2; ++a2) {
+                    double M = M1[c1 * k1 + a1] * M2[c2 * k2 + a2];
+                    if (f1 == f2) M -= M1[c2 * k1 + a1] * M2[c1 * k2 + a2];
+                    double tau34 = ta[f2][a2] - tc[f2][c2];
+                    const double sgnfull = sgn12 * (tau34 < 0.0 ? -1.0 : 1.0);
+                    if (tau34 < 0.0) tau34 += beta;
+                    M = -sgnfull * M;
+                    if (w->g4leg) {
+                        legendre_p(2.0 / beta * tau34 - 1.0, nl, leg34);
+                        for (int l = 0; l < nl; ++l) for (int lp = 0; lp < nl; ++lp) for (int wm = -nwb; wm <= nwb; ++wm) {
+                            const double ph = 2.0 * (double)wm * M_PI * tau14 / beta, v = leg34[lp] * M * leg12[l];
+                            double *g = w->g4leg + (((((size_t)f1 * nf + f2) * nt + l) * nt + lp) * nw + (wm + nwb)) * 2;
+                            g[0] += v * cos(ph); g[1] += v * sin(ph);
+                        }
+                    }
+                    if (w->g4tau) {
+                        const int b12 = (int)(nt * tau12 / beta), b14 = (int)(nt * tau14 / beta), b34 = (int)(nt * tau34 / beta);
+                        w->g4tau[((((size_t)f1 * nf + f2) * nt + b12) * nt + b34) * nt + b14] += M;
+                    }
+                }
+            }
+        }
+    }
+    for (int f = 0; f < nf; ++f) { free(tc[f]); free(ta[f]); }
+    free(leg12); free(leg34);
+}
+
 /* measure_g4iw_worm with the exact transform (CTQMC.F90:1618-1701, Nfft_worm.F90:94-137): every measurement adds
  * cfgsign/eta * exp(i[nu1 (t1-t2) + nu2 (t3-t4) + omega (t1-t4)]) (ph; WormPHConvention != 0: omega (t2-t3)) */
 static void meas_g4iw_worm(ora_walker *w)
@@ -1432,6 +1503,7 @@ void ora_measure_once(ora_walker *w)
         free(tc); free(ta);
     }
     if (w->p.accum_gtau == 2) autocorr_add(w);                          /* gtau_accum%add(), CTQMC.F90:2439 */
+    if (w->g4tau || w->g4leg) meas_g4leg(w);                            /* CTQMC.F90:8578 */
     if (w->g4iw || w->g4iwpp) meas_g4iw(w);                             /* CTQMC.F90:8579 */
 }
 
@@ -1485,6 +1557,18 @@ void ora_measure_finish(ora_walker *w)
         if (w->g4iw) for (size_t i = 0; i < n4; ++i) w->g4iw[i] *= zs / (beta * beta);
         if (w->g4iwpp) for (size_t i = 0; i < n4; ++i) w->g4iwpp[i] *= zs / (beta * beta);
         if (w->g2iw) for (size_t i = 0; i < (size_t)nf * n2 * n2 * 2; ++i) w->g2iw[i] *= zs / beta;
+    }
+    if (w->g4leg) {                                                                     /* 8775-8780 */
+        const int nt = w->p.n4tau, nl = w->p.n4leg, nw = 2 * w->p.n4iwb + 1;
+        for (int ff = 0; ff < nf * nf; ++ff) for (int l = 0; l < nl; ++l) for (int lp = 0; lp < nl; ++lp) for (int m = 0; m < nw; ++m) {
+            double *g = w->g4leg + ((((size_t)ff * nt + l) * nt + lp) * nw + m) * 2;
+            const double fac = zs * sqrt(2.0 * l + 1.0) * sqrt(2.0 * lp + 1.0) * (((lp + 1) & 1) ? -1.0 : 1.0) / beta;
+            g[0] *= fac; g[1] *= fac;
+        }
+    }
+    if (w->g4tau) {                                                                     /* 8783-8786 */
+        const double nt = (double)w->p.n4tau, fac = zs * (nt / beta) * (nt / beta) * (nt / beta) / beta;
+        for (size_t i = 0; i < (size_t)nf * nf * w->p.n4tau * w->p.n4tau * w->p.n4tau; ++i) w->g4tau[i] *= fac;
     }
     if (w->isector == 2 && (w->giww || w->gtauw)) {   /* wormScaling(SectorG), CTQMC.F90:8825, 8843-8876 */
         double scal = (w->cnt_meas_w != 0) ? w->cnt_sampling_w / (w->cnt_meas_w * w->cnt_sampling) * 4.0 / beta / w->mean_sign : 0.0;
@@ -1611,6 +1695,16 @@ int ora_get_g4iw(const ora_walker *w, double *o, int pp)
     const double *src = pp ? w->g4iwpp : w->g4iw;
     if (!src) return 0;
     memcpy(o, src, sizeof(double) * n4); return 1;
+}
+int ora_get_g4tau(const ora_walker *w, double *o)
+{
+    if (!w->g4tau) return 0;
+    memcpy(o, w->g4tau, sizeof(double) * (size_t)w->nflav * w->nflav * w->p.n4tau * w->p.n4tau * w->p.n4tau); return 1;
+}
+int ora_get_g4leg(const ora_walker *w, double *o)
+{
+    if (!w->g4leg) return 0;
+    memcpy(o, w->g4leg, sizeof(double) * (size_t)w->nflav * w->nflav * w->p.n4tau * w->p.n4tau * (2 * w->p.n4iwb + 1) * 2); return 1;
 }
 int ora_get_g4iw_worm(const ora_walker *w, double *o, int pp)
 {

@@ -44,6 +44,7 @@ typedef struct ora_params {
     int fourpnt;            /* module variable fourpnt (impurity.py:515); bit 4 = Matsubara G4 in Z space (CTQMC.F90:226) */
     int n4iwf, n4iwb;       /* N4iwf, N4iwb */
     int meas_g2iw, meas_g4iwpp, zphconv;   /* MeasG2iw, MeasG4iwPP, ZPHConvention */
+    int n4tau, n4leg;       /* N4tau, N4leg: fourpnt bit 1 = imaginary-time G4 (g4tau), bit 2 = Legendre G4 (g4leg), CTQMC.F90:226, 544-551 */
     /* worm sampling, sector 4 = two-particle Green's function (CTQMC.F90:335-378, 434) */
     double p_worm_ins, p_worm_rep;         /* PercentageWormInsert, PercentageWormReplace */
     double worm_eta;                       /* WormEta */
@@ -115,6 +116,9 @@ void ora_get_histo(const ora_walker *w, double *out);     /* (Nd,2,MaxHisto+1) *
  * g4iw / g4iw_pp (Nd,2,Nd,2,2N4iwf,2N4iwf,2N4iwb+1).  Return 0 if the quantity was not measured. */
 int ora_get_g2iw(const ora_walker *w, double *out_reim);
 int ora_get_g4iw(const ora_walker *w, double *out_reim, int pp);
+/* g4tau (Nd,2,Nd,2,N4tau,N4tau,N4tau) and g4leg (Nd,2,Nd,2,N4tau,N4tau,2N4iwb+1) complex interleaved (MeasGtau4PntLeg) */
+int ora_get_g4tau(const ora_walker *w, double *out);
+int ora_get_g4leg(const ora_walker *w, double *out_reim);
 void ora_get_densitymatrix_diag(const ora_walker *w, double *out);  /* 4^Nd, occupation basis, block order */
 void ora_get_densitymatrix(const ora_walker *w, double *out);       /* (4^Nd)^2 row major, occupation basis, block order
                                                                        (after Transform_DensityMatrix_EB_to_OCCB, CTQMC.F90:3163) */

@@ -20,7 +20,7 @@ class OraParams(C.Structure):
                 ("maxhisto", C.c_int), ("p_glob", C.c_double), ("p_shift", C.c_double), ("taudiffmax", C.c_double),
                 ("has_szt", C.c_int), ("qns", C.c_char * 64), ("epsevec", C.c_double),
                 ("fourpnt", C.c_int), ("n4iwf", C.c_int), ("n4iwb", C.c_int), ("meas_g2iw", C.c_int),
-                ("meas_g4iwpp", C.c_int), ("zphconv", C.c_int),
+                ("meas_g4iwpp", C.c_int), ("zphconv", C.c_int), ("n4tau", C.c_int), ("n4leg", C.c_int),
                 ("p_worm_ins", C.c_double), ("p_worm_rep", C.c_double), ("worm_eta", C.c_double),
                 ("worm_meas_g4iw", C.c_int), ("g4ph", C.c_int), ("g4pp", C.c_int), ("wormphconv", C.c_int),
                 ("worm_meas_giw", C.c_int), ("worm_meas_gtau", C.c_int), ("epsblock", C.c_double), ("accum_gtau", C.c_int)]
@@ -84,6 +84,8 @@ def lib():
     L.ora_get_hashybs.argtypes = [vp, ip]
     L.ora_get_g2iw.argtypes = [vp, dp]; L.ora_get_g2iw.restype = C.c_int
     L.ora_get_g4iw.argtypes = [vp, dp, C.c_int]; L.ora_get_g4iw.restype = C.c_int
+    L.ora_get_g4tau.argtypes = [vp, dp]; L.ora_get_g4tau.restype = C.c_int
+    L.ora_get_g4leg.argtypes = [vp, dp]; L.ora_get_g4leg.restype = C.c_int
     L.ora_get_accpair.argtypes = [vp, lp]
     L.ora_get_counters.argtypes = [vp, dp]
     L.ora_mean_sign.argtypes = [vp]; L.ora_mean_sign.restype = C.c_double
@@ -109,6 +111,7 @@ def params_from_pstring(ps, nd, beta, fourpnt=0):
                      qns=ps.get_str("QuantumNumbers").encode()[:63], epsevec=ps.get_real("EPSEVEC"),
                      fourpnt=fourpnt, n4iwf=ps.get_int("N4iwf"), n4iwb=ps.get_int("N4iwb"), meas_g2iw=ps.get_int("MeasG2iw"),
                      meas_g4iwpp=ps.get_int("MeasG4iwPP"), zphconv=int(ps.get_int("ZPHConvention") != 0),
+                     n4tau=ps.get_int("N4tau"), n4leg=ps.get_int("N4leg"),
                      p_worm_ins=ps.get_real("PercentageWormInsert"), p_worm_rep=ps.get_real("PercentageWormReplace"),
                      worm_eta=ps.get_real("WormEta"), worm_meas_g4iw=ps.get_int("WormMeasG4iw"),
                      g4ph=int(ps.get_int("G4ph") != 0), g4pp=int(ps.get_int("G4pp") != 0),
@@ -226,6 +229,14 @@ class OracleWalker:
         a = np.zeros(p.ntau)
         if self.L.ora_get_gtau_worm(self.h, a):
             r["gtau_worm"] = a
+        if p.fourpnt & 1:
+            a = np.zeros((nd, 2, nd, 2, p.n4tau, p.n4tau, p.n4tau))
+            if self.L.ora_get_g4tau(self.h, a):
+                r["g4tau"] = a
+        if p.fourpnt & 2:
+            a = np.zeros((nd, 2, nd, 2, p.n4tau, p.n4tau, 2 * p.n4iwb + 1, 2))
+            if self.L.ora_get_g4leg(self.h, a):
+                r["g4leg"] = a[..., 0] + 1j * a[..., 1]
         if p.fourpnt & 4:
             n2 = 2 * (p.n4iwf + p.n4iwb)
             a = np.zeros((nd, 2, n2, n2, 2))

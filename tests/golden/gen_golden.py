@@ -144,6 +144,36 @@ G4 = {   # recorded configuration (meas_<cfg>.npz) measured with the Z-space Mat
 }
 
 
+G4L = {   # recorded configuration (meas_<cfg>.npz) measured with the Legendre / imaginary-time two-particle estimators (FourPnt = 3)
+    "C1": dict(N4tau=5, N4leg=4, N4iwb=2),
+    "C3": dict(N4tau=4, N4leg=3, N4iwb=1),
+    "C4S": dict(N4tau=3, N4leg=3, N4iwb=1),
+}
+
+
+def gen_g4leg(only=None):
+    import ast
+    for name, extra in G4L.items():
+        if only and name not in only:
+            continue
+        g = np.load(os.path.join(OUT, "meas_%s.npz" % name), allow_pickle=False)
+        over = ast.literal_eval(str(g["overrides"])); over.update(extra)
+        cfg = str(g["config"]); nftau = int(g["nftau"])
+        p, ps = pstring_for(cfg, nftau, over)
+        s = refdrive.RefSolver(p, ps, int(g["seed"]), fourpnt=3)
+        s.set_taudiffmax(over["TaudiffMax"])
+        c = {k: g["cfg_" + k] for k in ("taus", "orbs", "spins", "cas", "hashybs")}
+        c["outer_sst"] = int(g["cfg_outer_sst"]); c["outer_state"] = int(g["cfg_outer_state"])
+        s.set_config(c)
+        s.measure()
+        r = s.results(("g4tau", "g4leg", "gleg", "mean_sign"))
+        s.close()
+        np.savez_compressed(os.path.join(OUT, "g4leg_%s.npz" % name), config=cfg, nftau=nftau, seed=int(g["seed"]),
+                            overrides=repr(over), **{"cfg_" + k: g["cfg_" + k] for k in ("taus", "orbs", "spins", "cas", "hashybs", "outer_sst", "outer_state")},
+                            **{"res_" + k: v for k, v in r.items()})
+        print("g4leg", name, {k: v.shape for k, v in r.items()})
+
+
 def gen_g4(only=None):
     import ast
     for name, extra in G4.items():
@@ -224,7 +254,7 @@ def gen_worm(only=None):
         print("worm", name, "steps(worm, Z) of the eta search", steps, "cntsampling", r["cntsampling"][[0, sector - 1]], "nops", len(c_end["taus"]))
 
 
-KINDS = ("traj", "stat", "g4", "worm", "calib", "accum")
+KINDS = ("traj", "stat", "g4", "worm", "calib", "accum", "g4leg")
 
 ACCUM = {   # AccumGtau = 2 (autocorrelation accumulator: gtau_blocks) and 0 (G(tau), G(l) not measured), one seeded chain
     # name: (config, nftau, overrides, seed)
@@ -301,3 +331,5 @@ if __name__ == "__main__":
         gen_calib(only)
     if "accum" in which:
         gen_accum(only)
+    if "g4leg" in which:
+        gen_g4leg(only)

@@ -162,6 +162,26 @@ def test_oracle_two_particle_matsubara_estimators(name):
     w.close()
 
 
+@pytest.mark.parametrize("name", ["C1", "C3", "C4S"])
+def test_oracle_g4_legendre_and_tau_on_recorded_configuration(name):
+    """MeasGtau4PntLeg (FourPnt = 3): g4tau and g4leg of a recorded configuration agree with the reference."""
+    g = util.load_golden("g4leg_%s.npz" % name)
+    over = g["overrides"]
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    w = pyoracle.OracleWalker(p, pset, ("std", int(g["seed"])), fourpnt=3)
+    w.set_taudiffmax(over["TaudiffMax"])
+    assert w.set_config(util.cfg_from(g, "cfg_")) == 0
+    w.measure()
+    r = w.results()
+    assert r["g4tau"].shape == g["res_g4tau"].shape and rel(r["g4tau"], g["res_g4tau"]) < 1e-10
+    # the reference adds its whole (0:N4tau-1) cache row block, of which only the first N4leg rows are set
+    # (CTQMC.F90:2677-2679, 2722-2727): entries with l >= N4leg hold uninitialised memory there and are not compared
+    nl = over["N4leg"]
+    assert r["g4leg"].shape == g["res_g4leg"].shape
+    assert rel(r["g4leg"][..., :nl, :nl, :], g["res_g4leg"][..., :nl, :nl, :]) < 1e-10
+    w.close()
+
+
 @pytest.mark.parametrize("name", ["C1a", "C1b", "C3a", "C4Sa"])
 def test_oracle_worm_sampling_retraces_reference(name):
     """Worm sampling in sector 4 (G4iw): eta-search step counts, sector step counts, acceptance ratios, the final
