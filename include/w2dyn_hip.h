@@ -131,6 +131,7 @@ int w2dyn_get_walker_state(w2dyn_solver *s, int walker, double *out6);
  *       "tracecontribstates" | "statessuperstates" (int32) | "eigenstatesenergies" | "occbasismapping" (4^Nd,Nd,2) int32 |
  *       "accadd" (16) | "accrem" (16) | "accpair" (Nd,2,Ntau) int64 | "cntsampling" (16) int64 | "lhisto" | "rhisto" |
  *       "gtau_full" | "gleg_full" | per-bin: "gleg_bins" (nbins,Nd,2,NLegMax), "gtau_bins", "occ_bins", "giw_bins" |
+ *       FourPnt & 1: "g4tau" (Nd,2,Nd,2,N4tau,N4tau,N4tau); FourPnt & 2: "g4leg" (Nd,2,Nd,2,N4tau,N4tau,2N4iwb+1) complex |
  *       FourPnt & 4: "g4iw", "g4iw_pp" (Nd,2,Nd,2,2N4iwf,2N4iwf,2N4iwb+1) complex, "g2iw" (+ "_bins") |
  *       worm sampling (FourPnt & 8): "g4iw_worm", "g4iwpp_worm" (2N4iwf,2N4iwf,2N4iwb+1) complex (+ "_bins"),
  *       worm sector 2 (WormMeasGiw / WormMeasGtau): "giw_worm" (2Niw) complex, "gtau_worm" (Ntau) (+ "_bins": nbins leading),
@@ -143,7 +144,7 @@ int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out);
 
 /* timing of the last w2dyn_sweep / w2dyn_measure_once launches, measured with HIP events on the context's own
  * stream: average kernel duration in ms and number of launches since the last reset (bench.py roofline leg) */
-int w2dyn_kernel_time(w2dyn_solver *s, const char *kernel /* "sweep" | "sweep_worm" | "sweep_calibrate" | "meas_gleg" | "meas_misc" | "meas_giw" | "meas_g2iw" | "meas_g4iw" | "meas_g4w" | "meas_gw" */,
+int w2dyn_kernel_time(w2dyn_solver *s, const char *kernel /* "sweep" | "sweep_worm" | "sweep_calibrate" | "meas_gleg" | "meas_misc" | "meas_giw" | "meas_g2iw" | "meas_g4iw" | "meas_g4w" | "meas_gw" | "meas_gtau_ac" | "meas_g4leg" */,
                       double *avg_ms, int64_t *launches, int reset);
 
 #ifdef __cplusplus

@@ -181,6 +181,45 @@ def test_recorded_configuration_vs_reference_golden(name):
 
 
 @pytest.mark.parametrize("name", ["C1", "C3", "C4S"])
+def test_two_particle_legendre_and_tau_vs_reference_golden(name):
+    """MeasGtau4PntLeg (FourPnt = 3): g4tau and g4leg of a recorded configuration == what the REFERENCE printed (g4leg up
+    to N4leg: the reference leaves uninitialised memory beyond, see tests/test_oracle_golden.py), and in a sampled run
+    the mean over chains == the mean of the oracle chains with the same streams."""
+    g = util.load_golden("g4leg_%s.npz" % name)
+    over = g["overrides"]; nl = over["N4leg"]
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    q = MCTQMC(nwalkers=5, walkers_per_bin=2)
+    q.fourpnt = 3
+    q.init_rnd(int(g["seed"])); q.init_paras(ps)
+    q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+    q.set_taudiffmax(over["TaudiffMax"])
+    c = util.cfg_from(g, "cfg_")
+    q.set_mc_config(len(c["taus"]), c["taus"], c["orbs"], c["spins"], c["cas"], c["hashybs"], c["outer_sst"], c["outer_state"])
+    q.ctqmc_measure(1, 1)
+    assert q.g4tau.shape == g["res_g4tau"].shape and rel(q.g4tau, g["res_g4tau"]) < TOL
+    assert q.g4leg.shape == g["res_g4leg"].shape
+    assert rel(q.g4leg[..., :nl, :nl, :], g["res_g4leg"][..., :nl, :nl, :]) < TOL
+    assert np.all(q.g4leg[..., nl:, :, :] == 0.0) and np.all(q.g4leg[..., :, nl:, :] == 0.0)
+    q.dest_ctqmc(); q.close()
+    # sampled run, chain by chain against the oracle
+    over2 = dict(over, Nwarmups=1500, Nmeas=5, NCorr=20)
+    p, ps, pset = util.setup(g["config"], g["nftau"], over2)
+    nw = 4
+    q = MCTQMC(nwalkers=nw, walkers_per_bin=1); q.fourpnt = 3
+    q.init_rnd(33); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+    q.set_taudiffmax(over["TaudiffMax"]); q.ctqmc_warmup(over2["Nwarmups"]); q.ctqmc_measure(1, 1)
+    gt = 0.0; gl = 0.0; ms = 0.0
+    for w in range(nw):
+        o = pyoracle.OracleWalker(p, pset, ("philox", 33, w), fourpnt=3)
+        o.set_taudiffmax(over["TaudiffMax"]); o.warmup(over2["Nwarmups"]); o.measure()
+        r = o.results()
+        gt = gt + r["g4tau"] * r["mean_sign"] / nw; gl = gl + r["g4leg"] * r["mean_sign"] / nw; ms += r["mean_sign"] / nw
+        o.close()
+    assert rel(q.g4tau, gt / ms) < TOL and rel(q.g4leg, gl / ms) < TOL
+    q.dest_ctqmc(); q.close()
+
+
+@pytest.mark.parametrize("name", ["C1", "C3", "C4S"])
 def test_two_particle_matsubara_vs_reference_golden(name):
     """Z-space g2iw / g4iw / g4iw_pp (FourPnt = 4) of a recorded configuration == what the REFERENCE printed."""
     g = util.load_golden("g4_%s.npz" % name)

@@ -1967,6 +1967,64 @@ __global__ __launch_bounds__(256) void k_gtau_blocks(DevConst C, const double *d
     }
 }
 
+// MeasGtau4PntLeg (CTQMC.F90:2609-2763), FourPnt bits 1 (imaginary-time bins, g4tau) and 2 (mixed Legendre / Matsubara
+// representation, g4leg): one workgroup per (chain, flavour pair), threads stride over the k1^2 k2^2 quadruples
+// (a1, c1, c2, a2): M = M1(c1,a1) M2(c2,a2) - [f1 == f2] M(c2,a1) M(c1,a2) with the fermionic signs of tau12 and tau34;
+// no configuration sign.  First version: every quadruple adds its N4leg^2 (2 N4iwb + 1) terms with atomics - the direct
+// term factorises into GEMM-shaped contractions, which is the next step for production sizes.
+__global__ __launch_bounds__(256) void k_meas_g4leg(DevConst C, double *acc_tau, double *acc_leg, int nbl, int nt, int nl, int nwb)
+{
+    const int w = blockIdx.x, nf = C.nflav, f1 = blockIdx.y / nf, f2 = blockIdx.y - f1 * nf, kmax = C.kmax;
+    if (C.ws[w].sector > 1) return;
+    const int bin = (w / C.walkers_per_bin) % nbl, nw = 2 * nwb + 1;
+    const size_t w1 = (size_t)w * nf + f1, w2 = (size_t)w * nf + f2;
+    const int k1 = C.K[w1], k2 = C.K[w2];
+    const double *M1 = C.M + w1 * kmax * kmax, *M2 = C.M + w2 * kmax * kmax;
+    const double *tc1 = C.TC + w1 * kmax, *ta1 = C.TA + w1 * kmax, *tc2 = C.TC + w2 * kmax, *ta2 = C.TA + w2 * kmax;
+    const double beta = C.beta;
+    double *gt = acc_tau ? acc_tau + ((size_t)bin * nf * nf + blockIdx.y) * nt * nt * nt : nullptr;
+    double *gl = acc_leg ? acc_leg + ((size_t)bin * nf * nf + blockIdx.y) * nl * nl * nw * 2 : nullptr;
+    const long long total = (long long)k1 * k1 * k2 * k2;
+    for (long long q = threadIdx.x; q < total; q += 256) {
+        const int a2 = (int)(q % k2), c2 = (int)((q / k2) % k2), c1 = (int)((q / ((long long)k2 * k2)) % k1), a1 = (int)(q / ((long long)k2 * k2 * k1));
+        double M = M1[(size_t)c1 * kmax + a1] * M2[(size_t)c2 * kmax + a2];
+        if (f1 == f2) M -= M1[(size_t)c2 * kmax + a1] * M2[(size_t)c1 * kmax + a2];
+        double tau12 = ta1[a1] - tc1[c1], tau14 = ta1[a1] - tc2[c2], tau34 = ta2[a2] - tc2[c2];
+        double sg = 1.0;
+        if (tau12 < 0.0) { tau12 += beta; sg = -sg; }
+        if (tau14 < 0.0) tau14 += beta;
+        if (tau34 < 0.0) { tau34 += beta; sg = -sg; }
+        M = -sg * M;
+        if (gt) {
+            const int b12 = (int)(nt * tau12 / beta), b14 = (int)(nt * tau14 / beta), b34 = (int)(nt * tau34 / beta);
+            atomicAdd(&gt[((size_t)b12 * nt + b34) * nt + b14], M);
+        }
+        if (gl) {
+            const double x12 = 2.0 / beta * tau12 - 1.0, x34 = 2.0 / beta * tau34 - 1.0;
+            double s1, c1p; sincos(2.0 * M_PI * tau14 / beta, &s1, &c1p);
+            double p12m = 0.0, p12 = 1.0;                           // P_{l-1}, P_l at x12 (Bonnet's recursion, LegendrePoly.F90:36-44)
+            for (int l = 0; l < nl; ++l) {
+                if (l == 1) { p12m = 1.0; p12 = x12; }
+                else if (l > 1) { const double pn = ((2 * l - 1) * x12 * p12 - (l - 1) * p12m) / l; p12m = p12; p12 = pn; }
+                double p34m = 0.0, p34 = 1.0;
+                for (int lp = 0; lp < nl; ++lp) {
+                    if (lp == 1) { p34m = 1.0; p34 = x34; }
+                    else if (lp > 1) { const double pn = ((2 * lp - 1) * x34 * p34 - (lp - 1) * p34m) / lp; p34m = p34; p34 = pn; }
+                    const double v = p34 * M * p12;
+                    double *g = gl + ((size_t)l * nl + lp) * nw * 2;
+                    double cr = 1.0, ci = 0.0;                       // exp(i m phi), m = 0, +-1, ...
+                    atomicAdd(&g[2 * nwb], v);
+                    for (int m = 1; m <= nwb; ++m) {
+                        const double c2r = cr * c1p - ci * s1; ci = cr * s1 + ci * c1p; cr = c2r;
+                        atomicAdd(&g[2 * (nwb + m)], v * cr); atomicAdd(&g[2 * (nwb + m) + 1], v * ci);
+                        atomicAdd(&g[2 * (nwb - m)], v * cr); atomicAdd(&g[2 * (nwb - m) + 1], -v * ci);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Matsubara estimator (measure_giw_nfft + naive get_giw, CTQMC.F90:1015-1056, Nfft_z.F90:376-414):
 // giw(n) += sum_ij M(c_j,a_i) exp(-i w_n tau_c_j) exp(+i w_n tau_a_i), no configuration sign.
 // One wave per (bin, flavour, frequency chunk of 64): lane = frequency; the pair loop is wave-uniform, so M and the

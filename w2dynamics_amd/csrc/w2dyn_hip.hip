@@ -53,6 +53,7 @@ struct w2dyn_solver {
     bool mat = false;                // matrix local-trace path (blocks with more than one state)
     // Z-space two-particle Matsubara estimators (FourPnt & 4)
     int n4iwf = 0, n4iwb = 0, meas_g2iw = 0, meas_g4iwpp = 0, zph = 0, nb4 = 0;
+    int n4tau = 0, n4leg = 0, nbl = 0; double *acc_g4tau = nullptr, *acc_g4leg = nullptr;     // FourPnt bits 1, 2 (MeasGtau4PntLeg)
     double2 *G2 = nullptr, *acc4 = nullptr, *acc4pp = nullptr, *acc2 = nullptr;
     // worm sampling (sector 4): move probabilities, eta, estimator switches, accumulator bins, sector of the running call
     double p_wins = 0, p_wrep = 0, worm_eta = 0;
@@ -327,8 +328,13 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     }
     if (!get_str(s, "EnableOuterTruncation", sv)) return W2DYN_EINVAL;
     if (sv == "YES") return fail(s, W2DYN_EUNSUPPORTED, "EnableOuterTruncation = YES is not supported");
-    if (s->fourpnt & ~12)
-        return fail(s, W2DYN_EUNSUPPORTED, "FourPnt = %d is not supported (bits 4 = Matsubara two-particle Green's function in Z space, 8 = worm estimators)", s->fourpnt);
+    if (s->fourpnt & ~15)
+        return fail(s, W2DYN_EUNSUPPORTED, "FourPnt = %d is not supported (bits 1 = imaginary-time, 2 = Legendre, 4 = Matsubara two-particle Green's function in Z space, 8 = worm estimators)", s->fourpnt);
+    if (!get_int(s, "N4tau", iv)) return W2DYN_EINVAL; s->n4tau = (int)iv;
+    if (!get_int(s, "N4leg", iv)) return W2DYN_EINVAL; s->n4leg = (int)iv;
+    if ((s->fourpnt & 3) && s->n4tau < 1) return fail(s, W2DYN_EINVAL, "N4tau=%d", s->n4tau);
+    if ((s->fourpnt & 2) && (s->n4leg < 2 || s->n4leg > s->n4tau))       // G4leg is allocated with N4tau (CTQMC.F90:549) and filled up to N4leg
+        return fail(s, W2DYN_EINVAL, "FourPnt & 2 needs 2 <= N4leg <= N4tau (N4leg=%d, N4tau=%d)", s->n4leg, s->n4tau);
     if (!get_real(s, "PercentageWormInsert", s->p_wins)) return W2DYN_EINVAL;
     if (!get_real(s, "PercentageWormReplace", s->p_wrep)) return W2DYN_EINVAL;
     if (!get_real(s, "WormEta", s->worm_eta)) return W2DYN_EINVAL;                      // CTQMC.F90:434
@@ -525,6 +531,14 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
         s->ac_lev = lev;
         if ((rc = dev_alloc(s, s->ac_dat, n))) return rc;
         if ((rc = dev_alloc(s, s->ac_out, B * (size_t)nf * lev * s->ntau))) return rc;
+    }
+    s->acc_g4tau = s->acc_g4leg = nullptr; s->nbl = 0;
+    if (s->fourpnt & 3) {
+        const size_t pt = (s->fourpnt & 1) ? (size_t)nf * nf * s->n4tau * s->n4tau * s->n4tau : 0;
+        const size_t pl = (s->fourpnt & 2) ? (size_t)nf * nf * s->n4leg * s->n4leg * (2 * s->n4iwb + 1) * 2 : 0;
+        s->nbl = (int)std::max<size_t>(1, std::min<size_t>(B, ((size_t)2 << 30) / std::max<size_t>((pt + pl) * sizeof(double), 1)));
+        if (pt) { if ((rc = dev_alloc(s, s->acc_g4tau, (size_t)s->nbl * pt))) return rc; }
+        if (pl) { if ((rc = dev_alloc(s, s->acc_g4leg, (size_t)s->nbl * pl))) return rc; }
     }
     C.acc_giww = C.acc_gtauw = nullptr;
     if (s->worm_meas_giw) { if ((rc = dev_alloc(s, C.acc_giww, B * (size_t)C.niw2 * 2))) return rc; }
@@ -723,6 +737,8 @@ int w2dyn_measure_begin(w2dyn_solver *s)
         if (C.acc_g4w) HIPCHK(hipMemsetAsync(C.acc_g4w, 0, sizeof(double) * one, s->stream));
         if (C.acc_g4wpp) HIPCHK(hipMemsetAsync(C.acc_g4wpp, 0, sizeof(double) * one, s->stream));
     }
+    if (s->acc_g4tau) HIPCHK(hipMemsetAsync(s->acc_g4tau, 0, sizeof(double) * s->nbl * nf * nf * s->n4tau * s->n4tau * s->n4tau, s->stream));
+    if (s->acc_g4leg) HIPCHK(hipMemsetAsync(s->acc_g4leg, 0, sizeof(double) * s->nbl * nf * nf * s->n4leg * s->n4leg * (2 * s->n4iwb + 1) * 2, s->stream));
     if (C.acc_giww) HIPCHK(hipMemsetAsync(C.acc_giww, 0, sizeof(double) * B * C.niw2 * 2, s->stream));
     if (C.acc_gtauw) HIPCHK(hipMemsetAsync(C.acc_gtauw, 0, sizeof(double) * B * s->ntau, s->stream));
     if (s->fourpnt & 4) {
@@ -792,6 +808,12 @@ int w2dyn_measure_once(w2dyn_solver *s)
         hipLaunchKernelGGL(k_meas_giw, dim3(s->C.nbins, s->nflav, (s->C.niw2 + 63) / 64), dim3(64), 0, s->stream, s->C);
         HIPCHK(hipGetLastError());
         if ((rc = time_end(s, "meas_giw"))) return rc;
+    }
+    if (s->fourpnt & 3) {           // CTQMC.F90:8578
+        if ((rc = time_begin(s))) return rc;
+        hipLaunchKernelGGL(k_meas_g4leg, dim3(s->nwalkers, s->nflav * s->nflav), dim3(256), 0, s->stream, s->C, s->acc_g4tau, s->acc_g4leg, s->nbl, s->n4tau, s->n4leg, s->n4iwb);
+        HIPCHK(hipGetLastError());
+        if ((rc = time_end(s, "meas_g4leg"))) return rc;
     }
     if (s->fourpnt & 4) {           // CTQMC.F90:8579
         const int n2 = 2 * (s->n4iwf + s->n4iwb);
@@ -975,6 +997,33 @@ int w2dyn_measure_finish(w2dyn_solver *s)
         R["accadd"] = aa; R["accrem"] = ar;
         R["accglob"] = {s->counters[C_ACCGLOB] / s->counters[C_TRYGLOB]};
         R["accshift"] = {s->counters[C_ACCSHIFT] / s->counters[C_TRYSHIFT]};
+    }
+    if (s->fourpnt & 3) {     // CTQMC.F90:8772-8786: zScaling (N4tau/beta)^3 / beta; zScaling sqrt(2l+1) sqrt(2l'+1) (-1)^(l'+1) / beta
+        const int nt = s->n4tau, nl = s->n4leg, nwm = 2 * s->n4iwb + 1;
+        const double zs = -1.0 / (nmeas_tot * ms);
+        if (s->acc_g4tau) {
+            const size_t per = (size_t)nf * nf * nt * nt * nt;
+            std::vector<double> raw((size_t)s->nbl * per), tot(per, 0.0);
+            (void)hipMemcpy(raw.data(), s->acc_g4tau, raw.size() * sizeof(double), hipMemcpyDeviceToHost);
+            const double fac = zs * ((double)nt / beta) * ((double)nt / beta) * ((double)nt / beta) / beta;
+            for (int b = 0; b < s->nbl; ++b) for (size_t i = 0; i < per; ++i) tot[i] += raw[(size_t)b * per + i];
+            for (size_t i = 0; i < per; ++i) tot[i] *= fac;
+            R["g4tau"] = tot;
+        }
+        if (s->acc_g4leg) {
+            const size_t per = (size_t)nf * nf * nl * nl * nwm * 2;
+            std::vector<double> raw((size_t)s->nbl * per), tot((size_t)nf * nf * nt * nt * nwm * 2, 0.0);     // result shape uses N4tau (CTQMC.F90:549)
+            (void)hipMemcpy(raw.data(), s->acc_g4leg, raw.size() * sizeof(double), hipMemcpyDeviceToHost);
+            for (int ff = 0; ff < nf * nf; ++ff) for (int l = 0; l < nl; ++l) for (int lp = 0; lp < nl; ++lp) {
+                const double fac = zs * std::sqrt(2.0 * l + 1.0) * std::sqrt(2.0 * lp + 1.0) * (((lp + 1) & 1) ? -1.0 : 1.0) / beta;
+                for (int m = 0; m < 2 * nwm; ++m) {
+                    double a = 0.0;
+                    for (int b = 0; b < s->nbl; ++b) a += raw[(size_t)b * per + (((size_t)ff * nl + l) * nl + lp) * nwm * 2 + m];
+                    tot[(((size_t)ff * nt + l) * nt + lp) * nwm * 2 + m] = a * fac;
+                }
+            }
+            R["g4leg"] = tot;
+        }
     }
     if (s->fourpnt & 4) {     // CTQMC.F90:8790-8800: G4iw * zScaling / beta^2, G2iw * zScaling / beta, zScaling = -1/(N mean_sign)
         const size_t n2 = 2 * (size_t)(s->n4iwf + s->n4iwb), n4 = (size_t)nf * nf * 4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1), ng2 = (size_t)nf * n2 * n2;
@@ -1406,6 +1455,7 @@ int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out)
     else if (n == "nbw") *out = s->nbw;
     else if (n == "wormeta") *out = s->worm_eta;
     else if (n == "ntau") *out = s->ntau;
+    else if (n == "n4tau") *out = s->n4tau;
     else if (n == "n4iwf") *out = s->n4iwf;
     else if (n == "n4iwb") *out = s->n4iwb;
     else if (n == "nsst") *out = s->lp.nsst;

@@ -299,6 +299,13 @@ class MCTQMC:
             nwf, nwb = self._n4iwf, self._n4iwb
             lead = (int(self.scalar("nbw")),) if name.endswith("_bins") else ()
             return a.reshape(lead + (2 * nwf, 2 * nwf, 2 * nwb + 1))
+        if name == "g4tau":       # FourPnt & 1: G4tau(Nd,2,Nd,2,N4tau,N4tau,N4tau), CTQMC.F90:545
+            nt = int(self.scalar("n4tau"))
+            return self.result(name).reshape(nd, 2, nd, 2, nt, nt, nt)
+        if name == "g4leg":       # FourPnt & 2: G4leg(Nd,2,Nd,2,N4tau,N4tau,2*N4iwb+1), filled up to N4leg, CTQMC.F90:549
+            nt = int(self.scalar("n4tau"))
+            a = self.result(name).reshape(-1, 2); a = a[:, 0] + 1j * a[:, 1]
+            return a.reshape(nd, 2, nd, 2, nt, nt, 2 * self._n4iwb + 1)
         if name in ("gtau_blocks", "gtau_blocks_bins"):
             # AccumGtau = 2: gtau_blocks(Nd,2,Ntau,nlevels) (CTQMC.F90:508), mean over the chains (of a bin)
             a = self.result(name)
