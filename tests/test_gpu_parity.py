@@ -180,11 +180,14 @@ def test_recorded_configuration_vs_reference_golden(name):
     q.dest_ctqmc(); q.close()
 
 
+@pytest.mark.parametrize("atomics", ["", "1"], ids=["factorised", "atomics"])
 @pytest.mark.parametrize("name", ["C1", "C3", "C4S"])
-def test_two_particle_legendre_and_tau_vs_reference_golden(name):
+def test_two_particle_legendre_and_tau_vs_reference_golden(monkeypatch, name, atomics):
     """MeasGtau4PntLeg (FourPnt = 3): g4tau and g4leg of a recorded configuration == what the REFERENCE printed (g4leg up
     to N4leg: the reference leaves uninitialised memory beyond, see tests/test_oracle_golden.py), and in a sampled run
     the mean over chains == the mean of the oracle chains with the same streams."""
+    if atomics:      # g4leg has two kernels: the factorised one (default) and one atomic add per term (fallback for large tables)
+        monkeypatch.setenv("W2DYN_G4LEG_ATOMICS", "1")
     g = util.load_golden("g4leg_%s.npz" % name)
     over = g["overrides"]; nl = over["N4leg"]
     p, ps, pset = util.setup(g["config"], g["nftau"], over)
