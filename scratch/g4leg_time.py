@@ -13,6 +13,6 @@ q.sweep(200); q.measure_once(); q.sync(); q.kernel_time("meas_g4leg", reset=True
 for _ in range(3): q.sweep(200); q.measure_once()
 q.sync(); t, n = q.kernel_time("meas_g4leg"); q.measure_finish()
 k = q.histo; ks = np.arange(k.shape[-1]); k1 = (k * ks).sum(-1).mean(); k4 = ((k * ks ** 2).sum(-1) ** 2).mean()
-flop = nw * 4 * k4 * (2 * nl * nl)      # exchange term k^4 nl^2 FMAs on two of the four flavour pairs, 2 flop each
-print("g4leg chains=%d N4leg=%d N4iwb=%d <k>=%.1f: %.3f ms per pass (%d launches), ~%.2f TFLOP/s of the k^4 nl^2 exchange sums, atomics=%s" % (nw, nl, nwb, k1, t, n, flop / (t * 1e-3) / 1e12, os.environ.get("W2DYN_G4LEG_ATOMICS", "")))
+flop = nw * 4 * k4 * (2 * nl * nl)      # what the unfactorised exchange sums (k^4 nl^2 FMAs) would cost, for comparison
+print("g4leg chains=%d N4leg=%d N4iwb=%d <k>=%.1f: %.3f ms per pass (%d launches), equivalent to %.2f TFLOP/s of unfactorised k^4 nl^2 exchange sums, atomics=%s" % (nw, nl, nwb, k1, t, n, flop / (t * 1e-3) / 1e12, os.environ.get("W2DYN_G4LEG_ATOMICS", "")))
 q.dest_ctqmc(); q.close()

@@ -2028,7 +2028,7 @@ __global__ __launch_bounds__(256) void k_meas_g4leg(DevConst C, double *acc_tau,
 // g4leg without per-term atomics.  For a fixed annihilator a1 (flavour f1) and creator c2 (flavour f2) the phase
 // exp(i w_m tau14) is a common factor and the sum over (c1, a2) splits:
 //   S(l,l') = -[ A(l) B(l') - [f1 == f2] M1(c2,a1) E(l,l') ],   A(l) = sum_c1 s12 P_l(x12) M1(c1,a1),
-//   B(l') = sum_a2 s34 P_l'(x34) M2(c2,a2),   E(l,l') = sum_{c1,a2} s12 P_l(x12) M2(c1,a2) s34 P_l'(x34)
+//   B(l') = sum_a2 s34 P_l'(x34) M2(c2,a2),   E(l,l') = sum_c1 s12 P_l(x12) T(c1,l'),  T(c1,l') = sum_a2 M2(c1,a2) s34 P_l'(x34)
 // (s12, s34: signs of tau12, tau34).  One workgroup per (chain, flavour pair); thread = (l, l') with its N4iwb + 1
 // non-negative frequencies in registers (S is real: the negative ones are the conjugates), Legendre tables of the
 // current (a1, c2) in LDS, one atomic flush per workgroup.
@@ -2045,7 +2045,7 @@ __global__ __launch_bounds__(256) void k_meas_g4leg_fact(DevConst C, double *acc
     const double *M1 = C.M + w1 * kmax * kmax, *M2 = C.M + w2 * kmax * kmax;
     const double *tc1 = C.TC + w1 * kmax, *ta1 = C.TA + w1 * kmax, *tc2 = C.TC + w2 * kmax, *ta2 = C.TA + w2 * kmax;
     const double beta = C.beta;
-    double *L12 = sm, *L34 = L12 + (size_t)k1 * nl, *A = L34 + (size_t)k2 * nl, *B = A + nl;
+    double *L12 = sm, *L34 = L12 + (size_t)k1 * nl, *T = L34 + (size_t)k2 * nl, *A = T + (size_t)k1 * nl, *B = A + nl;
     double *gl = acc_leg + ((size_t)bin * nf * nf + blockIdx.y) * nl * nl * nw * 2;
     auto legendre_row = [&](double x, double sgn, double *row) {
         double pm = 0.0, p = 1.0;
@@ -2061,34 +2061,37 @@ __global__ __launch_bounds__(256) void k_meas_g4leg_fact(DevConst C, double *acc
         double re[NWB1], im[NWB1];
 #pragma unroll
         for (int m = 0; m < NWB1; ++m) { re[m] = 0.0; im[m] = 0.0; }
-        for (int a1 = 0; a1 < k1; ++a1) {
+        for (int c2 = 0; c2 < k2; ++c2) {
             __syncthreads();
-            for (int c1 = tid; c1 < k1; c1 += 256) {
-                double t = ta1[a1] - tc1[c1], sg = 1.0;
+            for (int a2 = tid; a2 < k2; a2 += 256) {
+                double t = ta2[a2] - tc2[c2], sg = 1.0;
                 if (t < 0.0) { t += beta; sg = -1.0; }
-                legendre_row(2.0 / beta * t - 1.0, sg, L12 + (size_t)c1 * nl);
+                legendre_row(2.0 / beta * t - 1.0, sg, L34 + (size_t)a2 * nl);
             }
-            for (int c2 = 0; c2 < k2; ++c2) {
+            __syncthreads();
+            if (tid < nl) { double b = 0.0; for (int a2 = 0; a2 < k2; ++a2) b += L34[(size_t)a2 * nl + tid] * M2[(size_t)c2 * kmax + a2]; B[tid] = b; }
+            if (f1 == f2)                                        // T(c1, l') = sum_a2 M2(c1, a2) s34 P_l'(x34): once per c2
+                for (int e = tid; e < k1 * nl; e += 256) {
+                    const int c1 = e / nl, q = e - c1 * nl;
+                    double t = 0.0;
+                    for (int a2 = 0; a2 < k2; ++a2) t += M2[(size_t)c1 * kmax + a2] * L34[(size_t)a2 * nl + q];
+                    T[e] = t;
+                }
+            for (int a1 = 0; a1 < k1; ++a1) {
                 __syncthreads();
-                for (int a2 = tid; a2 < k2; a2 += 256) {
-                    double t = ta2[a2] - tc2[c2], sg = 1.0;
+                for (int c1 = tid; c1 < k1; c1 += 256) {
+                    double t = ta1[a1] - tc1[c1], sg = 1.0;
                     if (t < 0.0) { t += beta; sg = -1.0; }
-                    legendre_row(2.0 / beta * t - 1.0, sg, L34 + (size_t)a2 * nl);
+                    legendre_row(2.0 / beta * t - 1.0, sg, L12 + (size_t)c1 * nl);
                 }
                 __syncthreads();
                 if (tid < nl) { double a = 0.0; for (int c1 = 0; c1 < k1; ++c1) a += L12[(size_t)c1 * nl + tid] * M1[(size_t)c1 * kmax + a1]; A[tid] = a; }
-                else if (tid < 2 * nl) { const int q = tid - nl; double b = 0.0; for (int a2 = 0; a2 < k2; ++a2) b += L34[(size_t)a2 * nl + q] * M2[(size_t)c2 * kmax + a2]; B[q] = b; }
                 __syncthreads();
                 if (own) {
                     double S = -A[l] * B[lp];
                     if (f1 == f2) {
                         double E = 0.0;
-                        for (int c1 = 0; c1 < k1; ++c1) {
-                            const double u = L12[(size_t)c1 * nl + l];
-                            double t = 0.0;
-                            for (int a2 = 0; a2 < k2; ++a2) t += M2[(size_t)c1 * kmax + a2] * L34[(size_t)a2 * nl + lp];
-                            E += u * t;
-                        }
+                        for (int c1 = 0; c1 < k1; ++c1) E += L12[(size_t)c1 * nl + l] * T[(size_t)c1 * nl + lp];
                         S += M1[(size_t)c2 * kmax + a1] * E;
                     }
                     double t14 = ta1[a1] - tc2[c2];

@@ -813,7 +813,7 @@ int w2dyn_measure_once(w2dyn_solver *s)
         if ((rc = time_begin(s))) return rc;
         // g4leg: factorised kernel (registers hold the N4iwb + 1 non-negative frequencies of one (l, l')) when its tables fit
         // into LDS and N4iwb < 24; otherwise, and for g4tau, the quadruple kernel with one atomic add per term
-        const size_t lds_f = (size_t)(2 * s->C.kmax + 2) * s->n4leg * sizeof(double);
+        const size_t lds_f = (size_t)(3 * s->C.kmax + 2) * s->n4leg * sizeof(double);
         const bool fact = s->acc_g4leg && s->n4iwb < 24 && lds_f <= 64 * 1024 && !getenv("W2DYN_G4LEG_ATOMICS");
         if (s->acc_g4tau || !fact)
             hipLaunchKernelGGL(k_meas_g4leg, dim3(s->nwalkers, s->nflav * s->nflav), dim3(256), 0, s->stream, s->C, s->acc_g4tau, fact ? nullptr : s->acc_g4leg, s->nbl, s->n4tau, s->n4leg, s->n4iwb);
