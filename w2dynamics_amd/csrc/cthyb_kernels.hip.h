@@ -2029,10 +2029,11 @@ __global__ __launch_bounds__(256) void k_meas_g4leg(DevConst C, double *acc_tau,
 // exp(i w_m tau14) is a common factor and the sum over (c1, a2) splits:
 //   S(l,l') = -[ A(l) B(l') - [f1 == f2] M1(c2,a1) E(l,l') ],   A(l) = sum_c1 s12 P_l(x12) M1(c1,a1),
 //   B(l') = sum_a2 s34 P_l'(x34) M2(c2,a2),   E(l,l') = sum_c1 s12 P_l(x12) T(c1,l'),  T(c1,l') = sum_a2 M2(c1,a2) s34 P_l'(x34)
-// (s12, s34: signs of tau12, tau34).  One workgroup per (chain, flavour pair); thread = (l, l') with its N4iwb + 1
-// non-negative frequencies in registers (S is real: the negative ones are the conjugates), Legendre tables of the
-// current (a1, c2) in LDS, one atomic flush per workgroup.
-template <int NWB1>
+// (s12, s34: signs of tau12, tau34).  One workgroup per (chain, flavour pair); thread = NPT pairs (l, l'), each with its N4iwb + 1
+// non-negative frequencies in registers (S is real: the negative ones are the conjugates), Legendre tables, the
+// phases and column a1 of M1 of the current (a1, c2) in LDS (prepared by different waves), one atomic flush per
+// workgroup.
+template <int NWB1, int NPT>
 __global__ __launch_bounds__(256) void k_meas_g4leg_fact(DevConst C, double *acc_leg, int nbl, int nl, int nwb)
 {
     extern __shared__ double sm[];
@@ -2045,22 +2046,29 @@ __global__ __launch_bounds__(256) void k_meas_g4leg_fact(DevConst C, double *acc
     const double *M1 = C.M + w1 * kmax * kmax, *M2 = C.M + w2 * kmax * kmax;
     const double *tc1 = C.TC + w1 * kmax, *ta1 = C.TA + w1 * kmax, *tc2 = C.TC + w2 * kmax, *ta2 = C.TA + w2 * kmax;
     const double beta = C.beta;
-    double *L12 = sm, *L34 = L12 + (size_t)k1 * nl, *T = L34 + (size_t)k2 * nl, *A = T + (size_t)k1 * nl, *B = A + nl;
+    double *L12 = sm, *L34 = L12 + (size_t)k1 * nl, *T = L34 + (size_t)k2 * nl, *B = T + (size_t)k1 * nl;
+    double *CA = B + nl, *CB = CA + nl, *Mc = CB + nl, *PH = Mc + k1 + 1;   // PH: 2 * NWB1 doubles
     double *gl = acc_leg + ((size_t)bin * nf * nf + blockIdx.y) * nl * nl * nw * 2;
+    // Bonnet recursion with its coefficients tabulated: P_l = CA(l) x P_{l-1} - CB(l) P_{l-2}
+    for (int q = tid; q < nl; q += 256) { CA[q] = q ? (double)(2 * q - 1) / q : 0.0; CB[q] = q ? (double)(q - 1) / q : 0.0; }
     auto legendre_row = [&](double x, double sgn, double *row) {
         double pm = 0.0, p = 1.0;
-        for (int l = 0; l < nl; ++l) {
-            if (l == 1) { pm = 1.0; p = x; }
-            else if (l > 1) { const double pn = ((2 * l - 1) * x * p - (l - 1) * pm) / l; pm = p; p = pn; }
-            row[l] = sgn * p;
+        for (int q = 0; q < nl; ++q) {
+            if (q == 1) { pm = 1.0; p = x; }
+            else if (q > 1) { const double pn = CA[q] * x * p - CB[q] * pm; pm = p; p = pn; }
+            row[q] = sgn * p;
         }
     };
-    for (int p0 = 0; p0 < nl * nl; p0 += 256) {                  // tiles of 256 (l, l') pairs
-        const int pr = p0 + tid; const bool own = pr < nl * nl;
-        const int l = own ? pr / nl : 0, lp = own ? pr - l * nl : 0;
-        double re[NWB1], im[NWB1];
+    for (int p0 = 0; p0 < nl * nl; p0 += 256 * NPT) {            // tiles of 256 * NPT (l, l') pairs, NPT per thread
+        bool own[NPT]; int l[NPT], lp[NPT];
+        double re[NPT][NWB1], im[NPT][NWB1];
 #pragma unroll
-        for (int m = 0; m < NWB1; ++m) { re[m] = 0.0; im[m] = 0.0; }
+        for (int u = 0; u < NPT; ++u) {
+            const int pr = p0 + u * 256 + tid;
+            own[u] = pr < nl * nl; l[u] = own[u] ? pr / nl : 0; lp[u] = own[u] ? pr - l[u] * nl : 0;
+#pragma unroll
+            for (int m = 0; m < NWB1; ++m) { re[u][m] = 0.0; im[u][m] = 0.0; }
+        }
         for (int c2 = 0; c2 < k2; ++c2) {
             __syncthreads();
             for (int a2 = tid; a2 < k2; a2 += 256) {
@@ -2079,40 +2087,50 @@ __global__ __launch_bounds__(256) void k_meas_g4leg_fact(DevConst C, double *acc
                 }
             for (int a1 = 0; a1 < k1; ++a1) {
                 __syncthreads();
-                for (int c1 = tid; c1 < k1; c1 += 256) {
-                    double t = ta1[a1] - tc1[c1], sg = 1.0;
-                    if (t < 0.0) { t += beta; sg = -1.0; }
-                    legendre_row(2.0 / beta * t - 1.0, sg, L12 + (size_t)c1 * nl);
+                // wave 0: Legendre rows of tau12; wave 1: the phases exp(i w_m tau14); waves 2, 3: column a1 of M1
+                if (tid < 64) {
+                    for (int c1 = tid; c1 < k1; c1 += 64) {
+                        double t = ta1[a1] - tc1[c1], sg = 1.0;
+                        if (t < 0.0) { t += beta; sg = -1.0; }
+                        legendre_row(2.0 / beta * t - 1.0, sg, L12 + (size_t)c1 * nl);
+                    }
+                } else if (tid < 128) {
+                    const int m = tid - 64;
+                    if (m <= nwb) {
+                        double t14 = ta1[a1] - tc2[c2];
+                        if (t14 < 0.0) t14 += beta;
+                        double sn, cs; sincos(2.0 * M_PI * (double)m * t14 / beta, &sn, &cs);
+                        PH[2 * m] = cs; PH[2 * m + 1] = sn;
+                    }
+                } else {
+                    for (int c1 = tid - 128; c1 < k1; c1 += 128) Mc[c1] = M1[(size_t)c1 * kmax + a1];
+                    if (tid == 255) Mc[k1] = M1[(size_t)c2 * kmax + a1];
                 }
                 __syncthreads();
-                if (tid < nl) { double a = 0.0; for (int c1 = 0; c1 < k1; ++c1) a += L12[(size_t)c1 * nl + tid] * M1[(size_t)c1 * kmax + a1]; A[tid] = a; }
-                __syncthreads();
-                if (own) {
-                    double S = -A[l] * B[lp];
-                    if (f1 == f2) {
-                        double E = 0.0;
-                        for (int c1 = 0; c1 < k1; ++c1) E += L12[(size_t)c1 * nl + l] * T[(size_t)c1 * nl + lp];
-                        S += M1[(size_t)c2 * kmax + a1] * E;
-                    }
-                    double t14 = ta1[a1] - tc2[c2];
-                    if (t14 < 0.0) t14 += beta;
-                    double s1, c1p; sincos(2.0 * M_PI * t14 / beta, &s1, &c1p);
-                    double cr = 1.0, ci = 0.0;
 #pragma unroll
-                    for (int m = 0; m < NWB1; ++m) {
-                        if (m <= nwb) { re[m] += S * cr; im[m] += S * ci; }
-                        const double c2r = cr * c1p - ci * s1; ci = cr * s1 + ci * c1p; cr = c2r;
-                    }
+                for (int u = 0; u < NPT; ++u) {
+                    if (!own[u]) continue;
+                    double Aa = 0.0, E = 0.0;
+                    if (f1 == f2)
+                        for (int c1 = 0; c1 < k1; ++c1) { const double p = L12[(size_t)c1 * nl + l[u]]; Aa += p * Mc[c1]; E += p * T[(size_t)c1 * nl + lp[u]]; }
+                    else
+                        for (int c1 = 0; c1 < k1; ++c1) Aa += L12[(size_t)c1 * nl + l[u]] * Mc[c1];
+                    const double S = Mc[k1] * E - Aa * B[lp[u]];
+#pragma unroll
+                    for (int m = 0; m < NWB1; ++m)
+                        if (m <= nwb) { re[u][m] += S * PH[2 * m]; im[u][m] += S * PH[2 * m + 1]; }
                 }
             }
         }
-        if (own) {
-            double *g = gl + ((size_t)l * nl + lp) * nw * 2;
+#pragma unroll
+        for (int u = 0; u < NPT; ++u) {
+            if (!own[u]) continue;
+            double *g = gl + ((size_t)l[u] * nl + lp[u]) * nw * 2;
 #pragma unroll
             for (int m = 0; m < NWB1; ++m) {
                 if (m <= nwb) {
-                    atomicAdd(&g[2 * (nwb + m)], re[m]);
-                    if (m > 0) { atomicAdd(&g[2 * (nwb + m) + 1], im[m]); atomicAdd(&g[2 * (nwb - m)], re[m]); atomicAdd(&g[2 * (nwb - m) + 1], -im[m]); }
+                    atomicAdd(&g[2 * (nwb + m)], re[u][m]);
+                    if (m > 0) { atomicAdd(&g[2 * (nwb + m) + 1], im[u][m]); atomicAdd(&g[2 * (nwb - m)], re[u][m]); atomicAdd(&g[2 * (nwb - m) + 1], -im[u][m]); }
                 }
             }
         }

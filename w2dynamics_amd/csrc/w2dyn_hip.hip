@@ -813,15 +813,19 @@ int w2dyn_measure_once(w2dyn_solver *s)
         if ((rc = time_begin(s))) return rc;
         // g4leg: factorised kernel (registers hold the N4iwb + 1 non-negative frequencies of one (l, l')) when its tables fit
         // into LDS and N4iwb < 24; otherwise, and for g4tau, the quadruple kernel with one atomic add per term
-        const size_t lds_f = (size_t)(3 * s->C.kmax + 2) * s->n4leg * sizeof(double);
+        const size_t lds_f = ((size_t)(3 * s->C.kmax + 3) * s->n4leg + s->C.kmax + 1 + 2 * 24) * sizeof(double);
         const bool fact = s->acc_g4leg && s->n4iwb < 24 && lds_f <= 64 * 1024 && !getenv("W2DYN_G4LEG_ATOMICS");
         if (s->acc_g4tau || !fact)
             hipLaunchKernelGGL(k_meas_g4leg, dim3(s->nwalkers, s->nflav * s->nflav), dim3(256), 0, s->stream, s->C, s->acc_g4tau, fact ? nullptr : s->acc_g4leg, s->nbl, s->n4tau, s->n4leg, s->n4iwb);
         if (fact) {
             const dim3 grid(s->nwalkers, s->nflav * s->nflav);
-            if (s->n4iwb < 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_g4leg_fact<4>), grid, dim3(256), lds_f, s->stream, s->C, s->acc_g4leg, s->nbl, s->n4leg, s->n4iwb);
-            else if (s->n4iwb < 12) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_g4leg_fact<12>), grid, dim3(256), lds_f, s->stream, s->C, s->acc_g4leg, s->nbl, s->n4leg, s->n4iwb);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_g4leg_fact<24>), grid, dim3(256), lds_f, s->stream, s->C, s->acc_g4leg, s->nbl, s->n4leg, s->n4iwb);
+            // one (l, l') pair per thread: two pairs per thread (a single tile up to N4leg = 22) measured slower (214 ms
+            // against 162 ms per pass at N4leg = 20, N4iwb = 10: the second set of accumulators costs occupancy)
+#define W2DYN_G4LEG_FACT(NWB1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_g4leg_fact<NWB1, 1>), grid, dim3(256), lds_f, s->stream, s->C, s->acc_g4leg, s->nbl, s->n4leg, s->n4iwb)
+            if (s->n4iwb < 4) W2DYN_G4LEG_FACT(4);
+            else if (s->n4iwb < 12) W2DYN_G4LEG_FACT(12);
+            else W2DYN_G4LEG_FACT(24);
+#undef W2DYN_G4LEG_FACT
         }
         HIPCHK(hipGetLastError());
         if ((rc = time_end(s, "meas_g4leg"))) return rc;
