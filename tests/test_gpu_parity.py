@@ -222,6 +222,24 @@ def test_two_particle_legendre_and_tau_vs_reference_golden(monkeypatch, name, at
     q.dest_ctqmc(); q.close()
 
 
+def test_two_particle_legendre_kernels_agree_at_benchmark_size(monkeypatch):
+    """g4leg at N4leg = 20, N4iwb = 10 (400 (l, l') pairs: two tiles of the factorised kernel, the <12> instantiation):
+    the factorised kernel == the per-term atomics kernel on the same sampled chains."""
+    g = util.load_golden("g4leg_C1.npz")
+    over = dict(g["overrides"], N4tau=20, N4leg=20, N4iwb=10, Nwarmups=3000, Nmeas=3, NCorr=30)
+    res = []
+    for atomics in ("", "1"):
+        if atomics:
+            monkeypatch.setenv("W2DYN_G4LEG_ATOMICS", "1")
+        p, ps, pset = util.setup(g["config"], g["nftau"], over)
+        q = MCTQMC(nwalkers=6, walkers_per_bin=2); q.fourpnt = 2
+        q.init_rnd(71); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+        q.set_taudiffmax(over["TaudiffMax"]); q.ctqmc_warmup(over["Nwarmups"]); q.ctqmc_measure(1, 1)
+        res.append(np.array(q.g4leg)); q.dest_ctqmc(); q.close()
+    assert res[0].shape[-3:] == (20, 20, 21) and np.abs(res[0]).max() > 0.0
+    assert rel(res[0], res[1]) < TOL
+
+
 @pytest.mark.parametrize("name", ["C1", "C3", "C4S"])
 def test_two_particle_matsubara_vs_reference_golden(name):
     """Z-space g2iw / g4iw / g4iw_pp (FourPnt = 4) of a recorded configuration == what the REFERENCE printed."""
