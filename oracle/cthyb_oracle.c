@@ -71,6 +71,8 @@ struct ora_walker {
     double *accpairtau; int napt, apt_index;   /* AccPairTau list of the window calibration, phase 1 (CTQMC.F90:67, 70) */
     /* accumulators */
     double *gleg, *gtau, *giw, *histo, *dm, *outer_histo;
+    /* MeasOuterHistograms (CTQMC.F90:3285-3339): per block [nsst] and per eigenstate [nstates], block order */
+    double *sign_sst, *tcontrib_sst, *outer_state_histo, *sign_state, *tcontrib_state;
     double *g2iw, *g4iw, *g4iwpp;    /* complex interleaved, NULL when not measured */
     double meas_sign; int64_t cnt_sign;
     double mean_sign;
@@ -1120,6 +1122,9 @@ ora_walker *ora_create(const ora_params *p, const double *U, const double *ftau_
     w->histo = (double *)calloc((size_t)w->nflav * (p->maxhisto + 1), sizeof(double));
     w->dm = (double *)calloc((size_t)w->nstates, sizeof(double));
     w->outer_histo = (double *)calloc((size_t)w->nstates, sizeof(double));
+    w->sign_sst = (double *)calloc((size_t)w->nstates, sizeof(double)); w->tcontrib_sst = (double *)calloc((size_t)w->nstates, sizeof(double));
+    w->outer_state_histo = (double *)calloc((size_t)w->nstates, sizeof(double));
+    w->sign_state = (double *)calloc((size_t)w->nstates, sizeof(double)); w->tcontrib_state = (double *)calloc((size_t)w->nstates, sizeof(double));
     if (p->fourpnt & 4) {                                                           /* CTQMC.F90:552-559, 838-840 */
         size_t n2 = 2 * (size_t)(p->n4iwf + p->n4iwb), n4 = (size_t)w->nflav * w->nflav * 4 * p->n4iwf * p->n4iwf * (2 * p->n4iwb + 1) * 2;
         w->g4iw = (double *)calloc(n4, sizeof(double));
@@ -1165,7 +1170,7 @@ void ora_destroy(ora_walker *w)
     if (!w) return;
     for (int f = 0; f < w->nflav; ++f) free(w->M[f]);
     free(w->ops); free(w->ftab); ora_locprob_free(w->lp); free(w->ptr); free(w->dmblk); free(w->dmoff); free(w->accpair); free(w->accpairtau); free(w->gleg); free(w->gtau); free(w->giw);
-    free(w->histo); free(w->dm); free(w->outer_histo); free(w->g2iw); free(w->g4iw); free(w->g4iwpp); free(w->g4w); free(w->g4wpp); free(w->g4tau); free(w->g4leg); free(w->giww); free(w->gtauw); free(w->acbuf); free(w->acdat); free(w);
+    free(w->histo); free(w->dm); free(w->outer_histo); free(w->sign_sst); free(w->tcontrib_sst); free(w->outer_state_histo); free(w->sign_state); free(w->tcontrib_state); free(w->g2iw); free(w->g4iw); free(w->g4iwpp); free(w->g4w); free(w->g4wpp); free(w->g4tau); free(w->g4leg); free(w->giww); free(w->gtauw); free(w->acbuf); free(w->acdat); free(w);
 }
 
 void ora_set_taudiffmax(ora_walker *w, double x) { init_window(w, x); }
@@ -1479,7 +1484,19 @@ void ora_measure_once(ora_walker *w)
     }
     w->cnt_meas += 1;
     w->meas_sign += w->cfgsign; w->cnt_sign += 1;                       /* MeasSign, CTQMC.F90:3343-3350 */
-    w->outer_histo[w->outer_sst] += 1.0;                                /* MeasOuterHistograms, 3285-3339 */
+    {                                                                   /* MeasOuterHistograms, 3285-3339 (no state sampling) */
+        const ora_locprob *lp = w->lp; const int o = w->outer_sst, n = lp->sst_n[o], off = lp->sst_off[o];
+        full_trace_part(w, o, w->ptr);                                  /* parttrace of the current configuration (Trace.F90:6118) */
+        w->outer_histo[o] += 1.0;
+        w->sign_sst[o] += w->cfgsign;
+        for (int i = 0; i < n; ++i) {
+            const double c = w->ptr[i].sign != 0.0 ? exp(w->ptr[i].log) : 0.0;
+            w->outer_state_histo[off + i] += 1.0;
+            /* a vanishing partial trace carries sign(1.0, 0.0) = +1 in the reference (Trace.F90:6029-6030) */
+            w->sign_state[off + i] += w->tr.sign * (w->ptr[i].sign < 0.0 ? -1.0 : 1.0) * w->cfgsign;
+            w->tcontrib_sst[o] += c; w->tcontrib_state[off + i] += c;
+        }
+    }
     for (int f = 0; f < nf; ++f) {                                      /* MeasExpOrder, 3264-3282 */
         int k = w->k[f], last = w->p.maxhisto;
         w->histo[(size_t)f * (last + 1) + (k < last ? k : last)] += 1.0;
@@ -1543,7 +1560,11 @@ void ora_measure_finish(ora_walker *w)
     for (size_t i = 0; i < (size_t)nf * w->p.ntau; ++i)                                 /* 8726-8731 */
         w->gtau[i] = -(w->gtau[i] / w->cnt_meas) / (-w->mean_sign) * (double)w->p.ntau / (beta * beta);
     for (size_t i = 0; i < (size_t)nf * (w->p.maxhisto + 1); ++i) w->histo[i] /= w->cnt_meas;   /* 8755 */
-    for (int s = 0; s < w->nstates; ++s) w->outer_histo[s] /= w->cnt_meas;              /* 8760 */
+    for (int s = 0; s < w->nstates; ++s) {                                              /* 8757-8764 (0/0 = NaN for blocks never visited) */
+        w->sign_sst[s] /= w->outer_histo[s]; w->sign_state[s] /= w->outer_state_histo[s];
+        w->outer_histo[s] /= w->cnt_meas; w->outer_state_histo[s] /= w->cnt_meas;
+        w->tcontrib_sst[s] /= w->cnt_meas; w->tcontrib_state[s] /= w->cnt_meas;
+    }
     for (int f = 0; f < nf; ++f)
         for (int l = 0; l < w->p.nlegmax; ++l) {                                        /* 8766-8771 */
             double *g = &w->gleg[(size_t)f * w->p.nlegmax + l];
@@ -1681,6 +1702,12 @@ void ora_get_giw(const ora_walker *w, double *o) { memcpy(o, w->giw, sizeof(doub
 void ora_get_histo(const ora_walker *w, double *o) { memcpy(o, w->histo, sizeof(double) * (size_t)w->nflav * (w->p.maxhisto + 1)); }
 void ora_get_densitymatrix_diag(const ora_walker *w, double *o) { memcpy(o, w->dm, sizeof(double) * (size_t)w->nstates); }
 void ora_get_outer_histo(const ora_walker *w, double *o) { memcpy(o, w->outer_histo, sizeof(double) * (size_t)w->nstates); }
+void ora_get_outer_histograms(const ora_walker *w, double *sign_sst, double *tcontrib_sst, double *outer_state, double *sign_state, double *tcontrib_state)
+{
+    const size_t n = sizeof(double) * (size_t)w->nstates;
+    memcpy(sign_sst, w->sign_sst, n); memcpy(tcontrib_sst, w->tcontrib_sst, n); memcpy(outer_state, w->outer_state_histo, n);
+    memcpy(sign_state, w->sign_state, n); memcpy(tcontrib_state, w->tcontrib_state, n);
+}
 void ora_get_accpair(const ora_walker *w, int64_t *o) { memcpy(o, w->accpair, sizeof(int64_t) * (size_t)w->nflav * w->naccpair); }
 void ora_get_energies(const ora_walker *w, double *o) { memcpy(o, w->E, sizeof(double) * (size_t)w->nstates); }
 int ora_get_g2iw(const ora_walker *w, double *o)

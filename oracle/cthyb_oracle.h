@@ -123,6 +123,9 @@ void ora_get_densitymatrix_diag(const ora_walker *w, double *out);  /* 4^Nd, occ
 void ora_get_densitymatrix(const ora_walker *w, double *out);       /* (4^Nd)^2 row major, occupation basis, block order
                                                                        (after Transform_DensityMatrix_EB_to_OCCB, CTQMC.F90:3163) */
 void ora_get_outer_histo(const ora_walker *w, double *out);         /* first nsst entries: OuterSuperstateHisto */
+/* the other arrays of MeasOuterHistograms (CTQMC.F90:3285-3339, normalised 8757-8764), 4^Nd doubles each: SignHistoSuperstates,
+ * TraceContribSuperstates (first nsst entries), OuterStateHisto, SignHistoStates, TraceContribStates (eigenstates, block order) */
+void ora_get_outer_histograms(const ora_walker *w, double *sign_sst, double *tcontrib_sst, double *outer_state, double *sign_state, double *tcontrib_state);
 int ora_nsst(const ora_walker *w);
 int ora_nsmax(const ora_walker *w);
 void ora_get_blocks(const ora_walker *w, int *sst_n, int *sst_off, int *states);  /* [nsst],[nsst],[4^Nd] */

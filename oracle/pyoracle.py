@@ -64,6 +64,7 @@ def lib():
     for n in ("gleg", "gtau", "giw", "histo", "densitymatrix_diag", "outer_histo", "energies"):
         getattr(L, "ora_get_" + n).argtypes = [vp, dp]
     L.ora_get_densitymatrix.argtypes = [vp, dp]
+    L.ora_get_outer_histograms.argtypes = [vp, dp, dp, dp, dp, dp]
     L.ora_nsst.argtypes = [vp]; L.ora_nsst.restype = C.c_int
     L.ora_nsmax.argtypes = [vp]; L.ora_nsmax.restype = C.c_int
     L.ora_get_blocks.argtypes = [vp, ip, ip, ip]
@@ -209,11 +210,14 @@ class OracleWalker:
         a = np.zeros(4 ** nd); self.L.ora_get_densitymatrix_diag(self.h, a); r["dm_diag"] = a
         a = np.zeros(4 ** nd); self.L.ora_get_outer_histo(self.h, a); r["outersuperstatehisto"] = a[:self.nsst].copy()
         a = np.zeros(4 ** nd); self.L.ora_get_energies(self.h, a); r["eigenstatesenergies"] = a
+        hs = [np.zeros(4 ** nd) for _ in range(5)]; self.L.ora_get_outer_histograms(self.h, *hs)
+        r["signhistosuperstates"] = hs[0][:self.nsst].copy(); r["tracecontribsuperstates"] = hs[1][:self.nsst].copy()
+        r["outerstatehisto"] = hs[2]; r["signhistostates"] = hs[3]; r["tracecontribstates"] = hs[4]
         r["accpair"] = self.accpair()
         a = np.zeros(13); self.L.ora_get_counters(self.h, a); r["counters"] = a
         r["mean_sign"] = self.L.ora_mean_sign(self.h)
         occ = np.zeros((nd, 2, nd, 2)); rho1 = np.zeros((2 * nd, 2 * nd))
-        rho2 = np.zeros((2 * nd,) * 4) if nd <= 3 else None
+        rho2 = np.zeros((2 * nd,) * 4) if nd <= 5 else None
         self.L.ora_get_occ(self.h, occ, rho1, rho2.ctypes.data if rho2 is not None else None)
         if p.fourpnt & 8:
             for key, pp in (("g4iw_worm", 0), ("g4iwpp_worm", 1)):
@@ -249,7 +253,7 @@ class OracleWalker:
         r["occ"] = occ; r["rho1"] = rho1
         if rho2 is not None:
             r["rho2"] = rho2
-        if nd <= 3:
+        if nd <= 5:
             a = np.zeros((4 ** nd, 4 ** nd)); self.L.ora_get_densitymatrix(self.h, a); r["densitymatrix"] = a
         return r
 

@@ -57,10 +57,16 @@ TRAJ = {
                               NLookup_nfft=0), 32),
     "C3A": ("C3A", 501, dict(Nwarmups=3000, Nmeas=100, NCorr=30, TaudiffMax=6.0, Ntau=100, NLegMax=12, Niw=8, MeasGiw=1,
                              NLookup_nfft=0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 78),
+    # BASELINE.json configs[4], Z-space part: 5 orbitals, density-density, beta = 100 (1024 one-state blocks, 10 flavours)
+    "C5Z": ("C5Z", 501, dict(Nwarmups=4000, Nmeas=50, NCorr=100, TaudiffMax=10.0, Ntau=100, NLegMax=40, Niw=8, MeasGiw=1,
+                             NLookup_nfft=0, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 31),
 }
 
 KEYS = ("gleg", "gtau", "giw", "histo", "occ", "outersuperstatehisto", "accpair", "mean_sign", "accadd", "accrem",
-        "accglob", "accshift", "eigenstatesenergies", "densitymatrix", "rho1", "rho2", "statessuperstates")
+        "accglob", "accshift", "eigenstatesenergies", "densitymatrix", "rho1", "rho2", "statessuperstates",
+        # MeasOuterHistograms (CTQMC.F90:3285-3339, normalised 8757-8764); lhisto / rhisto are never filled (8698-8699)
+        "signhistosuperstates", "tracecontribsuperstates", "outerstatehisto", "signhistostates", "tracecontribstates",
+        "lhisto", "rhisto")
 
 
 def pstring_for(cfgname, nftau, over):
@@ -212,6 +218,11 @@ WORM = {   # worm sampling in sector 4 (two-particle Green's function), one comp
     "C4Sa": ("C4S", 501, dict(Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=50, NLegMax=8, Niw=4, N4iwf=2, N4iwb=1,
                               PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=1e-4, WormMeasG4iw=1,
                               PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 80, 1 + 0 * 64 + 1 * 16 + 3 * 4 + 2),
+    # BASELINE.json configs[4]: 5-orbital density-density, beta = 100, component 12 = flavours (0, 0, 1, 1), the
+    # frequency box of the bench line (N4iwf = 10, N4iwb = 5); eta balanced beforehand with the reference's count_steps
+    "C5a": ("C5Z", 501, dict(Nwarmups=4000, Nmeas=200, NCorr=100, TaudiffMax=10.0, Ntau=50, NLegMax=8, Niw=4, N4iwf=10, N4iwb=5,
+                             PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=1.1e-7, WormMeasG4iw=1,
+                             PercentageGlobalMove=0.005, PercentageTauShiftMove=0.005), 81, 12),
 }
 
 

@@ -19,6 +19,14 @@ def rel(a, b):
     return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300)
 
 
+def rel_nan(a, b):
+    """rel() for arrays with 0/0 = NaN entries (outer blocks never visited, CTQMC.F90:8757-8758): same NaN pattern required."""
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    m = ~np.isnan(b)
+    return rel(a[m], b[m]) if m.any() else 0.0
+
+
 def make_gpu(p, ps, seed, nw, wpb=1, kmax=0):
     q = MCTQMC(nwalkers=nw, walkers_per_bin=wpb, kmax=kmax)
     q.init_rnd(seed); q.init_paras(ps)
@@ -26,7 +34,7 @@ def make_gpu(p, ps, seed, nw, wpb=1, kmax=0):
     return q
 
 
-BASE = dict(Ntau=100, NLegMax=12, Niw=8, MeasGiw=1, NLookup_nfft=0)
+BASE = dict(Ntau=100, NLegMax=12, Niw=8, MeasGiw=1)      # NLookup_nfft keeps its default (10000): G(iw) is the exact sum whatever it says
 TRAJ = [
     ("C1", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=20, TaudiffMax=2.0, PercentageGlobalMove=0.0, PercentageTauShiftMove=0.0), 1234),
     ("C1", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=20, TaudiffMax=-1.0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 99),
@@ -138,6 +146,9 @@ def _retrace(cfg, nftau, over, seed):
                     assert rel(a, b) < TOL
         oracles.append(o)
     q.ctqmc_measure(1, 1)
+    # a-18: the arrays of MeasOuterHistograms per chain (one chain per bin)
+    HIST = ("outersuperstatehisto", "signhistosuperstates", "tracecontribsuperstates", "outerstatehisto", "signhistostates", "tracecontribstates")
+    hbins = {k: getattr(q, k + "_bins") for k in HIST}
     bins = {k: getattr(q, k + "_bins") for k in ("gleg", "gtau", "giw", "histo", "occ")}
     tot = {k: 0.0 for k in bins}
     msign = 0.0; dm = 0.0; rho1 = 0.0
@@ -147,6 +158,8 @@ def _retrace(cfg, nftau, over, seed):
             assert rel(bins[k][w], r[k]) < TOL, (k, w)
             tot[k] = tot[k] + r[k] / nw
         msign += r["mean_sign"] / nw
+        for k in HIST:      # trace contributions: exp of a log trace of magnitude ~ beta * U, hence 1e-9
+            assert rel_nan(hbins[k][w], r[k]) < (1e-9 if k.startswith("tracecontrib") else 1e-12), (k, w)
         assert q.get_walker_state(w)["cfgsign"] == o.state()["cfgsign"]
         # every chain has the same number of measurements, so sign-weighted chain results average like this
         if "densitymatrix" in r:
@@ -156,9 +169,9 @@ def _retrace(cfg, nftau, over, seed):
     if msign == -1.0:
         for k in bins:      # the module-level arrays are the means over chains
             assert rel(getattr(q, k), tot[k]) < TOL, k
-    if p.nd <= 3:
-        assert rel(q.densitymatrix, dm / nw / msign) < TOL
-        assert rel(q.rho1, rho1 / nw / msign) < TOL
+    assert rel(q.densitymatrix, dm / nw / msign) < TOL
+    assert rel(q.rho1, rho1 / nw / msign) < TOL
+    assert np.all(np.isnan(q.lhisto)) and np.all(q.rhisto == 0.0)       # what the reference returns (CTQMC.F90:8698-8699)
     assert np.abs(q.eigenstatesenergies - r["eigenstatesenergies"]).max() < 1e-12
     q.dest_ctqmc(); q.close()
 
@@ -379,7 +392,10 @@ def test_full_run_statistics_vs_reference(name):
     q.dest_ctqmc(); q.close()
 
 
-WORM_CASES = ["C1a", "C1b", "C3a", "C4Sa"]      # C4Sa: matrix trace path (2-orbital Kanamori)
+# C4Sa: matrix trace path (2-orbital Kanamori); C5a: BASELINE.json configs[4] (5 orbitals, beta = 100, N4iwf = 10, N4iwb = 5,
+# component 12 = flavours 0011: lane-split level integrals over 10 flavours, window lists of more than 64 operators in LDS)
+WORM_CASES = ["C1a", "C1b", "C3a", "C4Sa", "C5a"]
+WORM2_CASES = ["C1a", "C1b", "C3a", "C4Sa"]       # sector 2 (one-particle worm)
 
 
 def _worm_gpu(g, nw, wpb, seed):
@@ -460,7 +476,7 @@ def test_worm_sampling_vs_reference_statistics(name):
     q.dest_ctqmc(); q.close()
 
 
-@pytest.mark.parametrize("name", WORM_CASES)
+@pytest.mark.parametrize("name", WORM2_CASES)
 def test_g_worm_sampling_chains_vs_oracle(name):
     """Worm sampling in sector 2 (one-particle Green's function, two worm operators): every chain retraces the oracle
     chain with the same stream through count_steps, the mixed Z / worm loop and the giw_worm / gtau_worm estimators;
@@ -508,7 +524,7 @@ def test_g_worm_sampling_chains_vs_oracle(name):
     q.dest_ctqmc(); q.close()
 
 
-@pytest.mark.parametrize("name", WORM_CASES)
+@pytest.mark.parametrize("name", WORM2_CASES)
 def test_g_worm_sampling_vs_reference_statistics(name):
     """The REFERENCE's giw_worm / gtau_worm of one short chain (worm2_*.npz, mt19937) is one draw from the distribution
     of the single-chain bins of a GPU run with the same parameters (6 sigma of the bin scatter, elementwise)."""
@@ -716,4 +732,5 @@ def test_solver_worm_component_with_eta_search():
     s.set_problem(synth.config("C3", nftau=501), compute_fourpoint=8)
     r2 = s.solve_component(0, 4, 1, cfg)
     st = r2["steps-worm-partition/00001"]
-    assert 0.5 < st[3] / st[0] < 2.0
+    # brentq stops at xtol = 0.001 in eta (impurity.py:744-779), a sizeable relative error for eta of a few 1e-3: looser band
+    assert 0.3 < st[3] / st[0] < 3.0

@@ -59,6 +59,8 @@ namespace w2dyn {
 
 constexpr int MAXFLAV = 16;
 constexpr int KMAX_LIMIT = 256;
+constexpr int GLEG_RED_ROWS = 16, GLEG_RED_STRIDE = 65;      // k_meas_gleg: LDS transpose tile of the end-of-launch reduction
+constexpr int G2_FC = 32;                                    // k_meas_g2iw: frequency chunk of the two-step transform
 
 enum Counter { C_TRYADD, C_ACCADD, C_QNADD, C_TRYREM, C_ACCREM, C_QNREM, C_TRYGLOB, C_ACCGLOB, C_QNGLOB,
                C_TRYSHIFT, C_ACCSHIFT, C_SAMPLING,
@@ -111,6 +113,8 @@ struct DevConst {
     double *acc_outer;    // [nbins][nstates]
     double *acc_signouter;// [nbins][nstates]
     double *acc_sign;     // [nbins]
+    double *acc_signstate;// [nbins][nstates] sign per outer eigenstate, block order (SignHistoStates, CTQMC.F90:3313-3319)
+    double *acc_tcstate;  // [nbins][nstates] partial-trace weights per outer eigenstate (TraceContribStates, 3332-3337)
     unsigned long long *accpair;  // [nflav][ntau]
     // local problem in block form.  nouter = number of outer blocks (= nstates for one-state blocks); dmsize = doubles of
     // the block-diagonal density matrix; mat != 0 selects the matrix local-trace path (cthyb_matrix.hip.h)
@@ -1278,6 +1282,52 @@ __device__ W2DYN_INLINE void glob_logtraces(Ctx &x, const int *gmap, bool flip, 
     ltr_new = -(un + wave_sum(pn));
 }
 
+// log of the scalar local trace of the current configuration as the reference carries it (Trace%Trace%log,
+// Trace.F90:5595-5724: energies relative to the ground level): the `old` half of glob_logtraces plus Egs * beta
+__device__ W2DYN_INLINE double scalar_logtrace(Ctx &x)
+{
+    const DevConst &C = x.C;
+    const int nf = C.nflav, nd = C.nd;
+    const double beta = C.beta;
+    double sreg = 0.0;                               // lane f: S_f
+    for (int f = 0; f < nf; ++f) {
+        const int k = x.order(f);
+        const double *cf = x.tc(f), *af = x.ta(f);
+        double p = 0.0;
+        for (int e = x.lane; e < k; e += 64) p += (beta - cf[e]) - (beta - af[e]);
+        p = wave_sum(p);
+        if (x.lane == f) sreg = p;
+    }
+    double uo = 0.0, po = 0.0;
+    for (int f = 0; f < nf; ++f) {
+        const double sf = readlane_d(sreg, f);
+        const double nf0 = (double)((x.outer >> flav_bit(f, nd)) & 1);
+        uo += C.eps[f] * (nf0 * beta + sf);
+        const int kf = x.order(f);
+        const double *cf = x.tc(f), *af = x.ta(f);
+        for (int g = f + 1; g < nf; ++g) {
+            const double u = C.udd[f * nf + g];
+            if (u == 0.0) continue;
+            const double sg = readlane_d(sreg, g);
+            const double ng0 = (double)((x.outer >> flav_bit(g, nd)) & 1);
+            uo += u * (nf0 * ng0 * beta + nf0 * sg + ng0 * sf);
+            const int kg = x.order(g);
+            if (kf == 0 || kg == 0) continue;
+            const double *cg = x.tc(g), *ag = x.ta(g);
+            for (int base = 0; base < 2 * kg; base += 64) {
+                const int iy = base + x.lane;
+                if (iy < 2 * kg) {
+                    const double ty = iy < kg ? cg[iy] : ag[iy - kg];
+                    double dc = 0.0, da = 0.0;
+                    for (int ix = 0; ix < kf; ++ix) { dc += beta - fmax(cf[ix], ty); da += beta - fmax(af[ix], ty); }
+                    po += u * (iy < kg ? dc - da : da - dc);
+                }
+            }
+        }
+    }
+    return C.egs * beta - (uo + wave_sum(po));
+}
+
 __device__ W2DYN_INLINE void step_glob(Ctx &x)
 {
     const DevConst &C = x.C;
@@ -1585,6 +1635,10 @@ __global__ __launch_bounds__(256, MAT == 0 ? W2DYN_WPE : W2DYN_WPE_MAT) void k_s
     ctx_store(x);
 }
 
+// The library is built from several translation units (csrc/tu_*.hip, launch.hpp) that all include this header; kernel
+// templates are instantiated where they are launched, the plain kernels below are compiled by the one unit that
+// defines their W2DYN_TU_* macro.
+#ifdef W2DYN_TU_SCALAR
 // rebuild M, det and NPairs of every chain from its tau arrays (set_mc_config, Trace.F90:6972-6999)
 __global__ __launch_bounds__(256) void k_rebuild(DevConst C)
 {
@@ -1606,6 +1660,7 @@ __global__ __launch_bounds__(256) void k_rebuild(DevConst C)
     x.npairs = build_window(x);
     ctx_store(x);
 }
+#endif  // W2DYN_TU_SCALAR
 
 // ---------------------------------------------------------------------------------------------------------------
 // estimators
@@ -1744,6 +1799,22 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
     }
     if (x.lane == 0) atomicAdd(&C.acc_dm[(size_t)bin * C.dmsize + sb2], -cfgsign);
     }
+    // MeasOuterHistograms (CTQMC.F90:3285-3339): sign and weight exp(log|partial trace|) of every state of the outer block
+    if constexpr (MAT == 0) {
+        const double c = exp(scalar_logtrace(x));          // one state per block: the partial trace is the trace
+        if (x.lane == 0) {
+            atomicAdd(&C.acc_tcstate[(size_t)bin * C.nstates + x.outer], c);
+            atomicAdd(&C.acc_signstate[(size_t)bin * C.nstates + x.outer], cfgsign);
+        }
+    } else {
+        double pt = 0.0, lsc = 0.0;                        // lane i < n: partial trace of outer state i on the common scale exp(lsc)
+        mat_part_traces<MAT>(x, pt, lsc);
+        const int n = uni(x.t_n[x.outer]), off = uni(x.t_off[x.outer]);
+        if (x.lane < n) {
+            atomicAdd(&C.acc_tcstate[(size_t)bin * C.nstates + off + x.lane], fabs(pt) * exp(lsc));
+            atomicAdd(&C.acc_signstate[(size_t)bin * C.nstates + off + x.lane], x.tr_sign * (pt < 0.0 ? -1.0 : 1.0) * cfgsign);
+        }
+    }
     if (x.lane == 0) {
         C.cfgsign[x.w] = cfgsign;
         atomicAdd(&C.acc_sign[bin], cfgsign);
@@ -1757,6 +1828,7 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
     }
 }
 
+#ifdef W2DYN_TU_MEAS
 // Legendre and tau-bin estimators (MeasGtauRem, CTQMC.F90:2252-2440): THE data-parallel kernel.
 // One wave per (bin, flavour).  The wave walks the chains of its bin; lanes take (creator, annihilator) pairs; every
 // lane runs the Legendre three-term recursion for its pair and accumulates m*P_l into NLEG register accumulators,
@@ -1773,7 +1845,6 @@ template <int N> struct GlegAlpha {
     constexpr GlegAlpha() : a{} { for (int l = 0; l < N; ++l) a[l] = l < 2 ? 1.0 : ((double)(l - 1) / (double)l) * a[l - 2]; }
 };
 __device__ __constant__ GlegAlpha<128> g_gleg_alpha = GlegAlpha<128>();
-constexpr int GLEG_RED_ROWS = 16, GLEG_RED_STRIDE = 65;      // LDS transpose tile of the end-of-launch reduction
 
 struct GlegRaw { double m, ta, tc; int j; };      // loads only, so that the next pass can be in flight during the recursion
 struct GlegElem { double m, x; int idt; };
@@ -2173,7 +2244,6 @@ __global__ __launch_bounds__(64) void k_meas_giw(DevConst C)
 // Z-space two-particle Matsubara estimators (measure_g4iw_nfft with the exact-sum transform, CTQMC.F90:2130-2234,
 // Nfft_z.F90:416-453)
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int G2_FC = 32;      // frequency chunk of the two-step transform
 
 // g2(wa, wc) = sum_{ic,ia} exp(-i nu_wc tau_c(ic)) M(ic,ia) exp(+i nu_wa tau_a(ia)) for one chain and flavour, as
 // U(ic,wa) = sum_ia M(ic,ia) Ea(ia,wa) followed by g2(wa,wc) = sum_ic Ec(ic,wc) U(ic,wa): 8 k n2 (k + n2) flop
@@ -2284,5 +2354,6 @@ __global__ __launch_bounds__(256) void k_meas_g4iw(DevConst C, int nwf, int nwb,
         double2 *d = acc2 + (size_t)b4 * ng2 + e; double2 o = *d; o.x += re; o.y += im; *d = o;
     }
 }
+#endif  // W2DYN_TU_MEAS
 
 }  // namespace w2dyn

@@ -350,6 +350,7 @@ constexpr int MAT_CH = 4, MAT_NB = 4;
 // call the caller's state is saved once per trace and the loop runs out of registers.
 struct MatSeqArgs {
     unsigned tsst, om, ot, conn, tn, toff, teval, opbuf, top;      // byte offsets; top = 0xffffffff: operators in global memory
+    unsigned ptout;                                                // 0xffffffff or byte offset of nsm + 1 doubles: partial traces of the outer states, then their common log scale
     const double *opmat;
     int n, skip1, skip2, nsm, spb, nf2, nsst;
     double beta, egs;
@@ -495,6 +496,13 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
         double part = 0.0;
 #pragma unroll
         for (int b = 0; b < MAT_NB; ++b) part += diag[b] ? v[b] * fdec : 0.0;
+        if (uni((int)a.ptout) != -1) {               // estimator pass only: hand the partial traces to the caller
+            double *pto = (double *)(lds_base + uni((int)a.ptout));
+#pragma unroll
+            for (int b = 0; b < MAT_NB; ++b) if (diag[b]) pto[b * spb + ms] = v[b] * fdec;
+            if (lane == 0) pto[nsm] = lacc;
+            lds_sync();
+        }
         const double tot = wave_sum(part);
         if (tot == 0.0 || !(fabs(tot) > 0.0)) return res;
         res.x = lacc + log(fabs(tot)); res.y = tot < 0.0 ? -1.0 : 1.0;
@@ -502,7 +510,7 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
     return res;
 }
 
-__device__ __forceinline__ void mat_trace_seq(Ctx &x, const int *tsst, int n, int skip1, int skip2, double &tlog, double &tsign)
+__device__ __forceinline__ void mat_trace_seq(Ctx &x, const int *tsst, int n, int skip1, int skip2, double &tlog, double &tsign, double *ptout = nullptr)
 {
     extern __shared__ unsigned char lds_base[];
     const DevConst &C = x.C;
@@ -510,6 +518,7 @@ __device__ __forceinline__ void mat_trace_seq(Ctx &x, const int *tsst, int n, in
     MatSeqArgs a;
     a.tsst = off(tsst); a.om = off(x.om); a.ot = off(x.ot); a.conn = off(x.t_conn); a.tn = off(x.t_n); a.toff = off(x.t_off);
     a.teval = off(x.t_eval); a.opbuf = off(x.opbuf); a.top = x.t_op ? off(x.t_op) : 0xffffffffu;
+    a.ptout = ptout ? off(ptout) : 0xffffffffu;
     a.opmat = C.opmat;
     a.n = n; a.skip1 = skip1; a.skip2 = skip2; a.nsm = C.nsm; a.spb = x.spb_; a.nf2 = 2 * C.nflav; a.nsst = C.nsst;
     a.beta = C.beta; a.egs = C.egs;
@@ -559,6 +568,30 @@ __device__ W2DYN_INLINE void mat_trace_current(Ctx &x)
 {
     if (!(uni(x.osst[x.nops]) == x.outer)) { x.tr_log = -HUGE_VAL; x.tr_sign = 0.0; return; }
     mat_trace_trial<MATN>(x, x.osst, x.nops, -1, -1, x.tr_log, x.tr_sign);
+}
+
+// Partial traces of the states of the outer block for the stored configuration (parttrace, Trace.F90:6029-6031): lane i < n
+// receives <i| ... |i> on the common scale exp(lsc); zero everywhere when the trace vanishes.  Tree path: the diagonal of the
+// full product; sequential path: the evaluator leaves them in LDS.
+template <int MATN>
+__device__ W2DYN_INLINE void mat_part_traces(Ctx &x, double &pt, double &lsc)
+{
+    pt = 0.0; lsc = 0.0;
+    if (!(uni(x.osst[x.nops]) == x.outer)) return;
+    if constexpr (MATN >= 2 && MATN <= 4) {
+        double P[MATN * MATN]; int ex; double lsum;
+        mat_tree_product<MATN>(x, x.osst, x.nops, -1, -1, 0, x.nops, 0.0, x.C.beta, P, ex, lsum);
+#pragma unroll
+        for (int i = 0; i < MATN; ++i) { const double d = uni(P[i * MATN + i]); if (x.lane == i) pt = d; }
+        lsc = lsum + (double)uni(ex) * 0.6931471805599453;
+    } else {
+        // the evaluator's own operator stage (>= 4 * 64 doubles) takes the nsm + 1 results once the last operator is applied
+        double tl, ts;
+        double *buf = x.opbuf;
+        mat_trace_seq(x, x.osst, x.nops, -1, -1, tl, ts, buf);
+        wave_sync();
+        if (ts != 0.0) { pt = x.lane < uni(x.t_n[x.outer]) ? buf[x.lane] : 0.0; lsc = uni(buf[x.C.nsm]); }
+    }
 }
 
 // check_qn_all_ssts (Trace.F90:1402-1433): number of outer blocks for which the operator sequence is allowed;

@@ -333,6 +333,7 @@ __global__ __launch_bounds__(256, W2DYN_WPE_WORM) void k_sweep_worm(DevConst C, 
     ctx_store(x);
 }
 
+#ifdef W2DYN_TU_MEAS
 // G4iw worm estimator: every chain that is in worm space adds cfgsign/eta * exp(i[nu1 x1 + nu2 x2 + omega x3]) to its
 // bin, ph: x = (t1-t2, t3-t4, t1-t4 | t2-t3), pp: x = (t1-t3, t2-t4, t3-t2).  One workgroup per bin loops over the
 // bin's chains; the three one-dimensional phase tables of a chain go through LDS, accumulators stay in registers
@@ -439,3 +440,4 @@ __global__ __launch_bounds__(256) void k_meas_gw(DevConst C)
     __syncthreads();
     if (C.acc_gtauw) { double *acc = C.acc_gtauw + (size_t)bin * C.ntau; for (int i = tid; i < C.ntau; i += 256) acc[i] += gth[i]; }
 }
+#endif  // W2DYN_TU_MEAS

@@ -1,0 +1,41 @@
+// Launchers of the kernels of libw2dyn_hip.so.  The kernels are compiled in several translation units (tu_*.hip, built in
+// parallel); each unit defines the launchers of the kernels it instantiates, the host unit (w2dyn_hip.hip) calls them.
+#pragma once
+#include "cthyb_kernels.hip.h"
+
+namespace w2dyn {
+
+struct LaunchCfg { dim3 grid, block; size_t lds; hipStream_t stream; };
+
+// mat: 0 = one-state blocks (closed-form trace); 2, 3, 4 = matrix path, blocks padded to that size (tree product);
+// 9 = matrix path, sequential propagation (blocks of 5..16 states)
+void launch_sweep(int mat, bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling);
+void launch_sweep_worm(int nworm, int mat, const LaunchCfg &l, const DevConst &C, long long nsteps);
+void launch_meas_misc(int mat, const LaunchCfg &l, const DevConst &C);
+void launch_rebuild(const LaunchCfg &l, const DevConst &C);
+
+// pieces (one per translation unit)
+void launch_sweep_scalar(bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling);
+void launch_sweep_tree(int mat, bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling);
+void launch_sweep_seq(bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling);
+void launch_sweep_worm_scalar(int nworm, const LaunchCfg &l, const DevConst &C, long long nsteps);
+void launch_sweep_worm_tree(int nworm, int mat, const LaunchCfg &l, const DevConst &C, long long nsteps);
+void launch_sweep_worm_seq(int nworm, const LaunchCfg &l, const DevConst &C, long long nsteps);
+void launch_meas_misc_scalar(const LaunchCfg &l, const DevConst &C);
+void launch_meas_misc_tree(int mat, const LaunchCfg &l, const DevConst &C);
+void launch_meas_misc_seq(const LaunchCfg &l, const DevConst &C);
+
+// estimators (tu_meas.hip); grids and LDS sizes are worked out here from the DevConst
+void launch_meas_gleg(const DevConst &C, hipStream_t st);
+void launch_meas_gtau_ac(const DevConst &C, hipStream_t st, double *dat, int nlev, long long n);
+void launch_gtau_blocks(const DevConst &C, hipStream_t st, const double *dat, int nlev, long long n, double *out);
+void launch_meas_giw(const DevConst &C, hipStream_t st);
+void launch_meas_g4leg(const DevConst &C, hipStream_t st, double *acc_tau, double *acc_leg, int nbl, int nt, int nl, int nwb);
+size_t g4leg_fact_lds(const DevConst &C, int nl);
+void launch_meas_g4leg_fact(const DevConst &C, hipStream_t st, double *acc_leg, int nbl, int nl, int nwb);
+void launch_meas_g2iw(const DevConst &C, hipStream_t st, int n2, double2 *G2);
+void launch_meas_g4iw(const DevConst &C, hipStream_t st, int nwf, int nwb, int zph, int nb4, const double2 *G2, double2 *acc4, double2 *acc4pp, double2 *acc2);
+void launch_meas_g4w(const DevConst &C, hipStream_t st, int pp, int nbw);
+void launch_meas_gw(const DevConst &C, hipStream_t st);
+
+}  // namespace w2dyn

@@ -1,0 +1,65 @@
+// translation unit: the estimator kernels that read (M, tau) of all chains (G(l), G(tau), G(iw), two-particle estimators,
+// worm estimators, autocorrelation accumulator)
+#define W2DYN_TU_MEAS
+#include "launch.hpp"
+namespace w2dyn {
+template <int T> static void gleg_(const DevConst &C, hipStream_t st)
+{
+    const int lds_hist = C.ntau <= 7000;       // tau histogram in LDS (< 64 KB with the reduction tile), else global atomics
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_gleg<T>), dim3(C.nbins, C.nflav), dim3(64),
+                       sizeof(double) * ((lds_hist ? C.ntau : 0) + GLEG_RED_ROWS * GLEG_RED_STRIDE), st, C, lds_hist);
+}
+void launch_meas_gleg(const DevConst &C, hipStream_t st)
+{
+    if (C.nleg <= 16) gleg_<16>(C, st);
+    else if (C.nleg <= 32) gleg_<32>(C, st);
+    else if (C.nleg <= 64) gleg_<64>(C, st);
+    else if (C.nleg <= 100) gleg_<100>(C, st);
+    else gleg_<128>(C, st);
+}
+void launch_meas_gtau_ac(const DevConst &C, hipStream_t st, double *dat, int nlev, long long n)
+{
+    hipLaunchKernelGGL(k_meas_gtau_ac, dim3(C.nwalkers, C.nflav), dim3(256), (size_t)C.ntau * sizeof(double), st, C, dat, nlev, n);
+}
+void launch_gtau_blocks(const DevConst &C, hipStream_t st, const double *dat, int nlev, long long n, double *out)
+{
+    hipLaunchKernelGGL(k_gtau_blocks, dim3(C.nbins, C.nflav * nlev), dim3(256), 0, st, C, dat, nlev, n, out);
+}
+void launch_meas_giw(const DevConst &C, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_meas_giw, dim3(C.nbins, C.nflav, (C.niw2 + 63) / 64), dim3(64), 0, st, C);
+}
+void launch_meas_g4leg(const DevConst &C, hipStream_t st, double *acc_tau, double *acc_leg, int nbl, int nt, int nl, int nwb)
+{
+    hipLaunchKernelGGL(k_meas_g4leg, dim3(C.nwalkers, C.nflav * C.nflav), dim3(256), 0, st, C, acc_tau, acc_leg, nbl, nt, nl, nwb);
+}
+size_t g4leg_fact_lds(const DevConst &C, int nl) { return ((size_t)(3 * C.kmax + 3) * nl + C.kmax + 1 + 2 * 24) * sizeof(double); }
+void launch_meas_g4leg_fact(const DevConst &C, hipStream_t st, double *acc_leg, int nbl, int nl, int nwb)
+{
+    // one (l, l') pair per thread: two pairs per thread (a single tile up to N4leg = 22) measured slower (214 ms
+    // against 162 ms per pass at N4leg = 20, N4iwb = 10: the second set of accumulators costs occupancy)
+    const dim3 grid(C.nwalkers, C.nflav * C.nflav);
+    const size_t lds = g4leg_fact_lds(C, nl);
+    if (nwb < 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_g4leg_fact<4, 1>), grid, dim3(256), lds, st, C, acc_leg, nbl, nl, nwb);
+    else if (nwb < 12) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_g4leg_fact<12, 1>), grid, dim3(256), lds, st, C, acc_leg, nbl, nl, nwb);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_g4leg_fact<24, 1>), grid, dim3(256), lds, st, C, acc_leg, nbl, nl, nwb);
+}
+void launch_meas_g2iw(const DevConst &C, hipStream_t st, int n2, double2 *G2)
+{
+    hipLaunchKernelGGL(k_meas_g2iw, dim3(C.nwalkers, C.nflav), dim3(256), (size_t)3 * C.kmax * G2_FC * sizeof(double2), st, C, n2, G2);
+}
+void launch_meas_g4iw(const DevConst &C, hipStream_t st, int nwf, int nwb, int zph, int nb4, const double2 *G2, double2 *acc4, double2 *acc4pp, double2 *acc2)
+{
+    const int n2 = 2 * (nwf + nwb);
+    const size_t n4 = (size_t)C.nflav * C.nflav * 4 * nwf * nwf * (2 * nwb + 1), ng2 = (size_t)C.nflav * n2 * n2;
+    hipLaunchKernelGGL(k_meas_g4iw, dim3((unsigned)(((n4 > ng2 ? n4 : ng2) + 255) / 256), nb4), dim3(256), 0, st, C, nwf, nwb, zph, nb4, G2, acc4, acc4pp, acc2);
+}
+void launch_meas_g4w(const DevConst &C, hipStream_t st, int pp, int nbw)
+{
+    hipLaunchKernelGGL(k_meas_g4w, dim3(nbw), dim3(256), (size_t)(4 * C.nwf + 2 * C.nwb + 1) * sizeof(double2), st, C, pp, nbw);
+}
+void launch_meas_gw(const DevConst &C, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_meas_gw, dim3(C.nbins), dim3(256), (size_t)C.ntau * sizeof(double), st, C);
+}
+}  // namespace w2dyn

@@ -3,14 +3,16 @@
 // diagonal-hybridisation Z-space path; refuses every other mode loudly.  No CPU fallback exists: all sampling and
 // all estimators run in the kernels of cthyb_kernels.hip.h.
 #include "../../include/w2dyn_hip.h"
-#include "cthyb_kernels.hip.h"
+#include "launch.hpp"
 #include "local_problem.hpp"
 
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <csignal>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -26,6 +28,27 @@ struct Param { std::string key, value; };
 struct KTimer {
     double total_ms = 0.0; int64_t launches = 0;
 };
+
+// Soft abort (Signals.F90:117-137): SIGTERM / SIGINT / SIGUSR1 are trapped from init_solver to the end of ctqmc_measure
+// (CTQMC.F90:8076-8078, 9352-9355); the handler only raises this flag, the sampling loops look at it between launches.
+volatile sig_atomic_t g_signal_fired = 0;
+bool g_traps_installed = false;
+struct sigaction g_prev_term, g_prev_int, g_prev_usr1;
+void trap_notify(int) { g_signal_fired = 1; }
+void install_traps()
+{
+    if (g_traps_installed) return;
+    struct sigaction sa; memset(&sa, 0, sizeof sa);
+    sa.sa_handler = trap_notify; sigemptyset(&sa.sa_mask);
+    sigaction(SIGTERM, &sa, &g_prev_term); sigaction(SIGINT, &sa, &g_prev_int); sigaction(SIGUSR1, &sa, &g_prev_usr1);
+    g_traps_installed = true;
+}
+void clear_traps()      // reset_notify + clear_trap, CTQMC.F90:9352-9355
+{
+    if (!g_traps_installed) return;
+    sigaction(SIGTERM, &g_prev_term, nullptr); sigaction(SIGINT, &g_prev_int, nullptr); sigaction(SIGUSR1, &g_prev_usr1, nullptr);
+    g_traps_installed = false; g_signal_fired = 0;
+}
 
 }  // namespace
 
@@ -79,7 +102,10 @@ struct w2dyn_solver {
     std::vector<long long> res_accpair;
     std::vector<double> counters;                        // summed over walkers, C_NCOUNT
     std::map<std::string, KTimer> timers;
-    bool timing = true;
+    bool timing = false;                                  // HIP-event timing of every launch (a host sync per launch): bench / profiling only, w2dyn_set_timing
+    // position of every chain in its random stream, kept across init_solver / dest_ctqmc until the next init_rnd: the
+    // reference seeds once (impurity.py:387, CTQMC.F90:9404-9408) and its generator state survives init_solver
+    std::vector<unsigned long long> stream_pos;
 };
 
 namespace {
@@ -145,8 +171,20 @@ template <class T> int dev_upload(w2dyn_solver *s, const T *&ptr, const std::vec
     return 0;
 }
 
+// remember where every chain stands in its random stream (see w2dyn_solver::stream_pos)
+void stash_streams(w2dyn_solver *s)
+{
+    if (!s->have_solver || !s->C.ws) return;
+    std::vector<WalkerScalars> ws(s->nwalkers);
+    if (hipStreamSynchronize(s->stream) != hipSuccess) return;
+    if (hipMemcpy(ws.data(), s->C.ws, ws.size() * sizeof(WalkerScalars), hipMemcpyDeviceToHost) != hipSuccess) return;
+    s->stream_pos.resize(ws.size());
+    for (size_t w = 0; w < ws.size(); ++w) s->stream_pos[w] = ws[w].ndraw;
+}
+
 void free_device(w2dyn_solver *s)
 {
+    stash_streams(s);
     for (void *p : s->allocs) (void)hipFree(p);
     s->allocs.clear();
     s->have_solver = false;
@@ -165,39 +203,17 @@ void host_init_window(w2dyn_solver *s, double tdm, int &num_windows, double &tau
 }
 
 
-struct Launch { dim3 grid, block; size_t lds; };
-Launch walker_launch(const w2dyn_solver *s)
+LaunchCfg walker_launch(const w2dyn_solver *s)
 {
-    Launch l;
+    LaunchCfg l;
     l.block = dim3(256);
     l.grid = dim3((s->nwalkers + 3) / 4);
     l.lds = (size_t)s->C.shared_lds + 4 * (size_t)s->C.lds_per_wave;
+    l.stream = s->stream;
     return l;
 }
 
 int mat_variant(const w2dyn_solver *s) { return !s->mat ? 0 : (s->lp.nsmax <= 2 ? 2 : (s->lp.nsmax <= 4 ? s->lp.nsmax : 9)); }
-
-template <bool CALIB> void launch_sweep(w2dyn_solver *s, const Launch &l, long long nsteps, int count)
-{
-    switch (mat_variant(s)) {
-    case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<0, CALIB>), l.grid, l.block, l.lds, s->stream, s->C, nsteps, count); break;
-    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<2, CALIB>), l.grid, l.block, l.lds, s->stream, s->C, nsteps, count); break;
-    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<3, CALIB>), l.grid, l.block, l.lds, s->stream, s->C, nsteps, count); break;
-    case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<4, CALIB>), l.grid, l.block, l.lds, s->stream, s->C, nsteps, count); break;
-    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<9, CALIB>), l.grid, l.block, l.lds, s->stream, s->C, nsteps, count); break;
-    }
-}
-
-template <int NW> void launch_sweep_worm(w2dyn_solver *s, const Launch &l, long long nsteps)
-{
-    switch (mat_variant(s)) {
-    case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_worm<NW, 0>), l.grid, l.block, l.lds, s->stream, s->C, nsteps); break;
-    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_worm<NW, 2>), l.grid, l.block, l.lds, s->stream, s->C, nsteps); break;
-    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_worm<NW, 3>), l.grid, l.block, l.lds, s->stream, s->C, nsteps); break;
-    case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_worm<NW, 4>), l.grid, l.block, l.lds, s->stream, s->C, nsteps); break;
-    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_worm<NW, 9>), l.grid, l.block, l.lds, s->stream, s->C, nsteps); break;
-    }
-}
 
 int time_begin(w2dyn_solver *s) { if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream)); return 0; }
 int time_end(w2dyn_solver *s, const char *name)
@@ -225,16 +241,30 @@ int check_walker_errors(w2dyn_solver *s)
     return 0;
 }
 
-template <int T> void launch_gleg(w2dyn_solver *s)
-{
-    const int lds_hist = s->C.ntau <= 7000;       // tau histogram in LDS (< 64 KB with the reduction tile), else global atomics
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_gleg<T>), dim3(s->C.nbins, s->nflav), dim3(64),
-                       sizeof(double) * ((lds_hist ? s->C.ntau : 0) + GLEG_RED_ROWS * GLEG_RED_STRIDE), s->stream, s->C, lds_hist);
-}
-
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 }  // namespace
+
+namespace w2dyn {
+void launch_sweep(int mat, bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count)
+{
+    if (mat == 0) launch_sweep_scalar(calib, l, C, nsteps, count);
+    else if (mat <= 4) launch_sweep_tree(mat, calib, l, C, nsteps, count);
+    else launch_sweep_seq(calib, l, C, nsteps, count);
+}
+void launch_sweep_worm(int nworm, int mat, const LaunchCfg &l, const DevConst &C, long long nsteps)
+{
+    if (mat == 0) launch_sweep_worm_scalar(nworm, l, C, nsteps);
+    else if (mat <= 4) launch_sweep_worm_tree(nworm, mat, l, C, nsteps);
+    else launch_sweep_worm_seq(nworm, l, C, nsteps);
+}
+void launch_meas_misc(int mat, const LaunchCfg &l, const DevConst &C)
+{
+    if (mat == 0) launch_meas_misc_scalar(l, C);
+    else if (mat <= 4) launch_meas_misc_tree(mat, l, C);
+    else launch_meas_misc_seq(l, C);
+}
+}  // namespace w2dyn
 
 extern "C" {
 
@@ -275,7 +305,14 @@ int w2dyn_set_layout(w2dyn_solver *s, int nwalkers, int64_t first_walker, int km
     return 0;
 }
 
-int w2dyn_init_rnd(w2dyn_solver *s, int64_t nseed) { if (!s) return W2DYN_EINVAL; s->seed = nseed; return 0; }
+int w2dyn_init_rnd(w2dyn_solver *s, int64_t nseed)
+{
+    if (!s) return W2DYN_EINVAL;
+    s->seed = nseed; s->stream_pos.clear();      // a new seed starts every chain's stream at its beginning
+    return 0;
+}
+
+int w2dyn_set_timing(w2dyn_solver *s, int on) { if (!s) return W2DYN_EINVAL; s->timing = on != 0; return 0; }
 
 int w2dyn_init_paras(w2dyn_solver *s, const char *parastr)
 {
@@ -363,7 +400,10 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if (!get_int(s, "NLegMax", iv)) return W2DYN_EINVAL; s->nleg = (int)iv;
     if (!get_int(s, "Niw", iv)) return W2DYN_EINVAL; s->niw = (int)iv;
     if (!get_int(s, "MeasGiw", iv)) return W2DYN_EINVAL; s->meas_giw = (int)iv;
-    if (s->meas_giw) { if (!get_int(s, "NLookup_nfft", iv)) return W2DYN_EINVAL; if (iv != 0) return fail(s, W2DYN_EUNSUPPORTED, "MeasGiw needs NLookup_nfft = 0 (exact sums)"); }
+    // NLookup_nfft (configspec:71, default 10000) only sizes the reference's NFFT lookup buffer (CTQMC.F90:578-595,
+    // Nfft_z.F90:205-278); G(iw) is the exact sum here whatever its value (it differs from the NFFT result by the NFFT
+    // truncation error, ~1e-12), so the key is read and otherwise ignored
+    if (s->meas_giw) { if (!get_int(s, "NLookup_nfft", iv)) return W2DYN_EINVAL; }
     if (!get_int(s, "NCorr", iv)) return W2DYN_EINVAL; s->ncorr = (int)iv;
     if (!get_int(s, "Nmeas", iv)) return W2DYN_EINVAL; s->nmeas = iv;
     if (!get_int(s, "AccumGtau", iv)) return W2DYN_EINVAL;
@@ -513,6 +553,8 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if ((rc = dev_alloc(s, C.acc_outer, B * nouter))) return rc;
     if ((rc = dev_alloc(s, C.acc_signouter, B * nouter))) return rc;
     if ((rc = dev_alloc(s, C.acc_sign, B))) return rc;
+    if ((rc = dev_alloc(s, C.acc_signstate, B * s->nstates))) return rc;
+    if ((rc = dev_alloc(s, C.acc_tcstate, B * s->nstates))) return rc;
     if ((rc = dev_alloc(s, C.accpair, (size_t)nf * s->ntau))) return rc;
     s->accpair_default = C.accpair; C.naccpair = s->ntau; C.accpair_max = s->beta; C.calib = 0;
     s->accpairtau.clear(); s->accpairtau_chains.clear();
@@ -568,11 +610,15 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
         if ((size_t)3 * kmax * G2_FC * sizeof(double2) > 160 * 1024) return fail(s, W2DYN_EUNSUPPORTED, "kmax=%d too large for the two-particle transform", kmax);
     }
     // initial chain state: empty configuration, outer superstate drawn with the chain's first random number
+    // (streams go on from where the previous solve of this context left them; a context whose chain count changed starts
+    // every chain behind the furthest position reached so far, so that no chain ever re-uses draws)
+    unsigned long long pos_max = 0;
+    for (unsigned long long v : s->stream_pos) pos_max = std::max(pos_max, v);
     std::vector<WalkerScalars> ws(W);
     for (size_t w = 0; w < W; ++w) {
         WalkerScalars &x = ws[w];
         memset(&x, 0, sizeof x);
-        w2dyn_rng_state r{(uint64_t)s->seed, (uint64_t)s->first_walker + w, 0};
+        w2dyn_rng_state r{(uint64_t)s->seed, (uint64_t)s->first_walker + w, s->stream_pos.size() == W ? s->stream_pos[w] : pos_max};
         double u = w2dyn_uniform(&r);
         int sel = nouter - 1;
         for (int st = 0; st < nouter; ++st) if (s->outer_cum[st] >= u && s->outer_w[st] != 0.0) { sel = st; break; }
@@ -582,6 +628,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     HIPCHK(hipStreamSynchronize(s->stream));
     s->have_solver = true; s->aborted = 0; s->meas_done = 0; s->steps_done = 0;
     s->res.clear(); s->counters.assign(C_NCOUNT, 0.0);
+    install_traps();                                                                  // CTQMC.F90:8076-8078
     return 0;
 }
 
@@ -622,14 +669,13 @@ int w2dyn_sweep(w2dyn_solver *s, int64_t nsteps, int count_as_sampling)
     if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "sweep before init_solver");
     if (nsteps <= 0) return 0;
     HIPCHK(hipSetDevice(s->device));
-    Launch l = walker_launch(s);
+    LaunchCfg l = walker_launch(s);
     int rc;
     if ((rc = time_begin(s))) return rc;
     // instantiations: 0 = one-state blocks (closed-form trace); 2, 3, 4 = matrix path with blocks padded to that size
     // (tree product); 9 = matrix path, sequential propagation (blocks of 5..8 states)
-    if (s->cur_isector == 4) launch_sweep_worm<4>(s, l, (long long)nsteps);   // counts its own steps
-    else if (s->cur_isector == 2) launch_sweep_worm<2>(s, l, (long long)nsteps);
-    else launch_sweep<false>(s, l, (long long)nsteps, count_as_sampling);
+    if (s->cur_isector == 4 || s->cur_isector == 2) launch_sweep_worm(s->cur_isector, mat_variant(s), l, s->C, (long long)nsteps);   // counts its own steps
+    else launch_sweep(mat_variant(s), false, l, s->C, (long long)nsteps, count_as_sampling);
     HIPCHK(hipGetLastError());
     if ((rc = time_end(s, s->cur_isector != 1 ? "sweep_worm" : "sweep"))) return rc;
     s->steps_done += nsteps;
@@ -669,12 +715,12 @@ int w2dyn_ctqmc_calibrate(w2dyn_solver *s, int list, int phase1pairnum, int phas
         C.phase2pairnum = phase2pairnum; C.calib = 2;
     }
     const long long chunk = std::min(1000, nprogress);          // the completion test runs every min(1000, nprogress) steps
-    Launch l = walker_launch(s);
+    LaunchCfg l = walker_launch(s);
     std::vector<int> cnt(list ? W : W * nf);
     bool done = false;
-    for (long long it = 0; it < 1000000 && !done; ++it) {
+    for (long long it = 0; it < 1000000 && !done && !g_signal_fired; ++it) {      // CTQMC.F90:8123
         if ((rc = time_begin(s))) return rc;
-        launch_sweep<true>(s, l, chunk, 0);
+        launch_sweep(mat_variant(s), true, l, s->C, chunk, 0);
         HIPCHK(hipGetLastError());
         if ((rc = time_end(s, "sweep_calibrate"))) return rc;
         HIPCHK(hipMemcpyAsync(cnt.data(), list ? C.apt_cnt : C.calib_pairs, cnt.size() * sizeof(int), hipMemcpyDeviceToHost, s->stream));
@@ -683,7 +729,7 @@ int w2dyn_ctqmc_calibrate(w2dyn_solver *s, int list, int phase1pairnum, int phas
         for (int v : cnt) if (v < (list ? phase1pairnum : phase2pairnum)) { done = false; break; }
         if ((it & 15) == 15 || done) { if ((rc = check_walker_errors(s))) return rc; }
     }
-    if (!done) return fail(s, W2DYN_ENUMERIC, "ctqmc_calibrate: not every chain completed phase %d within 10^9 steps", list ? 1 : 2);
+    if (!done && !g_signal_fired) return fail(s, W2DYN_ENUMERIC, "ctqmc_calibrate: not every chain completed phase %d within 10^9 steps", list ? 1 : 2);
     if (list) {
         // every chain owns a list like every MPI rank of the reference does; `accpairtau` is the mean over chains of the
         // sorted lists, so that sorted[int(0.995 n)] is the chain average of the percentile (impurity.py:1159-1162)
@@ -709,7 +755,13 @@ int w2dyn_ctqmc_warmup(w2dyn_solver *s, int64_t n)
     accpair_to_default(s);
     if ((rc = w2dyn_init_counters(s))) return rc;
     double t0 = now_s();
-    if ((rc = w2dyn_sweep(s, n, 0))) return rc;
+    // launches of at most WARMUP_CHUNK steps: a chain's trajectory does not depend on how its steps are cut into launches,
+    // and a signal (CTQMC.F90:8214) is noticed between two of them
+    const int64_t WARMUP_CHUNK = 200000;
+    for (int64_t done = 0; done < n && !g_signal_fired; done += WARMUP_CHUNK) {
+        if ((rc = w2dyn_sweep(s, std::min<int64_t>(WARMUP_CHUNK, n - done), 0))) return rc;
+        if (done + WARMUP_CHUNK < n) { if ((rc = w2dyn_sync(s))) return rc; }
+    }
     if ((rc = check_walker_errors(s))) return rc;
     s->time_warmup = now_s() - t0;
     return 0;
@@ -730,6 +782,8 @@ int w2dyn_measure_begin(w2dyn_solver *s)
     HIPCHK(hipMemsetAsync(C.acc_outer, 0, sizeof(double) * B * C.nouter, s->stream));
     HIPCHK(hipMemsetAsync(C.acc_signouter, 0, sizeof(double) * B * C.nouter, s->stream));
     HIPCHK(hipMemsetAsync(C.acc_sign, 0, sizeof(double) * B, s->stream));
+    HIPCHK(hipMemsetAsync(C.acc_signstate, 0, sizeof(double) * B * s->nstates, s->stream));
+    HIPCHK(hipMemsetAsync(C.acc_tcstate, 0, sizeof(double) * B * s->nstates, s->stream));
     HIPCHK(hipMemsetAsync(C.acc_nz, 0, sizeof(double) * B, s->stream));
     HIPCHK(hipMemsetAsync(C.acc_nw, 0, sizeof(double) * B, s->stream));
     {
@@ -755,31 +809,24 @@ int w2dyn_measure_once(w2dyn_solver *s)
 {
     if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "measure before init_solver");
     HIPCHK(hipSetDevice(s->device));
-    Launch l = walker_launch(s);
+    LaunchCfg l = walker_launch(s);
     int rc;
     if ((rc = time_begin(s))) return rc;
-    switch (mat_variant(s)) {
-    case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_misc<0>), l.grid, l.block, l.lds, s->stream, s->C); break;
-    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_misc<2>), l.grid, l.block, l.lds, s->stream, s->C); break;
-    case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_misc<3>), l.grid, l.block, l.lds, s->stream, s->C); break;
-    case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_misc<4>), l.grid, l.block, l.lds, s->stream, s->C); break;
-    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_misc<9>), l.grid, l.block, l.lds, s->stream, s->C); break;
-    }
+    launch_meas_misc(mat_variant(s), l, s->C);
     HIPCHK(hipGetLastError());
     if ((rc = time_end(s, "meas_misc"))) return rc;
     if (s->cur_isector != 1) {      // component sampling: no Z-space Green's function estimators (CTQMC.F90:8554), worm estimator instead
         if (s->cur_isector == 2) {
             if (s->C.acc_giww || s->C.acc_gtauw) {
                 if ((rc = time_begin(s))) return rc;
-                hipLaunchKernelGGL(k_meas_gw, dim3(s->C.nbins), dim3(256), (size_t)s->ntau * sizeof(double), s->stream, s->C);
+                launch_meas_gw(s->C, s->stream);
                 HIPCHK(hipGetLastError());
                 if ((rc = time_end(s, "meas_gw"))) return rc;
             }
         } else if (s->C.acc_g4w || s->C.acc_g4wpp) {
             if ((rc = time_begin(s))) return rc;
-            const size_t lds = (size_t)(4 * s->n4iwf + 2 * s->n4iwb + 1) * sizeof(double2);
-            if (s->C.acc_g4w) hipLaunchKernelGGL(k_meas_g4w, dim3(s->nbw), dim3(256), lds, s->stream, s->C, 0, s->nbw);
-            if (s->C.acc_g4wpp) hipLaunchKernelGGL(k_meas_g4w, dim3(s->nbw), dim3(256), lds, s->stream, s->C, 1, s->nbw);
+            if (s->C.acc_g4w) launch_meas_g4w(s->C, s->stream, 0, s->nbw);
+            if (s->C.acc_g4wpp) launch_meas_g4w(s->C, s->stream, 1, s->nbw);
             HIPCHK(hipGetLastError());
             if ((rc = time_end(s, "meas_g4w"))) return rc;
         }
@@ -788,24 +835,20 @@ int w2dyn_measure_once(w2dyn_solver *s)
     }
     if (s->accum_gtau != 0) {          // AccumGtau = 0: MeasGtauRem returns at once, neither G(l) nor G(tau) (CTQMC.F90:2267)
     if ((rc = time_begin(s))) return rc;
-    if (s->nleg <= 16) launch_gleg<16>(s);
-    else if (s->nleg <= 32) launch_gleg<32>(s);
-    else if (s->nleg <= 64) launch_gleg<64>(s);
-    else if (s->nleg <= 100) launch_gleg<100>(s);
-    else launch_gleg<128>(s);
+    launch_meas_gleg(s->C, s->stream);
     HIPCHK(hipGetLastError());
     if ((rc = time_end(s, "meas_gleg"))) return rc;
     }
     if (s->accum_gtau == 2) {
         if ((rc = time_begin(s))) return rc;
-        hipLaunchKernelGGL(k_meas_gtau_ac, dim3(s->nwalkers, s->nflav), dim3(256), (size_t)s->ntau * sizeof(double), s->stream, s->C, s->ac_dat, s->ac_lev, s->ac_n);
+        launch_meas_gtau_ac(s->C, s->stream, s->ac_dat, s->ac_lev, s->ac_n);
         HIPCHK(hipGetLastError());
         if ((rc = time_end(s, "meas_gtau_ac"))) return rc;
         s->ac_n += 1;
     }
     if (s->meas_giw) {
         if ((rc = time_begin(s))) return rc;
-        hipLaunchKernelGGL(k_meas_giw, dim3(s->C.nbins, s->nflav, (s->C.niw2 + 63) / 64), dim3(64), 0, s->stream, s->C);
+        launch_meas_giw(s->C, s->stream);
         HIPCHK(hipGetLastError());
         if ((rc = time_end(s, "meas_giw"))) return rc;
     }
@@ -813,33 +856,21 @@ int w2dyn_measure_once(w2dyn_solver *s)
         if ((rc = time_begin(s))) return rc;
         // g4leg: factorised kernel (registers hold the N4iwb + 1 non-negative frequencies of one (l, l')) when its tables fit
         // into LDS and N4iwb < 24; otherwise, and for g4tau, the quadruple kernel with one atomic add per term
-        const size_t lds_f = ((size_t)(3 * s->C.kmax + 3) * s->n4leg + s->C.kmax + 1 + 2 * 24) * sizeof(double);
+        const size_t lds_f = g4leg_fact_lds(s->C, s->n4leg);
         const bool fact = s->acc_g4leg && s->n4iwb < 24 && lds_f <= 64 * 1024 && !getenv("W2DYN_G4LEG_ATOMICS");
-        if (s->acc_g4tau || !fact)
-            hipLaunchKernelGGL(k_meas_g4leg, dim3(s->nwalkers, s->nflav * s->nflav), dim3(256), 0, s->stream, s->C, s->acc_g4tau, fact ? nullptr : s->acc_g4leg, s->nbl, s->n4tau, s->n4leg, s->n4iwb);
-        if (fact) {
-            const dim3 grid(s->nwalkers, s->nflav * s->nflav);
-            // one (l, l') pair per thread: two pairs per thread (a single tile up to N4leg = 22) measured slower (214 ms
-            // against 162 ms per pass at N4leg = 20, N4iwb = 10: the second set of accumulators costs occupancy)
-#define W2DYN_G4LEG_FACT(NWB1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_g4leg_fact<NWB1, 1>), grid, dim3(256), lds_f, s->stream, s->C, s->acc_g4leg, s->nbl, s->n4leg, s->n4iwb)
-            if (s->n4iwb < 4) W2DYN_G4LEG_FACT(4);
-            else if (s->n4iwb < 12) W2DYN_G4LEG_FACT(12);
-            else W2DYN_G4LEG_FACT(24);
-#undef W2DYN_G4LEG_FACT
-        }
+        if (s->acc_g4tau || !fact) launch_meas_g4leg(s->C, s->stream, s->acc_g4tau, fact ? nullptr : s->acc_g4leg, s->nbl, s->n4tau, s->n4leg, s->n4iwb);
+        if (fact) launch_meas_g4leg_fact(s->C, s->stream, s->acc_g4leg, s->nbl, s->n4leg, s->n4iwb);
         HIPCHK(hipGetLastError());
         if ((rc = time_end(s, "meas_g4leg"))) return rc;
     }
     if (s->fourpnt & 4) {           // CTQMC.F90:8579
         const int n2 = 2 * (s->n4iwf + s->n4iwb);
-        const size_t n4 = (size_t)s->nflav * s->nflav * 4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1), ng2 = (size_t)s->nflav * n2 * n2;
         if ((rc = time_begin(s))) return rc;
-        hipLaunchKernelGGL(k_meas_g2iw, dim3(s->nwalkers, s->nflav), dim3(256), (size_t)3 * s->C.kmax * G2_FC * sizeof(double2), s->stream, s->C, n2, s->G2);
+        launch_meas_g2iw(s->C, s->stream, n2, s->G2);
         HIPCHK(hipGetLastError());
         if ((rc = time_end(s, "meas_g2iw"))) return rc;
         if ((rc = time_begin(s))) return rc;
-        hipLaunchKernelGGL(k_meas_g4iw, dim3((unsigned)((std::max(n4, ng2) + 255) / 256), s->nb4), dim3(256), 0, s->stream, s->C, s->n4iwf, s->n4iwb, s->zph, s->nb4,
-                           s->G2, s->acc4, s->acc4pp, s->acc2);
+        launch_meas_g4iw(s->C, s->stream, s->n4iwf, s->n4iwb, s->zph, s->nb4, s->G2, s->acc4, s->acc4pp, s->acc2);
         HIPCHK(hipGetLastError());
         if ((rc = time_end(s, "meas_g4iw"))) return rc;
     }
@@ -855,13 +886,21 @@ int w2dyn_measure_finish(w2dyn_solver *s)
     if ((rc = check_walker_errors(s))) return rc;
     const DevConst &C = s->C;
     const int nf = s->nflav, nd = s->nd, B = C.nbins, W = s->nwalkers, ns = s->nstates;
-    auto fetch = [&](const double *dev, size_t n) { std::vector<double> v(n); (void)hipMemcpy(v.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost); return v; };
+    hipError_t fetch_err = hipSuccess;
+    auto fetch = [&](const double *dev, size_t n) {
+        std::vector<double> v(n);
+        hipError_t e = hipMemcpy(v.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess && fetch_err == hipSuccess) fetch_err = e;
+        return v;
+    };
     std::vector<double> gleg = fetch(C.acc_gleg, (size_t)B * nf * s->nleg), gtau = fetch(C.acc_gtau, (size_t)B * nf * s->ntau);
     std::vector<double> giw = fetch(C.acc_giw, (size_t)B * nf * C.niw2 * 2), histo = fetch(C.acc_histo, (size_t)B * nf * (s->maxhisto + 1));
     const int no = C.nouter, dms = C.dmsize;
     const LocalProblem &lp = s->lp;
     std::vector<double> dm = fetch(C.acc_dm, (size_t)B * dms), outer = fetch(C.acc_outer, (size_t)B * no), souter = fetch(C.acc_signouter, (size_t)B * no);
     std::vector<double> sgn = fetch(C.acc_sign, B);
+    std::vector<double> sgnstate = fetch(C.acc_signstate, (size_t)B * ns), tcstate = fetch(C.acc_tcstate, (size_t)B * ns);
+    if (fetch_err != hipSuccess) return fail(s, W2DYN_EHIP, "measure_finish: copying the accumulators to the host: %s", hipGetErrorString(fetch_err));
     std::vector<WalkerScalars> ws(W);
     HIPCHK(hipMemcpy(ws.data(), C.ws, ws.size() * sizeof(WalkerScalars), hipMemcpyDeviceToHost));
     s->res_accpair.resize((size_t)nf * s->ntau);
@@ -872,6 +911,7 @@ int w2dyn_measure_finish(w2dyn_solver *s)
     // measurements in Z space per bin: every chain at every measurement in a Z run, the chains found in Z space in a
     // worm run (CntMeas(SectorZ), CTQMC.F90:8541-8545)
     std::vector<double> nz = fetch(C.acc_nz, B), nwm = fetch(C.acc_nw, B);
+    if (fetch_err != hipSuccess) return fail(s, W2DYN_EHIP, "measure_finish: copying the accumulators to the host: %s", hipGetErrorString(fetch_err));
     double nmeas_tot = 0.0; for (double v : nz) nmeas_tot += v;
     double ssum = 0.0; for (double v : sgn) ssum += v;
     s->mean_sign = ssum / nmeas_tot;                               // CTQMC.F90:8670
@@ -895,16 +935,32 @@ int w2dyn_measure_finish(w2dyn_solver *s)
     reduce_bins(histo, (size_t)nf * (s->maxhisto + 1), "histo", [&](double v, double n, size_t) { return v / n; });                                // 8755
     reduce_bins(dm, dms, "dmblocks", [&](double v, double n, size_t) { double zs = -1.0 / (n * ms); return v * zs; });                             // 8706-8708
     reduce_bins(outer, no, "outersuperstatehisto", [&](double v, double n, size_t) { return v / n; });                                             // 8760
-    {   // SignHistoSuperstates / OuterSuperstateHisto before the latter is normalised (CTQMC.F90:8757)
-        std::vector<double> so(no, 0.0), oo(no, 0.0);
-        for (int b = 0; b < B; ++b) for (int i = 0; i < no; ++i) { so[i] += souter[(size_t)b * no + i]; oo[i] += outer[(size_t)b * no + i]; }
-        for (int i = 0; i < no; ++i) so[i] = so[i] / oo[i];
-        R["signhistosuperstates"] = so;
-        // per-state versions: every state of the outer block counts (CTQMC.F90:3298-3300); the per-state sign needs the
-        // partial traces in a particular eigenbasis and is reported with the block's value
-        std::vector<double> os(ns, 0.0), ss(ns, 0.0);
-        for (int b = 0; b < no; ++b) for (int i = 0; i < lp.sst_n[b]; ++i) { os[lp.sst_off[b] + i] = R["outersuperstatehisto"][b]; ss[lp.sst_off[b] + i] = so[b]; }
-        R["outerstatehisto"] = os; R["signhistostates"] = ss;
+    {   // MeasOuterHistograms (CTQMC.F90:3285-3339), normalised as in 8757-8764: sign sums over visit counts (0/0 = NaN
+        // for blocks never visited, as in the reference), visits and trace contributions over the number of measurements
+        auto outer_hists = [&](const double *ou, const double *so_, const double *ss_, const double *tc_, double n,
+                               double *sign_sst, double *ostate, double *sign_state, double *tc_sst, double *tc_state) {
+            for (int b = 0; b < no; ++b) {
+                sign_sst[b] = so_[b] / ou[b]; tc_sst[b] = 0.0;
+                for (int i = 0; i < lp.sst_n[b]; ++i) {       // every state of the outer block counts as visited (3298-3300)
+                    const int st = lp.sst_off[b] + i;
+                    ostate[st] = ou[b] / n; sign_state[st] = ss_[st] / ou[b]; tc_state[st] = tc_[st] / n; tc_sst[b] += tc_[st] / n;
+                }
+            }
+        };
+        std::vector<double> ou(no, 0.0), so(no, 0.0), ss(ns, 0.0), tc(ns, 0.0);
+        for (int b = 0; b < B; ++b) {
+            for (int i = 0; i < no; ++i) { ou[i] += outer[(size_t)b * no + i]; so[i] += souter[(size_t)b * no + i]; }
+            for (int i = 0; i < ns; ++i) { ss[i] += sgnstate[(size_t)b * ns + i]; tc[i] += tcstate[(size_t)b * ns + i]; }
+        }
+        std::vector<double> a1(no), a2(ns), a3(ns), a4(no), a5(ns);
+        outer_hists(ou.data(), so.data(), ss.data(), tc.data(), nmeas_tot, a1.data(), a2.data(), a3.data(), a4.data(), a5.data());
+        R["signhistosuperstates"] = a1; R["outerstatehisto"] = a2; R["signhistostates"] = a3; R["tracecontribsuperstates"] = a4; R["tracecontribstates"] = a5;
+        std::vector<double> b1((size_t)B * no), b2((size_t)B * ns), b3((size_t)B * ns), b4((size_t)B * no), b5((size_t)B * ns);
+        for (int b = 0; b < B; ++b)
+            outer_hists(&outer[(size_t)b * no], &souter[(size_t)b * no], &sgnstate[(size_t)b * ns], &tcstate[(size_t)b * ns], binw(b),
+                        &b1[(size_t)b * no], &b2[(size_t)b * ns], &b3[(size_t)b * ns], &b4[(size_t)b * no], &b5[(size_t)b * ns]);
+        R["signhistosuperstates_bins"] = b1; R["outerstatehisto_bins"] = b2; R["signhistostates_bins"] = b3;
+        R["tracecontribsuperstates_bins"] = b4; R["tracecontribstates_bins"] = b5;
     }
     {   // diagonal of the density matrix in the occupation basis, block order (Transform_DensityMatrix_EB_to_OCCB, 3163-3179)
         auto to_occ_diag = [&](const double *blocks, double *out) {
@@ -917,10 +973,6 @@ int w2dyn_measure_finish(w2dyn_solver *s)
         to_occ_diag(R["dmblocks"].data(), d.data());
         for (int b = 0; b < B; ++b) to_occ_diag(&R["dmblocks_bins"][(size_t)b * dms], &db[(size_t)b * ns]);
         R["dmdiag"] = d; R["dmdiag_bins"] = db;
-    }
-    {   // trace contributions: one state per block, parttrace == trace, contribution exp(log tr) is not tracked; the
-        // reference divides sums of exp(parttrace%log) by CntMeas (8763-8764). Report the visit frequencies' support.
-        R["tracecontribsuperstates"] = std::vector<double>(no, 0.0); R["tracecontribstates"] = std::vector<double>(ns, 0.0);
     }
     // density matrix and its contractions (CTQMC.F90:2842-3060 for one-state blocks; eigenbasis == occupation basis)
     auto occ_of = [&](const double *d, std::vector<double> &occ, std::vector<double> &rho1, std::vector<double> &rho2) {
@@ -984,7 +1036,7 @@ int w2dyn_measure_finish(w2dyn_solver *s)
     s->res_isector = s->cur_isector;
     if (s->ac_dat) {     // gtau_blocks (CTQMC.F90:8733-8739, unscaled): per accumulator bin and averaged over the bins' chains
         const size_t per = (size_t)nf * s->ac_lev * ntau;
-        hipLaunchKernelGGL(k_gtau_blocks, dim3(B, nf * s->ac_lev), dim3(256), 0, s->stream, s->C, s->ac_dat, s->ac_lev, s->ac_n, s->ac_out);
+        launch_gtau_blocks(s->C, s->stream, s->ac_dat, s->ac_lev, s->ac_n, s->ac_out);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s->stream));
         std::vector<double> bins((size_t)B * per), tot(per, 0.0);
@@ -1119,7 +1171,9 @@ int w2dyn_measure_finish(w2dyn_solver *s)
         R["worm_counters"] = wc;
     }
     R["eigenstatesenergies"] = s->energies;
-    R["lhisto"] = std::vector<double>(100, 0.0); R["rhisto"] = std::vector<double>(100, 0.0);
+    // lhisto / rhisto: the reference never fills DTrace%lhisto / rhisto (only zeroed, Trace.F90:596-597), so its results
+    // are 0/0 = NaN and 0/(sum of acceptance ratios) = 0 (CTQMC.F90:8698-8699)
+    R["lhisto"] = std::vector<double>(100, std::nan("")); R["rhisto"] = std::vector<double>(100, 0.0);
     {   // gtau_full / gleg_full are only filled by the off-diagonal estimators (CTQMC.F90:8752, 8768): zero here
         R["gtau_full"] = std::vector<double>((size_t)nf * nf * ntau, 0.0); R["gleg_full"] = std::vector<double>((size_t)nf * nf * nleg, 0.0);
     }
@@ -1156,17 +1210,25 @@ int w2dyn_ctqmc_measure(w2dyn_solver *s, int isector, int icomponent)
     if ((rc = w2dyn_measure_begin(s))) return rc;
     double t0 = now_s(), tsteps = 0.0;
     s->no_sampling = isector != 1 && s->worm_eta == 0.0;       // CTQMC.F90:8409-8418: nothing is sampled with eta = 0
+    // Launches are asynchronous; the host waits for the stream every MEAS_SYNC measurements, so that it never runs more than
+    // that far ahead of the GPU and a signal (SIGTERM / SIGINT / SIGUSR1, CTQMC.F90:8430) ends the run within that many
+    // measurements: the measurements done so far are normalised and `aborted` says so (CTQMC.F90:8648-8658)
+    const int64_t MEAS_SYNC = 32;
+    bool interrupted = false;
     for (int64_t m = 0; m < s->nmeas && !s->no_sampling; ++m) {
+        if (g_signal_fired) { interrupted = true; break; }
         double a = now_s();
         if ((rc = w2dyn_sweep(s, s->ncorr, 1))) return rc;
-        if (!s->timing) { /* asynchronous */ }
         tsteps += now_s() - a;
         if ((rc = w2dyn_measure_once(s))) return rc;
+        if ((m % MEAS_SYNC) == MEAS_SYNC - 1) { if ((rc = w2dyn_sync(s))) return rc; }
     }
     if ((rc = w2dyn_sync(s))) return rc;
     s->time_sim = now_s() - t0; s->time_sim_steps = tsteps;
     rc = w2dyn_measure_finish(s);
+    if (interrupted && rc == 0) s->aborted = s->meas_done == 0 ? 2 : 1;
     s->cur_isector = 1; s->C.isector = 1; s->C.p_wins = 0.0;
+    clear_traps();                                                                    // CTQMC.F90:9352-9355
     return rc;
 }
 
@@ -1227,8 +1289,8 @@ int w2dyn_count_steps(w2dyn_solver *s, int isector, int icomponent, int64_t nfix
     HIPCHK(hipMemcpy(C.TA, TA0.data(), TA0.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemset(C.accpair, 0, sizeof(unsigned long long) * s->nflav * C.naccpair));
     s->cur_isector = 1; s->C.isector = 1; s->C.p_wins = 0.0;
-    Launch l = walker_launch(s);
-    hipLaunchKernelGGL(k_rebuild, l.grid, l.block, l.lds, s->stream, s->C);
+    LaunchCfg l = walker_launch(s);
+    launch_rebuild(l, s->C);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s->stream));
     return check_walker_errors(s);
@@ -1239,6 +1301,7 @@ int w2dyn_dest_ctqmc(w2dyn_solver *s)
     if (!s) return W2DYN_EINVAL;
     (void)hipSetDevice(s->device);
     free_device(s);
+    clear_traps();
     return 0;
 }
 
@@ -1327,8 +1390,8 @@ int w2dyn_set_mc_config(w2dyn_solver *s, int walker, int n, const double *taus, 
         HIPCHK(hipMemcpy(C.TA + (size_t)w * nf * kmax, TA.data(), sizeof(double) * nf * kmax, hipMemcpyHostToDevice));
     }
     // M, det and NPairs of every chain rebuilt on the device (Trace.F90:6990-6999)
-    Launch l = walker_launch(s);
-    hipLaunchKernelGGL(k_rebuild, l.grid, l.block, l.lds, s->stream, s->C);
+    LaunchCfg l = walker_launch(s);
+    launch_rebuild(l, s->C);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s->stream));
     return check_walker_errors(s);
@@ -1361,16 +1424,16 @@ int w2dyn_restore_mc_configs(w2dyn_solver *s)
     HIPCHK(hipStreamSynchronize(s->stream));
     std::vector<WalkerScalars> ws(W);
     HIPCHK(hipMemcpy(ws.data(), C.ws, W * sizeof(WalkerScalars), hipMemcpyDeviceToHost));
-    for (size_t w = 0; w < W; ++w) {       // configuration and position in the chain's random stream; counters and window start afresh
-        ws[w].outer = s->snap_ws[w].outer; ws[w].ndraw = s->snap_ws[w].ndraw;
+    for (size_t w = 0; w < W; ++w) {       // the configuration only: counters and window start afresh, the random streams move on
+        ws[w].outer = s->snap_ws[w].outer;          // (CtHybConfig carries no generator state, impurity.py:45-107)
         ws[w].wpos = 0; ws[w].npairs = -1; ws[w].sector = 1;                   // Trace.F90:6917-6919, 6973-6975
     }
     HIPCHK(hipMemcpy(C.ws, ws.data(), W * sizeof(WalkerScalars), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(C.K, s->snap_K.data(), W * nf * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(C.TC, s->snap_TC.data(), W * nf * kmax * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(C.TA, s->snap_TA.data(), W * nf * kmax * sizeof(double), hipMemcpyHostToDevice));
-    Launch l = walker_launch(s);
-    hipLaunchKernelGGL(k_rebuild, l.grid, l.block, l.lds, s->stream, s->C);
+    LaunchCfg l = walker_launch(s);
+    launch_rebuild(l, s->C);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s->stream));
     return check_walker_errors(s);

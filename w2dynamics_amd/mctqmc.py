@@ -68,8 +68,7 @@ def load_library(path: str = LIB_PATH):
     L.w2dyn_get_result.argtypes = [vp, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.w2dyn_get_scalar.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double)]
     L.w2dyn_kernel_time.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
-    for name in dir(L):
-        pass
+    L.w2dyn_set_timing.argtypes = [vp, C.c_int]
     return L
 
 
@@ -80,7 +79,7 @@ EXPORTED_SYMBOLS = [
     "w2dyn_measure_once", "w2dyn_measure_finish", "w2dyn_sync", "w2dyn_get_mc_config_scalars", "w2dyn_get_mc_config",
     "w2dyn_set_mc_config", "w2dyn_get_minv", "w2dyn_get_walker_state", "w2dyn_get_result", "w2dyn_get_scalar",
     "w2dyn_kernel_time", "w2dyn_set_wormeta", "w2dyn_get_wormeta", "w2dyn_ctqmc_worm_warmup", "w2dyn_count_steps",
-    "w2dyn_ctqmc_calibrate", "w2dyn_set_sector", "w2dyn_save_mc_configs", "w2dyn_restore_mc_configs",
+    "w2dyn_ctqmc_calibrate", "w2dyn_set_sector", "w2dyn_save_mc_configs", "w2dyn_restore_mc_configs", "w2dyn_set_timing",
 ]
 
 _SCALARS = ("mean_sign", "aborted", "time_warmup", "time_sim", "time_sim_steps", "accglob", "accshift", "accadd4",
@@ -200,6 +199,10 @@ class MCTQMC:
     def measure_once(self): self._chk(self._L.w2dyn_measure_once(self._h))
     def measure_finish(self): self._chk(self._L.w2dyn_measure_finish(self._h))
     def sync(self): self._chk(self._L.w2dyn_sync(self._h))
+
+    def set_timing(self, on=True):
+        """HIP-event timing of every launch (bench / profiling): off by default, it costs a host sync per launch."""
+        self._chk(self._L.w2dyn_set_timing(self._h, int(bool(on))))
 
     def kernel_time(self, name, reset=False):
         ms, n = C.c_double(), C.c_int64()
