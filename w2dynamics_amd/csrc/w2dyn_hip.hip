@@ -29,6 +29,14 @@ struct KTimer {
     double total_ms = 0.0; int64_t launches = 0;
 };
 
+// Scratch of w2dyn_measure_once_noalloc: the per-chain g2(nu, nu') table that k_meas_g2iw writes and k_meas_g4iw reads
+// (the other entry points keep it in a hipMalloc'ed buffer sized at init_solver).  One copy per GPU, held until the process
+// ends.  `w2dyn_scratch` is a host-side stand-in for the symbol, not a device address: the address of each GPU's copy is
+// looked up once per device with hipGetSymbolAddress (scratch_address below) and only that pointer is handed to kernels.
+constexpr size_t W2DYN_SCRATCH_BYTES = (size_t)32 << 20;
+constexpr int W2DYN_MAX_DEVICES = 64;
+void *g_scratch_ptr[W2DYN_MAX_DEVICES] = {nullptr};
+
 // Soft abort (Signals.F90:117-137): SIGTERM / SIGINT / SIGUSR1 are trapped from init_solver to the end of ctqmc_measure
 // (CTQMC.F90:8076-8078, 9352-9355); the handler only raises this flag, the sampling loops look at it between launches.
 volatile sig_atomic_t g_signal_fired = 0;
@@ -52,8 +60,25 @@ void clear_traps()      // reset_notify + clear_trap, CTQMC.F90:9352-9355
 
 }  // namespace
 
+static __device__ __align__(256) unsigned char w2dyn_scratch[W2DYN_SCRATCH_BYTES];
+
+// address of the current device's copy of w2dyn_scratch; `device` must be the current device
+static hipError_t scratch_address(int device, void **out)
+{
+    if (device < 0 || device >= W2DYN_MAX_DEVICES) return hipErrorInvalidDevice;
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(w2dyn_scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
 struct w2dyn_solver {
     int device = 0;
+    void *scratch = nullptr;                         // this GPU's copy of w2dyn_scratch (looked up in w2dyn_create)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
@@ -275,7 +300,7 @@ int w2dyn_create(w2dyn_solver **out, int device)
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return W2DYN_EHIP;
     w2dyn_solver *s = new w2dyn_solver();
     s->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&s->stream) != hipSuccess ||
+    if (hipSetDevice(device) != hipSuccess || scratch_address(device, &s->scratch) != hipSuccess || hipStreamCreate(&s->stream) != hipSuccess ||
         hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { delete s; return W2DYN_EHIP; }
     *out = s;
     return 0;
@@ -805,9 +830,9 @@ int w2dyn_measure_begin(w2dyn_solver *s)
     return 0;
 }
 
-int w2dyn_measure_once(w2dyn_solver *s)
+// one pass of the estimators; g2buf: per-chain g2 table of the Matsubara two-particle estimators (FourPnt & 4)
+static int measure_once_impl(w2dyn_solver *s, double2 *g2buf)
 {
-    if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "measure before init_solver");
     HIPCHK(hipSetDevice(s->device));
     LaunchCfg l = walker_launch(s);
     int rc;
@@ -866,16 +891,39 @@ int w2dyn_measure_once(w2dyn_solver *s)
     if (s->fourpnt & 4) {           // CTQMC.F90:8579
         const int n2 = 2 * (s->n4iwf + s->n4iwb);
         if ((rc = time_begin(s))) return rc;
-        launch_meas_g2iw(s->C, s->stream, n2, s->G2);
+        launch_meas_g2iw(s->C, s->stream, n2, g2buf);
         HIPCHK(hipGetLastError());
         if ((rc = time_end(s, "meas_g2iw"))) return rc;
         if ((rc = time_begin(s))) return rc;
-        launch_meas_g4iw(s->C, s->stream, s->n4iwf, s->n4iwb, s->zph, s->nb4, s->G2, s->acc4, s->acc4pp, s->acc2);
+        launch_meas_g4iw(s->C, s->stream, s->n4iwf, s->n4iwb, s->zph, s->nb4, g2buf, s->acc4, s->acc4pp, s->acc2);
         HIPCHK(hipGetLastError());
         if ((rc = time_end(s, "meas_g4iw"))) return rc;
     }
     s->meas_done += 1;
     return 0;
+}
+
+int w2dyn_measure_once(w2dyn_solver *s)
+{
+    if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "measure before init_solver");
+    return measure_once_impl(s, s->G2);
+}
+
+int w2dyn_measure_once_noalloc(w2dyn_solver *s)
+{
+    if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "measure before init_solver");
+    if (!(s->fourpnt & 4) || s->cur_isector != 1) return fail(s, W2DYN_EINVAL, "measure_once_noalloc: a Z-space run with FourPnt & 4 (Matsubara two-particle estimators) is required");
+    const size_t n2 = 2 * (size_t)(s->n4iwf + s->n4iwb), need = (size_t)s->nwalkers * s->nflav * n2 * n2 * sizeof(double2);
+    if (need > W2DYN_SCRATCH_BYTES)
+        return fail(s, W2DYN_EINVAL, "measure_once_noalloc: %zu bytes of per-chain g2 tables (chains x flavours x (2 (N4iwf + N4iwb))^2 x 16) exceed the static scratch of %zu bytes", need, (size_t)W2DYN_SCRATCH_BYTES);
+    if (!s->scratch) return fail(s, W2DYN_EHIP, "measure_once_noalloc: no scratch address for device %d", s->device);
+    // nothing below allocates, frees or waits for the GPU: kernel launches on the context's stream only (timing is
+    // skipped).  k_meas_g2iw writes every entry of every chain's table, so the array's old contents never matter.
+    const bool timing = s->timing;
+    s->timing = false;
+    const int rc = measure_once_impl(s, (double2 *)s->scratch);
+    s->timing = timing;
+    return rc;
 }
 
 int w2dyn_measure_finish(w2dyn_solver *s)
@@ -1540,6 +1588,7 @@ int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out)
     else if (n == "nsmax") *out = s->lp.nsmax;
     else if (n == "matrix_trace") *out = s->mat ? 1 : 0;
     else if (n == "nslide") *out = s->C.nslide;
+    else if (n == "scratch_bytes") *out = (double)W2DYN_SCRATCH_BYTES;
     else return fail(s, W2DYN_EINVAL, "unknown scalar '%s'", name);
     return 0;
 }

@@ -58,6 +58,7 @@ def load_library(path: str = LIB_PATH):
     L.w2dyn_restore_mc_configs.argtypes = [vp]
     L.w2dyn_sweep.argtypes = [vp, C.c_int64, C.c_int]
     L.w2dyn_measure_once.argtypes = [vp]
+    L.w2dyn_measure_once_noalloc.argtypes = [vp]
     L.w2dyn_measure_finish.argtypes = [vp]
     L.w2dyn_sync.argtypes = [vp]
     L.w2dyn_get_mc_config_scalars.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -80,6 +81,7 @@ EXPORTED_SYMBOLS = [
     "w2dyn_set_mc_config", "w2dyn_get_minv", "w2dyn_get_walker_state", "w2dyn_get_result", "w2dyn_get_scalar",
     "w2dyn_kernel_time", "w2dyn_set_wormeta", "w2dyn_get_wormeta", "w2dyn_ctqmc_worm_warmup", "w2dyn_count_steps",
     "w2dyn_ctqmc_calibrate", "w2dyn_set_sector", "w2dyn_save_mc_configs", "w2dyn_restore_mc_configs", "w2dyn_set_timing",
+    "w2dyn_measure_once_noalloc",
 ]
 
 _SCALARS = ("mean_sign", "aborted", "time_warmup", "time_sim", "time_sim_steps", "accglob", "accshift", "accadd4",
@@ -197,6 +199,7 @@ class MCTQMC:
         self._chk(self._L.w2dyn_set_sector(self._h, int(isector), int(icomponent)))
     def sweep(self, nsteps, count_as_sampling=True): self._chk(self._L.w2dyn_sweep(self._h, int(nsteps), int(count_as_sampling)))
     def measure_once(self): self._chk(self._L.w2dyn_measure_once(self._h))
+    def measure_once_noalloc(self): self._chk(self._L.w2dyn_measure_once_noalloc(self._h))
     def measure_finish(self): self._chk(self._L.w2dyn_measure_finish(self._h))
     def sync(self): self._chk(self._L.w2dyn_sync(self._h))
 
