@@ -122,7 +122,7 @@ def params_from_pstring(ps, nd, beta, fourpnt=0):
 
 
 class OracleWalker:
-    """One chain of the CPU restatement; rng = ("std", seed) or ("philox", seed, walker)."""
+    """One chain of the CPU restatement; rng = ("std", seed), ("philox", seed, walker) or ("shared", other_walker)."""
 
     def __init__(self, problem, pset, rng=("std", 0), fourpnt=0):
         self.L = lib()
@@ -130,6 +130,8 @@ class OracleWalker:
         assert self.p.nftau == problem.nftau, "Nftau in the parameter string must match the F(tau) array"
         if rng[0] == "std":
             self.rng = self.L.ora_rng_std(int(rng[1]))
+        elif rng[0] == "shared":      # goes on drawing from another walker's generator (the reference seeds once per process)
+            self.rng = rng[1].rng
         else:
             self.rng = self.L.ora_rng_philox(int(rng[1]), int(rng[2]))
         self.nd = problem.nd

@@ -41,6 +41,8 @@ TRAJ = [
     ("C3", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=6.0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 77),
     ("C2", 2001, dict(BASE, Nwarmups=20000, Nmeas=10, NCorr=200, TaudiffMax=10.0, NLegMax=100, Ntau=1000), 5),
     ("C5Z", 501, dict(BASE, Nwarmups=4000, Nmeas=10, NCorr=100, TaudiffMax=10.0, NLegMax=40), 31),
+    # two windows of 2/3 beta: ~140 operators inside the window, i.e. the window list lives in LDS (more than 64 entries)
+    ("C5Z", 501, dict(BASE, Nwarmups=4000, Nmeas=10, NCorr=100, TaudiffMax=30.0, NLegMax=40, PercentageGlobalMove=0.02, PercentageTauShiftMove=0.02), 32),
     # matrix local-trace path: Kanamori (blocks of 1-3 states) and density-density U with coarse quantum numbers
     ("C4S", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=3.0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 4242),
     ("C3Q", 501, dict(BASE, Nwarmups=3000, Nmeas=20, NCorr=30, TaudiffMax=5.0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 99),
@@ -56,7 +58,7 @@ TRAJ = [
 ]
 
 
-@pytest.mark.parametrize("cfg,nftau,over,seed", TRAJ, ids=["C1-addrem", "C1-1window-allmoves", "C3-allmoves", "C2-default", "C5Z-default",
+@pytest.mark.parametrize("cfg,nftau,over,seed", TRAJ, ids=["C1-addrem", "C1-1window-allmoves", "C3-allmoves", "C2-default", "C5Z-default", "C5Z-wide-window-lds-list",
                               "C4S-kanamori-allmoves", "C3Q-coarse-blocks-allmoves", "C4-kanamori-default",
                               "C4SA-auto-blocks", "C4SX-auto-blocks-hopping", "C4SQ-all-alone", "C4A-auto-blocks-3orb",
                               "C4N-9-state-blocks", "C5K-5orb-kanamori-10-state-blocks"])
@@ -112,7 +114,7 @@ def test_matrix_path_lds_layouts_retrace_oracle(monkeypatch, in_lds):
     """The matrix path has two LDS layouts (operator matrices staged in LDS at one workgroup per CU, or left in global
     memory at two workgroups per CU; the host picks by size).  Both must retrace the oracle."""
     monkeypatch.setenv("W2DYN_MAT_OPS_IN_LDS", in_lds)
-    cfg, nftau, over, seed = TRAJ[5]
+    cfg, nftau, over, seed = [t for t in TRAJ if t[0] == "C4S"][0]
     _retrace(cfg, nftau, over, seed + 1)
 
 
@@ -296,6 +298,126 @@ def test_two_particle_matsubara_chains_vs_oracle():
     for k in tot:
         assert rel(getattr(q, k), tot[k]) < TOL, k
     q.dest_ctqmc(); q.close()
+
+
+def test_two_particle_matsubara_production_box_and_folded_bins(monkeypatch):
+    """a-14 at the frequency box of BASELINE.json's two-particle configuration (N4iwf = 10, N4iwb = 5) with the accumulator
+    budget cut so that the 6 sample bins fold onto 3 accumulator bins (chains b and b + 3 share one): every accumulator
+    bin equals the mean of the oracle chains it holds, the pooled result the mean of all."""
+    monkeypatch.setenv("W2DYN_ACC_BYTES", str(3 * (2 * 2 * 20 * 20 * 11 * 2 + 2 * 30 * 30) * 16 + 1000))
+    over = dict(BASE, Nwarmups=2000, Nmeas=4, NCorr=20, TaudiffMax=2.0, N4iwf=10, N4iwb=5, MeasG2iw=1, MeasG4iwPP=1,
+                PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05)
+    p, ps, pset = util.setup("C1", 501, over)
+    nw = 6
+    q = MCTQMC(nwalkers=nw, walkers_per_bin=1)
+    q.fourpnt = 4
+    q.init_rnd(13); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+    assert int(q.scalar("nb4")) == 3 and int(q.scalar("nbins")) == 6
+    q.set_taudiffmax(2.0); q.ctqmc_warmup(2000); q.ctqmc_measure(1, 1)
+    per = []
+    for w in range(nw):
+        o = pyoracle.OracleWalker(p, pset, ("philox", 13, w), fourpnt=4)
+        o.set_taudiffmax(2.0); o.warmup(2000); o.measure(); per.append(o.results()); o.close()
+    for k in ("g4iw", "g4iw_pp", "g2iw"):
+        b = getattr(q, k + "_bins")
+        assert b.shape[0] == 3 and b.shape[-1] == (30 if k == "g2iw" else 11)
+        for a in range(3):
+            assert rel(b[a], 0.5 * (per[a][k] + per[a + 3][k])) < TOL, (k, a)
+        assert rel(getattr(q, k), sum(r[k] for r in per) / nw) < TOL, k
+    q.dest_ctqmc(); q.close()
+
+
+def test_worm_estimator_folded_bins(monkeypatch):
+    """a-16 with folded accumulator bins (nbw < nbins) at N4iwf = 10, N4iwb = 5 (three passes of k_meas_g4w over the
+    frequency box): the pooled g4iw_worm follows from the oracle chains as in the unfolded case."""
+    g = util.load_golden("worm_C5a.npz")
+    monkeypatch.setenv("W2DYN_ACC_BYTES", str(2 * 20 * 20 * 11 * 16 + 100))
+    comp = int(g["component"]); nw = 4
+    q, p, pset, over = _worm_gpu(g, nw, 1, 22)
+    assert int(q.scalar("nbw")) == 2
+    q.ctqmc_warmup(over["Nwarmups"])
+    q.ctqmc_worm_warmup(0, 4, comp)
+    q.ctqmc_measure(4, comp)
+    pooled = 0.0; cw = cz = mw = 0.0; binsum = [0.0, 0.0]; bcw = [0.0, 0.0]; bcz = [0.0, 0.0]; bmw = [0.0, 0.0]
+    for w in range(nw):
+        o = pyoracle.OracleWalker(p, pset, ("philox", 22, w), fourpnt=8)
+        o.set_taudiffmax(over["TaudiffMax"]); o.warmup(over["Nwarmups"]); o.measure_sector(4, comp)
+        r = o.results(); oc = o.worm_counters()
+        raw = r["g4iw_worm"] * (oc["cnt_meas_w"] * r["counters"][11] / max(oc["cnt_sampling_w"], 1.0))     # undo the chain's own scaling
+        pooled = pooled + raw; binsum[w % 2] = binsum[w % 2] + raw
+        cw += oc["cnt_sampling_w"]; cz += r["counters"][11]; mw += oc["cnt_meas_w"]
+        bcw[w % 2] += oc["cnt_sampling_w"]; bcz[w % 2] += r["counters"][11]; bmw[w % 2] += oc["cnt_meas_w"]
+        o.close()
+    assert mw > 0
+    assert rel(q.g4iw_worm, pooled * cw / (mw * cz)) < TOL
+    bins = q.g4iw_worm_bins
+    assert bins.shape[0] == 2
+    for b in range(2):
+        assert rel(bins[b], binsum[b] * bcw[b] / (bmw[b] * bcz[b])) < TOL, b
+    q.dest_ctqmc(); q.close()
+
+
+def test_random_streams_continue_across_solves():
+    """The reference seeds its generator once (impurity.py:387) and the state survives init_solver / dest_ctqmc: a second
+    solve of the same context goes on in every chain's stream instead of replaying it (iteration 2 of a DMFT loop must
+    not repeat iteration 1).  Checked against oracle chains whose second solve shares the first one's generator."""
+    over = dict(BASE, Nwarmups=1500, Nmeas=10, NCorr=20, TaudiffMax=2.0, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05)
+    p, ps, pset = util.setup("C1", 501, over)
+    nw = 4
+    q = MCTQMC(nwalkers=nw, walkers_per_bin=1)
+    q.init_rnd(41); q.init_paras(ps)
+    first, second = [], []
+    for it in range(2):
+        q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, it + 1)
+        q.set_taudiffmax(2.0); q.ctqmc_warmup(1500); q.ctqmc_measure(1, 1)
+        (first if it == 0 else second).append((np.array(q.gleg_bins), [q.get_walker_state(w)["ndraw"] for w in range(nw)]))
+        q.dest_ctqmc()
+    assert not np.array_equal(first[0][0], second[0][0])
+    assert all(b > a for a, b in zip(first[0][1], second[0][1]))
+    for w in range(nw):
+        o1 = pyoracle.OracleWalker(p, pset, ("philox", 41, w))
+        o1.set_taudiffmax(2.0); o1.warmup(1500); o1.measure()
+        assert rel(first[0][0][w], o1.results()["gleg"]) < TOL
+        o2 = pyoracle.OracleWalker(p, pset, ("shared", o1))
+        o2.set_taudiffmax(2.0); o2.warmup(1500); o2.measure()
+        assert rel(second[0][0][w], o2.results()["gleg"]) < TOL, w
+        o2.close(); o1.close()
+    q.init_rnd(41)                                   # a new seed call starts the streams afresh
+    q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+    q.set_taudiffmax(2.0); q.ctqmc_warmup(1500); q.ctqmc_measure(1, 1)
+    assert np.array_equal(np.array(q.gleg_bins), first[0][0])
+    q.dest_ctqmc(); q.close()
+
+
+def test_soft_abort_by_signal():
+    """SIGUSR1 during ctqmc_measure (trapped from init_solver on, CTQMC.F90:8076-8078): the run stops between two launches,
+    what was measured is normalised, aborted = 1 (CTQMC.F90:8648-8658); the handlers are gone afterwards."""
+    import os, signal, threading, time
+    prev = signal.signal(signal.SIGUSR1, lambda *a: None)       # a stray late signal must not kill the test process
+    try:
+        over = dict(BASE, Nwarmups=1000, Nmeas=2000000, NCorr=50, TaudiffMax=2.0)
+        p, ps, pset = util.setup("C1", 501, over)
+        q = MCTQMC(nwalkers=256, walkers_per_bin=8)
+        q.init_rnd(3); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+        q.set_taudiffmax(2.0); q.ctqmc_warmup(1000)
+        t = threading.Timer(0.5, lambda: os.kill(os.getpid(), signal.SIGUSR1))
+        t0 = time.time(); t.start()
+        q.ctqmc_measure(1, 1)
+        t.join()
+        assert time.time() - t0 < 30.0
+        done = int(q.scalar("meas_done"))
+        assert q.aborted == 1 and 0 < done < over["Nmeas"]
+        assert q.mean_sign == -1.0 and np.abs(q.histo.sum(axis=-1) - 1.0).max() < 1e-12 and np.all(np.isfinite(q.gleg))
+        assert abs(q.occ[0, 0, 0, 0] - 0.5) < 0.05
+        q.dest_ctqmc()
+        # a complete run afterwards reports aborted = 0
+        _, ps2, _ = util.setup("C1", 501, dict(over, Nmeas=5))
+        q.init_paras(ps2); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 2)
+        q.set_taudiffmax(2.0); q.ctqmc_warmup(100); q.ctqmc_measure(1, 1)
+        assert q.aborted == 0 and int(q.scalar("meas_done")) == 5
+        q.dest_ctqmc(); q.close()
+    finally:
+        signal.signal(signal.SIGUSR1, prev)
 
 
 def test_ragged_and_empty_chains():

@@ -215,6 +215,15 @@ void free_device(w2dyn_solver *s)
     s->have_solver = false;
 }
 
+// memory budget of each family of two-particle accumulator bins (g4iw / g4iw_pp / g2iw, g4tau / g4leg, g4iw_worm): when one
+// bin per sample bin would exceed it, several sample bins share an accumulator bin (fewer, larger samples for the error bar).
+// W2DYN_ACC_BYTES overrides the default of 2 GiB.
+size_t acc_budget()
+{
+    if (const char *e = getenv("W2DYN_ACC_BYTES")) { const long long v = atoll(e); if (v > 0) return (size_t)v; }
+    return (size_t)2 << 30;
+}
+
 inline int flav_bit_h(int f, int nd) { return (f >> 1) + nd * (f & 1); }
 
 // window parameters, Trace.F90:1608-1648
@@ -603,7 +612,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if (s->fourpnt & 3) {
         const size_t pt = (s->fourpnt & 1) ? (size_t)nf * nf * s->n4tau * s->n4tau * s->n4tau : 0;
         const size_t pl = (s->fourpnt & 2) ? (size_t)nf * nf * s->n4leg * s->n4leg * (2 * s->n4iwb + 1) * 2 : 0;
-        s->nbl = (int)std::max<size_t>(1, std::min<size_t>(B, ((size_t)2 << 30) / std::max<size_t>((pt + pl) * sizeof(double), 1)));
+        s->nbl = (int)std::max<size_t>(1, std::min<size_t>(B, acc_budget() / std::max<size_t>((pt + pl) * sizeof(double), 1)));
         if (pt) { if ((rc = dev_alloc(s, s->acc_g4tau, (size_t)s->nbl * pt))) return rc; }
         if (pl) { if ((rc = dev_alloc(s, s->acc_g4leg, (size_t)s->nbl * pl))) return rc; }
     }
@@ -615,7 +624,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     }
     if (s->g4ph || s->g4pp) {
         const size_t n = (size_t)4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1) * 2 * ((s->g4ph ? 1 : 0) + (s->g4pp ? 1 : 0));
-        s->nbw = (int)std::max<size_t>(1, std::min<size_t>(B, ((size_t)2 << 30) / (n * sizeof(double))));
+        s->nbw = (int)std::max<size_t>(1, std::min<size_t>(B, acc_budget() / (n * sizeof(double))));
         const size_t one = (size_t)s->nbw * 4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1) * 2;
         if (s->g4ph) { if ((rc = dev_alloc(s, C.acc_g4w, one))) return rc; }
         if (s->g4pp) { if ((rc = dev_alloc(s, C.acc_g4wpp, one))) return rc; }
@@ -627,7 +636,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
         const size_t g2bytes = W * ng2 * sizeof(double2);
         if (g2bytes > ((size_t)32 << 30)) return fail(s, W2DYN_EUNSUPPORTED, "two-particle measurement: %zu bytes of per-chain g2 scratch; use fewer chains or frequencies", g2bytes);
         const size_t per = (n4 * (1 + (s->meas_g4iwpp ? 1 : 0)) + (s->meas_g2iw ? ng2 : 0)) * sizeof(double2);
-        s->nb4 = (int)std::max<size_t>(1, std::min<size_t>(B, ((size_t)2 << 30) / std::max<size_t>(per, 1)));
+        s->nb4 = (int)std::max<size_t>(1, std::min<size_t>(B, acc_budget() / std::max<size_t>(per, 1)));
         if ((rc = dev_alloc(s, s->G2, W * ng2))) return rc;
         if ((rc = dev_alloc(s, s->acc4, (size_t)s->nb4 * n4))) return rc;
         if (s->meas_g4iwpp) { if ((rc = dev_alloc(s, s->acc4pp, (size_t)s->nb4 * n4))) return rc; }
@@ -1579,6 +1588,7 @@ int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out)
     else if (n == "num_windows") *out = s->C.num_windows;
     else if (n == "nb4") *out = s->nb4;
     else if (n == "nbw") *out = s->nbw;
+    else if (n == "nbl") *out = s->nbl;
     else if (n == "wormeta") *out = s->worm_eta;
     else if (n == "ntau") *out = s->ntau;
     else if (n == "n4tau") *out = s->n4tau;
