@@ -126,6 +126,20 @@ def cpu_baseline(cores, wname, nmeas=6000, nwarm=50000, eta=1.0):
                       "%d measurements x NCorr=%d steps timed, same %s workload" % (cores, nwarm, nmeas, WORKLOADS[wname]["overrides"]["NCorr"], wname)}
 
 
+def issue_profile(config):
+    """Instruction mix of the sweep kernel from the committed rocprofv3 --pmc passes (profiles/*_sweep_instmix.json, made
+    by profiles/instmix.sh): the kernel is bound by vector-instruction issue and dependent-chain latency, not by HBM."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sweep_instmix.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("config", "C2") == config:
+            return d, os.path.basename(f)
+    return None, None
+
+
 def pmc_traffic(kernel, chains, config):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*_pmc.json, made by
     profiles/collect.sh + pmc_summary.py on the same command); None when no pass exists for this chain count."""
@@ -211,6 +225,7 @@ def main():
             q.wormeta[:] = eta
         q.set_sector(4, worm["component"])
     sweep_key = "sweep_worm" if worm else "sweep"
+    q.set_timing(True)      # HIP-event pairs around every launch, read out after the timed region (no host wait per launch)
     q.measure_begin()
     for _ in range(a.warmup):
         q.sweep(ncorr); q.measure_once()
@@ -290,7 +305,8 @@ def main():
             # the warm-up rounds are measured into the same accumulators: the error below belongs to steps+warmup rounds
             "gleg_err": {"max_stderr_l_lt_20": float(gl_err[..., :20].max()), "bins": int(nb),
                          "wall_s": dt * (a.steps + a.warmup) / a.steps},
-            "roofline": {"kernel": kname, "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": kname, "bound": "hbm", "note": "algorithmic bytes against HBM peak as the contract asks; the chain state is L2/LDS resident and the kernel is bound by vector-instruction issue and latency: see roofline_issue",
+                         "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach_gbs / HBM_PEAK_GBS, "traffic": tr_sweep, "traffic_source": tr_src, "avg_launch_ms": sweep_ms, "launches": nsweep,
                          "algorithmic_bytes_per_launch": bytes_sweep},
             "roofline_meas": {"kernel": mname, "bound": "mfma", "note": "fp64 vector FMA bound (fp64 vector peak == fp64 MFMA peak on MI355X)",
@@ -298,6 +314,19 @@ def main():
                               "traffic": tr_gleg, "avg_launch_ms": gleg_ms, "launches": ngleg, "algorithmic_flops_per_launch": flops_gleg},
             "kernel_ms": {kname: sweep_ms, mname: gleg_ms, "k_meas_misc": misc_ms},
         }
+        # the bound that matters for the sweep kernel ("fp64 vector issue rate and wavefront divergence"): vector
+        # instructions issued per Monte-Carlo step against the wave-instructions the algorithm itself needs, i.e. the
+        # FMA work of the proposals and accepted updates at 64 lanes: 2k^2/64 per det-ratio proposal, 4k^2/64 per accepted move
+        prof, prof_src = issue_profile(a.config)
+        alg_valu = ((c["tryadd"] - c["qnadd"]) * (2 * k2 + 10 * k1) + (c["accadd"] + c["accrem"]) * 4 * k2) / 64.0 / max(nlaunch_steps, 1)
+        out["roofline_issue"] = {"kernel": kname, "bound": "valu-issue", "algorithmic_valu_instr_per_step": alg_valu,
+                                 "steps_per_s_per_simd": value / world / 1024.0,
+                                 "source": prof_src}
+        if prof:
+            pm = prof["per_mc_step"]; wf = prof.get("wave_time_fraction", {})
+            out["roofline_issue"].update({"issued_valu_instr_per_step": pm["SQ_INSTS_VALU"], "issued_salu_instr_per_step": pm["SQ_INSTS_SALU"],
+                                          "frac": alg_valu / pm["SQ_INSTS_VALU"], "valu_busy_of_simd_time": wf.get("valu_busy_simd"),
+                                          "waves_per_simd": prof.get("waves_per_simd"), "wave_waiting_fraction": wf.get("waiting")})
         if over.get("AccumGtau") == 2:
             # algorithmic bytes of k_meas_gtau_ac: every touched level of every (chain, flavour, tau bin) is one
             # read-modify-write of (spill, mean, sqdiff) = 48 B; launch number n touches 1 + (trailing one bits of n) levels
@@ -315,9 +344,13 @@ def main():
             cs = q.cntsampling
             out["worm"] = {"eta": eta, "steps_z": int(cs[0]), "steps_worm": int(cs[3]), "component": worm["component"]}
         if world == 1 and not a.no_cpu_baseline:
+            # the GPU box gives one GPU's job 16 of the host's cores (worker pools beyond that are killed by its process
+            # guard); os.cpu_count() reports the whole machine, stated next to the cores actually used
             cores = a.cpu_cores or max(1, min(16, os.cpu_count() or 1))
             try:
                 out["cpu_baseline"] = cpu_baseline(cores, a.config, eta=eta)
+                out["cpu_baseline"]["host_cpus"] = os.cpu_count()
+                out["cpu_baseline"]["cores_note"] = "16 = this GPU's share of the host (1/8 of an 8-GPU node's cores); the reference scales linearly in ranks"
                 out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
                 ce = out["cpu_baseline"].get("gleg_err")
                 if ce:       # Monte-Carlo errors fall as 1/sqrt(time): CPU error scaled to the GPU's wall time

@@ -450,12 +450,47 @@ def test_ragged_and_empty_chains():
     o.close(); q.dest_ctqmc(); q.close()
 
 
-def test_capacity_overflow_is_reported():
-    p, ps, pset = util.setup("C1", 501, dict(BASE, Nwarmups=3000, Nmeas=1, NCorr=1, TaudiffMax=-1.0))
+def test_capacity_grows_instead_of_overflowing():
+    """The reference's matrices grow with the expansion order (MatrixUpdate.F90:410-442 reallocates); here a chain that
+    fills its kmax slots stops, the host enlarges the arrays and the chain goes on: with kmax = 2 (C1 needs ~8) warm-up,
+    calibration-free run and estimators retrace the oracle exactly as with the default capacity."""
+    over = dict(BASE, Nwarmups=3000, Nmeas=20, NCorr=20, TaudiffMax=-1.0, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05)
+    p, ps, pset = util.setup("C1", 501, over)
+    nw = 8
+    q = make_gpu(p, ps, 3, nw, wpb=1, kmax=2)
+    assert int(q.scalar("kmax")) == 2
+    q.set_taudiffmax(-1.0)
+    q.ctqmc_warmup(3000)
+    assert int(q.scalar("kmax")) > 2
+    q.ctqmc_measure(1, 1)
+    kmax_seen = 0
+    for w in range(nw):
+        o = pyoracle.OracleWalker(p, pset, ("philox", 3, w))
+        o.set_taudiffmax(-1.0); o.warmup(3000); o.measure()
+        r = o.results(); c = o.get_config()
+        n, osst, _ = q.get_mc_config_scalars(w)
+        assert n == len(c["taus"]) and osst == c["outer_sst"]
+        if n:
+            assert np.abs(q.get_mc_config(n, w)[0] - c["taus"]).max() < 1e-11
+        for k in ("gleg", "gtau", "occ", "histo"):
+            assert rel(getattr(q, k + "_bins")[w], r[k]) < TOL, (k, w)
+        for sp in (1, 2):
+            a, b = q.get_minv(w, 1, sp), o.minv(1, sp)
+            assert a.shape == b.shape and (a.size == 0 or rel(a, b) < TOL)
+        kmax_seen = max(kmax_seen, q.get_minv(w, 1, 1).shape[0], q.get_minv(w, 1, 2).shape[0])
+        o.close()
+    assert kmax_seen > 2
+    q.dest_ctqmc(); q.close()
+
+
+def test_capacity_overflow_inside_measurement_run_is_reported():
+    """Chains that stop at capacity in the middle of the asynchronous measurement loop cannot be repaired afterwards (their
+    measurements would be taken at the wrong steps): the run fails loudly with W2DYN_EOVERFLOW."""
+    p, ps, pset = util.setup("C1", 501, dict(BASE, Nwarmups=0, Nmeas=64, NCorr=100, TaudiffMax=-1.0))
     q = make_gpu(p, ps, 3, 8, kmax=2)
     q.set_taudiffmax(-1.0)
     with pytest.raises(W2DynError) as e:
-        q.ctqmc_warmup(3000)
+        q.ctqmc_measure(1, 1)          # no warm-up: the chains grow from the empty configuration inside the run
     assert e.value.code == -4
     q.close()
 

@@ -85,6 +85,9 @@ struct WalkerScalars {
     // worm sampling: current sector (0/1 = Z, 2 = one-particle worm c c+, 4 = two-particle worm c c+ c c+) and the
     // worm operators in wormContainer order (Trace.F90:123-125): times and flavours (the first `sector` entries count)
     int sector; int wflav[4]; double wtau[4];
+    // steps of an interrupted sweep launch still to do: a chain stops (ERR_KMAX set) as soon as one of its flavours has filled
+    // its kmax slots; the host enlarges the arrays and lets it finish (w2dyn_hip.hip: finish_paused)
+    long long todo;
 };
 
 struct DevConst {
@@ -104,6 +107,7 @@ struct DevConst {
     int *K;
     double *TC, *TA, *M, *MB, *TS;     // MB: second matrix buffer (global moves), TS: tau scratch [w][f][2][kmax]
     double *cfgsign;                   // [nwalkers] sign as seen by the estimators (= -sign, CTQMC.F90:3574)
+    int *flags;                        // [0] largest expansion order any chain has stored, [1] chains paused at capacity
     // accumulators (per bin)
     double *acc_gleg;     // [nbins][nflav][nleg]
     double *acc_gtau;     // [nbins][nflav][ntau]
@@ -771,6 +775,7 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
     }
     if (x.lane == 0) { Mf[(size_t)k * kmax + k] = invS; tcp[k] = tau2; tap[k] = tau1; }
     x.set_order(f, k + 1);
+    if (k + 1 >= kmax) x.err |= ERR_KMAX;              // flavour full: the sweep loop stops before the next step (capacity is enlarged by the host)
     wave_sync();
     x.det_sign *= (S < 0.0 ? -1.0 : 1.0) * sig;
     x.det_log += log(fabs(S));
@@ -1533,11 +1538,19 @@ __device__ __forceinline__ void ctx_load(Ctx &x)
     }
 }
 
-__device__ __forceinline__ void ctx_store(Ctx &x)
+__device__ __forceinline__ void ctx_store(Ctx &x, long long todo = 0)
 {
     const DevConst &C = x.C;
     const int w = x.w, nf = C.nflav, kmax = C.kmax;
     wave_sync();
+    {   // what the host looks at between launches: the largest order stored so far (read first: the atomic is rarely needed)
+        int mk = 0;
+        for (int f = 0; f < nf; ++f) mk = max(mk, x.order(f));
+        if (x.lane == 0) {
+            if (mk > C.flags[0]) atomicMax(&C.flags[0], mk);
+            if (todo > 0) atomicAdd(&C.flags[1], 1);
+        }
+    }
     for (int f = 0; f < nf; ++f) {
         int k = x.order(f);
         double *gc = C.TC + ((size_t)w * nf + f) * kmax, *ga = C.TA + ((size_t)w * nf + f) * kmax;
@@ -1547,12 +1560,28 @@ __device__ __forceinline__ void ctx_store(Ctx &x)
     if (x.lane < C_NCOUNT) s.cnt[x.lane] = x.cnt[x.lane] + (unsigned long long)x.cntreg;
     if (x.lane < nf) C.K[(size_t)w * nf + x.lane] = x.kreg;
     if (x.lane == 0) {
-        s.ndraw = x.rng_tell(); s.outer = x.outer; s.npairs = x.npairs; s.wpos = x.wpos; s.err = x.err;
+        s.ndraw = x.rng_tell(); s.outer = x.outer; s.npairs = x.npairs; s.wpos = x.wpos; s.err = x.err; s.todo = todo;
         s.det_sign = x.det_sign; s.det_log = x.det_log;
         s.sector = x.sector;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { s.wtau[i] = x.wtau[i]; s.wflav[i] = x.wfl[i]; }
     }
+}
+
+// Steps the chain has to do in this launch.  A normal launch (resume = 0) gives every chain nsteps; a chain still paused at
+// capacity from an earlier launch only notes them down.  A resume launch lets the paused chains finish what they owe.
+__device__ __forceinline__ long long launch_steps(const DevConst &C, int w, int lane, long long nsteps, int resume)
+{
+    WalkerScalars &s = C.ws[w];
+    const long long owed = ((long long)uni((int)(s.todo >> 32)) << 32) | (long long)(unsigned)uni((int)s.todo);
+    if (resume) return owed;
+    if (owed > 0) { if (lane == 0) { s.todo = owed + nsteps; atomicAdd(&C.flags[1], 1); } return 0; }
+    return nsteps;
+}
+// a chain loaded with a full flavour (set_mc_config with k = kmax) pauses before its first step
+__device__ __forceinline__ void flag_full(Ctx &x)
+{
+    if (__ballot(x.lane < x.C.nflav && x.kreg >= x.C.kmax) != 0ull) x.err |= ERR_KMAX;
 }
 
 #include "cthyb_worm.hip.h"
@@ -1571,14 +1600,14 @@ __device__ __forceinline__ void ctx_store(Ctx &x)
 #endif
 
 template <int MAT, bool CALIB = false>
-__global__ __launch_bounds__(256, MAT == 0 ? W2DYN_WPE : W2DYN_WPE_MAT) void k_sweep(DevConst C, long long nsteps, int count_sampling)
+__global__ __launch_bounds__(256, MAT == 0 ? W2DYN_WPE : W2DYN_WPE_MAT) void k_sweep(DevConst C, long long nsteps_launch, int count_sampling, int resume)
 {
     extern __shared__ unsigned char smem[];
     stage_shared_tables(C, smem);
     Ctx x(C);
     ctx_setup(x, smem);
     if (x.w >= C.nwalkers) return;
-    if constexpr (CALIB) {
+    if constexpr (CALIB) if (!resume) {
         bool done;
         if (C.calib == 1) done = C.apt_cnt[x.w] >= C.napt;
         else {
@@ -1587,13 +1616,17 @@ __global__ __launch_bounds__(256, MAT == 0 ? W2DYN_WPE : W2DYN_WPE_MAT) void k_s
         }
         if (uni((int)done)) return;
     }
+    const long long nsteps = launch_steps(C, x.w, x.lane, nsteps_launch, resume);
+    if (nsteps == 0) return;
     ctx_load(x);
+    flag_full(x);
     if constexpr (MAT != 0) mat_trace_current<MAT>(x);
     const double pg = C.p_glob, ps = C.p_shift;
     // position inside the window-shift period: (TryAdd+TryRem) mod NSlide (CTQMC.F90:8255, 8531)
     unsigned int phase = (unsigned int)((x.cnt[C_TRYADD] + x.cnt[C_TRYREM]) % (unsigned long long)C.nslide);
     phase = (unsigned int)uni((int)phase);
-    for (long long it = 0; it < nsteps; ++it) {
+    long long it = 0;
+    for (; it < nsteps && !(x.err & ERR_KMAX); ++it) {
         double r = x.draw();
 #ifdef W2DYN_STAMPS
         unsigned long long t0_ = __builtin_amdgcn_s_memtime();
@@ -1631,8 +1664,8 @@ __global__ __launch_bounds__(256, MAT == 0 ? W2DYN_WPE : W2DYN_WPE_MAT) void k_s
             } else x.wpos = 0;
         }
     }
-    if (count_sampling && x.lane == 0) x.cnt[C_SAMPLING] += (unsigned long long)nsteps;
-    ctx_store(x);
+    if (count_sampling && x.lane == 0) x.cnt[C_SAMPLING] += (unsigned long long)it;
+    ctx_store(x, nsteps - it);
 }
 
 // The library is built from several translation units (csrc/tu_*.hip, launch.hpp) that all include this header; kernel

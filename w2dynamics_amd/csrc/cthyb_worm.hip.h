@@ -284,19 +284,23 @@ __device__ W2DYN_INLINE void step_worm_rem_mat(Ctx &x)
 // sweep kernel with worm sampling: Z space CTQMC.F90:8431-8488, worm space 8489-8528.  MAT = 0: scalar trace path,
 // otherwise the matrix trace path instantiation (2, 3, 4, 9 as in k_sweep)
 template <int NW, int MAT>
-__global__ __launch_bounds__(256, W2DYN_WPE_WORM) void k_sweep_worm(DevConst C, long long nsteps)
+__global__ __launch_bounds__(256, W2DYN_WPE_WORM) void k_sweep_worm(DevConst C, long long nsteps_launch, int resume)
 {
     extern __shared__ unsigned char smem[];
     stage_shared_tables(C, smem);
     Ctx x(C);
     ctx_setup(x, smem);
     if (x.w >= C.nwalkers) return;
+    const long long nsteps = launch_steps(C, x.w, x.lane, nsteps_launch, resume);
+    if (nsteps == 0) return;
     ctx_load(x);
+    flag_full(x);
     if constexpr (MAT != 0) mat_trace_current<MAT>(x);
     const double pg = C.p_glob, ps = C.p_shift, pw = C.p_wins, pr = C.p_wrep;
     unsigned int phase = (unsigned int)((x.cnt[C_TRYADD] + x.cnt[C_TRYREM] + x.cnt[C_W_TRYADD] + x.cnt[C_W_TRYREM]) % (unsigned long long)C.nslide);
     phase = (unsigned int)uni((int)phase);
-    for (long long it = 0; it < nsteps; ++it) {
+    long long it = 0;
+    for (; it < nsteps && !(x.err & ERR_KMAX); ++it) {
 #ifdef W2DYN_STAMPS_WORM      // diagnostic build: shader-clock cycles per move type
         const unsigned long long t0_ = __builtin_amdgcn_s_memtime(); int kind_;
 #define WORM_KIND(c) kind_ = (c)
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(256, W2DYN_WPE_WORM) void k_sweep_worm(DevConst C, 
             } else x.wpos = 0;
         }
     }
-    ctx_store(x);
+    ctx_store(x, nsteps - it);
 }
 
 #ifdef W2DYN_TU_MEAS

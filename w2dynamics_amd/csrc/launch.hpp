@@ -9,18 +9,20 @@ struct LaunchCfg { dim3 grid, block; size_t lds; hipStream_t stream; };
 
 // mat: 0 = one-state blocks (closed-form trace); 2, 3, 4 = matrix path, blocks padded to that size (tree product);
 // 9 = matrix path, sequential propagation (blocks of 5..16 states)
-void launch_sweep(int mat, bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling);
-void launch_sweep_worm(int nworm, int mat, const LaunchCfg &l, const DevConst &C, long long nsteps);
+void launch_sweep(int mat, bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling, int resume);
+void launch_sweep_worm(int nworm, int mat, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume);
 void launch_meas_misc(int mat, const LaunchCfg &l, const DevConst &C);
 void launch_rebuild(const LaunchCfg &l, const DevConst &C);
+// chain arrays from capacity kold to knew > kold (tau arrays and M blocks keep their contents, row stride changes)
+void launch_relayout(const DevConst &C, hipStream_t st, int kold, int knew, const double *tc, const double *ta, const double *m, double *tc2, double *ta2, double *m2);
 
 // pieces (one per translation unit)
-void launch_sweep_scalar(bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling);
-void launch_sweep_tree(int mat, bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling);
-void launch_sweep_seq(bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling);
-void launch_sweep_worm_scalar(int nworm, const LaunchCfg &l, const DevConst &C, long long nsteps);
-void launch_sweep_worm_tree(int nworm, int mat, const LaunchCfg &l, const DevConst &C, long long nsteps);
-void launch_sweep_worm_seq(int nworm, const LaunchCfg &l, const DevConst &C, long long nsteps);
+void launch_sweep_scalar(bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling, int resume);
+void launch_sweep_tree(int mat, bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling, int resume);
+void launch_sweep_seq(bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling, int resume);
+void launch_sweep_worm_scalar(int nworm, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume);
+void launch_sweep_worm_tree(int nworm, int mat, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume);
+void launch_sweep_worm_seq(int nworm, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume);
 void launch_meas_misc_scalar(const LaunchCfg &l, const DevConst &C);
 void launch_meas_misc_tree(int mat, const LaunchCfg &l, const DevConst &C);
 void launch_meas_misc_seq(const LaunchCfg &l, const DevConst &C);

@@ -1,14 +1,14 @@
 // translation unit: Z-space sweep and misc estimators on the matrix trace path, blocks of 2..4 states (tree product)
 #include "launch.hpp"
 namespace w2dyn {
-template <int MAT> static void sweep_(bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count)
+template <int MAT> static void sweep_(bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count, int resume)
 {
-    if (calib) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<MAT, true>), l.grid, l.block, l.lds, l.stream, C, nsteps, count);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<MAT, false>), l.grid, l.block, l.lds, l.stream, C, nsteps, count);
+    if (calib) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<MAT, true>), l.grid, l.block, l.lds, l.stream, C, nsteps, count, resume);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<MAT, false>), l.grid, l.block, l.lds, l.stream, C, nsteps, count, resume);
 }
-void launch_sweep_tree(int mat, bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count)
+void launch_sweep_tree(int mat, bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count, int resume)
 {
-    if (mat == 2) sweep_<2>(calib, l, C, nsteps, count); else if (mat == 3) sweep_<3>(calib, l, C, nsteps, count); else sweep_<4>(calib, l, C, nsteps, count);
+    if (mat == 2) sweep_<2>(calib, l, C, nsteps, count, resume); else if (mat == 3) sweep_<3>(calib, l, C, nsteps, count, resume); else sweep_<4>(calib, l, C, nsteps, count, resume);
 }
 void launch_meas_misc_tree(int mat, const LaunchCfg &l, const DevConst &C)
 {

@@ -127,6 +127,8 @@ struct w2dyn_solver {
     std::vector<long long> res_accpair;
     std::vector<double> counters;                        // summed over walkers, C_NCOUNT
     std::map<std::string, KTimer> timers;
+    std::vector<hipEvent_t> ev_pool; std::vector<std::pair<std::string, size_t>> ev_pending;   // see drain_timers
+    int last_count_sampling = 0;
     bool timing = false;                                  // HIP-event timing of every launch (a host sync per launch): bench / profiling only, w2dyn_set_timing
     // position of every chain in its random stream, kept across init_solver / dest_ctqmc until the next init_rnd: the
     // reference seeds once (impurity.py:387, CTQMC.F90:9404-9408) and its generator state survives init_solver
@@ -237,6 +239,37 @@ void host_init_window(w2dyn_solver *s, double tdm, int &num_windows, double &tau
 }
 
 
+// Everything that follows from the expansion-order capacity kmax: window-list capacity, order limit of the LDS inversion,
+// LDS layout of the sweep kernels (init_solver, and again whenever the capacity is enlarged)
+int configure_kmax(w2dyn_solver *s, int kmax)
+{
+    DevConst &C = s->C; const LocalProblem &lp = s->lp; const int nf = s->nflav;
+    C.kmax = kmax;
+    C.wcap = std::max(kmax, std::min(2 * nf * kmax, 256));
+    C.kgj = std::min(kmax, 32);
+    C.shared_lds = 0; C.op_in_lds = 0;
+    if (s->mat) {
+        const size_t nop = (size_t)lp.nsst * nf * 2 * C.nsm * C.nsm;
+        size_t ints = (size_t)lp.nsst * nf * 4 * sizeof(short) + 2 * (size_t)lp.nsst * sizeof(int);
+        ints = (ints + 7) & ~(size_t)7;
+        size_t small = ints + (size_t)s->nstates * sizeof(double);
+        // Occupancy first: when two workgroups (2 waves per SIMD) fit into the CU's 160 KB with the operator matrices left
+        // in global memory (they are L2 resident) and a 16x16 Gauss-Jordan tile, take that layout: measured 1.55x on the
+        // t2g Kanamori problem against operators staged in LDS at one wave per SIMD.  W2DYN_MAT_OPS_IN_LDS=1/0 overrides.
+        const size_t per_wave16 = lds_bytes_per_wave(nf, kmax, C.wcap, std::min(C.kgj, 16), C.nsm);
+        bool two_groups = ((small + 15) & ~(size_t)15) + 4 * per_wave16 <= 80 * 1024;
+        if (const char *e = getenv("W2DYN_MAT_OPS_IN_LDS")) two_groups = (atoi(e) == 0);
+        if (two_groups) C.kgj = std::min(C.kgj, 16);
+        C.op_in_lds = (!two_groups && small + nop * sizeof(double) <= 64 * 1024) ? 1 : 0;
+        C.shared_lds = (int)((small + (C.op_in_lds ? nop * sizeof(double) : 0) + 15) & ~(size_t)15);
+    }
+    C.lds_per_wave = (int)lds_bytes_per_wave(nf, kmax, C.wcap, C.kgj, C.mat ? C.nsm : 0);
+    if ((size_t)C.shared_lds + 4 * (size_t)C.lds_per_wave > 160 * 1024 && C.kgj > 16) { C.kgj = 16; C.lds_per_wave = (int)lds_bytes_per_wave(nf, kmax, C.wcap, C.kgj, C.mat ? C.nsm : 0); }
+    if ((size_t)C.shared_lds + 4 * (size_t)C.lds_per_wave > 160 * 1024) return fail(s, W2DYN_EUNSUPPORTED, "kmax=%d needs %d bytes of LDS per chain: too large", kmax, C.lds_per_wave);
+    if ((s->fourpnt & 4) && (size_t)3 * kmax * G2_FC * sizeof(double2) > 160 * 1024) return fail(s, W2DYN_EUNSUPPORTED, "kmax=%d too large for the two-particle transform", kmax);
+    return 0;
+}
+
 LaunchCfg walker_launch(const w2dyn_solver *s)
 {
     LaunchCfg l;
@@ -249,14 +282,106 @@ LaunchCfg walker_launch(const w2dyn_solver *s)
 
 int mat_variant(const w2dyn_solver *s) { return !s->mat ? 0 : (s->lp.nsmax <= 2 ? 2 : (s->lp.nsmax <= 4 ? s->lp.nsmax : 9)); }
 
-int time_begin(w2dyn_solver *s) { if (s->timing) HIPCHK(hipEventRecord(s->ev0, s->stream)); return 0; }
+// ---- expansion-order capacity --------------------------------------------------------------------------------------
+// The reference's matrices grow with the expansion order; here every flavour has kmax slots.  A chain whose flavour fills
+// up stops before its next step (ERR_KMAX, WalkerScalars::todo = steps it still owes of that launch); the host then moves
+// all chains to larger arrays and lets the stopped ones finish.  Trajectories do not depend on kmax.
+int read_flags(w2dyn_solver *s, int &max_order, int &paused)
+{
+    int f[4] = {0, 0, 0, 0};
+    HIPCHK(hipStreamSynchronize(s->stream));
+    HIPCHK(hipMemcpy(f, s->C.flags, sizeof f, hipMemcpyDeviceToHost));
+    max_order = f[0]; paused = f[1];
+    return 0;
+}
+
+int grow_kmax(w2dyn_solver *s, int knew)
+{
+    DevConst &C = s->C; const int kold = C.kmax, nf = s->nflav; const size_t W = s->nwalkers;
+    knew = std::min((knew + 7) & ~7, (int)KMAX_LIMIT);
+    if (knew <= kold) return fail(s, W2DYN_EOVERFLOW, "a chain reached the expansion-order capacity kmax=%d, the largest this library handles", kold);
+    HIPCHK(hipStreamSynchronize(s->stream));
+    double *tc = C.TC, *ta = C.TA, *m = C.M, *ts = C.TS, *mb = C.MB;
+    int rc;
+    if ((rc = configure_kmax(s, knew))) { configure_kmax(s, kold); return fail(s, W2DYN_EOVERFLOW, "a chain reached the expansion-order capacity kmax=%d and the LDS layout does not allow more", kold); }
+    if ((rc = dev_alloc(s, C.TC, W * nf * knew))) return rc;
+    if ((rc = dev_alloc(s, C.TA, W * nf * knew))) return rc;
+    if ((rc = dev_alloc(s, C.TS, W * nf * 2 * knew))) return rc;
+    if ((rc = dev_alloc(s, C.M, W * nf * knew * knew))) return rc;
+    if ((rc = dev_alloc(s, C.MB, W * nf * knew * knew))) return rc;
+    launch_relayout(C, s->stream, kold, knew, tc, ta, m, C.TC, C.TA, C.M);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (double *p : {tc, ta, m, ts, mb}) {
+        (void)hipFree(p);
+        s->allocs.erase(std::remove(s->allocs.begin(), s->allocs.end(), (void *)p), s->allocs.end());
+    }
+    return 0;
+}
+
+// After a sweep launch the host has waited for: enlarge the capacity while chains are stopped at it and let them finish the
+// steps they owe.  kind: 0 = Z-space sweep, 1 = calibration sweep, 2 = worm sweep of the current sector.
+int finish_paused(w2dyn_solver *s, int kind)
+{
+    if (kind == 0 && s->cur_isector != 1) kind = 2;
+    for (int round = 0; round < 64; ++round) {
+        int maxk = 0, paused = 0, rc;
+        if ((rc = read_flags(s, maxk, paused))) return rc;
+        if (paused == 0) return 0;
+        if ((rc = grow_kmax(s, 2 * s->C.kmax))) return rc;
+        std::vector<WalkerScalars> ws(s->nwalkers);
+        HIPCHK(hipMemcpy(ws.data(), s->C.ws, ws.size() * sizeof(WalkerScalars), hipMemcpyDeviceToHost));
+        for (auto &w : ws) w.err &= ~ERR_KMAX;
+        HIPCHK(hipMemcpy(s->C.ws, ws.data(), ws.size() * sizeof(WalkerScalars), hipMemcpyHostToDevice));
+        const int zero[4] = {maxk, 0, 0, 0};
+        HIPCHK(hipMemcpy(s->C.flags, zero, sizeof zero, hipMemcpyHostToDevice));
+        LaunchCfg l = walker_launch(s);
+        if (kind == 2) launch_sweep_worm(s->cur_isector, mat_variant(s), l, s->C, 0, 1);
+        else launch_sweep(mat_variant(s), kind == 1, l, s->C, 0, s->last_count_sampling, 1);
+        HIPCHK(hipGetLastError());
+    }
+    return fail(s, W2DYN_EOVERFLOW, "expansion-order capacity: chains still stopped after repeated enlargement");
+}
+
+// between launches of a long run: enlarge early when the largest order comes within a quarter of the capacity, so that a
+// chain stopping in the middle of the asynchronous measurement loop (which cannot be repaired afterwards) stays exceptional
+int grow_if_close(w2dyn_solver *s)
+{
+    int maxk = 0, paused = 0, rc;
+    if ((rc = read_flags(s, maxk, paused))) return rc;
+    if (paused) return fail(s, W2DYN_EOVERFLOW, "a chain reached the expansion-order capacity kmax=%d between two checks of a measurement run; start with a larger kmax (w2dyn_set_layout)", s->C.kmax);
+    if (maxk + std::max(8, s->C.kmax / 4) > s->C.kmax && s->C.kmax < KMAX_LIMIT) return grow_kmax(s, 2 * s->C.kmax);
+    return 0;
+}
+
+// Kernel timing (w2dyn_set_timing): every launch is bracketed by a pair of HIP events recorded on the context's stream; the
+// host does not wait for them - the pairs are read out when the stream is waited for anyway (w2dyn_sync, w2dyn_kernel_time)
+// or when the pool of pairs runs out.
+constexpr size_t TIMER_POOL = 2048;
+int drain_timers(w2dyn_solver *s)
+{
+    if (s->ev_pending.empty()) return 0;
+    HIPCHK(hipStreamSynchronize(s->stream));
+    for (auto &pe : s->ev_pending) {
+        float ms = 0; HIPCHK(hipEventElapsedTime(&ms, s->ev_pool[2 * pe.second], s->ev_pool[2 * pe.second + 1]));
+        auto &t = s->timers[pe.first]; t.total_ms += ms; t.launches += 1;
+    }
+    s->ev_pending.clear();
+    return 0;
+}
+int time_begin(w2dyn_solver *s)
+{
+    if (!s->timing) return 0;
+    if (s->ev_pending.size() >= TIMER_POOL) { int rc = drain_timers(s); if (rc) return rc; }
+    while (s->ev_pool.size() < 2 * (s->ev_pending.size() + 1)) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); s->ev_pool.push_back(e); }
+    HIPCHK(hipEventRecord(s->ev_pool[2 * s->ev_pending.size()], s->stream));
+    return 0;
+}
 int time_end(w2dyn_solver *s, const char *name)
 {
     if (!s->timing) return 0;
-    HIPCHK(hipEventRecord(s->ev1, s->stream));
-    HIPCHK(hipEventSynchronize(s->ev1));
-    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
-    auto &t = s->timers[name]; t.total_ms += ms; t.launches += 1;
+    HIPCHK(hipEventRecord(s->ev_pool[2 * s->ev_pending.size() + 1], s->stream));
+    s->ev_pending.emplace_back(name, s->ev_pending.size());
     return 0;
 }
 
@@ -267,7 +392,7 @@ int check_walker_errors(w2dyn_solver *s)
     HIPCHK(hipStreamSynchronize(s->stream));
     int e = 0;
     for (auto &w : ws) e |= w.err;
-    if (e & ERR_KMAX) return fail(s, W2DYN_EOVERFLOW, "a chain reached the expansion-order capacity kmax=%d; raise it with w2dyn_set_layout", s->C.kmax);
+    if (e & ERR_KMAX) return fail(s, W2DYN_EOVERFLOW, "a chain stopped at the expansion-order capacity kmax=%d outside a phase that enlarges it; raise it with w2dyn_set_layout", s->C.kmax);
     if (e & ERR_WCAP) return fail(s, W2DYN_EOVERFLOW, "more than %d operators inside the sliding window; reduce TaudiffMax or raise kmax", s->C.wcap);
     if (e & ERR_DETRAT) return fail(s, W2DYN_ENUMERIC, "DetRat too small in removal");
     if (e & ERR_SINGULAR) return fail(s, W2DYN_ENUMERIC, "singular hybridisation matrix in full rebuild");
@@ -280,17 +405,17 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 }  // namespace
 
 namespace w2dyn {
-void launch_sweep(int mat, bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count)
+void launch_sweep(int mat, bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count, int resume)
 {
-    if (mat == 0) launch_sweep_scalar(calib, l, C, nsteps, count);
-    else if (mat <= 4) launch_sweep_tree(mat, calib, l, C, nsteps, count);
-    else launch_sweep_seq(calib, l, C, nsteps, count);
+    if (mat == 0) launch_sweep_scalar(calib, l, C, nsteps, count, resume);
+    else if (mat <= 4) launch_sweep_tree(mat, calib, l, C, nsteps, count, resume);
+    else launch_sweep_seq(calib, l, C, nsteps, count, resume);
 }
-void launch_sweep_worm(int nworm, int mat, const LaunchCfg &l, const DevConst &C, long long nsteps)
+void launch_sweep_worm(int nworm, int mat, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume)
 {
-    if (mat == 0) launch_sweep_worm_scalar(nworm, l, C, nsteps);
-    else if (mat <= 4) launch_sweep_worm_tree(nworm, mat, l, C, nsteps);
-    else launch_sweep_worm_seq(nworm, l, C, nsteps);
+    if (mat == 0) launch_sweep_worm_scalar(nworm, l, C, nsteps, resume);
+    else if (mat <= 4) launch_sweep_worm_tree(nworm, mat, l, C, nsteps, resume);
+    else launch_sweep_worm_seq(nworm, l, C, nsteps, resume);
 }
 void launch_meas_misc(int mat, const LaunchCfg &l, const DevConst &C)
 {
@@ -320,6 +445,7 @@ int w2dyn_destroy(w2dyn_solver *s)
     if (!s) return 0;
     (void)hipSetDevice(s->device);
     free_device(s);
+    for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -511,13 +637,10 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     C.nd = nd; C.nflav = nf; C.nstates = s->nstates; C.nftau = nftau; C.ntau = s->ntau; C.nleg = s->nleg; C.niw2 = 2 * s->niw;
     int kmax = s->kmax_req;
     if (kmax == 0) { kmax = (int)(0.4 * s->beta) + 24; kmax = (kmax + 7) & ~7; if (kmax > KMAX_LIMIT) kmax = KMAX_LIMIT; }   // overflow is detected and reported
-    C.kmax = kmax; C.nwalkers = s->nwalkers; C.has_szt = s->has_szt; C.maxhisto = s->maxhisto;
+    C.nwalkers = s->nwalkers; C.has_szt = s->has_szt; C.maxhisto = s->maxhisto;
     C.walkers_per_bin = s->walkers_per_bin; C.nbins = (s->nwalkers + s->walkers_per_bin - 1) / s->walkers_per_bin;
-    C.wcap = std::max(kmax, std::min(2 * nf * kmax, 256));
-    C.kgj = std::min(kmax, 32);
     { int G = 1, sh = 6; while (G < nf) { G <<= 1; --sh; } C.lane_shift = sh; }
     C.nouter = nouter; C.dmsize = s->dmoff[nouter]; C.mat = s->mat ? 1 : 0; C.nsst = lp.nsst; C.nsm = lp.nsmax;
-    C.shared_lds = 0; C.op_in_lds = 0;
     std::vector<double> opmat;
     if (s->mat) {
         const size_t nop = (size_t)lp.nsst * nf * 2 * C.nsm * C.nsm;
@@ -529,22 +652,8 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
             for (int i = 0; i < n2; ++i) for (int j = 0; j < n1; ++j) dst[i * C.nsm + j] = O[i + (size_t)n2 * j];
         }
         if (lp.nsst > 32767) return fail(s, W2DYN_EUNSUPPORTED, "%d blocks: more than the 16-bit block tables hold", lp.nsst);
-        size_t ints = (size_t)lp.nsst * nf * 4 * sizeof(short) + 2 * (size_t)lp.nsst * sizeof(int);
-        ints = (ints + 7) & ~(size_t)7;
-        size_t small = ints + (size_t)s->nstates * sizeof(double);
-        // Occupancy first: when two workgroups (2 waves per SIMD) fit into the CU's 160 KB with the operator matrices left
-        // in global memory (they are L2 resident) and a 16x16 Gauss-Jordan tile, take that layout: measured 1.55x on the
-        // t2g Kanamori problem against operators staged in LDS at one wave per SIMD.  W2DYN_MAT_OPS_IN_LDS=1/0 overrides.
-        const size_t per_wave16 = lds_bytes_per_wave(nf, kmax, C.wcap, std::min(C.kgj, 16), C.nsm);
-        bool two_groups = ((small + 15) & ~(size_t)15) + 4 * per_wave16 <= 80 * 1024;
-        if (const char *e = getenv("W2DYN_MAT_OPS_IN_LDS")) two_groups = (atoi(e) == 0);
-        if (two_groups) C.kgj = std::min(C.kgj, 16);
-        C.op_in_lds = (!two_groups && small + nop * sizeof(double) <= 64 * 1024) ? 1 : 0;
-        C.shared_lds = (int)((small + (C.op_in_lds ? nop * sizeof(double) : 0) + 15) & ~(size_t)15);
     }
-    C.lds_per_wave = (int)lds_bytes_per_wave(nf, kmax, C.wcap, C.kgj, C.mat ? C.nsm : 0);
-    if ((size_t)C.shared_lds + 4 * (size_t)C.lds_per_wave > 160 * 1024 && C.kgj > 16) { C.kgj = 16; C.lds_per_wave = (int)lds_bytes_per_wave(nf, kmax, C.wcap, C.kgj, C.mat ? C.nsm : 0); }
-    if ((size_t)C.shared_lds + 4 * (size_t)C.lds_per_wave > 160 * 1024) return fail(s, W2DYN_EUNSUPPORTED, "kmax=%d needs %d bytes of LDS per chain: too large", kmax, C.lds_per_wave);
+    { int rc0 = configure_kmax(s, kmax); if (rc0) return rc0; }
     C.beta = s->beta; C.p_glob = s->p_glob; C.p_shift = s->p_shift; C.egs = s->egs;
     C.seed = (unsigned long long)s->seed; C.first_walker = (unsigned long long)s->first_walker;
     host_init_window(s, s->taudiffmax_param, C.num_windows, C.taudiff_max);           // Trace.F90:605
@@ -578,6 +687,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if ((rc = dev_alloc(s, C.M, W * nf * kmax * kmax))) return rc;
     if ((rc = dev_alloc(s, C.MB, W * nf * kmax * kmax))) return rc;
     if ((rc = dev_alloc(s, C.cfgsign, W))) return rc;
+    if ((rc = dev_alloc(s, C.flags, 4))) return rc;
     const size_t B = C.nbins;
     if ((rc = dev_alloc(s, C.acc_gleg, B * nf * s->nleg))) return rc;
     if ((rc = dev_alloc(s, C.acc_gtau, B * nf * s->ntau))) return rc;
@@ -708,8 +818,9 @@ int w2dyn_sweep(w2dyn_solver *s, int64_t nsteps, int count_as_sampling)
     if ((rc = time_begin(s))) return rc;
     // instantiations: 0 = one-state blocks (closed-form trace); 2, 3, 4 = matrix path with blocks padded to that size
     // (tree product); 9 = matrix path, sequential propagation (blocks of 5..8 states)
-    if (s->cur_isector == 4 || s->cur_isector == 2) launch_sweep_worm(s->cur_isector, mat_variant(s), l, s->C, (long long)nsteps);   // counts its own steps
-    else launch_sweep(mat_variant(s), false, l, s->C, (long long)nsteps, count_as_sampling);
+    if (s->cur_isector == 4 || s->cur_isector == 2) launch_sweep_worm(s->cur_isector, mat_variant(s), l, s->C, (long long)nsteps, 0);   // counts its own steps
+    else launch_sweep(mat_variant(s), false, l, s->C, (long long)nsteps, count_as_sampling, 0);
+    s->last_count_sampling = count_as_sampling;
     HIPCHK(hipGetLastError());
     if ((rc = time_end(s, s->cur_isector != 1 ? "sweep_worm" : "sweep"))) return rc;
     s->steps_done += nsteps;
@@ -721,7 +832,7 @@ int w2dyn_sync(w2dyn_solver *s)
     if (!s) return W2DYN_EINVAL;
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->stream));
-    return 0;
+    return drain_timers(s);
 }
 
 int w2dyn_ctqmc_calibrate(w2dyn_solver *s, int list, int phase1pairnum, int phase2taugrid, int phase2pairnum, int nprogress)
@@ -754,9 +865,10 @@ int w2dyn_ctqmc_calibrate(w2dyn_solver *s, int list, int phase1pairnum, int phas
     bool done = false;
     for (long long it = 0; it < 1000000 && !done && !g_signal_fired; ++it) {      // CTQMC.F90:8123
         if ((rc = time_begin(s))) return rc;
-        launch_sweep(mat_variant(s), true, l, s->C, chunk, 0);
+        launch_sweep(mat_variant(s), true, l, s->C, chunk, 0, 0);
         HIPCHK(hipGetLastError());
         if ((rc = time_end(s, "sweep_calibrate"))) return rc;
+        if ((rc = finish_paused(s, 1))) return rc;
         HIPCHK(hipMemcpyAsync(cnt.data(), list ? C.apt_cnt : C.calib_pairs, cnt.size() * sizeof(int), hipMemcpyDeviceToHost, s->stream));
         HIPCHK(hipStreamSynchronize(s->stream));
         done = true;
@@ -794,8 +906,9 @@ int w2dyn_ctqmc_warmup(w2dyn_solver *s, int64_t n)
     const int64_t WARMUP_CHUNK = 200000;
     for (int64_t done = 0; done < n && !g_signal_fired; done += WARMUP_CHUNK) {
         if ((rc = w2dyn_sweep(s, std::min<int64_t>(WARMUP_CHUNK, n - done), 0))) return rc;
-        if (done + WARMUP_CHUNK < n) { if ((rc = w2dyn_sync(s))) return rc; }
+        if ((rc = finish_paused(s, 0))) return rc;
     }
+    if ((rc = grow_if_close(s))) return rc;
     if ((rc = check_walker_errors(s))) return rc;
     s->time_warmup = now_s() - t0;
     return 0;
@@ -1278,7 +1391,7 @@ int w2dyn_ctqmc_measure(w2dyn_solver *s, int isector, int icomponent)
         if ((rc = w2dyn_sweep(s, s->ncorr, 1))) return rc;
         tsteps += now_s() - a;
         if ((rc = w2dyn_measure_once(s))) return rc;
-        if ((m % MEAS_SYNC) == MEAS_SYNC - 1) { if ((rc = w2dyn_sync(s))) return rc; }
+        if ((m % MEAS_SYNC) == MEAS_SYNC - 1) { if ((rc = grow_if_close(s))) return rc; }
     }
     if ((rc = w2dyn_sync(s))) return rc;
     s->time_sim = now_s() - t0; s->time_sim_steps = tsteps;
@@ -1323,10 +1436,16 @@ int w2dyn_count_steps(w2dyn_solver *s, int isector, int icomponent, int64_t nfix
     HIPCHK(hipMemcpy(K0.data(), C.K, K0.size() * sizeof(int), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(TC0.data(), C.TC, TC0.size() * sizeof(double), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(TA0.data(), C.TA, TA0.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const int kmax0 = C.kmax;
     if ((rc = w2dyn_sweep(s, nfix, 1))) return rc;
-    if ((rc = w2dyn_sync(s))) return rc;
+    if ((rc = finish_paused(s, 2))) return rc;
     if ((rc = check_walker_errors(s))) return rc;
     HIPCHK(hipMemcpy(ws1.data(), C.ws, W * sizeof(WalkerScalars), hipMemcpyDeviceToHost));
+    if (C.kmax != kmax0) {      // the capacity was enlarged during the search: the saved tau arrays go to the new stride
+        std::vector<double> tc((size_t)W * nf * C.kmax, 0.0), ta((size_t)W * nf * C.kmax, 0.0);
+        for (size_t wf = 0; wf < W * nf; ++wf) for (int e = 0; e < K0[wf]; ++e) { tc[wf * C.kmax + e] = TC0[wf * kmax0 + e]; ta[wf * C.kmax + e] = TA0[wf * kmax0 + e]; }
+        TC0.swap(tc); TA0.swap(ta);
+    }
     s->steps_worm_chains.assign(W, 0);
     double sw = 0.0;
     for (size_t w = 0; w < W; ++w) { s->steps_worm_chains[w] = (long long)ws1[w].cnt[C_W_SAMPLING]; sw += (double)ws1[w].cnt[C_W_SAMPLING]; }
@@ -1474,9 +1593,16 @@ int w2dyn_restore_mc_configs(w2dyn_solver *s)
 {
     if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "restore_mc_configs before init_solver");
     const DevConst &C = s->C; const size_t W = s->nwalkers, nf = s->nflav, kmax = C.kmax;
-    if (s->snap_ws.size() != W || s->snap_nf != (int)nf || s->snap_kmax != (int)kmax)
-        return fail(s, W2DYN_EINVAL, "restore_mc_configs: no saved configurations of this shape (chains %zu/%zu, flavours %d/%zu, kmax %d/%zu)",
-                    s->snap_ws.size(), W, s->snap_nf, nf, s->snap_kmax, kmax);
+    if (s->snap_ws.size() != W || s->snap_nf != (int)nf)
+        return fail(s, W2DYN_EINVAL, "restore_mc_configs: no saved configurations of this shape (chains %zu/%zu, flavours %d/%zu)",
+                    s->snap_ws.size(), W, s->snap_nf, nf);
+    if (s->snap_kmax != (int)kmax) {      // saved at another capacity (it was enlarged in between, or set differently): re-stride
+        int need = 0; for (int k : s->snap_K) need = std::max(need, k);
+        if (need > (int)kmax) { int rc = grow_kmax(s, need + 8); if (rc) return rc; return w2dyn_restore_mc_configs(s); }
+        std::vector<double> tc(W * nf * kmax, 0.0), ta(W * nf * kmax, 0.0);
+        for (size_t wf = 0; wf < W * nf; ++wf) for (int e = 0; e < s->snap_K[wf]; ++e) { tc[wf * kmax + e] = s->snap_TC[wf * s->snap_kmax + e]; ta[wf * kmax + e] = s->snap_TA[wf * s->snap_kmax + e]; }
+        s->snap_TC.swap(tc); s->snap_TA.swap(ta); s->snap_kmax = (int)kmax;
+    }
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->stream));
     std::vector<WalkerScalars> ws(W);
@@ -1606,6 +1732,7 @@ int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out)
 int w2dyn_kernel_time(w2dyn_solver *s, const char *kernel, double *avg_ms, int64_t *launches, int reset)
 {
     if (!s || !kernel) return W2DYN_EINVAL;
+    { int rc = drain_timers(s); if (rc) return rc; }
     auto &t = s->timers[kernel];
     if (avg_ms) *avg_ms = t.launches ? t.total_ms / (double)t.launches : 0.0;
     if (launches) *launches = t.launches;
