@@ -10,6 +10,7 @@ def probe(cfg, nftau, over, nw, kmax=0, rounds=int(os.environ.get('PROBE_ROUNDS'
     p, ps, pset = util.setup(cfg, nftau, over)
     q = MCTQMC(nwalkers=nw, walkers_per_bin=8, kmax=kmax)
     q.init_rnd(1); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+    q.set_timing(True)
     q.set_taudiffmax(over["TaudiffMax"]); q.ctqmc_warmup(thermal); q.measure_begin()
     q.sweep(over["NCorr"]); q.measure_once(); q.sync()
     for k in ("sweep", "meas_gleg", "meas_misc"): q.kernel_time(k, reset=True)
@@ -28,6 +29,9 @@ def probe(cfg, nftau, over, nw, kmax=0, rounds=int(os.environ.get('PROBE_ROUNDS'
         if len(c) >= 24:
             print("   rem stages (cycles per rem try): window %.0f pick %.0f between %.0f trace+prob %.0f | add: draws+qn %.0f (per try), detratio %.0f trace/np/prob %.0f (per valid=%d), accept-update %.0f (per acc=%d)" % (
                 c[16] / c[3], c[17] / c[3], c[18] / c[3], c[19] / c[3], c[20] / c[0], c[21] / max(c[0] - c[2], 1), c[22] / max(c[0] - c[2], 1), c[0] - c[2], c[23] / max(c[1], 1), c[1]), flush=True)
+    if os.environ.get("PROBE_ACC") and len(c) >= 24:
+        print("   accepted add (cycles per accept, n=%d): ranks+RM/MQ %.0f update+store %.0f det/log %.0f window list %.0f | accepted rem (n=%d): ranks+dnp %.0f row/col %.0f update+store %.0f det/log+window list %.0f" % (
+            c[1], c[16] / c[1], c[17] / c[1], c[18] / c[1], c[19] / c[1], c[4], c[20] / c[4], c[21] / c[4], c[22] / c[4], c[23] / c[4]), flush=True)
     if os.environ.get("PROBE_PICK") and len(c) >= 24:
         print("   pick: n=%d, LDS path (nw>64) %.4f, mean nw %.1f, register-path cycles per pick %.0f" % (c[3], c[21] / max(c[3], 1), c[22] / max(c[3], 1), c[23] / max(c[3] - c[21], 1)), flush=True)
     if os.environ.get("PROBE_GLOB") and len(c) >= 24:

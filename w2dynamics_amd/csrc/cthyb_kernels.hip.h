@@ -31,6 +31,13 @@
 #define DBG_STAMP(x, c)
 #define DBG_START(x)
 #endif
+#ifdef W2DYN_STAMPS_ACC       // diagnostic build: stage stamps inside the accepted-move paths (add: DBG0-3, rem: DBG4-7)
+#define ACC_STAMP(x, c) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((x).lane == 0) (x).cnt[c] += t_ - (x).tstamp; (x).tstamp = t_; } while (0)
+#define ACC_START(x) (x).tstamp = __builtin_amdgcn_s_memtime()
+#else
+#define ACC_STAMP(x, c)
+#define ACC_START(x)
+#endif
 #ifdef W2DYN_STAMPS_GLOB      // diagnostic build: the stage stamps time the global move instead of the pair moves
 #define GLOB_STAMP(x, c) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((x).lane == 0) (x).cnt[c] += t_ - (x).tstamp; (x).tstamp = t_; } while (0)
 #define GLOB_START(x) (x).tstamp = __builtin_amdgcn_s_memtime()
@@ -721,6 +728,7 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
         return;
     }
 
+    ACC_START(x);
     // time-ordered ranks of the new operators for the cofactor sign (-1)^|FPos1-FPos2| (Trace.F90:2828)
     int pc = 0, pa = 0;
     for (int base = 0; base < k; base += 64) {
@@ -731,27 +739,29 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
     }
     const double sig = ((pc - pa) & 1) ? -1.0 : 1.0;
     // accepted: M' = [[M + MQ RM^T / S, -MQ/S], [-RM^T/S, 1/S]] with the new row/column appended at slot k.
-    // lane l computes RM_l (column sum, coalesced) and MQ_l (row sum) together, eight rows/columns per round trip.
-    for (int l0 = 0; l0 < k; l0 += 64) {
-        int l = l0 + x.lane;
-        int lc = l < k ? l : k - 1;
-        double rm = 0.0, mq = 0.0;
-        for (int i0 = 0; i0 < k; i0 += ADD_UNROLL) {
-            double mc[ADD_UNROLL], mr[ADD_UNROLL];
+    // MQ_i = sum_j M_ij Q_j and RM_j = sum_i R_i M_ij come from one coalesced pass over the flattened block (element e in
+    // lane e mod 64): every element adds its two products to the LDS vectors with ds_add_f64, instead of every lane
+    // walking a row and a column of M (strided loads, three dependent round trips at k = 17)
+    for (int e = x.lane; e < k; e += 64) { x.MQ[e] = 0.0; x.RM[e] = 0.0; }
+    lds_sync();
+    for (int e0 = 0; e0 < kk; e0 += 256) {
+        double mv[4]; int iv[4], jv[4];
 #pragma unroll
-            for (int u = 0; u < ADD_UNROLL; ++u) {
-                int i = i0 + u < k ? i0 + u : k - 1;
-                mc[u] = Mf[(size_t)i * kmax + lc];
-                mr[u] = Mf[(size_t)lc * kmax + i];
-            }
-#pragma unroll
-            for (int u = 0; u < ADD_UNROLL; ++u) {
-                if (i0 + u < k) { rm += x.R[i0 + u] * mc[u]; mq += mr[u] * x.Q[i0 + u]; }
-            }
+        for (int u = 0; u < 4; ++u) {
+            int e = e0 + u * 64 + x.lane;
+            int ec = e < kk ? e : kk - 1;
+            int i = (int)(((unsigned)ec * magic) >> 24), j = ec - i * k;
+            iv[u] = i; jv[u] = j;
+            mv[u] = Mf[(size_t)i * kmax + j];
         }
-        if (l < k) { x.RM[l] = rm; x.MQ[l] = mq; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int e = e0 + u * 64 + x.lane;
+            if (e < kk) { atomicAdd(&x.MQ[iv[u]], mv[u] * x.Q[jv[u]]); atomicAdd(&x.RM[jv[u]], x.R[iv[u]] * mv[u]); }
+        }
     }
-    wave_sync();
+    lds_sync();
+    ACC_STAMP(x, C_DBG0);
     double invS = 1.0 / S;
     for (int e0 = 0; e0 < kk; e0 += 256) {
         double mv[4]; int iv[4], jv[4];
@@ -777,10 +787,13 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
     x.set_order(f, k + 1);
     if (k + 1 >= kmax) x.err |= ERR_KMAX;              // flavour full: the sweep loop stops before the next step (capacity is enlarged by the host)
     wave_sync();
+    ACC_STAMP(x, C_DBG1);
     x.det_sign *= (S < 0.0 ? -1.0 : 1.0) * sig;
     x.det_log += log(fabs(S));
     x.npairs = np_new;
+    ACC_STAMP(x, C_DBG2);
     window_list_add(x, f, k, tau2, tau1);
+    ACC_STAMP(x, C_DBG3);
     if constexpr (MAT) { x.tr_log = tl_new; x.tr_sign = ts_new; mat_commit_sst(x); }
     DBG_STAMP(x, C_DBG7);
     if (WORM && x.sector != 1) x.count(C_W_ACCADD); else x.count(C_ACCADD);
@@ -954,6 +967,7 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
     if (!(rnd < prob)) return;
     if (fabs(S) < 1e-12) { x.err |= ERR_DETRAT; return; }   // CTQMC.F90:4062 stops here
 
+    ACC_START(x);
     // NPairs after the removal: every pair that contains one of the two operators disappears; time-ordered ranks
     // of the two operators for the cofactor sign (Trace.F90:2958-2959)
     int dnp = 0, pc = 0, pa = 0;
@@ -968,14 +982,17 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
     dnp += 1;   // the removed pair itself (it was picked from the removable ones)
     const double sig = ((pc - pa) & 1) ? -1.0 : 1.0;
 
-    for (int e = x.lane; e < k; e += 64) { x.RM[e] = Mf[(size_t)ic * kmax + e]; x.MQ[e] = Mf[(size_t)e * kmax + ia]; }
-    wave_sync();
-    // M'_ij = M_ij - M_i,ia M_ic,j / M_ic,ia for i != ic, j != ia; the last row/column move into the freed slots.
-    // Every source element is read by exactly one lane before anything is written over it (row ic / column ia are
-    // only read above), so the update is done in place.
+    ACC_STAMP(x, C_DBG4);
+    // M'_ij = M_ij - M_i,ia M_ic,j / M_ic,ia for i != ic, j != ia; the last row/column move into the freed slots.  A lane
+    // writes either to the place it read from or into row ic / column ia, which are sources of nothing but the two
+    // vectors read first, so the update is done in place and no wait separates the loads of a chunk from its stores.
     const int last = k - 1;
     const int kk = k * k;
     const unsigned magic = (1u << 24) / (unsigned)k + 1u;
+    const double invS = 1.0 / S;
+    for (int e = x.lane; e < k; e += 64) { x.RM[e] = Mf[(size_t)ic * kmax + e]; x.MQ[e] = Mf[(size_t)e * kmax + ia] * invS; }
+    wave_sync();
+    ACC_STAMP(x, C_DBG5);
     for (int e0 = 0; e0 < kk; e0 += 256) {
         double mv[4]; int iv[4], jv[4];
 #pragma unroll
@@ -986,24 +1003,25 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
             iv[u] = i; jv[u] = j;
             mv[u] = Mf[(size_t)i * kmax + j];
         }
-        wave_sync();      // all loads of this batch are done before any store of it (a store may hit another lane's source)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             int e = e0 + u * 64 + x.lane;
             int i = iv[u], j = jv[u];
             if (e < kk && i != ic && j != ia) {
                 int id = (i == last) ? ic : i, jd = (j == last) ? ia : j;
-                Mf[(size_t)id * kmax + jd] = mv[u] - x.MQ[i] * x.RM[j] / S;
+                Mf[(size_t)id * kmax + jd] = mv[u] - x.MQ[i] * x.RM[j];
             }
         }
     }
     if (x.lane == 0) { tcp[ic] = tcp[last]; tap[ia] = tap[last]; }
     x.set_order(f, last);
     wave_sync();
+    ACC_STAMP(x, C_DBG6);
     x.det_sign *= (S < 0.0 ? -1.0 : 1.0) * sig;
     x.det_log += log(fabs(S));
     x.npairs = np - dnp;
     window_list_rem(x, f, e1, e2, ic, ia, last, tau_c, tau_a);
+    ACC_STAMP(x, C_DBG7);
     if constexpr (MAT) { mat_remove(x, i2); mat_remove(x, i1); x.tr_log = tl_new; x.tr_sign = ts_new; mat_commit_sst(x); }
     if (WORM && x.sector != 1) x.count(C_W_ACCREM); else x.count(C_ACCREM);
     accpair_add<CALIB>(x, f, t2 - t1);
