@@ -247,19 +247,20 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    # the exchange step of the path: accumulators of all ranks combined by one all-reduce (untimed here, it runs once
-    # per solve; its duration is reported)
+    # the exchange step of the path (untimed here, it runs once per solve; its duration is reported): the moments of the
+    # per-bin results are made on the GPU and the packed device buffer goes through ONE RCCL all-reduce; mean and
+    # standard error over the accumulator bins of all ranks come out of it (w2dyn_reduce_pack, statistics.PackedMoments)
     q.measure_finish()
+    from w2dynamics_amd.statistics import DistributedSample
     t1 = time.perf_counter()
-    gl, gt, oc, hi = comm.allreduce_packed([q.gleg, q.gtau, q.occ, q.histo])
+    if rehearse:           # gloo rehearsal on one GPU: host path
+        sg, sh = DistributedSample(q.gleg_bins, comm), DistributedSample(q.histo_bins, comm)
+    else:
+        pack = q.reduce_pack(["gleg", "gtau", "histo"] + (["g4iw_worm"] if worm else []), comm).allreduce()
+        sg, sh = pack.sample("gleg"), pack.sample("histo")
+    gl, hi, gl_err, nb = sg.mean(), sh.mean(), sg.stderr(), float(sg.ntotal)
     t_reduce = time.perf_counter() - t1
-    gl /= world; oc /= world; hi /= world
-    # G(l) error reached in the timed wall time: standard error over the accumulator bins of all ranks (sum and sum of
-    # squares of the per-bin results through the same all-reduce)
-    gb = np.asarray(q.gleg_bins, dtype=np.float64)
-    s1, s2, nb = comm.allreduce_packed([gb.sum(axis=0), (gb ** 2).sum(axis=0), np.array([float(gb.shape[0])])])
-    nb = float(nb[0])
-    gl_err = np.sqrt(np.maximum(s2 / nb - (s1 / nb) ** 2, 0.0) * nb / max(nb - 1.0, 1.0) / nb)
+    oc = DistributedSample(q.occ_bins, comm).mean()
 
     sweep_ms, nsweep = q.kernel_time(sweep_key)
     gleg_ms, ngleg = q.kernel_time("meas_g4w" if worm else "meas_gleg")

@@ -107,6 +107,18 @@ int w2dyn_measure_finish(w2dyn_solver *s);
  * event timing.  chains x flavours x (2 (N4iwf + N4iwb))^2 x 16 bytes beyond 32 MiB -> W2DYN_EINVAL.  All contexts of a GPU
  * share the array: calls that overlap on one GPU (two contexts, two streams) race. */
 int w2dyn_measure_once_noalloc(w2dyn_solver *s);
+
+/* Cross-rank reduction input, made on the GPU.  Replaces the host side of the reference's exchange step: there every
+ * result array is copied out of the module and all-reduced per quantity and per statistic
+ * (w2dyn/auxiliaries/statistics.py:130-209 on the arrays of impurity.py:1198-1283).  `names`: comma-separated per-bin results
+ * of the finished run ("gleg,gtau,giw,histo,g4iw,g4iw_pp,g2iw,g4iw_worm,g4iwpp_worm,giw_worm,gtau_worm" as present).  For
+ * name i with B bins of P = counts[i] doubles (complex: re, im interleaved) the buffer holds at offsets[i]
+ *     [ B | S = sum_b x_b (P) | sum_b (x_b - S/B)^2 (P) | S^2/B (P) ],          x_b = the normalised bin (what "<name>_bins" returns)
+ * so that ONE sum-all-reduce of the whole buffer over the ranks gives count, mean and variance of every quantity:
+ * sum_i |x_i - m|^2 = [sum of the third block] + [sum of the fourth block] - (sum S)^2 / (sum B).
+ * *dev_ptr is device memory owned by the context (valid until the next w2dyn_reduce_pack or w2dyn_destroy), complete when
+ * the call returns; hand it to RCCL as it is.  Call between ctqmc_measure and dest_ctqmc. */
+int w2dyn_reduce_pack(w2dyn_solver *s, const char *names, void **dev_ptr, size_t *ndoubles, size_t *offsets, size_t *counts, int max_names);
 int w2dyn_sync(w2dyn_solver *s);                    /* wait for the context's stream */
 
 /* configuration of one chain ---------------------------------------------------------------------------------- */

@@ -53,6 +53,20 @@ def _worker(rank, world, port, out):
         res["allreduce"] = buf
         a, b, c = comm.allreduce_packed([real.sum(0), cplx.sum(0), np.array([rank + 1], dtype=np.int64)])
         res["packed_a"] = a; res["packed_b"] = b; res["packed_c"] = c
+        # moments packed the way w2dyn_reduce_pack lays them out (here made with numpy on a CPU tensor), all-reduced
+        # as one tensor and read back as samples: [B | S | sum (x - S/B)^2 | S^2/B] per quantity, complex interleaved
+        import torch
+        from w2dynamics_amd.statistics import PackedMoments
+        def record(x):
+            flat = np.ascontiguousarray(x).reshape(x.shape[0], -1)
+            flat = flat.view(np.float64) if np.iscomplexobj(flat) else flat
+            s1 = flat.sum(0)
+            return np.concatenate([[flat.shape[0]], s1, ((flat - s1 / flat.shape[0]) ** 2).sum(0), s1 ** 2 / flat.shape[0]])
+        ra, rb = record(real), record(cplx)
+        pm = PackedMoments(torch.from_numpy(np.concatenate([ra, rb])), {"real": (0, (ra.size - 1) // 3, real.shape[1:], False),
+                                                                       "cplx": (ra.size, (rb.size - 1) // 3, cplx.shape[1:], True)}, comm).allreduce()
+        res["pm_mean"] = pm.sample("real").mean(); res["pm_stderr"] = pm.sample("real").stderr()
+        res["pm_cmean"] = pm.sample("cplx", 0.5).mean(); res["pm_cstderr"] = pm.sample("cplx", 0.5).stderr(); res["pm_n"] = pm.sample("cplx").ntotal
         comm.Barrier()
         # chain sharding: rank r owns chains [r*W, (r+1)*W) of one global family; no chain belongs to two ranks
         W = 5
@@ -91,6 +105,11 @@ def test_two_rank_statistics_and_packed_allreduce(tmp_path):
     np.testing.assert_allclose(r["packed_b"], cplx.sum(0), rtol=1e-13)
     np.testing.assert_allclose(r["packed_c"], [3.0])
     np.testing.assert_array_equal(r["cover"], np.ones(10))
+    np.testing.assert_allclose(r["pm_mean"], real.mean(0), rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(r["pm_stderr"], real.std(0, ddof=1) / np.sqrt(n), rtol=1e-12)
+    np.testing.assert_allclose(r["pm_cmean"], 0.5 * cplx.mean(0), rtol=1e-13)
+    np.testing.assert_allclose(r["pm_cstderr"], 0.5 * cplx.std(0, ddof=1) / np.sqrt(n), rtol=1e-12)
+    assert int(r["pm_n"]) == n
 
 
 def test_single_process_comm_is_identity():

@@ -39,5 +39,7 @@ void launch_meas_g2iw(const DevConst &C, hipStream_t st, int n2, double2 *G2);
 void launch_meas_g4iw(const DevConst &C, hipStream_t st, int nwf, int nwb, int zph, int nb4, const double2 *G2, double2 *acc4, double2 *acc4pp, double2 *acc2);
 void launch_meas_g4w(const DevConst &C, hipStream_t st, int pp, int nbw);
 void launch_meas_gw(const DevConst &C, hipStream_t st);
+// moments of B normalised bins of `per` doubles for the cross-rank reduction: out[1 + 3 per] (w2dyn_reduce_pack)
+void launch_pack_moments(hipStream_t st, const double *acc, int B, size_t per, const double *scale, int nleg, double *out);
 
 }  // namespace w2dyn

@@ -62,4 +62,27 @@ void launch_meas_gw(const DevConst &C, hipStream_t st)
 {
     hipLaunchKernelGGL(k_meas_gw, dim3(C.nbins), dim3(256), (size_t)C.ntau * sizeof(double), st, C);
 }
+
+// Moments of the normalised per-bin results x_b[i] = acc[b][i] scale[b] (sqrt(2l+1), l = i mod nleg, for the Legendre
+// coefficients) for the cross-rank reduction: out = [ B | S_i = sum_b x_b[i] | sum_b (x_b[i] - S_i/B)^2 | S_i^2/B ].  Every
+// entry adds over ranks (parallel-axis formula, statistics.py of this package).  One thread per element, bins read with
+// unit stride across the wave; the second pass over the bins finds them in L2.
+__global__ void __launch_bounds__(256) k_pack_moments(const double *__restrict__ acc, int B, size_t per, const double *__restrict__ scale,
+                                                      int nleg, double *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) out[0] = (double)B;
+    if (i >= per) return;
+    const double ef = nleg ? sqrt(2.0 * (double)(i % (size_t)nleg) + 1.0) : 1.0;
+    double s1 = 0.0;
+    for (int b = 0; b < B; ++b) s1 += acc[(size_t)b * per + i] * (scale[b] * ef);
+    const double m = s1 / (double)B;
+    double m2 = 0.0;
+    for (int b = 0; b < B; ++b) { const double d = acc[(size_t)b * per + i] * (scale[b] * ef) - m; m2 += d * d; }
+    out[1 + i] = s1; out[1 + per + i] = m2; out[1 + 2 * per + i] = s1 * m;
+}
+void launch_pack_moments(hipStream_t st, const double *acc, int B, size_t per, const double *scale, int nleg, double *out)
+{
+    hipLaunchKernelGGL(k_pack_moments, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, acc, B, per, scale, nleg, out);
+}
 }  // namespace w2dyn

@@ -76,6 +76,10 @@ static hipError_t scratch_address(int device, void **out)
     return hipSuccess;
 }
 
+// one per-bin result as w2dyn_reduce_pack needs it: accumulator on the device, bins, doubles per bin, the factor that
+// normalises each bin (host-made in measure_finish), and Nleg if the element factor sqrt(2l+1) applies
+struct PackDesc { const double *dev; int B; size_t per; std::vector<double> scale; int nleg; };
+
 struct w2dyn_solver {
     int device = 0;
     void *scratch = nullptr;                         // this GPU's copy of w2dyn_scratch (looked up in w2dyn_create)
@@ -125,6 +129,8 @@ struct w2dyn_solver {
     double mean_sign = 0, time_warmup = 0, time_sim = 0, time_sim_steps = 0;
     std::map<std::string, std::vector<double>> res;      // normalised results (doubles / complex interleaved)
     std::vector<long long> res_accpair;
+    std::map<std::string, PackDesc> pack;                // filled by measure_finish, dropped with the accumulators
+    double *packbuf = nullptr, *packscale = nullptr; size_t packbuf_n = 0, packscale_n = 0;   // w2dyn_reduce_pack; live until w2dyn_destroy
     std::vector<double> counters;                        // summed over walkers, C_NCOUNT
     std::map<std::string, KTimer> timers;
     std::vector<hipEvent_t> ev_pool; std::vector<std::pair<std::string, size_t>> ev_pending;   // see drain_timers
@@ -214,6 +220,7 @@ void free_device(w2dyn_solver *s)
     stash_streams(s);
     for (void *p : s->allocs) (void)hipFree(p);
     s->allocs.clear();
+    s->pack.clear();
     s->have_solver = false;
 }
 
@@ -445,6 +452,8 @@ int w2dyn_destroy(w2dyn_solver *s)
     if (!s) return 0;
     (void)hipSetDevice(s->device);
     free_device(s);
+    if (s->packbuf) (void)hipFree(s->packbuf);
+    if (s->packscale) (void)hipFree(s->packscale);
     for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -1090,19 +1099,25 @@ int w2dyn_measure_finish(w2dyn_solver *s)
     auto &R = s->res;
     R.clear();
     // per-bin normalised arrays and their walker-weighted mean
-    auto reduce_bins = [&](const std::vector<double> &acc, size_t per, const char *name, auto norm) {
+    s->pack.clear();
+    auto reduce_bins = [&](const std::vector<double> &acc, size_t per, const char *name, auto norm, const double *dev = nullptr, int nleg_fac = 0) {
         std::vector<double> bins((size_t)B * per), tot(per, 0.0);
+        if (dev) {     // every normalisation is linear in the accumulated value: its factor per bin feeds w2dyn_reduce_pack
+            PackDesc d{dev, B, per, std::vector<double>(B), nleg_fac};
+            for (int b = 0; b < B; ++b) d.scale[b] = norm(1.0, binw(b), 0);
+            s->pack[name] = d;
+        }
         for (int b = 0; b < B; ++b) for (size_t i = 0; i < per; ++i) { tot[i] += acc[(size_t)b * per + i]; bins[(size_t)b * per + i] = norm(acc[(size_t)b * per + i], binw(b), i); }
         for (size_t i = 0; i < per; ++i) tot[i] = norm(tot[i], nmeas_tot, i);
         R[std::string(name) + "_bins"] = bins; R[name] = tot;
     };
     const int nleg = s->nleg, ntau = s->ntau;
     // GLeg*sqrt(2l+1)/beta, then -GLeg*zScaling with zScaling = -1/(N*mean_sign)          (CTQMC.F90:8697, 8766-8771)
-    reduce_bins(gleg, (size_t)nf * nleg, "gleg", [&](double v, double n, size_t i) { int l = (int)(i % nleg); double zs = -1.0 / (n * ms); return -(v * std::sqrt((double)(2 * l) + 1.0) / beta) * zs; });
+    reduce_bins(gleg, (size_t)nf * nleg, "gleg", [&](double v, double n, size_t i) { int l = (int)(i % nleg); double zs = -1.0 / (n * ms); return -(v * std::sqrt((double)(2 * l) + 1.0) / beta) * zs; }, C.acc_gleg, nleg);
     // Gtau = -mean/(-mean_sign) * Ntau/beta^2                                              (CTQMC.F90:8726-8731)
-    reduce_bins(gtau, (size_t)nf * ntau, "gtau", [&](double v, double n, size_t) { return -(v / n) / (-ms) * (double)ntau / (beta * beta); });
-    reduce_bins(giw, (size_t)nf * C.niw2 * 2, "giw", [&](double v, double n, size_t) { double zs = -1.0 / (n * ms); return v * zs / beta; });   // 8815-8817
-    reduce_bins(histo, (size_t)nf * (s->maxhisto + 1), "histo", [&](double v, double n, size_t) { return v / n; });                                // 8755
+    reduce_bins(gtau, (size_t)nf * ntau, "gtau", [&](double v, double n, size_t) { return -(v / n) / (-ms) * (double)ntau / (beta * beta); }, C.acc_gtau);
+    reduce_bins(giw, (size_t)nf * C.niw2 * 2, "giw", [&](double v, double n, size_t) { double zs = -1.0 / (n * ms); return v * zs / beta; }, C.acc_giw);   // 8815-8817
+    reduce_bins(histo, (size_t)nf * (s->maxhisto + 1), "histo", [&](double v, double n, size_t) { return v / n; }, C.acc_histo);                   // 8755
     reduce_bins(dm, dms, "dmblocks", [&](double v, double n, size_t) { double zs = -1.0 / (n * ms); return v * zs; });                             // 8706-8708
     reduce_bins(outer, no, "outersuperstatehisto", [&](double v, double n, size_t) { return v / n; });                                             // 8760
     {   // MeasOuterHistograms (CTQMC.F90:3285-3339), normalised as in 8757-8764: sign sums over visit counts (0/0 = NaN
@@ -1267,13 +1282,15 @@ int w2dyn_measure_finish(w2dyn_solver *s)
         auto reduce4 = [&](const double2 *dev, size_t per, const char *name, double extra) {
             std::vector<double> raw((size_t)s->nb4 * per * 2), bins((size_t)s->nb4 * per * 2), tot(per * 2, 0.0);
             (void)hipMemcpy(raw.data(), dev, raw.size() * sizeof(double), hipMemcpyDeviceToHost);
+            PackDesc d{(const double *)dev, s->nb4, per * 2, std::vector<double>(s->nb4), 0};
             for (int b = 0; b < s->nb4; ++b) {
                 double nb = 0.0;
                 for (int bin = b; bin < B; bin += s->nb4) nb += binw(bin);
+                d.scale[b] = (-1.0 / (nb * ms)) * extra;
                 for (size_t i = 0; i < per * 2; ++i) { double v = raw[(size_t)b * per * 2 + i]; tot[i] += v; bins[(size_t)b * per * 2 + i] = v * (-1.0 / (nb * ms)) * extra; }
             }
             for (size_t i = 0; i < per * 2; ++i) tot[i] *= (-1.0 / (nmeas_tot * ms)) * extra;
-            R[name] = tot; R[std::string(name) + "_bins"] = bins;
+            R[name] = tot; R[std::string(name) + "_bins"] = bins; s->pack[name] = d;
         };
         reduce4(s->acc4, n4, "g4iw", 1.0 / (beta * beta));
         if (s->acc4pp) reduce4(s->acc4pp, n4, "g4iw_pp", 1.0 / (beta * beta));
@@ -1296,6 +1313,9 @@ int w2dyn_measure_finish(w2dyn_solver *s)
         auto reducew = [&](const double *dev, const char *name) {
             std::vector<double> raw((size_t)nbw * n), tot(n, 0.0);
             (void)hipMemcpy(raw.data(), dev, raw.size() * sizeof(double), hipMemcpyDeviceToHost);
+            PackDesc d{dev, nbw, n, std::vector<double>(nbw), 0};
+            for (int b = 0; b < nbw; ++b) d.scale[b] = scal(cw[b], cz[b], mw[b]);
+            s->pack[name] = d;
             for (int b = 0; b < nbw; ++b) {
                 const double f = scal(cw[b], cz[b], mw[b]);
                 for (size_t i = 0; i < n; ++i) { tot[i] += raw[(size_t)b * n + i]; raw[(size_t)b * n + i] *= f; }
@@ -1319,6 +1339,9 @@ int w2dyn_measure_finish(w2dyn_solver *s)
         auto reduceg = [&](const double *dev, size_t n, const char *name, double extra) {
             std::vector<double> raw((size_t)B * n), tot(n, 0.0);
             (void)hipMemcpy(raw.data(), dev, raw.size() * sizeof(double), hipMemcpyDeviceToHost);
+            PackDesc d{dev, B, n, std::vector<double>(B), 0};
+            for (int b = 0; b < B; ++b) d.scale[b] = scal(cw[b], cz[b], nwm[b]) * extra;
+            s->pack[name] = d;
             for (int b = 0; b < B; ++b) {
                 const double f = scal(cw[b], cz[b], nwm[b]) * extra;
                 for (size_t i = 0; i < n; ++i) { tot[i] += raw[(size_t)b * n + i]; raw[(size_t)b * n + i] *= f; }
@@ -1693,6 +1716,42 @@ int w2dyn_get_result(w2dyn_solver *s, const char *name, void *out, size_t bytes,
     return 0;
 }
 
+int w2dyn_reduce_pack(w2dyn_solver *s, const char *names, void **dev_ptr, size_t *ndoubles, size_t *offsets, size_t *counts, int max_names)
+{
+    if (!s || !names || !dev_ptr || !ndoubles || !offsets || !counts) return fail(s, W2DYN_EINVAL, "reduce_pack: null argument");
+    if (s->pack.empty()) return fail(s, W2DYN_EINVAL, "reduce_pack needs the accumulators of a finished measurement (after ctqmc_measure, before dest_ctqmc / init_solver)");
+    HIPCHK(hipSetDevice(s->device));
+    std::vector<const PackDesc *> list;
+    size_t total = 0, nscale = 0;
+    for (const char *p = names; *p;) {
+        const char *q = strchr(p, ',');
+        const std::string nm = q ? std::string(p, q) : std::string(p);
+        p = q ? q + 1 : p + nm.size();
+        if (nm.empty()) continue;
+        auto it = s->pack.find(nm);
+        if (it == s->pack.end()) return fail(s, W2DYN_EUNSUPPORTED, "reduce_pack: no per-bin accumulator named '%s' in this run", nm.c_str());
+        if ((int)list.size() >= max_names) return fail(s, W2DYN_EINVAL, "reduce_pack: more than %d names", max_names);
+        offsets[list.size()] = total; counts[list.size()] = it->second.per;
+        total += 1 + 3 * it->second.per; nscale += (size_t)it->second.B;
+        list.push_back(&it->second);
+    }
+    if (list.empty()) return fail(s, W2DYN_EINVAL, "reduce_pack: empty list of names");
+    if (total > s->packbuf_n) { if (s->packbuf) (void)hipFree(s->packbuf); s->packbuf = nullptr; s->packbuf_n = 0; HIPCHK(hipMalloc(&s->packbuf, total * sizeof(double))); s->packbuf_n = total; }
+    if (nscale > s->packscale_n) { if (s->packscale) (void)hipFree(s->packscale); s->packscale = nullptr; s->packscale_n = 0; HIPCHK(hipMalloc(&s->packscale, nscale * sizeof(double))); s->packscale_n = nscale; }
+    std::vector<double> sc; sc.reserve(nscale);
+    for (const PackDesc *d : list) sc.insert(sc.end(), d->scale.begin(), d->scale.end());
+    HIPCHK(hipMemcpyAsync(s->packscale, sc.data(), nscale * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    size_t so = 0;
+    for (size_t i = 0; i < list.size(); ++i) {
+        launch_pack_moments(s->stream, list[i]->dev, list[i]->B, list[i]->per, s->packscale + so, list[i]->nleg, s->packbuf + offsets[i]);
+        so += (size_t)list[i]->B;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s->stream));      // the caller hands the buffer to another stream (torch.distributed)
+    *dev_ptr = s->packbuf; *ndoubles = total;
+    return 0;
+}
+
 int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out)
 {
     if (!s || !name || !out) return W2DYN_EINVAL;
@@ -1715,6 +1774,7 @@ int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out)
     else if (n == "nb4") *out = s->nb4;
     else if (n == "nbw") *out = s->nbw;
     else if (n == "nbl") *out = s->nbl;
+    else if (n == "device") *out = s->device;
     else if (n == "wormeta") *out = s->worm_eta;
     else if (n == "ntau") *out = s->ntau;
     else if (n == "n4tau") *out = s->n4tau;

@@ -70,6 +70,7 @@ def load_library(path: str = LIB_PATH):
     L.w2dyn_get_scalar.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double)]
     L.w2dyn_kernel_time.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
     L.w2dyn_set_timing.argtypes = [vp, C.c_int]
+    L.w2dyn_reduce_pack.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_int]
     return L
 
 
@@ -81,7 +82,7 @@ EXPORTED_SYMBOLS = [
     "w2dyn_set_mc_config", "w2dyn_get_minv", "w2dyn_get_walker_state", "w2dyn_get_result", "w2dyn_get_scalar",
     "w2dyn_kernel_time", "w2dyn_set_wormeta", "w2dyn_get_wormeta", "w2dyn_ctqmc_worm_warmup", "w2dyn_count_steps",
     "w2dyn_ctqmc_calibrate", "w2dyn_set_sector", "w2dyn_save_mc_configs", "w2dyn_restore_mc_configs", "w2dyn_set_timing",
-    "w2dyn_measure_once_noalloc",
+    "w2dyn_measure_once_noalloc", "w2dyn_reduce_pack",
 ]
 
 _SCALARS = ("mean_sign", "aborted", "time_warmup", "time_sim", "time_sim_steps", "accglob", "accshift", "accadd4",
@@ -206,6 +207,39 @@ class MCTQMC:
     def set_timing(self, on=True):
         """HIP-event timing of every launch (bench / profiling): off by default, it costs a host sync per launch."""
         self._chk(self._L.w2dyn_set_timing(self._h, int(bool(on))))
+
+    def reduce_pack(self, names, comm=None):
+        """Moments of the per-bin results `names` packed on the GPU for the cross-rank reduction (w2dyn_reduce_pack):
+        a `statistics.PackedMoments` whose tensor aliases the library's device buffer - no copy, no host round trip."""
+        import torch
+        from .statistics import PackedMoments
+        names = list(names)
+        ptr, n = C.c_void_p(), C.c_size_t()
+        offs, cnts = (C.c_size_t * len(names))(), (C.c_size_t * len(names))()
+        self._chk(self._L.w2dyn_reduce_pack(self._h, ",".join(names).encode(), C.byref(ptr), C.byref(n), offs, cnts, len(names)))
+        dev = int(self.scalar("device"))
+
+        class _Alias:      # a raw device pointer in the shape torch understands
+            __cuda_array_interface__ = {"shape": (n.value,), "typestr": "<f8", "data": (ptr.value, False), "version": 2}
+        tensor = torch.as_tensor(_Alias(), device=torch.device("cuda", dev))
+        layout = {}
+        nd, nwf, nwb = self._nd, self._n4iwf, self._n4iwb
+        for i, name in enumerate(names):
+            per = cnts[i]
+            cplx = name not in ("gleg", "gtau", "histo", "gtau_worm")
+            if name in ("gleg", "gtau", "histo", "giw"):
+                shape = (nd, 2, per // (2 * nd * (2 if cplx else 1)))
+            elif name in ("g4iw", "g4iw_pp"):
+                shape = (nd, 2, nd, 2, 2 * nwf, 2 * nwf, 2 * nwb + 1)
+            elif name == "g2iw":
+                shape = (nd, 2, 2 * (nwf + nwb), 2 * (nwf + nwb))
+            elif name in ("g4iw_worm", "g4iwpp_worm"):
+                shape = (2 * nwf, 2 * nwf, 2 * nwb + 1)
+            else:
+                shape = (per // (2 if cplx else 1),)
+            assert int(np.prod(shape)) * (2 if cplx else 1) == per, (name, shape, per)
+            layout[name] = (offs[i], per, shape, cplx)
+        return PackedMoments(tensor, layout, comm)
 
     def kernel_time(self, name, reset=False):
         ms, n = C.c_double(), C.c_int64()

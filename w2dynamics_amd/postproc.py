@@ -6,6 +6,9 @@
     (band, spin, iw) -> (iw, band, spin, band, spin)   `lattice_convention`  (impurity.py:35-42, orbspin.py:41-58)
     Sigma(iw) = G0^-1 - G^-1      Dyson equation on jackknife pseudovalues   (impurity.py:249-303,
                                    w2dyn/auxiliaries/statistics.py:251-339 DistributedJackknife)
+The functions keep the names the reference's caller uses; the formulations are this build's own (mirrored spherical
+Bessel matrix, index-contraction form of the moments, vectorised jackknife) and are pinned on outputs of the reference's
+modules in tests/golden/postproc.npz.
     Sigma moments from rho1/rho2  `get_siw_mom`                              (w2dyn/auxiliaries/postprocessing.py:353-387)
 
 Everything here is numpy on a few hundred KB; the sample axis is the accumulator bins of all ranks
@@ -20,36 +23,39 @@ from .statistics import DistributedSample
 
 
 def matfreq(beta, mattype, matorder):
-    """Matsubara frequencies symmetric around zero (transform.py:88-112)."""
-    half = int(matorder / 2)
-    if mattype == "fermi":
-        if matorder % 2:
-            raise ValueError("Number of Fermi frequencies must be even")
-        return (2 * np.pi / beta) * (np.arange(-half, half) + 0.5)
-    if mattype == "bose":
-        if matorder % 2 != 1:
-            raise ValueError("Number of Bose frequencies must be odd")
-        return (2 * np.pi / beta) * np.arange(-half, half + 1)
-    raise ValueError("mattype must be either 'fermi' or 'bose'")
+    """Matsubara frequencies symmetric around zero: `matorder` fermionic (even count) or bosonic (odd count) ones
+    (the convention of transform.py:88-112)."""
+    kinds = {"fermi": 1, "bose": 0}
+    if mattype not in kinds:
+        raise ValueError("mattype is 'fermi' or 'bose', not %r" % (mattype,))
+    odd = kinds[mattype]
+    if (matorder + odd) % 2 != 1:
+        raise ValueError("%d %s frequencies cannot be symmetric around zero (need an %s count)"
+                         % (matorder, mattype, "even" if odd else "odd"))
+    first = -(matorder // 2)
+    return (np.pi / beta) * (2 * np.arange(first, first + matorder) + odd)
 
 
 def leg2mat(legorder, matorder):
-    """T[n, l] = (-1)^n i^(l+1) sqrt(2l+1) j_l((2n+1) pi / 2) (Boehnke et al. 2011, E2; transform.py:221-254), with the
-    spherical Bessel function written through J_(l+1/2) as the reference does."""
-    half = int(matorder / 2)
-    ws = matfreq(2, "fermi", matorder) + 0j
-    ls = np.arange(int(legorder))
-    nfac = (-1.0) ** np.arange(-half, half) * np.sqrt(np.pi / (2 * ws))
-    lfac = (1j) ** (ls + 1) * np.sqrt(2 * ls + 1)
-    return nfac[:, None] * lfac * sps.jv(ls + 0.5, ws[:, None])
+    """T[n, l] = (-1)^n i^(l+1) sqrt(2l+1) j_l((2n+1) pi / 2) (Boehnke et al. 2011, eq. E2; the matrix of
+    transform.py:221-254).  Built for the positive frequencies from scipy's spherical Bessel function and mirrored:
+    T[-n-1, l] = conj(T[n, l]) because G(tau) is real."""
+    if matorder % 2:
+        raise ValueError("leg2mat needs an even number of fermionic frequencies")
+    half = matorder // 2
+    n = np.arange(half)
+    l = np.arange(int(legorder))
+    pos = sps.spherical_jn(l[None, :], (n[:, None] + 0.5) * np.pi) * np.sqrt(2.0 * l + 1.0) * 1j ** (l + 1)
+    pos[1::2] *= -1.0
+    return np.concatenate([pos[::-1].conj(), pos])
 
 
 def transform_last(tfmat, data):
-    """`transform(tfmat, data, onmismatch=Truncate.tofirst)` for the last axis (transform.py:480-512): the longer of
-    the two (matrix columns, data axis) is cut to the first entries of the shorter."""
+    """Apply `tfmat` (new, old) to the last axis of `data`; if the lengths differ, the longer of the two is cut to the
+    leading entries of the shorter (what `transform(..., Truncate.tofirst)` of transform.py:480-512 does)."""
     tfmat = np.asarray(tfmat); data = np.asarray(data)
     n = min(tfmat.shape[-1], data.shape[-1])
-    return np.tensordot(data[..., :n], tfmat[..., :n], (-1, -1))
+    return np.einsum("...l,nl->...n", data[..., :n], tfmat[..., :n])
 
 
 def promote_diagonal(diag):
@@ -97,70 +103,74 @@ def get_giw(result, niw, fttype="legendre", nleg=None):
 
 
 class DistributedJackknife:
-    """Leave-one-out statistics x'_i = (n xbar - x_i)/(n-1) and bias-corrected pseudovalues
-    y'_i = n f(xbar) - (n-1) f(x'_i) of a `DistributedSample` (statistics.py:251-339)."""
+    """Delete-one jackknife over a `DistributedSample` (the statistics of statistics.py:251-339): replicas
+    x'_i = xbar + (xbar - x_i)/(n-1) and bias-corrected pseudovalues y_i = f(xbar) + (n-1) (f(xbar) - f(x'_i)),
+    whose mean and standard error are the jackknife estimate of f and its error.  Needs one all-reduce (the sample's
+    cached moments); the replicas of this rank are formed in one vector operation."""
 
     def __init__(self, sample):
-        self.mpi_comm = sample.mpi_comm
-        self.nlocal = sample.nlocal
-        self.ntotal = sample.ntotal
-        ssum = sample.sum()
-        if self.ntotal < 2:
-            self.leaveoneout = None
-        else:
-            self.leaveoneout = (ssum - np.asarray(sample.local)) / (self.ntotal - 1)
-        self._mean = ssum / self.ntotal
+        self.comm = sample.comm
+        self.nlocal, self.ntotal = sample.nlocal, sample.ntotal
+        self._mean = sample.mean()
+        self.leaveoneout = None
+        if self.ntotal > 1:
+            self.leaveoneout = self._mean + (self._mean - np.asarray(sample.local)) / (self.ntotal - 1)
+
+    @property
+    def mpi_comm(self):
+        return self.comm
 
     def mean(self):
         return self._mean
 
-    def transform(self, f):
-        if self.ntotal < 2:
-            return DistributedSample([f(self._mean)], self.mpi_comm, self.ntotal)
-        ymean = f(self._mean)
-        yi = np.empty((self.nlocal,) + ymean.shape, ymean.dtype)
-        yi[...] = self.ntotal * ymean
-        for i in range(self.nlocal):
-            yi[i] -= (self.ntotal - 1) * f(self.leaveoneout[i])
-        return DistributedSample(yi, self.mpi_comm, self.ntotal)
+    def transform(self, f, batched=False):
+        """Pseudovalues of f as a DistributedSample.  `batched`: f accepts the whole (nlocal, ...) replica block."""
+        centre = np.asarray(f(self._mean))
+        if self.leaveoneout is None:                     # a single observation: nothing to leave out
+            return DistributedSample(centre[None], self.comm, self.ntotal)
+        if batched:
+            frep = np.asarray(f(self.leaveoneout))
+        else:
+            frep = np.stack([np.asarray(f(rep)) for rep in self.leaveoneout]) if self.nlocal else np.empty((0,) + centre.shape, centre.dtype)
+        return DistributedSample(centre + (self.ntotal - 1) * (centre - frep), self.comm, self.ntotal)
 
 
 def siw_dyson(giw_sample, g0inviw, diagonal_only=True):
     """Sigma(iw) = G0^-1(iw) - G^-1(iw) on jackknife pseudovalues of G(iw) (impurity.py:249-261, 302-303).
     `giw_sample`: DistributedSample of (iw, band, spin, band, spin) arrays; returns a DistributedSample."""
     g0inviw = np.asarray(g0inviw)
+    nfl = g0inviw.shape[-2] * g0inviw.shape[-1]
     if diagonal_only:
         g0d = extract_diagonal(g0inviw)
 
-        def get_siw(giw):
+        def dyson(giw):                                  # works on one replica and on a stack of them
             return promote_diagonal(g0d - 1.0 / extract_diagonal(giw))
     else:
-        def get_siw(giw):
-            shp = giw.shape
-            nfl = shp[1] * shp[2]
-            return g0inviw - np.linalg.inv(giw.reshape(-1, nfl, nfl)).reshape(shp)
-    return DistributedJackknife(giw_sample).transform(get_siw)
+        def dyson(giw):
+            return g0inviw - np.linalg.inv(giw.reshape(giw.shape[:-4] + (nfl, nfl))).reshape(giw.shape)
+    return DistributedJackknife(giw_sample).transform(dyson, batched=True)
 
 
 def get_siw_mom(u_matrix, rho1, rho2):
-    """Sigma(iw -> inf) = sigma_inf + sigma_1/(iw) from the one- and two-particle density matrices (Wang, Dang, Millis,
-    PRB 84, 073104; postprocessing.py:353-387).  Returns (band, spin, 2)."""
-    u_matrix = np.asarray(u_matrix)
-    nfl = u_matrix.shape[0]
-    nb = nfl // 2
-    r1 = np.asarray(rho1).reshape(nfl, nfl)
-    r2 = np.asarray(rho2).reshape(nfl, nfl, nfl, nfl)
-    ua = -0.5 * (u_matrix - u_matrix.swapaxes(0, 1) - u_matrix.swapaxes(2, 3) + u_matrix.swapaxes(0, 1).swapaxes(2, 3))
-    sigma_inf = np.tensordot(ua, r1, axes=([1, 2], [0, 1]))
-    L = -0.5 * np.tensordot(ua, ua, axes=([2, 3], [0, 1]))
-    first = 0.25 * np.tensordot(ua, ua, axes=(1, 2))
-    second = -np.tensordot(ua, ua, axes=(3, 0))
-    k1 = np.tensordot(first, r2, axes=([1, 2, 3, 4], [2, 3, 0, 1]))
-    k2 = np.tensordot(second, r2, axes=([1, 2, 3, 4], [0, 2, 1, 3]))
-    sigma_1 = -(k1 + k2 + np.tensordot(L, r1, axes=([1, 2], [0, 1])) - np.tensordot(sigma_inf, sigma_inf, axes=(1, 0)))
-    smoms = np.asarray([sigma_inf, sigma_1])
-    smoms = np.diagonal(smoms, axis1=1, axis2=2).copy()
-    return smoms.transpose().reshape(nb, 2, -1)
+    """High-frequency expansion Sigma(iw -> inf) = s0 + s1/(iw) from <c+c> and <c+c+cc> (Wang, Dang, Millis, PRB 84,
+    073104; the quantity of postprocessing.py:353-387), written as explicit index contractions with the
+    antisymmetrised interaction A_abcd = -(U_abcd - U_bacd - U_abdc + U_badc)/2:
+
+        s0_ad = A_abcd <c+_b c_c>
+        s1_ah = s0_ab s0_bh - A_abcd A_efbh <ef|cd>/4 + A_abcd A_dfgh <bf|cg> + A_abcd A_cdeh <c+_b c_e>/2
+
+    Returns the flavour diagonals as (band, spin, 2)."""
+    u = np.asarray(u_matrix)
+    nfl = u.shape[0]
+    r1 = np.asarray(rho1).reshape((nfl,) * 2)
+    r2 = np.asarray(rho2).reshape((nfl,) * 4)
+    A = -0.5 * (u - np.einsum("bacd->abcd", u) - np.einsum("abdc->abcd", u) + np.einsum("badc->abcd", u))
+    s0 = np.einsum("abcd,bc->ad", A, r1)
+    s1 = (s0 @ s0
+          - 0.25 * np.einsum("abcd,efbh,efcd->ah", A, A, r2, optimize=True)
+          + np.einsum("abcd,dfgh,bfcg->ah", A, A, r2, optimize=True)
+          + 0.5 * np.einsum("abcd,cdeh,be->ah", A, A, r1, optimize=True))
+    return np.stack([s0.diagonal(), s1.diagonal()], axis=-1).reshape(nfl // 2, 2, 2)
 
 
 def bethe_fiw(beta, niw, D=1.0):

@@ -9,7 +9,10 @@
 
 Chains are sharded over ranks without any collective in the sampling path: rank r runs chains
 [r*nwalkers, (r+1)*nwalkers) of one global stream family (reference: seed + rank, impurity.py:381).  The only
-exchange step is the final reduction (`statistics.DistributedSample`, RCCL all-reduce).
+exchange step is the final reduction (RCCL all-reduce): the one-particle results, whose bins the jackknife needs on the
+host anyway, go through `statistics.DistributedSample`; the two-particle arrays (hundreds of MB per GPU at production
+frequency boxes) are reduced to their moments on the GPU and all-reduced there (`MCTQMC.reduce_pack`,
+`statistics.PackedMoments`), only mean and error bar ever reach the host.
 """
 from __future__ import annotations
 
@@ -67,6 +70,15 @@ class HipCtHybSolver:
             result[key] = DistributedSample(getattr(q, key + "_bins"), self.comm)
         if self.qmc["MeasGiw"]:
             result["giw-meas"] = DistributedSample(q.giw_bins, self.comm)
+        if q.fourpnt & 4:      # get_resultset, impurity.py:1253-1262: g4iw, g4iw-pp, g2iw; moments made on the GPU
+            names = {"g4iw": "g4iw"}
+            if self.qmc["MeasG4iwPP"]:
+                names["g4iw-pp"] = "g4iw_pp"
+            if self.qmc["MeasG2iw"]:
+                names["g2iw"] = "g2iw"
+            pack = q.reduce_pack(names.values(), self.comm).allreduce()
+            for key, name in names.items():
+                result[key] = pack.sample(name)
         result["sign"] = DistributedSample(np.array([q.mean_sign]), self.comm)
         result["accept-ins"] = DistributedSample(np.array([q.accadd]), self.comm)
         result["accept-rem"] = DistributedSample(np.array([q.accrem]), self.comm)
@@ -170,11 +182,16 @@ class HipCtHybSolver:
             raise KeyboardInterrupt("CTQMC was interrupted by signal")
         nfl = 2 * p.nd
         result = {}
-        if isector == 4:
+        if isector == 4:       # moments made on the GPU and all-reduced there; normalised by nflavours^4 (impurity.py:1317-1323)
+            names = {}
             if self.qmc["G4ph"] == 1:
-                result["g4iw-worm/%05d" % icomponent] = DistributedSample(q.g4iw_worm_bins / nfl ** 4, self.comm)
+                names["g4iw-worm/%05d" % icomponent] = "g4iw_worm"
             if self.qmc["G4pp"] == 1:
-                result["g4iwpp-worm/%05d" % icomponent] = DistributedSample(q.g4iwpp_worm_bins / nfl ** 4, self.comm)
+                names["g4iwpp-worm/%05d" % icomponent] = "g4iwpp_worm"
+            if names:
+                pack = q.reduce_pack(names.values(), self.comm).allreduce()
+                for key, name in names.items():
+                    result[key] = pack.sample(name, 1.0 / nfl ** 4)
         if isector == 2:          # get_resultset_worm, impurity.py:1312-1315 (already divided by nflavours^2, CTQMC.F90:8871)
             if self.qmc["WormMeasGiw"] != 0:
                 result["giw-worm/%05d" % icomponent] = DistributedSample(q.giw_worm_bins, self.comm)

@@ -1,17 +1,24 @@
-"""Cross-rank statistics of the solver results: the "parallel reduction" of the hot path.
+"""Cross-rank statistics of the solver results: the exchange step of the hot path.
 
-Mirrors `w2dyn/auxiliaries/statistics.py:19-248` (`DistributedSample`): a sample is an (n, ...) array of
-observations distributed over ranks; mean / variance / standard error are obtained with sum-all-reduces
-(`statistics.py:95-97` uses mpi4py `Allreduce(IN_PLACE, SUM)`).  Here the collective is `torch.distributed.all_reduce`
-- RCCL over xGMI when the process group is "nccl" (one process per GPU), gloo on CPU in the tests.
+The reference wraps every result in `DistributedSample` (`w2dyn/auxiliaries/statistics.py`) and obtains mean and
+standard error with one MPI all-reduce per quantity and statistic.  This module offers the same *interface* (the names
+the reference's driver and result writer use: `mean`, `stderr`, `var`, `sum`, `apply`, `local`, `ntotal`, `join`), built
+differently:
 
-Semantics note: the reference has one observation per MPI rank; the HIP solver has `nbins`
-observations per GPU (accumulator bins of a few chains each), so `nlocal = nbins` and the error bar is taken over
-all bins of all GPUs.  The formulas are unchanged.
+  * every sample is reduced to its moments once - per rank the count n_r, the sum, and the squared deviations from the
+    rank's own mean - and ONE packed fp64 all-reduce combines (n_r, n_r m_r, M2_r, n_r |m_r|^2) of all ranks; mean,
+    variance and standard error are then read off the cached moments (between-rank part by the parallel-axis formula).
+    On xGMI a ring all-reduce is bound by one link, so one bucket instead of two or three collectives per quantity;
+  * the moments can also come straight from the GPU (`from_moments`, fed by `MCTQMC.reduce_pack`): the per-bin results
+    are summed and squared by a kernel and the packed device buffer goes into `torch.distributed.all_reduce` (RCCL) as it
+    is - no numpy round trip of data that already sits in HBM.
 
-`TorchComm` additionally offers the three mpi4py calls the reference's solver wrapper uses on its communicator
-(`Allreduce`, `Barrier`, `Get_rank/Get_size`; impurity.py:379, 575, statistics.py:97), so that the reference's own
-`DistributedSample` can run on top of RCCL unchanged.
+Semantics: the reference has one observation per MPI rank; here every GPU contributes `nbins` observations
+(accumulator bins of a few chains each), so the error bar is taken over all bins of all GPUs.
+
+`TorchComm` is an mpi4py-communicator look-alike (`Allreduce`, `Barrier`, `Get_rank`, `Get_size`) over a
+torch.distributed process group - "nccl" = RCCL with one process per GPU, "gloo" in the CPU tests - so the reference's own
+statistics class would run on it unchanged as well.
 """
 from __future__ import annotations
 
@@ -28,13 +35,26 @@ IN_PLACE = "IN_PLACE"
 SUM = "SUM"
 
 
+def _as_f64_view(a):
+    """(flat float64 view of a contiguous copy, restore function)."""
+    a = np.asarray(a)
+    cplx = np.iscomplexobj(a)
+    work = np.ascontiguousarray(a, dtype=np.complex128 if cplx else np.float64)
+    flat = work.view(np.float64).ravel()
+
+    def restore(buf):
+        return (buf.view(np.complex128) if cplx else buf).reshape(a.shape)
+    return flat, restore
+
+
 class TorchComm:
-    """mpi4py-communicator look-alike on top of a torch.distributed process group (None = single process)."""
+    """Communicator over a torch.distributed process group (None / not initialised = single process)."""
 
     def __init__(self, group=None, device=None):
         self.group = group
         self.active = dist is not None and dist.is_available() and dist.is_initialized()
-        if device is None and self.active and dist.get_backend(group) == "nccl":
+        self.backend = dist.get_backend(group) if self.active else None
+        if device is None and self.backend == "nccl":
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = device or "cpu"
 
@@ -48,123 +68,182 @@ class TorchComm:
         if self.active:
             dist.barrier(group=self.group)
 
+    # -- device path --------------------------------------------------------------------------------------------
+    def allreduce_tensor(self, t):
+        """In-place sum-all-reduce of a torch tensor where it lives (a CUDA tensor goes to RCCL untouched)."""
+        if self.active and (self.Get_size() > 1 or self.backend == "nccl"):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    # -- host path ----------------------------------------------------------------------------------------------
+    def _reduce_flat(self, flat):
+        if not self.active or (self.Get_size() == 1 and self.backend != "nccl"):
+            return flat
+        t = torch.from_numpy(flat).to(self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
     def Allreduce(self, sendbuf, recvbuf, op=SUM):
-        """In-place sum-all-reduce of a numpy array (sendbuf must be IN_PLACE as in statistics.py:97)."""
+        """mpi4py-style sum-all-reduce into `recvbuf` (sendbuf may be IN_PLACE)."""
         if op != SUM:
-            raise NotImplementedError("only SUM is needed by the solver statistics")
+            raise NotImplementedError("the solver statistics only sum")
         if sendbuf is not IN_PLACE:
             np.copyto(recvbuf, sendbuf)
-        if not self.active or self.Get_size() == 1:
-            return
-        arr = np.ascontiguousarray(recvbuf)
-        if np.iscomplexobj(arr):
-            t = torch.from_numpy(arr.view(np.float64).copy())
-        else:
-            t = torch.from_numpy(arr.copy())
-        t = t.to(self.device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        out = t.cpu().numpy()
-        if np.iscomplexobj(arr):
-            out = out.view(np.complex128)
-        recvbuf[...] = out.reshape(recvbuf.shape)
+        flat, restore = _as_f64_view(recvbuf)
+        recvbuf[...] = restore(self._reduce_flat(flat.copy()))
 
     def allreduce_packed(self, arrays):
-        """Sum-all-reduce several float64/complex128/int64 arrays with ONE collective (bucketed: on xGMI a ring
-        all-reduce is per-link bound, so few large messages beat many small ones)."""
-        if not self.active or self.Get_size() == 1:
-            return [np.array(a) for a in arrays]
-        flat = [np.ascontiguousarray(a).astype(np.complex128 if np.iscomplexobj(a) else np.float64).view(np.float64).ravel()
-                for a in arrays]
-        sizes = [f.size for f in flat]
-        t = torch.from_numpy(np.concatenate(flat)).to(self.device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        out = t.cpu().numpy()
+        """Sum-all-reduce several real / complex / integer arrays with ONE collective; returns new arrays."""
+        views = [_as_f64_view(a) for a in arrays]
+        if not views:
+            return []
+        out = self._reduce_flat(np.concatenate([v for v, _ in views]))
         res, pos = [], 0
-        for a, n in zip(arrays, sizes):
-            seg = out[pos:pos + n]; pos += n
-            a = np.asarray(a)
-            if np.iscomplexobj(a):
-                res.append(seg.view(np.complex128).reshape(a.shape))
-            else:
-                res.append(seg.reshape(a.shape).astype(a.dtype if a.dtype.kind == "f" else np.float64))
+        for v, restore in views:
+            res.append(np.array(restore(out[pos:pos + v.size])))
+            pos += v.size
         return res
 
 
 class DistributedSample:
-    """Same interface as the reference's class (statistics.py:19-248): local (n,...) observations + communicator."""
+    """Observations x_1..x_n of one quantity spread over the ranks: `local` holds this rank's (n_r, ...) block.
+
+    All statistics come from the cached moments of one packed all-reduce (module docstring)."""
 
     def __init__(self, local, comm=None, ntotal=None):
-        self.mpi_comm = comm if comm is not None else TorchComm()
-        self.local = np.asarray(local)
-        if self.local.ndim == 0:
-            self.local = self.local.ravel()
+        self.comm = comm if comm is not None else TorchComm()
+        block = np.asarray(local)
+        self.local = block.reshape(1) if block.ndim == 0 else block
         self.nlocal = self.local.shape[0]
+        self._moments = None
+        self._ntotal = None
         if ntotal is not None:
-            if ntotal < self.nlocal:
-                raise ValueError("ntotal must at least cover local")
-            if self.mpi_comm.Get_size() == 1 and ntotal != self.nlocal:
-                raise ValueError("ntotal inconsistent for single-core")
-            self.ntotal = ntotal
-        else:
-            n = np.array(self.nlocal, np.float64).reshape(1)
-            self._reduce_inplace(n)
-            self.ntotal = int(round(float(n[0])))
+            alone = self.comm.Get_size() == 1
+            if ntotal < self.nlocal or (alone and ntotal != self.nlocal):
+                raise ValueError("ntotal = %d does not fit %d local observations on %d rank(s)" % (ntotal, self.nlocal, self.comm.Get_size()))
+            self._ntotal = int(ntotal)
 
-    def _reduce_inplace(self, arr):
-        self.mpi_comm.Allreduce(IN_PLACE, arr, op=SUM)
+    # the reference's attribute name for the communicator (its result writer reads it)
+    @property
+    def mpi_comm(self):
+        return self.comm
 
-    def apply(self, func, inplace=False):
-        new = np.array([func(self.local[i, ...]) for i in range(self.local.shape[0])])
-        if inplace:
-            self.local = new
-            return self
-        return DistributedSample(new, self.mpi_comm, self.ntotal)
+    @classmethod
+    def from_moments(cls, n, s1, m2, between, comm=None, reduced=True):
+        """Sample known only through its moments - count, sum, squared deviations from the rank means and
+        n_r |m_r|^2 - e.g. one record of `PackedMoments` (made on the GPU, all-reduced there).  `reduced=False`: the
+        moments are this rank's and are all-reduced here.  `local` is not available for such a sample."""
+        self = cls.__new__(cls)
+        self.comm = comm if comm is not None else TorchComm()
+        self.local = None; self.nlocal = int(round(float(n)))
+        s1 = np.asarray(s1); m2 = np.asarray(m2, dtype=np.float64); between = np.asarray(between, dtype=np.float64)
+        if not reduced:
+            nn, s1, m2, between = self.comm.allreduce_packed([np.array([float(n)]), s1, m2, between])
+            n = nn[0]
+        n = float(n)
+        self._ntotal = int(round(n))
+        self._moments = (n, s1, m2 + np.maximum(between - n * np.abs(s1 / n) ** 2, 0.0))
+        return self
+
+    def _reduce(self):
+        if self._moments is None:
+            x = self.local
+            n_r = float(self.nlocal)
+            if self.nlocal:
+                m_r = x.mean(axis=0)
+                dev = x - m_r
+                m2_r = (dev.real ** 2 + dev.imag ** 2).sum(axis=0) if np.iscomplexobj(x) else (dev ** 2).sum(axis=0)
+            else:
+                m_r = np.zeros(x.shape[1:], x.dtype); m2_r = np.zeros(x.shape[1:])
+            n, s1, m2, between = self.comm.allreduce_packed([np.array([n_r]), n_r * m_r, m2_r, n_r * np.abs(m_r) ** 2])
+            n = float(n[0])
+            if self._ntotal is not None and self._ntotal != int(round(n)):
+                raise ValueError("ntotal = %d given, but the ranks hold %d observations" % (self._ntotal, int(round(n))))
+            self._ntotal = int(round(n))
+            # parallel-axis formula: sum_i |x_i - m|^2 = sum_r [ M2_r + n_r |m_r - m|^2 ]
+            m2 = m2 + np.maximum(between - n * np.abs(s1 / n) ** 2, 0.0) if self.comm.Get_size() > 1 else m2
+            self._moments = (n, s1, m2)
+        return self._moments
+
+    @property
+    def ntotal(self):
+        if self._ntotal is None:
+            self._reduce()
+        return self._ntotal
 
     def sum(self):
-        result = np.array(self.local.sum(0))
-        self._reduce_inplace(result)
-        return result
-
-    def _sqdiff(self, mean, dtype=float):
-        sq = np.array(sum(np.abs(b - mean).astype(dtype) ** 2 for b in self.local), dtype=dtype)
-        self._reduce_inplace(sq)
-        return sq
-
-    def _bidiff(self, mean, dtype=float):
-        mean = np.asarray(mean)
-        flat = np.reshape(self.local, (self.local.shape[0], -1)) - mean.ravel()
-        diff = np.einsum("ij,ik->jk", flat, np.conj(flat)).reshape(mean.shape * 2)
-        diff = np.array(diff)
-        self._reduce_inplace(diff)
-        return diff
+        return np.array(self._reduce()[1])
 
     def mean(self):
-        return self.sum() / self.ntotal
+        n, s1, _ = self._reduce()
+        return s1 / n
 
     def var(self, mean=None, ddof=1):
-        r = self._sqdiff(self.mean() if mean is None else mean)
-        return r / (self.ntotal - ddof)
+        n, s1, m2 = self._reduce()
+        if mean is not None:      # second moment about a caller-supplied point
+            m2 = m2 + n * np.abs(np.asarray(mean) - s1 / n) ** 2
+        return m2 / (n - ddof)
 
     def stddev(self, var=None, ddof=1):
         return np.sqrt(self.var(ddof=ddof) if var is None else var)
 
     def stderr(self, stddev=None, ddof=1):
-        if stddev is None:
-            r = self._sqdiff(self.mean())
-            return np.sqrt(r / (self.ntotal * (self.ntotal - ddof)))
-        return stddev / np.sqrt(self.ntotal)
+        n = self._reduce()[0]
+        return (self.stddev(ddof=ddof) if stddev is None else stddev) / np.sqrt(n)
 
     def cov(self, mean=None, ddof=1):
-        return self._bidiff(self.mean() if mean is None else mean) / (self.ntotal - ddof)
+        """Covariance matrix of the flattened observation, shape = shape + shape (second factor conjugated)."""
+        if self.local is None:
+            raise ValueError("covariances need the observations, not only their moments")
+        n, s1, _ = self._reduce()
+        centre = (s1 / n if mean is None else np.asarray(mean)).ravel()
+        d = self.local.reshape(self.nlocal, -1) - centre
+        outer, = self.comm.allreduce_packed([d.T @ d.conj()])
+        return outer.reshape(s1.shape * 2) / (n - ddof)
 
     def cov_of_mean(self, cov=None):
-        return (self.cov() if cov is None else cov) / self.ntotal
+        return (self.cov() if cov is None else cov) / self._reduce()[0]
+
+    def apply(self, func, inplace=False):
+        """Sample of func(x_i)."""
+        if self.local is None:
+            raise ValueError("apply needs the observations, not only their moments")
+        mapped = np.array([func(obs) for obs in self.local])
+        if inplace:
+            self.local = mapped; self._moments = None
+            return self
+        return DistributedSample(mapped, self.comm, self._ntotal)
 
 
 def join(*samples):
-    """statistics.py:5-16"""
+    """One sample holding the observations of all arguments (each rank concatenates its local blocks)."""
     if not samples:
-        raise ValueError("Must pass list of at least one sample")
-    comm = samples[0].mpi_comm
-    local = np.concatenate(tuple(s.local for s in samples), axis=0)
-    return DistributedSample(local, comm, sum(s.ntotal for s in samples))
+        raise ValueError("join() needs at least one sample")
+    return DistributedSample(np.concatenate([s.local for s in samples], axis=0), samples[0].comm, sum(s.ntotal for s in samples))
+
+
+class PackedMoments:
+    """Moments of several per-bin results in ONE device buffer (`MCTQMC.reduce_pack`, C ABI `w2dyn_reduce_pack`): the
+    buffer is all-reduced where it lives (RCCL) and only the reduced moments are copied to the host."""
+
+    def __init__(self, tensor, layout, comm=None):
+        self.tensor = tensor            # 1-d float64 torch tensor on the GPU, aliasing the library's buffer
+        self.layout = layout            # name -> (offset, doubles per bin, shape, is complex)
+        self.comm = comm if comm is not None else TorchComm()
+        self._host = None
+
+    def allreduce(self):
+        self.comm.allreduce_tensor(self.tensor)
+        self._host = self.tensor.cpu().numpy()
+        return self
+
+    def sample(self, name, scale=1.0):
+        """DistributedSample (moments only) of `scale` times one packed result; call after `allreduce`."""
+        if self._host is None:
+            raise RuntimeError("PackedMoments.sample before allreduce")
+        off, per, shape, cplx = self.layout[name]
+        rec = self._host[off:off + 1 + 3 * per]
+        n, s1, m2, bt = rec[0], rec[1:1 + per], rec[1 + per:1 + 2 * per], rec[1 + 2 * per:]
+        if cplx:
+            s1 = s1[0::2] + 1j * s1[1::2]; m2 = m2[0::2] + m2[1::2]; bt = bt[0::2] + bt[1::2]
+        return DistributedSample.from_moments(n, scale * s1.reshape(shape), scale ** 2 * m2.reshape(shape), scale ** 2 * bt.reshape(shape), self.comm)
