@@ -2,7 +2,9 @@
 
 Two runs in a row in one process, the second with fewer chains and a smaller frequency box, so that the static scratch
 still holds the first run's (larger) tables when the second one starts.  Same kernels and the same order of additions on
-both sides: the results must be identical bit for bit (bar of the other parity tests: 1e-10)."""
+both sides: the results must be identical bit for bit (bar of the other parity tests: 1e-10) - except G(l) and G(tau),
+whose kernel (the same in both entry points) cuts the element list into equal ranges and adds the two parts of a cut
+(bin, flavour) segment with atomics in arrival order: equal to rounding (1e-13 of the largest entry)."""
 import numpy as np
 import pytest
 
@@ -40,7 +42,11 @@ def test_noalloc_measurement_equals_measure_once_twice_in_a_row():
         got = _run(True, nw, nwf, nwb, seed)
         assert np.abs(ref["g4iw"]).max() > 0.0
         for k in ref:
-            assert got[k].shape == ref[k].shape and np.array_equal(got[k], ref[k]), k
+            assert got[k].shape == ref[k].shape, k
+            if k in ("gleg", "gtau"):
+                assert np.abs(got[k] - ref[k]).max() <= 1e-13 * np.abs(ref[k]).max(), k
+            else:
+                assert np.array_equal(got[k], ref[k]), k
 
 
 def test_noalloc_measurement_rejects_oversized_and_wrong_mode():

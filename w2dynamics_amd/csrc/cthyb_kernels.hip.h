@@ -66,7 +66,8 @@ namespace w2dyn {
 
 constexpr int MAXFLAV = 16;
 constexpr int KMAX_LIMIT = 256;
-constexpr int GLEG_RED_ROWS = 16, GLEG_RED_STRIDE = 65;      // k_meas_gleg: LDS transpose tile of the end-of-launch reduction
+constexpr int GLEG_SEG_BLOCK = 4096;     // k_gleg_segments: segments (bin, flavour) per workgroup
+constexpr int GLEG_RED_ROWS = 8, GLEG_RED_STRIDE = 65;      // k_meas_gleg: LDS transpose tile of the end-of-segment reduction
 constexpr int G2_FC = 32;                                    // k_meas_g2iw: frequency chunk of the two-step transform
 
 enum Counter { C_TRYADD, C_ACCADD, C_QNADD, C_TRYREM, C_ACCREM, C_QNREM, C_TRYGLOB, C_ACCGLOB, C_QNGLOB,
@@ -101,7 +102,7 @@ struct DevConst {
     int nd, nflav, nstates, nftau, ntau, nleg, niw2, kmax, nwalkers, num_windows, nslide, has_szt, maxhisto;
     int lane_shift;          // log2 of the lanes that share one flavour in level_integral: 64 / (nflav rounded up to a power of two)
     int walkers_per_bin, nbins, lds_per_wave, wcap, kgj;   // lds_per_wave in bytes; wcap: window-list capacity; kgj: LDS inversion order limit
-    double beta, taudiff_max, p_glob, p_shift, egs;
+    double beta, rbeta /* 1/beta, correctly rounded */, taudiff_max, p_glob, p_shift, egs;
     unsigned long long seed, first_walker;
     const double *ftab;      // [nflav][nftau]
     const double *energies;  // [nstates]
@@ -1887,125 +1888,276 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
 //
 // Work list: the (creator, annihilator) pairs of all chains of the bin, flattened (prefix sums of k_w^2 in LDS, binary
 // search per element), two elements per lane and pass so that two independent recursions are in flight.
-// Recursion in the rescaled form R_l = P_l / alpha_l with alpha_{l+1} = b_l alpha_{l-1} (alpha_0 = alpha_1 = 1):
-//   P_{l+1} = a_l x P_l - b_l P_{l-1}  (a_l = (2l+1)/(l+1), b_l = l/(l+1);  CTQMC.F90:2371-2388)
-//   R_{l+1} = c_l x R_l - R_{l-1},  c_l = a_l alpha_l / alpha_{l+1}
-// i.e. one multiply, one FMA and one accumulate-FMA per order and pair; alpha_l is applied once per launch.
-template <int N> struct GlegAlpha {
-    double a[N];
-    constexpr GlegAlpha() : a{} { for (int l = 0; l < N; ++l) a[l] = l < 2 ? 1.0 : ((double)(l - 1) / (double)l) * a[l - 2]; }
-};
-__device__ __constant__ GlegAlpha<128> g_gleg_alpha = GlegAlpha<128>();
-
-struct GlegRaw { double m, ta, tc; int j; };      // loads only, so that the next pass can be in flight during the recursion
+// The Legendre moments sum_e m_e P_l(x_e) (CTQMC.F90:2349-2393, recursion 2371-2388: a multiply and two FMAs per element and
+// order with order-dependent coefficients) are accumulated as Chebyshev moments c_j = sum_e m_e T_j(x_e) instead:
+// T_{j+1} = 2x T_j - T_{j-1} has constant coefficients, so an element and order cost two FMAs and no constants.  The
+// accumulators acc_gleg hold c_j; P_l = sum_j A_lj T_j with A_lj = (2 - delta_j0) g_(l-j)/2 g_(l+j)/2 >= 0, sum_j A_lj = 1
+// (g_k = binom(2k, k)/4^k; l - j even), a convex combination, turns them into Legendre moments once per run (k_gleg_legendre).
 struct GlegElem { double m, x; int idt; };
+struct GlegGroup {                 // per group of up to 64 chains of one (bin, flavour), in LDS
+    int2 pk[65];                   // (elements before chain j, its order k); pk[64].x = all elements of the group
+    unsigned long long mb[64];     // element offset of the chain's M block
+    unsigned long long tb[64];     // element offset of its tau arrays
+    double csl[64];                // configuration sign (0 for chains that do not measure)
+};
 
-__device__ __forceinline__ GlegRaw gleg_fetch(const DevConst &C, int f, int wc, const int *pre, const int *kpre, int g, int total)
+// Element g (clamped into the group's range; bit 31 marks a clamped one) -> packed (chain j, creator row ic, annihilator
+// column ia).  Up to 8 chains the chain is found by comparing with the 7 inner prefix sums held in scalar registers, else by
+// bisection in LDS.  e / k through the hardware reciprocal: (e + 1/2) / k is at least 1/(2k) >= 2^-9 away from an integer
+// and the two roundings shift it by less than k 2^-22.
+__device__ __forceinline__ int gleg_locate(const GlegGroup &G, int g, int total, int nstep, const int (&thr)[7])
 {
-    GlegRaw r; r.m = 0.0; r.ta = 0.0; r.tc = 0.0; r.j = -1;
-    if (g < total) {
-        int j = 0;
+    const int out = g >= total ? (int)0x80000000 : 0;
+    g = min(g, total - 1);
+    int j = 0;
+    if (nstep < 8) {
 #pragma unroll
-        for (int step = 32; step > 0; step >>= 1) if (pre[j + step] <= g) j += step;
-        const int k = kpre[j], e = g - pre[j], kmax = C.kmax;
-        const int ic = (int)(((float)e + 0.5f) * __frcp_rn((float)k)), ia = e - ic * k;   // exact: e < 2^16, k <= 256
-        const size_t wf = (size_t)(wc + j) * C.nflav + f;
-        r.m = C.M[wf * kmax * kmax + (size_t)ic * kmax + ia];
-        r.ta = C.TA[wf * kmax + ia]; r.tc = C.TC[wf * kmax + ic];
-        r.j = j;
-    }
-    return r;
+        for (int i = 0; i < 7; ++i) j += g >= thr[i] ? 1 : 0;
+    } else
+        for (int step = nstep; step > 0; step >>= 1) if (G.pk[j + step].x <= g) j += step;
+    const int2 c = G.pk[j];
+    const int e = g - c.x;
+    const int ic = (int)(((float)e + 0.5f) * __builtin_amdgcn_rcpf((float)c.y)), ia = e - ic * c.y;
+    return out | (j << 20) | (ic << 10) | ia;
+}
+__device__ __forceinline__ double gleg_load_m(const DevConst &C, const GlegGroup &G, int packed)
+{
+    return C.M[G.mb[(packed >> 20) & 63] + (unsigned)(((packed >> 10) & 1023) * C.kmax + (packed & 1023))];
 }
 
-__device__ __forceinline__ GlegElem gleg_finish(const DevConst &C, const GlegRaw &r, const double *csl)
+// d / beta, correctly rounded, from the correctly rounded reciprocal (made on the host) and two residual corrections
+// (Markstein: the first makes the quotient faithful, the second rounds it correctly); the hardware division sequence
+// costs ~40 instructions per element, this 5.  beta's significand is never all ones in practice; the tau-bin index it
+// feeds is checked against the oracle per chain.
+__device__ __forceinline__ double div_by_beta(double d, double beta, double rbeta)
 {
-    GlegElem o; o.m = 0.0; o.x = 0.0; o.idt = -1;
-    if (r.j >= 0) {
-        double m = r.m, d = r.ta - r.tc;
-        if (!(d > 0.0)) { d = C.beta + r.ta - r.tc; m = -m; }
-        o.m = m * csl[r.j];
-        int idt = (int)(d / C.beta * (double)C.ntau) + 1;
-        o.idt = (idt > C.ntau ? C.ntau : idt) - 1;
-        o.x = 2.0 / C.beta * d - 1.0;
-    }
+    double q = d * rbeta;
+    q = fma(fma(-q, beta, d), rbeta, q);
+    return fma(fma(-q, beta, d), rbeta, q);
+}
+
+__device__ __forceinline__ void gleg_load_tau(const DevConst &C, const GlegGroup &G, int packed, double &ta, double &tc)
+{
+    const unsigned long long tb = G.tb[(packed >> 20) & 63];
+#ifdef W2DYN_GLEG_NOTAU      // diagnostic: no tau loads
+    ta = (double)(packed & 1023) * 0.37 + (double)tb * 1e-9; tc = (double)((packed >> 10) & 1023) * 0.21;
+#else
+    ta = C.TA[tb + (unsigned)(packed & 1023)]; tc = C.TC[tb + (unsigned)((packed >> 10) & 1023)];
+#endif
+}
+
+__device__ __forceinline__ GlegElem gleg_finish(const DevConst &C, const GlegGroup &G, int packed, double m, double ta, double tc, double two_over_beta)
+{
+    GlegElem o;
+    double d = ta - tc;
+    if (!(d > 0.0)) { d = C.beta + ta - tc; m = -m; }
+    o.m = packed < 0 ? 0.0 : m * G.csl[(packed >> 20) & 63];
+    const int idt = (int)(div_by_beta(d, C.beta, C.rbeta) * (double)C.ntau) + 1;
+    o.idt = (idt > C.ntau ? C.ntau : idt) - 1;
+    o.x = two_over_beta * d - 1.0;
     return o;
 }
 
-template <int NLEG_TILE>
-__global__ __launch_bounds__(64) void k_meas_gleg(DevConst C, int lds_hist)
+// Work list of k_meas_gleg: a segment is the element list (chain, ic, ia) of one (accumulator bin, flavour), numbered
+// bin-major; segpre[sg] = number of elements before segment sg, segpre[nbins nflav] = all of them.  A workgroup of 1024
+// threads takes GLEG_SEG_BLOCK / nflav bins: the orders K[chain][flavour] of its chains are one contiguous array, read with
+// unit stride eight loads at a time and squared into LDS counters, which are then scanned (four consecutive segments per
+// thread).  With more than one workgroup the last one to finish (ticket counter, reset for the next launch) adds the
+// workgroup offsets.
+__global__ __launch_bounds__(1024) void k_gleg_segments(DevConst C, unsigned long long *segpre, unsigned long long *blocktot, unsigned *ticket)
 {
-    extern __shared__ double hist[];            // tau-bin histogram of this (bin, flavour): ntau doubles when lds_hist
-    __shared__ int pre[65], kpre[64];
-    __shared__ double csl[64];
-    const int bin = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
-    const int nleg = C.nleg, ntau = C.ntau;
-    double acc[NLEG_TILE];
+    __shared__ unsigned cnt[GLEG_SEG_BLOCK];
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned last;
+    const int nf = C.nflav, wpb = C.walkers_per_bin, nseg = C.nbins * nf, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int bpb = GLEG_SEG_BLOCK / nf;                       // bins per workgroup
+    const int bin0 = blockIdx.x * bpb, bin1 = min(bin0 + bpb, C.nbins), seg0 = bin0 * nf, nloc = (bin1 - bin0) * nf;
+    for (int i = tid; i < GLEG_SEG_BLOCK; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    const int p0 = bin0 * wpb * nf, p1 = min(bin1 * wpb, C.nwalkers) * nf;       // chains x flavours < 2^31 (checked on the host)
+    for (int pb = p0 + tid; pb < p1; pb += 8 * 1024) {
+        int kv[8];
 #pragma unroll
-    for (int l = 0; l < NLEG_TILE; ++l) acc[l] = 0.0;
-    double *gt = C.acc_gtau + ((size_t)bin * C.nflav + f) * ntau;
-    if (lds_hist)
-        for (int i = lane; i < ntau; i += 64) hist[i] = 0.0;
-    const int w0 = bin * C.walkers_per_bin, w1 = min(w0 + C.walkers_per_bin, C.nwalkers);
-    for (int wc = w0; wc < w1; wc += 64) {
-        wave_sync();
-        int km = (wc + lane < w1) ? C.K[(size_t)(wc + lane) * C.nflav + f] : 0;
-        int incl = km * km;
+        for (int u = 0; u < 8; ++u) { const int p = pb + u * 1024; kv[u] = p < p1 ? C.K[p] : 0; }
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-        pre[lane + 1] = incl; kpre[lane] = km;
-        csl[lane] = (wc + lane < w1) ? C.cfgsign[wc + lane] : 0.0;
-        if (lane == 0) pre[0] = 0;
-        wave_sync();
-        const int total = pre[64];
-        GlegRaw r0 = gleg_fetch(C, f, wc, pre, kpre, lane, total), r1 = gleg_fetch(C, f, wc, pre, kpre, 64 + lane, total);
-        for (int base = 0; base < total; base += 128) {
-            const GlegElem e0 = gleg_finish(C, r0, csl), e1 = gleg_finish(C, r1, csl);
-            r0 = gleg_fetch(C, f, wc, pre, kpre, base + 128 + lane, total);     // next pass: loads overlap the recursion
-            r1 = gleg_fetch(C, f, wc, pre, kpre, base + 192 + lane, total);
+        for (int u = 0; u < 8; ++u) {
+            const int p = pb + u * 1024;
+            if (kv[u] > 0) { const int w = p / nf, f = p - w * nf; atomicAdd(&cnt[(w / wpb - bin0) * nf + f], (unsigned)(kv[u] * kv[u])); }
+        }
+    }
+    __syncthreads();
+    unsigned long long c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = 4 * tid + i < nloc ? cnt[4 * tid + i] : 0u;
+    const unsigned long long mine = c[0] + c[1] + c[2] + c[3];
+    unsigned long long incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned long long t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    unsigned long long run = incl - mine;
+    for (int i = 0; i < wv; ++i) run += wsum[i];
+    if (blockIdx.x == 0 && tid == 0) segpre[0] = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { run += c[i]; if (4 * tid + i < nloc) segpre[seg0 + 4 * tid + i + 1] = run; }     // inclusive, within the workgroup
+    if (gridDim.x == 1) return;
+    if (tid == 1023) blocktot[blockIdx.x] = run;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    unsigned long long off = 0;
+    for (unsigned b = 1; b < gridDim.x; ++b) {
+        off += __builtin_nontemporal_load(&blocktot[b - 1]);
+        const int sb = (int)b * bpb * nf, sn = (min((int)(b + 1) * bpb, C.nbins) - (int)b * bpb) * nf;
+        for (int i = tid; i < sn; i += 1024) segpre[sb + i + 1] = __builtin_nontemporal_load(&segpre[sb + i + 1]) + off;
+    }
+    if (tid == 0) *ticket = 0;
+    (void)nseg;
+}
+
+// One wave per workgroup, as many workgroups as the GPU holds at once (two per SIMD: every lane keeps one accumulator per
+// order in registers, 2 NLEG VGPRs).  The global element list is cut into equal ranges (multiples of 128), one per wave, so
+// that all waves finish together whatever the expansion orders of the chains are; a wave walks the segments its range
+// touches, takes each one's elements in passes of 128 (two per lane, two independent recursions in flight; a pass costs
+// 2 fp64 FMAs per element and order, see above), and at the end of a segment sums the lane accumulators through an LDS
+// transpose and adds them and the segment's tau histogram (LDS) to the bin's accumulators with return-less atomics (a
+// segment cut by a range boundary has two owners; and nobody waits for the memory round trip).  Everything per element outside the recursion is kept
+// branch-free and short (~60 instructions): it is paid 128 times per pass against 400 instructions of recursion.
+template <int NLEG_TILE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NLEG_TILE > 100 ? 1 : 2, 8))) void k_meas_gleg(DevConst C, int lds_hist, const unsigned long long *__restrict__ segpre)
+{
+    extern __shared__ double hist[];            // [ntau if lds_hist] tau-bin histogram of the current segment, then the reduction tile
+    __shared__ GlegGroup G;
+    const int lane0 = threadIdx.x, nleg = C.nleg, ntau = C.ntau, nseg = C.nbins * C.nflav;
+    const unsigned long long all = segpre[nseg];
+    unsigned long long chunk = (all + gridDim.x - 1) / gridDim.x;
+    chunk = (chunk + 127) / 128 * 128;
+    // the 64-bit division runs on the vector unit: bring the (uniform) result back to scalar registers
+    chunk = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(chunk >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((unsigned)chunk);
+    const unsigned long long g0 = (unsigned long long)blockIdx.x * chunk, g1 = min(g0 + chunk, all);
+    if (g0 >= g1) return;
+    int sg = 0;                                 // the segment that holds element g0: last one with segpre[sg] <= g0
+    for (int step = 1 << 30; step > 0; step >>= 1) if (sg + step < nseg && segpre[sg + step] <= g0) sg += step;
+    double *red = hist + (lds_hist ? ntau : 0);
+    if (lds_hist) for (int i = lane0; i < ntau; i += 64) hist[i] = 0.0;
+    const double two_over_beta = 2.0 / C.beta;
+    for (; sg < nseg; ++sg) {
+        const unsigned long long sb = segpre[sg], se = segpre[sg + 1];
+        if (sb >= g1) break;
+        if (se == sb) continue;
+        const int lo = (int)(max(g0, sb) - sb), hi = (int)(min(g1, se) - sb);      // this wave's part of the segment
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));      // per-segment values derived from the lane index are recomputed, not kept (and spilled) across the pass loop
+        const int bin = sg / C.nflav, f = sg - bin * C.nflav;
+        double acc[NLEG_TILE];
+#pragma unroll
+        for (int l = 0; l < NLEG_TILE; ++l) acc[l] = 0.0;
+        double *gt = C.acc_gtau + ((size_t)bin * C.nflav + f) * ntau;
+        const int w0 = bin * C.walkers_per_bin, w1 = min(w0 + C.walkers_per_bin, C.nwalkers);
+        int goff = 0;                           // elements of the segment before the current group of 64 chains
+        for (int wc = w0; wc < w1 && goff < hi; wc += 64) {
+            wave_sync();
+            const size_t wf = (size_t)(wc + lane) * C.nflav + f;
+            const int km = (wc + lane < w1) ? C.K[wf] : 0, nch = min(w1 - wc, 64);
+            int incl = km * km;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+            G.pk[lane] = make_int2(incl - km * km, km);
+            if (lane == 63) G.pk[64] = make_int2(incl, 0);
+            G.mb[lane] = wf * C.kmax * C.kmax; G.tb[lane] = wf * C.kmax;
+            G.csl[lane] = (wc + lane < w1) ? C.cfgsign[wc + lane] : 0.0;
+            int thr[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) thr[i] = __builtin_amdgcn_readlane(incl, i);
+            wave_sync();
+            const int gtot = __builtin_amdgcn_readlane(incl, 63);
+            const int total = min(gtot, hi - goff);           // local element range [base0, total) of this group
+            int base = max(lo - goff, 0);
+            goff += gtot;
+            if (base >= total) continue;
+            int nstep = 32;
+            while (nstep >= nch && nstep > 0) nstep >>= 1;    // chains beyond nch have no elements: the prefix is flat there
+            // M (HBM, a gather) is requested two passes ahead; the tau values of a pass (reused by k elements each: cache
+            // hits) are requested before the pass's M gather (loads complete in order: waiting for them also waits for
+            // the M request of the pass before, not for the one just made)
+            int iA0 = gleg_locate(G, base + lane, total, nstep, thr), iA1 = gleg_locate(G, base + 64 + lane, total, nstep, thr);
+            double mA0 = gleg_load_m(C, G, iA0), mA1 = gleg_load_m(C, G, iA1);
+            int iB0 = gleg_locate(G, base + 128 + lane, total, nstep, thr), iB1 = gleg_locate(G, base + 192 + lane, total, nstep, thr);
+            double mB0 = gleg_load_m(C, G, iB0), mB1 = gleg_load_m(C, G, iB1);
+            for (; base < total; base += 128) {
+                double ta0, tc0, ta1, tc1;          // requested before the next M gather: loads complete in order
+                gleg_load_tau(C, G, iA0, ta0, tc0); gleg_load_tau(C, G, iA1, ta1, tc1);
+                const int iC0 = gleg_locate(G, base + 256 + lane, total, nstep, thr), iC1 = gleg_locate(G, base + 320 + lane, total, nstep, thr);
+                const double mC0 = gleg_load_m(C, G, iC0), mC1 = gleg_load_m(C, G, iC1);
+                const GlegElem e0 = gleg_finish(C, G, iA0, mA0, ta0, tc0, two_over_beta), e1 = gleg_finish(C, G, iA1, mA1, ta1, tc1, two_over_beta);
 #ifndef W2DYN_GLEG_NOHIST
-            if (e0.idt >= 0) { if (lds_hist) atomicAdd(&hist[e0.idt], e0.m); else atomicAdd(&gt[e0.idt], e0.m); }
-            if (e1.idt >= 0) { if (lds_hist) atomicAdd(&hist[e1.idt], e1.m); else atomicAdd(&gt[e1.idt], e1.m); }
+                if (iA0 >= 0) { if (lds_hist) atomicAdd(&hist[e0.idt], e0.m); else atomicAdd(&gt[e0.idt], e0.m); }
+                if (iA1 >= 0) { if (lds_hist) atomicAdd(&hist[e1.idt], e1.m); else atomicAdd(&gt[e1.idt], e1.m); }
 #endif
-            double p0 = 1.0, q0 = e0.x, p1 = 1.0, q1 = e1.x;      // R_{l-1}, R_l of the two elements
-            acc[0] += e0.m; acc[0] += e1.m;
-            if (NLEG_TILE > 1) { acc[1] = fma(e0.m, q0, acc[1]); acc[1] = fma(e1.m, q1, acc[1]); }
-            double alm1 = 1.0, al = 1.0;                           // alpha_{l-1}, alpha_l: folded at compile time
+                iA0 = iB0; iA1 = iB1; mA0 = mB0; mA1 = mB1; iB0 = iC0; iB1 = iC1; mB0 = mC0; mB1 = mC1;
+                // T_{l-1}, T_l of the two elements; T_{l+1} = 2x T_l - T_{l-1}: one FMA for the polynomial, one for the moment
+                double p0 = 1.0, q0 = e0.x, p1 = 1.0, q1 = e1.x;
+                const double x0 = e0.x + e0.x, x1 = e1.x + e1.x;
+                acc[0] += e0.m; acc[0] += e1.m;
+                if (NLEG_TILE > 1) { acc[1] = fma(e0.m, q0, acc[1]); acc[1] = fma(e1.m, q1, acc[1]); }
+#ifndef W2DYN_GLEG_NOREC      // diagnostic: everything but the recursion
 #pragma unroll
-            for (int il = 2; il < NLEG_TILE; ++il) {               // orders >= nleg are computed but never stored
-                const int l = il - 1;
-                const double a = (2.0 * (double)l + 1.0) / (double)(l + 1), b = (double)l / (double)(l + 1);
-                const double aln = b * alm1, c = a * al / aln;
-                double n0 = fma(c * e0.x, q0, -p0), n1 = fma(c * e1.x, q1, -p1);
-                acc[il] = fma(e0.m, n0, acc[il]); acc[il] = fma(e1.m, n1, acc[il]);
-                p0 = q0; q0 = n0; p1 = q1; q1 = n1;
-                alm1 = al; al = aln;
+#else
+#pragma unroll
+                for (int il = 2; il < NLEG_TILE; ++il) acc[il] += x0 + x1;
+                if (0)
+#endif
+                for (int il = 2; il < NLEG_TILE; ++il) {               // orders >= nleg are computed but never stored
+                    const double n0 = fma(x0, q0, -p0), n1 = fma(x1, q1, -p1);
+                    acc[il] = fma(e0.m, n0, acc[il]); acc[il] = fma(e1.m, n1, acc[il]);
+                    p0 = q0; q0 = n0; p1 = q1; q1 = n1;
+                }
+            }
+        }
+        // cross-lane reduction of the NLEG accumulators through an LDS transpose, 8 orders at a time: lane = (order, eighth)
+        // sums 8 lanes' partials, three DPP steps finish the sum.  (100 separate wave reductions cost ~6000 instr.)
+        double *gl = C.acc_gleg + ((size_t)bin * C.nflav + f) * nleg;
+#pragma unroll
+        for (int c0 = 0; c0 < NLEG_TILE; c0 += GLEG_RED_ROWS) {
+            wave_sync();
+#pragma unroll
+            for (int i = 0; i < GLEG_RED_ROWS; ++i)
+                if (c0 + i < NLEG_TILE) red[i * GLEG_RED_STRIDE + lane] = acc[c0 + i];
+            wave_sync();
+            const int lo8 = lane >> 3, part = lane & 7;
+            double sres = 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sres += red[lo8 * GLEG_RED_STRIDE + part * 8 + j];
+            sres += dpp_d<0xB1>(sres);          // quad_perm [1,0,3,2]
+            sres += dpp_d<0x4E>(sres);          // quad_perm [2,3,0,1]
+            sres += dpp_d<0x141>(sres);         // row_half_mirror: lanes 0-3 <-> 7-4 of every 8
+            const int l = c0 + lo8;
+            // atomics without return value even where the segment has one owner: a plain += waits a memory round trip
+            // per tile (and per 64 tau bins below) with nothing else to do
+            if (part == 0 && l < nleg && l < NLEG_TILE) atomicAdd(&gl[l], sres);
+        }
+        if (lds_hist) {
+            wave_sync();
+            for (int i = lane; i < ntau; i += 64) {
+                const double h = hist[i];
+                if (h != 0.0) { hist[i] = 0.0; atomicAdd(&gt[i], h); }
             }
         }
     }
-    // cross-lane reduction of the NLEG accumulators through an LDS transpose, 16 orders at a time: lane = (order, quarter)
-    // sums 16 lanes' partials, two DPP steps finish the quarter sum.  (100 separate wave reductions cost ~6000 instr.)
-    double *gl = C.acc_gleg + ((size_t)bin * C.nflav + f) * nleg;
-    double *red = hist + (lds_hist ? ntau : 0);
-#pragma unroll
-    for (int c0 = 0; c0 < NLEG_TILE; c0 += GLEG_RED_ROWS) {
-        wave_sync();
-#pragma unroll
-        for (int i = 0; i < GLEG_RED_ROWS; ++i)
-            if (c0 + i < NLEG_TILE) red[i * GLEG_RED_STRIDE + lane] = acc[c0 + i];
-        wave_sync();
-        const int lo = lane >> 2, part = lane & 3;
-        double sres = 0.0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) sres += red[lo * GLEG_RED_STRIDE + part * 16 + j];
-        sres += dpp_d<0xB1>(sres);          // quad_perm [1,0,3,2]
-        sres += dpp_d<0x4E>(sres);          // quad_perm [2,3,0,1]
-        const int l = c0 + lo;
-        if (part == 0 && l < nleg && l < NLEG_TILE) gl[l] += g_gleg_alpha.a[l] * sres;
-    }
-    if (lds_hist) {
-        wave_sync();
-        for (int i = lane; i < ntau; i += 64) { double h = hist[i]; if (h != 0.0) gt[i] += h; }
-    }
+}
+
+// Chebyshev moments of all (bin, flavour) -> Legendre moments: out[r][l] = sum_{j <= l} tab[l][j] in[r][j]
+__global__ __launch_bounds__(256) void k_gleg_legendre(const double *__restrict__ in, const double *__restrict__ tab, int nleg, size_t nrows, double *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nrows * nleg) return;
+    const size_t r = i / nleg; const int l = (int)(i - r * nleg);
+    double a = 0.0;
+    for (int j = l & 1; j <= l; j += 2) a = fma(tab[(size_t)l * nleg + j], in[r * nleg + j], a);
+    out[i] = a;
 }
 
 // AccumGtau = 2: autocorrelation accumulator of the G(tau) measurement series (autocorracc_add, Accumulators.F90:283-331),

@@ -28,7 +28,10 @@ void launch_meas_misc_tree(int mat, const LaunchCfg &l, const DevConst &C);
 void launch_meas_misc_seq(const LaunchCfg &l, const DevConst &C);
 
 // estimators (tu_meas.hip); grids and LDS sizes are worked out here from the DevConst
-void launch_meas_gleg(const DevConst &C, hipStream_t st);
+// segpre: nbins * nflav + 1 element counts (work list, made by the launch itself); ncu: compute units of the device
+void launch_meas_gleg(const DevConst &C, hipStream_t st, unsigned long long *segpre, int ncu);
+// acc_gleg holds Chebyshev moments; tab[l][j]: Legendre polynomial l in Chebyshev polynomials (nleg x nleg)
+void launch_gleg_legendre(hipStream_t st, const double *in, const double *tab, int nleg, size_t nrows, double *out);
 void launch_meas_gtau_ac(const DevConst &C, hipStream_t st, double *dat, int nlev, long long n);
 void launch_gtau_blocks(const DevConst &C, hipStream_t st, const double *dat, int nlev, long long n, double *out);
 void launch_meas_giw(const DevConst &C, hipStream_t st);

@@ -2,20 +2,32 @@
 // worm estimators, autocorrelation accumulator)
 #define W2DYN_TU_MEAS
 #include "launch.hpp"
+#include <algorithm>
 namespace w2dyn {
-template <int T> static void gleg_(const DevConst &C, hipStream_t st)
+template <int T> static void gleg_(const DevConst &C, hipStream_t st, unsigned long long *segpre, int ncu)
 {
     const int lds_hist = C.ntau <= 7000;       // tau histogram in LDS (< 64 KB with the reduction tile), else global atomics
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_gleg<T>), dim3(C.nbins, C.nflav), dim3(64),
-                       sizeof(double) * ((lds_hist ? C.ntau : 0) + GLEG_RED_ROWS * GLEG_RED_STRIDE), st, C, lds_hist);
+    const size_t lds = sizeof(double) * ((lds_hist ? C.ntau : 0) + GLEG_RED_ROWS * GLEG_RED_STRIDE);
+    // as many one-wave workgroups as run at once: two per SIMD by registers (T > 100: one), fewer if the histograms fill the LDS
+    const int per_cu = std::max(1, std::min(T > 100 ? 4 : 8, (int)((size_t)(160 * 1024) / (lds + sizeof(GlegGroup) + 64))));
+    const int nseg = C.nbins * C.nflav;
+    // segpre[0 .. nseg] are the prefix sums; behind them: per-workgroup totals and the ticket counter of k_gleg_segments
+    unsigned long long *blocktot = segpre + nseg + 1;
+    const int bpb = GLEG_SEG_BLOCK / C.nflav, nblk = (C.nbins + bpb - 1) / bpb;
+    hipLaunchKernelGGL(k_gleg_segments, dim3(nblk), dim3(1024), 0, st, C, segpre, blocktot, (unsigned *)(blocktot + nblk));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_gleg<T>), dim3(ncu * per_cu), dim3(64), lds, st, C, lds_hist, segpre);
 }
-void launch_meas_gleg(const DevConst &C, hipStream_t st)
+void launch_meas_gleg(const DevConst &C, hipStream_t st, unsigned long long *segpre, int ncu)
 {
-    if (C.nleg <= 16) gleg_<16>(C, st);
-    else if (C.nleg <= 32) gleg_<32>(C, st);
-    else if (C.nleg <= 64) gleg_<64>(C, st);
-    else if (C.nleg <= 100) gleg_<100>(C, st);
-    else gleg_<128>(C, st);
+    if (C.nleg <= 16) gleg_<16>(C, st, segpre, ncu);
+    else if (C.nleg <= 32) gleg_<32>(C, st, segpre, ncu);
+    else if (C.nleg <= 64) gleg_<64>(C, st, segpre, ncu);
+    else if (C.nleg <= 100) gleg_<100>(C, st, segpre, ncu);
+    else gleg_<128>(C, st, segpre, ncu);
+}
+void launch_gleg_legendre(hipStream_t st, const double *in, const double *tab, int nleg, size_t nrows, double *out)
+{
+    hipLaunchKernelGGL(k_gleg_legendre, dim3((unsigned)((nrows * nleg + 255) / 256)), dim3(256), 0, st, in, tab, nleg, nrows, out);
 }
 void launch_meas_gtau_ac(const DevConst &C, hipStream_t st, double *dat, int nlev, long long n)
 {

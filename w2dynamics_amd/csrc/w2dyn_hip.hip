@@ -129,6 +129,8 @@ struct w2dyn_solver {
     double mean_sign = 0, time_warmup = 0, time_sim = 0, time_sim_steps = 0;
     std::map<std::string, std::vector<double>> res;      // normalised results (doubles / complex interleaved)
     std::vector<long long> res_accpair;
+    double *gleg_leg = nullptr, *gleg_tab = nullptr;            // Legendre moments made from acc_gleg (Chebyshev moments) by measure_finish; conversion table
+    unsigned long long *gleg_segpre = nullptr; int ncu = 256;   // work list of k_meas_gleg; compute units of the device
     std::map<std::string, PackDesc> pack;                // filled by measure_finish, dropped with the accumulators
     double *packbuf = nullptr, *packscale = nullptr; size_t packbuf_n = 0, packscale_n = 0;   // w2dyn_reduce_pack; live until w2dyn_destroy
     std::vector<double> counters;                        // summed over walkers, C_NCOUNT
@@ -443,6 +445,7 @@ int w2dyn_create(w2dyn_solver **out, int device)
     s->device = device;
     if (hipSetDevice(device) != hipSuccess || scratch_address(device, &s->scratch) != hipSuccess || hipStreamCreate(&s->stream) != hipSuccess ||
         hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { delete s; return W2DYN_EHIP; }
+    if (hipDeviceGetAttribute(&s->ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || s->ncu <= 0) s->ncu = 256;
     *out = s;
     return 0;
 }
@@ -468,7 +471,7 @@ int w2dyn_set_layout(w2dyn_solver *s, int nwalkers, int64_t first_walker, int km
 {
     if (!s) return W2DYN_EINVAL;
     if (s->have_solver) return fail(s, W2DYN_EINVAL, "set_layout must precede init_solver");
-    if (nwalkers <= 0 || first_walker < 0 || kmax < 0 || kmax > KMAX_LIMIT || walkers_per_bin <= 0)
+    if (nwalkers <= 0 || nwalkers > (1 << 26) || first_walker < 0 || kmax < 0 || kmax > KMAX_LIMIT || walkers_per_bin <= 0)
         return fail(s, W2DYN_EINVAL, "bad layout (nwalkers=%d kmax=%d walkers_per_bin=%d)", nwalkers, kmax, walkers_per_bin);
     s->nwalkers = nwalkers; s->first_walker = first_walker; s->kmax_req = kmax; s->walkers_per_bin = walkers_per_bin;
     return 0;
@@ -663,7 +666,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
         if (lp.nsst > 32767) return fail(s, W2DYN_EUNSUPPORTED, "%d blocks: more than the 16-bit block tables hold", lp.nsst);
     }
     { int rc0 = configure_kmax(s, kmax); if (rc0) return rc0; }
-    C.beta = s->beta; C.p_glob = s->p_glob; C.p_shift = s->p_shift; C.egs = s->egs;
+    C.beta = s->beta; C.rbeta = 1.0 / s->beta; C.p_glob = s->p_glob; C.p_shift = s->p_shift; C.egs = s->egs;
     C.seed = (unsigned long long)s->seed; C.first_walker = (unsigned long long)s->first_walker;
     host_init_window(s, s->taudiffmax_param, C.num_windows, C.taudiff_max);           // Trace.F90:605
     C.nslide = std::max(2 * nd, (int)std::floor((double)s->ncorr / (double)C.num_windows));   // CTQMC.F90:8069
@@ -699,6 +702,22 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if ((rc = dev_alloc(s, C.flags, 4))) return rc;
     const size_t B = C.nbins;
     if ((rc = dev_alloc(s, C.acc_gleg, B * nf * s->nleg))) return rc;
+    {   // prefix sums, workgroup totals, ticket of k_gleg_segments (layout: tu_meas.hip)
+        const size_t bpb = GLEG_SEG_BLOCK / nf, n = B * nf + 1 + (B + bpb - 1) / bpb + 1;
+        if ((rc = dev_alloc(s, s->gleg_segpre, n))) return rc;
+        HIPCHK(hipMemsetAsync(s->gleg_segpre, 0, sizeof(unsigned long long) * n, s->stream));
+    }
+    if ((rc = dev_alloc(s, s->gleg_leg, B * nf * s->nleg))) return rc;
+    if ((rc = dev_alloc(s, s->gleg_tab, (size_t)s->nleg * s->nleg))) return rc;
+    {   // Legendre polynomials in Chebyshev polynomials: P_l = sum_k g_k g_(l-k) T_|l-2k|, g_k = binom(2k, k) / 4^k
+        const int nl = s->nleg;
+        std::vector<long double> g(nl + 1, 1.0L);
+        for (int k = 1; k <= nl; ++k) g[k] = g[k - 1] * (long double)(2 * k - 1) / (long double)(2 * k);
+        std::vector<double> tab((size_t)nl * nl, 0.0);
+        for (int l = 0; l < nl; ++l)
+            for (int k = 0; 2 * k <= l; ++k) tab[(size_t)l * nl + (l - 2 * k)] = (double)((2 * k == l ? 1.0L : 2.0L) * g[k] * g[l - k]);
+        HIPCHK(hipMemcpy(s->gleg_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     if ((rc = dev_alloc(s, C.acc_gtau, B * nf * s->ntau))) return rc;
     if ((rc = dev_alloc(s, C.acc_giw, B * nf * C.niw2 * 2))) return rc;
     if ((rc = dev_alloc(s, C.acc_histo, B * nf * (s->maxhisto + 1)))) return rc;
@@ -991,7 +1010,7 @@ static int measure_once_impl(w2dyn_solver *s, double2 *g2buf)
     }
     if (s->accum_gtau != 0) {          // AccumGtau = 0: MeasGtauRem returns at once, neither G(l) nor G(tau) (CTQMC.F90:2267)
     if ((rc = time_begin(s))) return rc;
-    launch_meas_gleg(s->C, s->stream);
+    launch_meas_gleg(s->C, s->stream, s->gleg_segpre, s->ncu);
     HIPCHK(hipGetLastError());
     if ((rc = time_end(s, "meas_gleg"))) return rc;
     }
@@ -1072,7 +1091,9 @@ int w2dyn_measure_finish(w2dyn_solver *s)
         if (e != hipSuccess && fetch_err == hipSuccess) fetch_err = e;
         return v;
     };
-    std::vector<double> gleg = fetch(C.acc_gleg, (size_t)B * nf * s->nleg), gtau = fetch(C.acc_gtau, (size_t)B * nf * s->ntau);
+    launch_gleg_legendre(s->stream, C.acc_gleg, s->gleg_tab, s->nleg, (size_t)B * nf, s->gleg_leg);
+    HIPCHK(hipStreamSynchronize(s->stream));
+    std::vector<double> gleg = fetch(s->gleg_leg, (size_t)B * nf * s->nleg), gtau = fetch(C.acc_gtau, (size_t)B * nf * s->ntau);
     std::vector<double> giw = fetch(C.acc_giw, (size_t)B * nf * C.niw2 * 2), histo = fetch(C.acc_histo, (size_t)B * nf * (s->maxhisto + 1));
     const int no = C.nouter, dms = C.dmsize;
     const LocalProblem &lp = s->lp;
@@ -1113,7 +1134,7 @@ int w2dyn_measure_finish(w2dyn_solver *s)
     };
     const int nleg = s->nleg, ntau = s->ntau;
     // GLeg*sqrt(2l+1)/beta, then -GLeg*zScaling with zScaling = -1/(N*mean_sign)          (CTQMC.F90:8697, 8766-8771)
-    reduce_bins(gleg, (size_t)nf * nleg, "gleg", [&](double v, double n, size_t i) { int l = (int)(i % nleg); double zs = -1.0 / (n * ms); return -(v * std::sqrt((double)(2 * l) + 1.0) / beta) * zs; }, C.acc_gleg, nleg);
+    reduce_bins(gleg, (size_t)nf * nleg, "gleg", [&](double v, double n, size_t i) { int l = (int)(i % nleg); double zs = -1.0 / (n * ms); return -(v * std::sqrt((double)(2 * l) + 1.0) / beta) * zs; }, s->gleg_leg, nleg);
     // Gtau = -mean/(-mean_sign) * Ntau/beta^2                                              (CTQMC.F90:8726-8731)
     reduce_bins(gtau, (size_t)nf * ntau, "gtau", [&](double v, double n, size_t) { return -(v / n) / (-ms) * (double)ntau / (beta * beta); }, C.acc_gtau);
     reduce_bins(giw, (size_t)nf * C.niw2 * 2, "giw", [&](double v, double n, size_t) { double zs = -1.0 / (n * ms); return v * zs / beta; }, C.acc_giw);   // 8815-8817
