@@ -45,5 +45,7 @@ if __name__ == "__main__":
     if args and not args[0].isdigit():
         cfg = args.pop(0)
     over = dict(NCorr=200 if cfg == "C2" else 100, TaudiffMax=10.0, Ntau=1000, NLegMax=100)
+    if os.environ.get("PROBE_NORARE"):      # no global / tau-shift moves (register experiments with those moves compiled out)
+        over.update(PercentageGlobalMove=0.0, PercentageTauShiftMove=0.0)
     for nw in [int(x) for x in (args or ["256", "2048", "8192", "16384"])]:
         probe(cfg, 5001, over, nw)

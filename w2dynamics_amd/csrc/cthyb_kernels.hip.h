@@ -145,6 +145,7 @@ struct DevConst {
     // calibration.  calib: 0 = off, 1 = phase 1 (per-chain list of accepted pair distances), 2 = phase 2 (histogram on
     // the calibrated window; per-chain, per-flavour counts decide when a chain is done), CTQMC.F90:8088-8178
     int naccpair, calib, napt, phase2pairnum;
+    int sweep_wpe3;               // scalar path: run the sweep kernel variant with three waves per SIMD (k_sweep<0, false, true>)
     double accpair_max;
     double *apt_tau;              // [nwalkers][napt]
     int *apt_cnt;                 // [nwalkers]
@@ -1618,8 +1619,11 @@ __device__ __forceinline__ void flag_full(Ctx &x)
 #define W2DYN_WPE 2      // the scalar-path kernel sits right at 256 registers: never let it tip over into one wave per SIMD
 #endif
 
-template <int MAT, bool CALIB = false>
-__global__ __launch_bounds__(256, MAT == 0 ? W2DYN_WPE : W2DYN_WPE_MAT) void k_sweep(DevConst C, long long nsteps_launch, int count_sampling, int resume)
+// WPE3: the same kernel held to 168 registers (three waves per SIMD).  With the branch weights below the ~90 spilled
+// registers land mostly in the rare moves, and the step rate rises by 6-10 % for up to three orbitals (C1, C2, C3); with five
+// (C5Z: longer flavour loops everywhere) the spills cost more than the third wave brings.  The host chooses (walker_launch).
+template <int MAT, bool CALIB = false, bool WPE3 = false>
+__global__ __launch_bounds__(256, MAT == 0 ? (WPE3 ? 3 : W2DYN_WPE) : W2DYN_WPE_MAT) void k_sweep(DevConst C, long long nsteps_launch, int count_sampling, int resume)
 {
     extern __shared__ unsigned char smem[];
     stage_shared_tables(C, smem);
@@ -1651,26 +1655,52 @@ __global__ __launch_bounds__(256, MAT == 0 ? W2DYN_WPE : W2DYN_WPE_MAT) void k_s
         unsigned long long t0_ = __builtin_amdgcn_s_memtime();
         int which_;
 #endif
-        if (r < (1.0 - ps - pg) / 2.0) { x.skip(2);
+        // The chain of moves twice: with branch weights in the three-waves variant - the rare moves contain deep loop nests,
+        // which the register allocator would otherwise take for the hot part of the kernel and spill the pair moves instead -,
+        // without in the others, where nothing spills and the weights only disturb the block layout (measured: 4 % slower).
+        if constexpr (WPE3) {
+            if (r < (1.0 - ps - pg) / 2.0) { x.skip(2);
 #ifndef W2DYN_NO_ADD
-            step_add<MAT, false, CALIB>(x);
+                step_add<MAT, false, CALIB>(x);
 #endif
-            STAMP_KIND(C_CYC_ADD); phase += 1; }
-        else if (r <= 1.0 - ps - pg) { x.skip(2);
+                STAMP_KIND(C_CYC_ADD); phase += 1; }
+            else if (__builtin_expect(r <= 1.0 - ps - pg, 1)) { x.skip(2);
 #ifndef W2DYN_NO_REM
-            step_rem<MAT, false, CALIB>(x);
+                step_rem<MAT, false, CALIB>(x);
 #endif
-            STAMP_KIND(C_CYC_REM); phase += 1; }
-        else if (r <= 1.0 - ps) {
+                STAMP_KIND(C_CYC_REM); phase += 1; }
+            else if (__builtin_expect(r <= 1.0 - ps, 0)) {
 #ifndef W2DYN_NO_GLOB
-            if constexpr (MAT != 0) step_glob_mat<MAT>(x); else step_glob(x);
+                if constexpr (MAT != 0) step_glob_mat<MAT>(x); else step_glob(x);
 #endif
-            STAMP_KIND(C_CYC_GLOB); }
-        else {
+                STAMP_KIND(C_CYC_GLOB); }
+            else {
 #ifndef W2DYN_NO_SHIFT
-            step_shift<MAT>(x);
+                step_shift<MAT>(x);
 #endif
-            STAMP_KIND(C_CYC_SHIFT); }
+                STAMP_KIND(C_CYC_SHIFT); }
+        } else {
+            if (r < (1.0 - ps - pg) / 2.0) { x.skip(2);
+#ifndef W2DYN_NO_ADD
+                step_add<MAT, false, CALIB>(x);
+#endif
+                STAMP_KIND(C_CYC_ADD); phase += 1; }
+            else if (r <= 1.0 - ps - pg) { x.skip(2);
+#ifndef W2DYN_NO_REM
+                step_rem<MAT, false, CALIB>(x);
+#endif
+                STAMP_KIND(C_CYC_REM); phase += 1; }
+            else if (r <= 1.0 - ps) {
+#ifndef W2DYN_NO_GLOB
+                if constexpr (MAT != 0) step_glob_mat<MAT>(x); else step_glob(x);
+#endif
+                STAMP_KIND(C_CYC_GLOB); }
+            else {
+#ifndef W2DYN_NO_SHIFT
+                step_shift<MAT>(x);
+#endif
+                STAMP_KIND(C_CYC_SHIFT); }
+        }
 #ifdef W2DYN_STAMPS
         if (x.lane == 0) x.cnt[which_] += __builtin_amdgcn_s_memtime() - t0_;
 #endif

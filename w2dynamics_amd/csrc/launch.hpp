@@ -18,6 +18,7 @@ void launch_relayout(const DevConst &C, hipStream_t st, int kold, int knew, cons
 
 // pieces (one per translation unit)
 void launch_sweep_scalar(bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling, int resume);
+void launch_sweep_scalar3(const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling, int resume);    // tu_scalar3.hip
 void launch_sweep_tree(int mat, bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling, int resume);
 void launch_sweep_seq(bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling, int resume);
 void launch_sweep_worm_scalar(int nworm, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume);

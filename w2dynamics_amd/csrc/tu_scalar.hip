@@ -5,6 +5,7 @@ namespace w2dyn {
 void launch_sweep_scalar(bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count, int resume)
 {
     if (calib) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<0, true>), l.grid, l.block, l.lds, l.stream, C, nsteps, count, resume);
+    else if (C.sweep_wpe3) launch_sweep_scalar3(l, C, nsteps, count, resume);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep<0, false>), l.grid, l.block, l.lds, l.stream, C, nsteps, count, resume);
 }
 void launch_meas_misc_scalar(const LaunchCfg &l, const DevConst &C) { hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_misc<0>), l.grid, l.block, l.lds, l.stream, C); }

@@ -272,6 +272,9 @@ int configure_kmax(w2dyn_solver *s, int kmax)
         C.op_in_lds = (!two_groups && small + nop * sizeof(double) <= 64 * 1024) ? 1 : 0;
         C.shared_lds = (int)((small + (C.op_in_lds ? nop * sizeof(double) : 0) + 15) & ~(size_t)15);
     }
+    // three waves per SIMD pay up to three orbitals (measured: C1, C2, C3 +6-10 %, C5Z -23 %); W2DYN_SWEEP_WPE=2|3 overrides
+    C.sweep_wpe3 = (!s->mat && nf <= 6) ? 1 : 0;
+    if (const char *e = getenv("W2DYN_SWEEP_WPE")) C.sweep_wpe3 = (!s->mat && atoi(e) == 3) ? 1 : 0;
     C.lds_per_wave = (int)lds_bytes_per_wave(nf, kmax, C.wcap, C.kgj, C.mat ? C.nsm : 0);
     if ((size_t)C.shared_lds + 4 * (size_t)C.lds_per_wave > 160 * 1024 && C.kgj > 16) { C.kgj = 16; C.lds_per_wave = (int)lds_bytes_per_wave(nf, kmax, C.wcap, C.kgj, C.mat ? C.nsm : 0); }
     if ((size_t)C.shared_lds + 4 * (size_t)C.lds_per_wave > 160 * 1024) return fail(s, W2DYN_EUNSUPPORTED, "kmax=%d needs %d bytes of LDS per chain: too large", kmax, C.lds_per_wave);
