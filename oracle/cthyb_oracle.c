@@ -71,6 +71,7 @@ struct ora_walker {
     double *accpairtau; int napt, apt_index;   /* AccPairTau list of the window calibration, phase 1 (CTQMC.F90:67, 70) */
     /* accumulators */
     double *gleg, *gtau, *giw, *histo, *dm, *outer_histo;
+    double *ntau_n0;                      /* [nflav][nflav][ntau+1], MeasSusz */
     /* MeasOuterHistograms (CTQMC.F90:3285-3339): per block [nsst] and per eigenstate [nstates], block order */
     double *sign_sst, *tcontrib_sst, *outer_state_histo, *sign_state, *tcontrib_state;
     double *g2iw, *g4iw, *g4iwpp;    /* complex interleaved, NULL when not measured */
@@ -1118,6 +1119,7 @@ ora_walker *ora_create(const ora_params *p, const double *U, const double *ftau_
     w->naccpair = p->ntau; w->accpair_max = p->beta;
     w->gleg = (double *)calloc((size_t)w->nflav * p->nlegmax, sizeof(double));
     w->gtau = (double *)calloc((size_t)w->nflav * p->ntau, sizeof(double));
+    w->ntau_n0 = p->meas_susz ? (double *)calloc((size_t)w->nflav * w->nflav * (p->ntau + 1), sizeof(double)) : NULL;
     w->giw = (double *)calloc((size_t)w->nflav * 2 * p->niw * 2, sizeof(double));
     w->histo = (double *)calloc((size_t)w->nflav * (p->maxhisto + 1), sizeof(double));
     w->dm = (double *)calloc((size_t)w->nstates, sizeof(double));
@@ -1169,7 +1171,7 @@ void ora_destroy(ora_walker *w)
 {
     if (!w) return;
     for (int f = 0; f < w->nflav; ++f) free(w->M[f]);
-    free(w->ops); free(w->ftab); ora_locprob_free(w->lp); free(w->ptr); free(w->dmblk); free(w->dmoff); free(w->accpair); free(w->accpairtau); free(w->gleg); free(w->gtau); free(w->giw);
+    free(w->ops); free(w->ftab); ora_locprob_free(w->lp); free(w->ptr); free(w->dmblk); free(w->dmoff); free(w->accpair); free(w->accpairtau); free(w->gleg); free(w->gtau); free(w->giw); free(w->ntau_n0);
     free(w->histo); free(w->dm); free(w->outer_histo); free(w->sign_sst); free(w->tcontrib_sst); free(w->outer_state_histo); free(w->sign_state); free(w->tcontrib_state); free(w->g2iw); free(w->g4iw); free(w->g4iwpp); free(w->g4w); free(w->g4wpp); free(w->g4tau); free(w->g4leg); free(w->giww); free(w->gtauw); free(w->acbuf); free(w->acdat); free(w);
 }
 
@@ -1474,6 +1476,40 @@ static void autocorr_add(ora_walker *w)
     w->acn += 1;
 }
 
+/* MeasSusz on the matrix solver: meas_ntau_n0 (Trace.F90:6472-6835).  For every flavour pair and every tau point t = 0 ..
+ * Ntau-1 the reference inserts the density n_1 = c+_1 c_1 at the reference time tauref = upper edge of the window and n_2
+ * at tauref + t beta/Ntau (points beyond beta: tauref - (Ntau - t) beta/Ntau) into the stored bra/ket vectors of the
+ * outer states and adds  -(bra n_2 ket) cfgsign / Trace.  Restated with the operator list itself: the four operators
+ * join the sequence and the local trace is taken from scratch (sum over the outer states as there). */
+static void meas_ntau_n0(ora_walker *w)
+{
+    const int nf = w->nflav, ntau = w->p.ntau;
+    const double beta = w->p.beta, tauD = beta / (double)ntau, tauref = w->wmax;
+    const logval tr0 = full_trace(w, w->outer_sst);
+    if (tr0.sign == 0.0) return;
+    for (int f1 = 0; f1 < nf; ++f1) {
+        for (int t = 0; t < ntau; ++t) {
+            double tauint = tauref + (double)t * tauD;
+            if (tauint > beta) tauint = tauref - (double)(ntau - t) * tauD;
+            for (int f2 = 0; f2 < nf; ++f2) {
+                /* annihilator first, then the creator at the same time: n = c+ c acting on the ket (6546-6555, 6613-6622);
+                 * n_1 enters the list before n_2, so that it stays the earlier one if both times coincide */
+                op_t o; memset(&o, 0, sizeof o);
+                int idx[4];
+                o.wid = 99;
+                o.tau = tauref; o.flav = f1; o.ca = 2; list_insert(w, o); o.ca = 1; list_insert(w, o);
+                o.tau = tauint; o.flav = f2; o.ca = 2; list_insert(w, o); o.ca = 1; list_insert(w, o);
+                const logval tr = full_trace(w, w->outer_sst);
+                int n = 0;
+                for (int i = w->nops - 1; i >= 0 && n < 4; --i) if (w->ops[i].wid == 99) idx[n++] = i;
+                for (int i = 0; i < n; ++i) list_remove(w, idx[i]);            /* descending indices */
+                if (tr.sign != 0.0)
+                    w->ntau_n0[((size_t)f1 * nf + f2) * (ntau + 1) + t] -= tr.sign * tr0.sign * exp(tr.log - tr0.log) * w->cfgsign;
+            }
+        }
+    }
+}
+
 void ora_measure_once(ora_walker *w)
 {
     int nf = w->nflav;
@@ -1520,6 +1556,7 @@ void ora_measure_once(ora_walker *w)
         free(tc); free(ta);
     }
     if (w->p.accum_gtau == 2) autocorr_add(w);                          /* gtau_accum%add(), CTQMC.F90:2439 */
+    if (w->ntau_n0) meas_ntau_n0(w);                                    /* CTQMC.F90:8556-8560 */
     if (w->g4tau || w->g4leg) meas_g4leg(w);                            /* CTQMC.F90:8578 */
     if (w->g4iw || w->g4iwpp) meas_g4iw(w);                             /* CTQMC.F90:8579 */
 }
@@ -1560,6 +1597,12 @@ void ora_measure_finish(ora_walker *w)
     for (size_t i = 0; i < (size_t)nf * w->p.ntau; ++i)                                 /* 8726-8731 */
         w->gtau[i] = -(w->gtau[i] / w->cnt_meas) / (-w->mean_sign) * (double)w->p.ntau / (beta * beta);
     for (size_t i = 0; i < (size_t)nf * (w->p.maxhisto + 1); ++i) w->histo[i] /= w->cnt_meas;   /* 8755 */
+    if (w->ntau_n0)                                                                     /* 8744-8746 */
+        for (int ff = 0; ff < nf * nf; ++ff) {
+            double *r = w->ntau_n0 + (size_t)ff * (w->p.ntau + 1);
+            for (int t = 0; t < w->p.ntau; ++t) r[t] *= zs;
+            r[w->p.ntau] = r[0];
+        }
     for (int s = 0; s < w->nstates; ++s) {                                              /* 8757-8764 (0/0 = NaN for blocks never visited) */
         w->sign_sst[s] /= w->outer_histo[s]; w->sign_state[s] /= w->outer_state_histo[s];
         w->outer_histo[s] /= w->cnt_meas; w->outer_state_histo[s] /= w->cnt_meas;
@@ -1741,6 +1784,14 @@ int ora_get_g4iw_worm(const ora_walker *w, double *o, int pp)
 }
 /* autocorracc_blocks (Accumulators.F90:343-361): sqdiff / (n - 1) per level, n halved from level to level;
  * out (Nd,2,Ntau,nlevels) C order; returns nlevels (0 if AccumGtau != 2); out may be NULL */
+int ora_get_ntau_n0(const ora_walker *w, double *o)
+{
+    if (!w->ntau_n0) return 0;
+    /* (Nd,2,Nd,2,Ntau+1) from flavour order f = 2 band + spin */
+    memcpy(o, w->ntau_n0, sizeof(double) * (size_t)w->nflav * w->nflav * (w->p.ntau + 1));
+    return 1;
+}
+
 int ora_get_gtau_blocks(const ora_walker *w, double *o)
 {
     if (!w->acdat) return 0;

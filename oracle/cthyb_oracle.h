@@ -53,6 +53,7 @@ typedef struct ora_params {
     int worm_meas_giw, worm_meas_gtau;            /* WormMeasGiw, WormMeasGtau */
     double epsblock;        /* EPSBLOCK: threshold of the automatic block partitioning, QuantumNumbers = All (CTQMC.F90:7972) */
     int accum_gtau;         /* AccumGtau: 0 = G(tau)/G(l) not measured, 1 = running mean, 2 = autocorrelation accumulator (CTQMC.F90:492-500) */
+    int meas_susz;          /* MeasSusz (matrix solver): <n(tau) n(0)>, meas_ntau_n0 (CTQMC.F90:534-540, Trace.F90:6472-6835) */
 } ora_params;
 
 typedef struct ora_walker ora_walker;
@@ -77,6 +78,7 @@ void ora_count_steps(ora_walker *w, int isector, int icomponent, int64_t nfix, i
 int ora_get_g4iw_worm(const ora_walker *w, double *out_reim, int pp);
 /* giw_worm (2Niw) complex interleaved / gtau_worm (Ntau) of the sampled component (CTQMC.F90:1061-1120, 8858-8876);
  * return 0 if not measured */
+int ora_get_ntau_n0(const ora_walker *w, double *out);       /* ntau_n0 (Nd,2,Nd,2,Ntau+1), MeasSusz = 1; returns 0 if not measured */
 int ora_get_gtau_blocks(const ora_walker *w, double *out);   /* gtau_blocks (Nd,2,Ntau,nlevels), AccumGtau = 2; returns nlevels */
 int ora_get_giw_worm(const ora_walker *w, double *out_reim);
 int ora_get_gtau_worm(const ora_walker *w, double *out);

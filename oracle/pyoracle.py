@@ -23,7 +23,8 @@ class OraParams(C.Structure):
                 ("meas_g4iwpp", C.c_int), ("zphconv", C.c_int), ("n4tau", C.c_int), ("n4leg", C.c_int),
                 ("p_worm_ins", C.c_double), ("p_worm_rep", C.c_double), ("worm_eta", C.c_double),
                 ("worm_meas_g4iw", C.c_int), ("g4ph", C.c_int), ("g4pp", C.c_int), ("wormphconv", C.c_int),
-                ("worm_meas_giw", C.c_int), ("worm_meas_gtau", C.c_int), ("epsblock", C.c_double), ("accum_gtau", C.c_int)]
+                ("worm_meas_giw", C.c_int), ("worm_meas_gtau", C.c_int), ("epsblock", C.c_double), ("accum_gtau", C.c_int),
+                ("meas_susz", C.c_int)]
 
 
 def build():
@@ -81,6 +82,7 @@ def lib():
     L.ora_get_worm_counters.argtypes = [vp, dp]
     L.ora_get_giw_worm.argtypes = [vp, dp]; L.ora_get_giw_worm.restype = C.c_int
     L.ora_get_gtau_blocks.argtypes = [vp, C.c_void_p]; L.ora_get_gtau_blocks.restype = C.c_int
+    L.ora_get_ntau_n0.argtypes = [vp, C.c_void_p]; L.ora_get_ntau_n0.restype = C.c_int
     L.ora_get_gtau_worm.argtypes = [vp, dp]; L.ora_get_gtau_worm.restype = C.c_int
     L.ora_get_hashybs.argtypes = [vp, ip]
     L.ora_get_g2iw.argtypes = [vp, dp]; L.ora_get_g2iw.restype = C.c_int
@@ -118,7 +120,8 @@ def params_from_pstring(ps, nd, beta, fourpnt=0):
                      g4ph=int(ps.get_int("G4ph") != 0), g4pp=int(ps.get_int("G4pp") != 0),
                      wormphconv=int(ps.get_int("WormPHConvention") != 0),
                      worm_meas_giw=int(ps.get_int("WormMeasGiw") != 0), worm_meas_gtau=int(ps.get_int("WormMeasGtau") != 0),
-                     epsblock=ps.get_real("EPSBLOCK"), accum_gtau=ps.get_int("AccumGtau"))
+                     epsblock=ps.get_real("EPSBLOCK"), accum_gtau=ps.get_int("AccumGtau"),
+                     meas_susz=int(ps.get_int("MeasSusz") == 1 and ps.get_int("segment") == 0))
 
 
 class OracleWalker:
@@ -226,6 +229,9 @@ class OracleWalker:
                 a = np.zeros((2 * p.n4iwf, 2 * p.n4iwf, 2 * p.n4iwb + 1, 2))
                 if self.L.ora_get_g4iw_worm(self.h, a, pp):
                     r[key] = a[..., 0] + 1j * a[..., 1]
+        a = np.zeros((nd, 2, nd, 2, p.ntau + 1))
+        if self.L.ora_get_ntau_n0(self.h, a.ctypes.data):
+            r["ntau_n0"] = a
         nlev = self.L.ora_get_gtau_blocks(self.h, None)
         if nlev:
             a = np.zeros((nd, 2, p.ntau, nlev)); self.L.ora_get_gtau_blocks(self.h, a.ctypes.data); r["gtau_blocks"] = a

@@ -265,7 +265,7 @@ def gen_worm(only=None):
         print("worm", name, "steps(worm, Z) of the eta search", steps, "cntsampling", r["cntsampling"][[0, sector - 1]], "nops", len(c_end["taus"]))
 
 
-KINDS = ("traj", "stat", "g4", "worm", "calib", "accum", "g4leg")
+KINDS = ("traj", "stat", "g4", "worm", "calib", "accum", "g4leg", "susz")
 
 ACCUM = {   # AccumGtau = 2 (autocorrelation accumulator: gtau_blocks) and 0 (G(tau), G(l) not measured), one seeded chain
     # name: (config, nftau, overrides, seed)
@@ -325,6 +325,33 @@ def gen_calib(only=None):
         print("calib", name, "taudiffmax", tdm, "accpair sums", acc.sum(axis=2).ravel(), "nops", len(c_end["taus"]))
 
 
+# MeasSusz = 1 on the matrix solver (meas_ntau_n0, Trace.F90:6472-6835): one measurement of <n(tau) n(0)> from a recorded
+# configuration (the end configuration of the trajectory golden), for a single window (C1: reference time beta), several
+# windows (C3: reference time at the window's upper edge) and blocks of more than one state (C4)
+SUSZ = {"C1": 24, "C3": 16, "C4": 12}
+
+
+def gen_susz(only=None):
+    for name, ntau in SUSZ.items():
+        if only and name not in only:
+            continue
+        cfg, nftau, over, seed = TRAJ[name]
+        g = np.load(os.path.join(OUT, "traj_%s.npz" % name), allow_pickle=False)
+        c_end = {k[4:]: g[k] for k in g.files if k.startswith("end_")}
+        c_end["outer_sst"] = int(c_end["outer_sst"]); c_end["outer_state"] = int(c_end["outer_state"])
+        over1 = dict(over); over1.update(Nmeas=1, NCorr=0, Nwarmups=0, MeasSusz=1, Ntau=ntau)
+        p, ps1 = pstring_for(cfg, nftau, over1)
+        s = refdrive.RefSolver(p, ps1, seed)
+        s.set_taudiffmax(over["TaudiffMax"])
+        s.set_config(c_end)
+        s.measure()
+        r = s.results(("ntau_n0", "mean_sign", "gtau", "occ"))
+        s.close()
+        np.savez_compressed(os.path.join(OUT, "susz_%s.npz" % name), config=cfg, nftau=nftau, seed=seed, overrides=repr(over1),
+                            **{"cfg_" + k: v for k, v in c_end.items()}, **{"res_" + k: v for k, v in r.items()})
+        print("susz", name, r["ntau_n0"].shape, "n(0)n(0) diag", [float(r["ntau_n0"][b, 0, b, 0, 0]) for b in range(p.nd)], "occ", np.einsum("bsbs->bs", r["occ"]).ravel())
+
+
 if __name__ == "__main__":
     if not refdrive.available():
         raise SystemExit("oracle/_ref is not built: run oracle/build_ref.sh in the build container")
@@ -344,3 +371,5 @@ if __name__ == "__main__":
         gen_accum(only)
     if "g4leg" in which:
         gen_g4leg(only)
+    if "susz" in which:
+        gen_susz(only)

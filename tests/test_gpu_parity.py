@@ -891,3 +891,63 @@ def test_solver_worm_component_with_eta_search():
     st = r2["steps-worm-partition/00001"]
     # brentq stops at xtol = 0.001 in eta (impurity.py:744-779), a sizeable relative error for eta of a few 1e-3: looser band
     assert 0.3 < st[3] / st[0] < 3.0
+
+
+@pytest.mark.parametrize("name", ["C1", "C3"])
+def test_susceptibility_recorded_configuration_vs_reference_golden(name):
+    """f-3, MeasSusz = 1 (matrix solver, meas_ntau_n0, Trace.F90:6472-6835): <n(tau) n(0)> of a recorded configuration ==
+    what the REFERENCE printed - one window (C1: reference time beta) and several windows (C3)."""
+    g = util.load_golden("susz_%s.npz" % name)
+    over = g["overrides"]
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    q = make_gpu(p, ps, int(g["seed"]), 4, wpb=4)
+    q.set_taudiffmax(over["TaudiffMax"])
+    c = util.cfg_from(g, "cfg_")
+    q.set_mc_config(len(c["taus"]), c["taus"], c["orbs"], c["spins"], c["cas"], c["hashybs"], c["outer_sst"], c["outer_state"])
+    q.ctqmc_measure(1, 1)
+    assert q.ntau_n0.shape == g["res_ntau_n0"].shape
+    assert rel(q.ntau_n0, g["res_ntau_n0"]) < TOL
+    q.dest_ctqmc(); q.close()
+
+
+@pytest.mark.parametrize("budget", [None, 100000], ids=["bin-per-chain", "folded-bins"])
+def test_susceptibility_chains_vs_oracle(monkeypatch, budget):
+    """MeasSusz in a sampled run (window shifts, global and tau-shift moves): every chain's <n(tau) n(0)> agrees with the
+    oracle chain of the same stream; with a small accumulator budget several sample bins share an accumulator bin
+    (atomic adds) and the pooled result is still the mean over the chains.  Ntau = 300: two tau points per thread."""
+    if budget:
+        monkeypatch.setenv("W2DYN_ACC_BYTES", str(budget))
+    over = dict(BASE, Nwarmups=3000, Nmeas=12, NCorr=30, TaudiffMax=6.0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1,
+                MeasSusz=1, Ntau=300)
+    p, ps, pset = util.setup("C3", 501, over)
+    nw = 6
+    q = make_gpu(p, ps, 41, nw, wpb=1)
+    q.set_taudiffmax(over["TaudiffMax"])
+    q.ctqmc_warmup(over["Nwarmups"])
+    q.ctqmc_measure(1, 1)
+    nbs = int(q.scalar("nbs"))
+    assert nbs == (nw if not budget else 100000 // (16 * 300 * 8))
+    res = []
+    for w in range(nw):
+        o = pyoracle.OracleWalker(p, pset, ("philox", 41, w))
+        o.set_taudiffmax(over["TaudiffMax"]); o.warmup(over["Nwarmups"]); o.measure()
+        res.append(o.results()["ntau_n0"]); o.close()
+    res = np.array(res)
+    if not budget:
+        for w in range(nw):
+            assert rel(q.ntau_n0_bins[w], res[w]) < TOL, w
+    else:
+        for b in range(nbs):
+            assert rel(q.ntau_n0_bins[b], res[b::nbs].mean(axis=0)) < TOL, b
+    assert rel(q.ntau_n0, res.mean(axis=0)) < TOL
+    q.dest_ctqmc(); q.close()
+
+
+def test_susceptibility_is_refused_on_the_matrix_trace_path():
+    p, ps, pset = util.setup("C4", 501, dict(BASE, Nwarmups=0, Nmeas=1, NCorr=1, TaudiffMax=6.0, MeasSusz=1))
+    q = MCTQMC(nwalkers=4, walkers_per_bin=1)
+    q.init_rnd(1); q.init_paras(ps)
+    with pytest.raises(W2DynError) as e:
+        q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+    assert e.value.code == -2 and "MeasSusz" in str(e.value)
+    q.close()

@@ -98,6 +98,23 @@ def test_oracle_recorded_configuration_measurement(name):
     w.close()
 
 
+@pytest.mark.parametrize("name", ["C1", "C3", "C4"])
+def test_oracle_susceptibility_on_recorded_configuration(name):
+    """MeasSusz = 1 on the matrix solver, <n(tau) n(0)> (meas_ntau_n0, Trace.F90:6472-6835): one measurement of a recorded
+    configuration against the reference's - one window (C1), several windows (C3), blocks of several states (C4)."""
+    g = util.load_golden("susz_%s.npz" % name)
+    over = g["overrides"]
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    w = pyoracle.OracleWalker(p, pset, ("std", int(g["seed"])))
+    w.set_taudiffmax(over["TaudiffMax"])
+    assert w.set_config(util.cfg_from(g, "cfg_")) == 0
+    w.measure()
+    r = w.results()
+    assert r["ntau_n0"].shape == g["res_ntau_n0"].shape and np.abs(g["res_ntau_n0"]).max() > 0.5
+    assert rel(r["ntau_n0"], g["res_ntau_n0"]) < 1e-10
+    w.close()
+
+
 def test_matrix_update_primitives_against_exact_inverse(oracle_lib):
     """MatrixUpdate.F90:489-631 (the reference's disabled self-test) idea: fast updates vs a fresh inverse."""
     L = oracle_lib

@@ -75,26 +75,116 @@ void launch_meas_gw(const DevConst &C, hipStream_t st)
     hipLaunchKernelGGL(k_meas_gw, dim3(C.nbins), dim3(256), (size_t)C.ntau * sizeof(double), st, C);
 }
 
+// MeasSusz = 1 on one-state blocks: <n_1(tauref) n_2(tauref + t beta/Ntau)> (meas_ntau_n0, Trace.F90:6472-6835, where the
+// densities are inserted into stored bra / ket vectors; with one state per block they are occupation numbers).  tauref is
+// the upper edge of the chain's window; points beyond beta are taken at tauref - (Ntau - t) beta/Ntau as there.
+// One workgroup per sample bin, thread = tau point (NT points per thread).  Chain by chain the tau arrays are staged in LDS
+// and every thread counts the operators before its times: occupation masks of up to 8 chains stay in registers, then
+// acc[f1][f2][t] -= cfgsign [n_f1(tauref)] [n_f2(t)] summed over the chains is added to the bin's accumulator (atomics
+// only where several sample bins share an accumulator bin).
+template <int NT>
+__global__ void __launch_bounds__(256) k_meas_susz(DevConst C, double *__restrict__ acc, int nbs)
+{
+    extern __shared__ double tops[];             // [2][nflav][kmax]: creator / annihilator times of the current chain
+    const int bin = blockIdx.x, ab = bin % nbs, tid = threadIdx.x, nf = C.nflav, nd = C.nd, kmax = C.kmax, ntau = C.ntau;
+    const double beta = C.beta, tauD = beta / (double)ntau;
+    const bool shared_bin = nbs < C.nbins;
+    double *out = acc + (size_t)ab * nf * nf * ntau;
+    const int w0 = bin * C.walkers_per_bin, w1 = min(w0 + C.walkers_per_bin, C.nwalkers);
+    for (int wc = w0; wc < w1; wc += 8) {
+        int m0[8], m[8][NT]; double sg[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int w = wc + c;
+            m0[c] = 0; sg[c] = 0.0;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) m[c][i] = 0;
+            if (w >= w1) continue;                                   // uniform
+            const WalkerScalars &ws = C.ws[w];
+            if (ws.sector > 1) continue;                             // chains in worm space measure no Z-space estimator
+            __syncthreads();
+            for (int f = 0; f < nf; ++f) {
+                const int k = C.K[(size_t)w * nf + f];
+                for (int e = tid; e < k; e += 256) {
+                    tops[(size_t)f * kmax + e] = C.TC[((size_t)w * nf + f) * kmax + e];
+                    tops[(size_t)(nf + f) * kmax + e] = C.TA[((size_t)w * nf + f) * kmax + e];
+                }
+            }
+            __syncthreads();
+            sg[c] = -C.cfgsign[w];
+            const int outer = ws.outer;
+            const double tauref = ((double)(ws.wpos + 2) / (double)(C.num_windows + 1)) * beta;       // Trace.F90:1698-1699
+            auto mask_at = [&](double t) {
+                int mk = 0;
+                for (int f = 0; f < nf; ++f) {
+                    const int k = C.K[(size_t)w * nf + f];
+                    int n = (outer >> ((f >> 1) + nd * (f & 1))) & 1;
+                    for (int e = 0; e < k; ++e) n += (tops[(size_t)f * kmax + e] <= t ? 1 : 0) - (tops[(size_t)(nf + f) * kmax + e] <= t ? 1 : 0);
+                    mk |= (n & 1) << f;
+                }
+                return mk;
+            };
+            m0[c] = mask_at(tauref);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int t = tid + 256 * i;
+                if (t < ntau) {
+                    double tauint = tauref + (double)t * tauD;
+                    if (tauint > beta) tauint = tauref - (double)(ntau - t) * tauD;
+                    m[c][i] = mask_at(tauint);
+                }
+            }
+        }
+        for (int f1 = 0; f1 < nf; ++f1)
+            for (int f2 = 0; f2 < nf; ++f2) {
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const int t = tid + 256 * i;
+                    double v = 0.0;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v += (((m0[c] >> f1) & 1) && ((m[c][i] >> f2) & 1)) ? sg[c] : 0.0;
+                    if (t < ntau && v != 0.0) {
+                        double *o = out + ((size_t)f1 * nf + f2) * ntau + t;
+                        if (shared_bin) atomicAdd(o, v); else *o += v;
+                    }
+                }
+            }
+    }
+}
+void launch_meas_susz(const DevConst &C, hipStream_t st, double *acc, int nbs)
+{
+    const size_t lds = (size_t)2 * C.nflav * C.kmax * sizeof(double);
+    const dim3 grid(C.nbins), block(256);
+    if (C.ntau <= 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_susz<1>), grid, block, lds, st, C, acc, nbs);
+    else if (C.ntau <= 512) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_susz<2>), grid, block, lds, st, C, acc, nbs);
+    else if (C.ntau <= 1024) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_susz<4>), grid, block, lds, st, C, acc, nbs);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_susz<8>), grid, block, lds, st, C, acc, nbs);
+}
+
 // Moments of the normalised per-bin results x_b[i] = acc[b][i] scale[b] (sqrt(2l+1), l = i mod nleg, for the Legendre
 // coefficients) for the cross-rank reduction: out = [ B | S_i = sum_b x_b[i] | sum_b (x_b[i] - S_i/B)^2 | S_i^2/B ].  Every
-// entry adds over ranks (parallel-axis formula, statistics.py of this package).  One thread per element, bins read with
-// unit stride across the wave; the second pass over the bins finds them in L2.
+// entry adds over ranks (parallel-axis formula, statistics.py of this package).  One thread per element and chunk of 64
+// bins (unit stride across the wave), three phases in stream order: sums, squared deviations from the mean, the rest.
+constexpr int PACK_BINS = 64;
 __global__ void __launch_bounds__(256) k_pack_moments(const double *__restrict__ acc, int B, size_t per, const double *__restrict__ scale,
-                                                      int nleg, double *__restrict__ out)
+                                                      int nleg, double *__restrict__ out, int phase)
 {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) out[0] = (double)B;
     if (i >= per) return;
+    if (phase == 2) { const double s1 = out[1 + i]; out[1 + 2 * per + i] = s1 * (s1 / (double)B); if (i == 0) out[0] = (double)B; return; }
     const double ef = nleg ? sqrt(2.0 * (double)(i % (size_t)nleg) + 1.0) : 1.0;
-    double s1 = 0.0;
-    for (int b = 0; b < B; ++b) s1 += acc[(size_t)b * per + i] * (scale[b] * ef);
-    const double m = s1 / (double)B;
-    double m2 = 0.0;
-    for (int b = 0; b < B; ++b) { const double d = acc[(size_t)b * per + i] * (scale[b] * ef) - m; m2 += d * d; }
-    out[1 + i] = s1; out[1 + per + i] = m2; out[1 + 2 * per + i] = s1 * m;
+    const int b0 = blockIdx.y * PACK_BINS, b1 = min(b0 + PACK_BINS, B);
+    const double m = phase == 1 ? out[1 + i] / (double)B : 0.0;
+    double a = 0.0;
+    for (int b = b0; b < b1; ++b) { const double d = acc[(size_t)b * per + i] * (scale[b] * ef) - m; a += phase == 1 ? d * d : d; }
+    atomicAdd(&out[1 + (phase == 1 ? per : 0) + i], a);
 }
 void launch_pack_moments(hipStream_t st, const double *acc, int B, size_t per, const double *scale, int nleg, double *out)
 {
-    hipLaunchKernelGGL(k_pack_moments, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, acc, B, per, scale, nleg, out);
+    (void)hipMemsetAsync(out, 0, (1 + 3 * per) * sizeof(double), st);
+    const dim3 grid((unsigned)((per + 255) / 256), (unsigned)((B + PACK_BINS - 1) / PACK_BINS));
+    hipLaunchKernelGGL(k_pack_moments, grid, dim3(256), 0, st, acc, B, per, scale, nleg, out, 0);
+    hipLaunchKernelGGL(k_pack_moments, grid, dim3(256), 0, st, acc, B, per, scale, nleg, out, 1);
+    hipLaunchKernelGGL(k_pack_moments, dim3(grid.x), dim3(256), 0, st, acc, B, per, scale, nleg, out, 2);
 }
 }  // namespace w2dyn

@@ -111,6 +111,7 @@ struct w2dyn_solver {
     double p_wins = 0, p_wrep = 0, worm_eta = 0;
     int worm_meas_g4iw = 0, g4ph = 0, g4pp = 0, wormphconv = 0, nbw = 0, cur_isector = 1;
     // G(tau) accumulator (AccumGtau, CTQMC.F90:492-500): 0 = G(tau)/G(l) not measured, 1 = mean, 2 = per-chain autocorrelation stack
+    bool meas_susz = false; int nbs = 0; double *acc_susz = nullptr;     // MeasSusz: <n(tau) n(0)>, accumulator bins [nbs][nflav][nflav][Ntau]
     int accum_gtau = 1, ac_lev = 0; long long ac_n = 0; double *ac_dat = nullptr, *ac_out = nullptr;
     int res_isector = 1;                             // sector of the run the result table was made from
     int worm_meas_giw = 0, worm_meas_gtau = 0;       // sector 2: WormMeasGiw, WormMeasGtau (CTQMC.F90:597-612)
@@ -526,7 +527,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     // ---- modes this build refuses ----
     struct { const char *key; long long allowed; } zero_int[] = {
         {"segment", 0}, {"offdiag", 0}, {"full_offdiag", 0}, {"statesampling", 0}, {"flavourchange_moves", 0}, {"Phonon", 0},
-        {"Screening", 0}, {"Uw", 0}, {"MeasGtauDetRat", 0}, {"MeasSusz", 0},
+        {"Screening", 0}, {"Uw", 0}, {"MeasGtauDetRat", 0},
         {"MeasExpResDensityMatrix", 0}, {"MeasSsquare", 0}, {"Gtau_mean_step", 0}, {"Gtau_mid_step", 0}, {"sign_step", 0},
         {"NSymMove", 0}, {"MeasDensityMatrix", 1}, {"Eigenbasis", 1}};
     for (auto &z : zero_int) {
@@ -584,6 +585,8 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if (!get_int(s, "AccumGtau", iv)) return W2DYN_EINVAL;
     if (iv < 0 || iv > 2) return fail(s, W2DYN_EINVAL, "invalid value %lld for AccumGtau (0, 1, 2)", iv);     // CTQMC.F90:502
     s->accum_gtau = (int)iv;
+    if (!get_int(s, "MeasSusz", iv)) return W2DYN_EINVAL;
+    s->meas_susz = iv == 1;              // CTQMC.F90:534-540 (matrix solver: b_meas_susz_mat)
     if (!get_int(s, "MaxHisto", iv)) return W2DYN_EINVAL; s->maxhisto = (int)iv;
     if (!get_real(s, "PercentageGlobalMove", s->p_glob)) return W2DYN_EINVAL;
     if (!get_real(s, "PercentageTauShiftMove", s->p_shift)) return W2DYN_EINVAL;
@@ -748,6 +751,16 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
         s->ac_lev = lev;
         if ((rc = dev_alloc(s, s->ac_dat, n))) return rc;
         if ((rc = dev_alloc(s, s->ac_out, B * (size_t)nf * lev * s->ntau))) return rc;
+    }
+    s->acc_susz = nullptr; s->nbs = 0;
+    if (s->meas_susz) {
+        // meas_ntau_n0 walks stored bra / ket vectors of the eigenbasis (Trace.F90:6472-6835); with one state per block the
+        // densities are numbers and the estimator is an occupation count, which is what k_meas_susz does
+        if (s->mat) return fail(s, W2DYN_EUNSUPPORTED, "MeasSusz = 1 is only supported when every block of H_loc holds one state (density-density interaction with Nt Szt Azt)");
+        if (s->ntau > 2048) return fail(s, W2DYN_EUNSUPPORTED, "MeasSusz = 1: Ntau = %d too large (at most 2048)", s->ntau);
+        const size_t per = (size_t)nf * nf * s->ntau * sizeof(double);
+        s->nbs = (int)std::max<size_t>(1, std::min<size_t>(B, acc_budget() / per));
+        if ((rc = dev_alloc(s, s->acc_susz, (size_t)s->nbs * nf * nf * s->ntau))) return rc;
     }
     s->acc_g4tau = s->acc_g4leg = nullptr; s->nbl = 0;
     if (s->fourpnt & 3) {
@@ -973,6 +986,7 @@ int w2dyn_measure_begin(w2dyn_solver *s)
     if (s->acc_g4leg) HIPCHK(hipMemsetAsync(s->acc_g4leg, 0, sizeof(double) * s->nbl * nf * nf * s->n4leg * s->n4leg * (2 * s->n4iwb + 1) * 2, s->stream));
     if (C.acc_giww) HIPCHK(hipMemsetAsync(C.acc_giww, 0, sizeof(double) * B * C.niw2 * 2, s->stream));
     if (C.acc_gtauw) HIPCHK(hipMemsetAsync(C.acc_gtauw, 0, sizeof(double) * B * s->ntau, s->stream));
+    if (s->acc_susz) HIPCHK(hipMemsetAsync(s->acc_susz, 0, sizeof(double) * (size_t)s->nbs * nf * nf * s->ntau, s->stream));
     if (s->fourpnt & 4) {
         const size_t n2 = 2 * (size_t)(s->n4iwf + s->n4iwb), n4 = (size_t)nf * nf * 4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1), ng2 = (size_t)nf * n2 * n2;
         HIPCHK(hipMemsetAsync(s->acc4, 0, sizeof(double2) * s->nb4 * n4, s->stream));
@@ -1023,6 +1037,12 @@ static int measure_once_impl(w2dyn_solver *s, double2 *g2buf)
         HIPCHK(hipGetLastError());
         if ((rc = time_end(s, "meas_gtau_ac"))) return rc;
         s->ac_n += 1;
+    }
+    if (s->acc_susz) {                // CTQMC.F90:8556-8560
+        if ((rc = time_begin(s))) return rc;
+        launch_meas_susz(s->C, s->stream, s->acc_susz, s->nbs);
+        HIPCHK(hipGetLastError());
+        if ((rc = time_end(s, "meas_susz"))) return rc;
     }
     if (s->meas_giw) {
         if ((rc = time_begin(s))) return rc;
@@ -1273,6 +1293,29 @@ int w2dyn_measure_finish(w2dyn_solver *s)
         R["accadd"] = aa; R["accrem"] = ar;
         R["accglob"] = {s->counters[C_ACCGLOB] / s->counters[C_TRYGLOB]};
         R["accshift"] = {s->counters[C_ACCSHIFT] / s->counters[C_TRYSHIFT]};
+    }
+    if (s->acc_susz && true) {      // CTQMC.F90:8744-8746: ntau_n0 * zScaling, point Ntau = point 0
+        const size_t per = (size_t)nf * nf * ntau, pero = (size_t)nf * nf * (ntau + 1);
+        std::vector<double> raw = fetch(s->acc_susz, (size_t)s->nbs * per), tot(pero, 0.0), bins((size_t)s->nbs * pero, 0.0);
+        if (fetch_err != hipSuccess) return fail(s, W2DYN_EHIP, "measure_finish: copying the accumulators to the host: %s", hipGetErrorString(fetch_err));
+        for (int b = 0; b < s->nbs; ++b) {
+            double nb = 0.0;
+            for (int bin = b; bin < B; bin += s->nbs) nb += binw(bin);
+            const double zb = -1.0 / (nb * ms);
+            for (int ff = 0; ff < nf * nf; ++ff) {
+                for (int t = 0; t < ntau; ++t) {
+                    const double v = raw[(size_t)b * per + (size_t)ff * ntau + t];
+                    tot[(size_t)ff * (ntau + 1) + t] += v; bins[(size_t)b * pero + (size_t)ff * (ntau + 1) + t] = v * zb;
+                }
+                bins[(size_t)b * pero + (size_t)ff * (ntau + 1) + ntau] = bins[(size_t)b * pero + (size_t)ff * (ntau + 1)];
+            }
+        }
+        const double zs = -1.0 / (nmeas_tot * ms);
+        for (int ff = 0; ff < nf * nf; ++ff) {
+            for (int t = 0; t < ntau; ++t) tot[(size_t)ff * (ntau + 1) + t] *= zs;
+            tot[(size_t)ff * (ntau + 1) + ntau] = tot[(size_t)ff * (ntau + 1)];
+        }
+        R["ntau_n0"] = tot; R["ntau_n0_bins"] = bins;
     }
     if (s->fourpnt & 3) {     // CTQMC.F90:8772-8786: zScaling (N4tau/beta)^3 / beta; zScaling sqrt(2l+1) sqrt(2l'+1) (-1)^(l'+1) / beta
         const int nt = s->n4tau, nl = s->n4leg, nwm = 2 * s->n4iwb + 1;
@@ -1798,6 +1841,7 @@ int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out)
     else if (n == "nb4") *out = s->nb4;
     else if (n == "nbw") *out = s->nbw;
     else if (n == "nbl") *out = s->nbl;
+    else if (n == "nbs") *out = s->nbs;
     else if (n == "device") *out = s->device;
     else if (n == "wormeta") *out = s->worm_eta;
     else if (n == "ntau") *out = s->ntau;

@@ -372,6 +372,10 @@ class MCTQMC:
             return self.result(name, np.int64)
         if name == "worm_counters":
             return self.result(name).reshape(-1, 8)
+        if name in ("ntau_n0", "ntau_n0_bins"):        # MeasSusz: ntau_n0(Nd,2,Nd,2,0:Ntau), CTQMC.F90:514
+            a = self.result(name)
+            lead = (int(self.scalar("nbs")),) if name.endswith("_bins") else ()
+            return a.reshape(lead + (nd, 2, nd, 2, -1))
         if name in ("gtau_full", "gleg_full"):
             return self.result(name).reshape(nd, 2, nd, 2, -1)
         if name == "occ":
