@@ -72,3 +72,40 @@ def test_self_energy_vs_reference_runs(name):
     assert np.abs(siw[-1].real - tail[-1].real).max() < 5 * serr[-1].max() + 0.05
     occ = np.einsum("bsbs->bs", r["occ"].mean())
     assert np.abs(occ - 0.5).max() < 0.02              # half filling
+
+
+def test_result_set_has_the_reference_keys_and_hdf5_layout():
+    """f-2: `HipCtHybSolver.solve()` returns the quantities of `CtHybSolver.get_resultset` (impurity.py:1198-1283) under
+    the reference's HDF5 names, and `hdf5_layout` gives what `write_impurity_result` (hdfout.py:369-397) puts below
+    `ineq-NNN`: `<quantity>/value` and `<quantity>/error` with the shapes of the reference's module variables."""
+    from w2dynamics_amd.solver import hdf5_layout
+    p = synth.make_problem(2, 10.0, 2.0, j=0.25, nftau=501)
+    over = dict(Nwarmups=2000, Nmeas=40, NCorr=20, TaudiffMax=4.0, Nftau=501, Ntau=50, NLegMax=20, Niw=8, MeasGiw=1, MeasSusz=1,
+                AccumGtau=2, N4iwf=2, N4iwb=1, MeasG2iw=1, MeasG4iwPP=1)
+    s = HipCtHybSolver(over, 3, nwalkers=64, walkers_per_bin=8)
+    s.set_problem(p, compute_fourpoint=4)
+    r = s.solve(0)
+    s.postprocessing(r)
+    always = {"gtau", "gtau-full", "rhist", "lhist", "hist", "ssts-states", "energies-eigenstates", "occbasis-mapping", "hist-sst",
+              "hist-state", "sign-sst", "sign-state", "contrib-sst", "contrib-state", "occ", "gleg", "gleg-full", "accept-ins",
+              "accept-ins4", "accept-rem", "accept-rem4", "accept-pair-tau", "accept-glob", "accept-shift", "accept-flavourchange",
+              "sign", "time-warmup", "time-simulation", "time-sampling"}
+    here = {"giw-meas", "g2iw", "densitymatrix", "rho1", "rho2", "g4iw", "g4iw-pp", "ntau-n0", "gtau-blocks"}
+    derived = {"giw", "smom", "siw", "time-qmc"}                    # impurity.py:610-640, 208-225
+    assert set(r) == always | here | derived
+    h = hdf5_layout(r)
+    nd, nst = 2, 16
+    shapes = {"gtau": (nd, 2, 50), "gleg": (nd, 2, 20), "occ": (nd, 2, nd, 2), "hist": (nd, 2, 501), "giw-meas": (nd, 2, 16),
+              "gtau-full": (nd, 2, nd, 2, 50), "gleg-full": (nd, 2, nd, 2, 20), "rho1": (nd, 2, nd, 2), "rho2": (nd, 2) * 4,
+              "densitymatrix": (nst, nst), "hist-sst": (nst,), "sign-state": (nst,), "ntau-n0": (nd, 2, nd, 2, 51),
+              "g4iw": (nd, 2, nd, 2, 4, 4, 3), "g4iw-pp": (nd, 2, nd, 2, 4, 4, 3), "g2iw": (nd, 2, 6, 6), "accept-ins": (16,),
+              "sign": (), "accept-glob": (), "accept-pair-tau": (nd, 2, 50), "lhist": (100,), "occbasis-mapping": (nst, nd, 2),
+              "giw": (16, nd, 2, nd, 2), "siw": (16, nd, 2, nd, 2), "smom": (2, nd, 2, nd, 2)}
+    for key, shp in shapes.items():
+        assert set(h[key]) == {"value", "error"}, key
+        assert h[key]["value"].shape == shp and h[key]["error"].shape == shp, (key, h[key]["value"].shape)
+    assert h["gtau-blocks"]["value"].shape[:3] == (nd, 2, 50)
+    assert set(h["time-qmc"]) == {"value"} and h["time-qmc"]["value"].shape == ()
+    assert r["gleg"].ntotal == 8 and np.all(h["gleg"]["error"][:, :, 0] > 0)
+    assert abs(float(h["sign"]["value"])) == 1.0
+    s.ctqmc.close()

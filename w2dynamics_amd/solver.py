@@ -27,6 +27,47 @@ from .statistics import DistributedSample, TorchComm
 
 RESULT_KEYS_BINNED = ("gleg", "gtau", "occ", "histo")
 
+# `CtHybSolver.get_resultset` (impurity.py:1198-1283): result key -> module variable, always present / present under a
+# condition on the QMC configuration.  The keys are the HDF5 quantity names (`<iter>/ineq-NNN/<key>/{value,error}`).
+RESULTSET_ALWAYS = {
+    "gtau": "gtau", "gtau-full": "gtau_full", "rhist": "rhisto", "lhist": "lhisto", "hist": "histo",
+    "ssts-states": "statessuperstates", "energies-eigenstates": "eigenstatesenergies", "occbasis-mapping": "occbasismapping",
+    "hist-sst": "outersuperstatehisto", "hist-state": "outerstatehisto", "sign-sst": "signhistosuperstates",
+    "sign-state": "signhistostates", "contrib-sst": "tracecontribsuperstates", "contrib-state": "tracecontribstates",
+    "occ": "occ", "gleg": "gleg", "gleg-full": "gleg_full", "accept-ins": "accadd", "accept-ins4": "accadd4",
+    "accept-rem": "accrem", "accept-rem4": "accrem4", "accept-pair-tau": "accpair", "accept-glob": "accglob",
+    "accept-shift": "accshift", "accept-flavourchange": "accflavc", "sign": "mean_sign", "time-warmup": "time_warmup",
+    "time-simulation": "time_sim", "time-sampling": "time_sim_steps",
+}
+RESULTSET_CONDITIONAL = (      # (key, module variable, condition on the QMC configuration and FourPnt)
+    ("giw-meas", "giw", lambda c, fp: c["MeasGiw"] != 0 and c["offdiag"] == 0),
+    ("g2iw", "g2iw", lambda c, fp: c["MeasG2iw"] != 0 and fp & 4),
+    ("densitymatrix", "densitymatrix", lambda c, fp: c["MeasDensityMatrix"] != 0 and c["segment"] == 0),
+    ("rho2", "rho2", lambda c, fp: c["MeasDensityMatrix"] != 0 and c["segment"] == 0),
+    ("rho1", "rho1", lambda c, fp: c["MeasDensityMatrix"] != 0 and c["segment"] == 0),
+    ("g4tau", "g4tau", lambda c, fp: fp & 1), ("g4leg", "g4leg", lambda c, fp: fp & 2), ("g4iw", "g4iw", lambda c, fp: fp & 4),
+    ("g4iw-pp", "g4iw_pp", lambda c, fp: fp & 4 and c["MeasG4iwPP"] != 0),
+    ("ntau-n0", "ntau_n0", lambda c, fp: c["segment"] == 0 and c["MeasSusz"] != 0),
+    ("gtau-blocks", "gtau_blocks", lambda c, fp: c["AccumGtau"] == 2),
+)
+# quantities with one observation per accumulator bin (their error bar comes from the bins): key -> "<variable>_bins"
+RESULTSET_BINNED = {"gtau": "gtau_bins", "gleg": "gleg_bins", "occ": "occ_bins", "hist": "histo_bins", "giw-meas": "giw_bins",
+                    "hist-sst": "outersuperstatehisto_bins", "hist-state": "outerstatehisto_bins", "sign-sst": "signhistosuperstates_bins",
+                    "sign-state": "signhistostates_bins", "contrib-sst": "tracecontribsuperstates_bins",
+                    "contrib-state": "tracecontribstates_bins", "gtau-blocks": "gtau_blocks_bins", "ntau-n0": "ntau_n0_bins"}
+
+
+def hdf5_layout(result):
+    """What `HdfOutput.write_impurity_result` (hdfout.py:369-397) writes below `ineq-NNN` for a result dictionary:
+    `<quantity>/value` and `<quantity>/error` for samples, `<quantity>/value` for plain arrays and numbers."""
+    out = {}
+    for key, val in result.items():
+        if isinstance(val, DistributedSample):
+            out[key] = {"value": np.asarray(val.mean()), "error": np.asarray(val.stderr())}
+        else:
+            out[key] = {"value": np.asarray(val)}
+    return out
+
 
 class HipCtHybSolver:
     def __init__(self, qmc_overrides, seed, comm=None, device=0, nwalkers=1024, walkers_per_bin=8, kmax=0):
@@ -65,11 +106,7 @@ class HipCtHybSolver:
         q.ctqmc_measure(1, 1)
         if q.aborted == 2:
             raise KeyboardInterrupt("CTQMC was interrupted by signal")
-        result = {}
-        for key in RESULT_KEYS_BINNED:
-            result[key] = DistributedSample(getattr(q, key + "_bins"), self.comm)
-        if self.qmc["MeasGiw"]:
-            result["giw-meas"] = DistributedSample(q.giw_bins, self.comm)
+        result = self.get_resultset()
         if q.fourpnt & 4:      # get_resultset, impurity.py:1253-1262: g4iw, g4iw-pp, g2iw; moments made on the GPU
             names = {"g4iw": "g4iw"}
             if self.qmc["MeasG4iwPP"]:
@@ -79,11 +116,6 @@ class HipCtHybSolver:
             pack = q.reduce_pack(names.values(), self.comm).allreduce()
             for key, name in names.items():
                 result[key] = pack.sample(name)
-        result["sign"] = DistributedSample(np.array([q.mean_sign]), self.comm)
-        result["accept-ins"] = DistributedSample(np.array([q.accadd]), self.comm)
-        result["accept-rem"] = DistributedSample(np.array([q.accrem]), self.comm)
-        result["rho1"] = DistributedSample(np.array([q.rho1]), self.comm)
-        result["rho2"] = DistributedSample(np.array([q.rho2]), self.comm)
         # Green's function for the Dyson equation, (iw, band, spin, band, spin), one sample per accumulator bin
         # (impurity.py:611-619), and the self-energy moments from rho1 / rho2 (impurity.py:628-640)
         niw = 2 * int(self.qmc["Niw"])
@@ -94,9 +126,33 @@ class HipCtHybSolver:
         nfl = 2 * p.nd
         result["smom"] = DistributedSample(np.array([_postproc.lattice_convention(
             _postproc.get_siw_mom(np.asarray(p.umatrix).reshape((nfl,) * 4), q.rho1, q.rho2))]), self.comm)
-        result["time-qmc"] = time.perf_counter() - t0
+        result["time-qmc"] = time.perf_counter() - t0         # a plain number, as in impurity.py:610
         q.dest_ctqmc()
         q.dest_paras()
+        return result
+
+    def get_resultset(self):
+        """`CtHybSolver.get_resultset` (impurity.py:1198-1283) on the module variables of the HIP front end: the same keys
+        under the same conditions, each a DistributedSample (impurity.py:641-642) - one observation per accumulator bin
+        where the library keeps bins, else one per rank.  The two-particle arrays of a FourPnt = 4 run are replaced by
+        their device-made moments in `solve`.  `rho1` / `rho2` in (band, spin, ...) shape as there."""
+        q, c, fp = self.ctqmc, self.qmc, int(self.ctqmc.fourpnt)
+        nd = self.problem.nd
+        names = dict(RESULTSET_ALWAYS)
+        names.update({key: var for key, var, cond in RESULTSET_CONDITIONAL if cond(c, fp)})
+        result = {}
+        for key, var in names.items():
+            if key in ("g4iw", "g4iw-pp", "g2iw"):
+                continue                                # device-made moments (solve)
+            if key in RESULTSET_BINNED:
+                local = np.asarray(getattr(q, RESULTSET_BINNED[key]))
+            else:
+                local = np.asarray(getattr(q, var))[None]
+            if key == "rho1":
+                local = local.reshape((1,) + (nd, 2) * 2)
+            elif key == "rho2":
+                local = local.reshape((1,) + (nd, 2) * 4)
+            result[key] = DistributedSample(local, self.comm)
         return result
 
     def postprocessing(self, result, g0inviw=None):
