@@ -162,7 +162,7 @@ __host__ __device__ inline size_t lds_bytes_per_wave(int nflav, int kmax, int wc
     size_t d = (size_t)2 * nflav * kmax + 2 * (size_t)kmax + ((mat ? u1 + u2 : (u1 > u2 ? u1 : u2)) + 7) / 8;
     size_t i = (size_t)MAXFLAV + kmax;                                         // K, piv
     if (mat) { d += wcap + 2; i += (size_t)3 * wcap + 8; }                     // ot; om, osst, tsst
-    if (mat > 4) { const size_t nt = mat <= 8 ? 8 : (mat <= 10 ? 10 : 16); d += 5 * nt * nt; }   // stage of MAT_CH operator matrices + vector tile (sequential trace, mat = block size)
+    if (mat > 4) { const size_t nt = mat <= 8 ? 8 : (mat <= 10 ? 10 : 16); d += 6 * nt * nt + 2; }   // stage of MAT_CH operator matrices + vector tile + product outside the window (sequential trace, mat = block size)
     size_t b = d * sizeof(double) + C_NCOUNT * sizeof(unsigned long long) + i * sizeof(int);
     return (b + 15) & ~(size_t)15;
 }
@@ -279,6 +279,7 @@ struct Ctx {
     int wvalid;                      // window list (registers or LDS) matches the current configuration and window
     // matrix local-trace path
     double *opbuf;                                   // stage of MAT_CH operator matrices (blocks of more than 4 states)
+    double *pmat; int pvalid, p_lo, p_hi;            // sequential trace: product of the operators outside the window (mat_trace_seq_window), its blocks
     double *ot; int *om, *osst, *tsst; int nops;     // time-ordered operator list, block sequence, trial block sequence (LDS)
     const short *t_conn, *t_shift;                   // 16-bit block numbers: the two tables are the bulk of the shared LDS (5 orbitals: 352 blocks x 20 operators)
     const int *t_n, *t_off; const double *t_eval, *t_op;   // block-shared tables (LDS); t_op null: operators stay in global memory
@@ -702,7 +703,7 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
             else if (j >= p_hi + 2) x.tsst[j] = x.osst[j - 2];
         }
         mat_insert(x, p_lo, lo, code_lo); mat_insert(x, p_hi + 1, hi, code_hi);
-        mat_trace_trial<MAT>(x, x.tsst, x.nops, -1, -1, tl_new, ts_new);
+        mat_trace_trial<MAT, (MAT > 4 && WORM == 0)>(x, x.tsst, x.nops, -1, -1, tl_new, ts_new);
         dlogtr = tl_new - x.tr_log;
     } else {
         double I = level_integral<WORM>(x, f, lo, hi);
@@ -954,7 +955,7 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
             else if (j >= i2 - 1) x.tsst[j] = x.osst[j + 2];
         }
         wave_sync();
-        mat_trace_trial<MAT>(x, x.tsst, x.nops - 2, i1, i2, tl_new, ts_new);
+        mat_trace_trial<MAT, (MAT > 4 && WORM == 0)>(x, x.tsst, x.nops - 2, i1, i2, tl_new, ts_new);
         dlogtr = tl_new - x.tr_log;
     } else {
         // the pair's own operators sit on the boundary of (t1,t2) and belong to flavour f, which level_integral skips
@@ -1055,6 +1056,7 @@ __device__ W2DYN_INLINE void step_shift(Ctx &x)
     for (int f = 0; f < C.nflav; ++f) nops += 2 * x.order(f);
     if (nops == 0) {
         step_change_outer(x);
+        x.pvalid = 0;
         if constexpr (MAT) { mat_walk_sst(x); mat_trace_current<MAT>(x); }
         return;
     }
@@ -1109,7 +1111,7 @@ __device__ W2DYN_INLINE void step_shift(Ctx &x)
         x.window_bounds();
     }
     x.npairs = -1; x.wvalid = 0;
-    if constexpr (MAT) { mat_build_list(x); mat_walk_sst(x); mat_trace_current<MAT>(x); }
+    if constexpr (MAT) { mat_build_list(x); mat_walk_sst(x); mat_trace_current<MAT>(x); x.pvalid = 0; }
     x.count(C_ACCSHIFT);
 }
 
@@ -1488,11 +1490,13 @@ __device__ __forceinline__ void ctx_setup(Ctx &x, unsigned char *smem)
     }
     x.K = (int *)(x.cnt + C_NCOUNT); x.piv = x.K + MAXFLAV;
     x.nops = 0; x.tr_log = 0.0; x.tr_sign = 1.0; x.ms_ = 0; x.mi_ = 0; x.spb_ = 1;
+    x.pmat = nullptr; x.pvalid = 0; x.p_lo = x.p_hi = -1;
     if (C.mat) {
         // per-wave list arrays behind the common slice; block-shared tables at the start of the dynamic LDS
         x.om = x.piv + C.kmax; x.osst = x.om + C.wcap; x.tsst = x.osst + C.wcap + 2;
         x.ot = (double *)(((size_t)(x.tsst + C.wcap + 2) + 7) & ~(size_t)7);
         x.opbuf = x.ot + C.wcap + 2;
+        { const int nt = C.nsm <= 8 ? 8 : (C.nsm <= 10 ? 10 : 16); x.pmat = x.opbuf + 5 * nt * nt; }
         const int nf2 = 2 * C.nflav;
         short *ti = (short *)smem;
         x.t_conn = ti; x.t_shift = ti + C.nsst * nf2; x.t_n = (const int *)(ti + 2 * C.nsst * nf2); x.t_off = x.t_n + C.nsst;
@@ -1709,7 +1713,7 @@ __global__ __launch_bounds__(256, MAT == 0 ? (WPE3 ? 3 : W2DYN_WPE) : W2DYN_WPE_
         if (phase == 0) {                                        // shift_window, Trace.F90:1652-1678
             if (C.num_windows > 1) {
                 x.wpos += 1; if (x.wpos == C.num_windows) x.wpos = 0;
-                x.window_bounds(); x.npairs = -1; x.wvalid = 0;
+                x.window_bounds(); x.npairs = -1; x.wvalid = 0; x.pvalid = 0;
             } else x.wpos = 0;
         }
     }

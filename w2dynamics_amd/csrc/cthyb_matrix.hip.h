@@ -351,16 +351,23 @@ constexpr int MAT_CH = 4, MAT_NB = 4;
 struct MatSeqArgs {
     unsigned tsst, om, ot, conn, tn, toff, teval, opbuf, top;      // byte offsets; top = 0xffffffff: operators in global memory
     unsigned ptout;                                                // 0xffffffff or byte offset of nsm + 1 doubles: partial traces of the outer states, then their common log scale
+    unsigned pin, pout;                                            // 0xffffffff or byte offset of NT * NT + 1 doubles: vectors to start from / to leave the result in ([vector][component], stride NT, then the log scale)
     const double *opmat;
     int n, skip1, skip2, nsm, spb, nf2, nsst;
+    // the stretch of the trial sequence to apply: cnt operators from trial index jbeg on (indices beyond n - 1 wrap around
+    // to 0, their times count from beta), between the times t0 and t1 (same unwrapped scale), from block sst_start to
+    // block sst_end, on ncols vectors.  The whole trace: jbeg 0, cnt n, t0 0, t1 beta, both blocks the outer one,
+    // ncols its states, unit start vectors, no result vectors (the sum of the diagonal is returned).
+    int jbeg, cnt, sst_start, sst_end, ncols;
+    double t0, t1;
     double beta, egs;
 };
 
 // padded block size the evaluator is instantiated for (stage and vector exchange use this stride)
 __host__ __device__ inline int mat_seq_pad(int nsm) { return nsm <= 8 ? 8 : (nsm <= 10 ? 10 : 16); }
 
-// NT: padded block size.  The lane's vector components v[b] (one per batch of outer states) stay in registers; for the
-// matrix-vector product they are exchanged through a small LDS tile (V[state][component], stride NT), so that one
+// NT: padded block size.  The lane's vector components v[b] (one per batch of vectors) stay in registers; for the
+// matrix-vector product they are exchanged through a small LDS tile (V[vector][component], stride NT), so that one
 // operator costs a handful of wide LDS reads issued back to back instead of NT dependent cross-lane shuffles per batch.
 template <int NT>
 __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
@@ -377,32 +384,42 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
     const double *ops_l = (const double *)(lds_base + (ops_lds ? uni((int)a.top) : 0));
     const double *ops_g = (const double *)(((unsigned long long)(unsigned)uni((int)((unsigned long long)a.opmat >> 32)) << 32) | (unsigned long long)(unsigned)uni((int)(unsigned long long)a.opmat));
     const int n = uni(a.n), skip1 = uni(a.skip1), skip2 = uni(a.skip2), nsm = uni(a.nsm), spb = uni(a.spb), nf2 = uni(a.nf2), nsst = uni(a.nsst);
-    const double beta = uni(a.beta), egs = uni(a.egs);
+    const int jbeg = uni(a.jbeg), cnt = uni(a.cnt), sst_start = uni(a.sst_start), sst_end = uni(a.sst_end), ncols = uni(a.ncols);
+    const double beta = uni(a.beta), egs = uni(a.egs), t0 = uni(a.t0), t1 = uni(a.t1);
+    const bool has_pin = uni((int)a.pin) != -1, has_pout = uni((int)a.pout) != -1;
     const int nsq = nsm * nsm, ms = lane / nsm, mi = lane - ms * nsm;
     double2 res = make_double2(-HUGE_VAL, 0.0);
-    const int outer = uni(tsst[0]);
-    if ((unsigned)outer >= (unsigned)nsst || uni(tsst[n]) != outer) return res;
-    const int nout = uni(t_n[outer]);
+    if ((unsigned)sst_start >= (unsigned)nsst || (unsigned)sst_end >= (unsigned)nsst) return res;
+    if (cnt > 0 && uni(tsst[jbeg >= n ? jbeg - n : jbeg]) != sst_start) return res;
+    if (cnt == 0 && sst_start != sst_end) return res;
     const bool act = lane < spb * nsm;
     bool diag[MAT_NB], valid[MAT_NB]; double v[MAT_NB];
+    double lacc = 0.0;
+    {
+        const double *pin = (const double *)(lds_base + (has_pin ? uni((int)a.pin) : 0));
 #pragma unroll
-    for (int b = 0; b < MAT_NB; ++b) {
-        const int st = b * spb + ms;
-        valid[b] = act && st < nout;
-        diag[b] = valid[b] && st == mi;
-        v[b] = diag[b] ? 1.0 : 0.0;
+        for (int b = 0; b < MAT_NB; ++b) {
+            const int st = b * spb + ms;
+            valid[b] = act && st < ncols;
+            diag[b] = valid[b] && st == mi;
+            v[b] = has_pin ? (valid[b] ? pin[st * NT + mi] : 0.0) : (diag[b] ? 1.0 : 0.0);
+        }
+        if (has_pin) lacc = uni(pin[NT * NT]);
     }
+    lds_sync();
     for (int e = lane; e < NT * NT; e += 64) vbuf[e] = 0.0;      // the padding of the vector tile stays zero from here on
     constexpr int NREG = (MAT_CH * NT * NT + 63) / 64;
     double reg[NREG];
-    auto fetch = [&](int c) {                       // operators c*MAT_CH .. of the trial sequence into registers
+    auto trial_index = [&](int q) { const int j = jbeg + q; return j >= n ? j - n : j; };
+    auto fetch = [&](int c) {                       // operators c*MAT_CH .. of the stretch into registers
 #pragma unroll
         for (int q = 0; q < NREG; ++q) {
             const int e = q * 64 + lane;
             reg[q] = 0.0;
             if (e < MAT_CH * NT * NT) {              // stage layout (operator, row, column) with the padded stride NT: constant divisors
-                const int jo = e / (NT * NT), r = e - jo * (NT * NT), i = r / NT, k = r - i * NT, j = c * MAT_CH + jo;
-                if (j < n && i < nsm && k < nsm) {
+                const int jo = e / (NT * NT), r = e - jo * (NT * NT), i = r / NT, k = r - i * NT, qq = c * MAT_CH + jo;
+                if (qq < cnt && i < nsm && k < nsm) {
+                    const int j = trial_index(qq);
                     const int sst = tsst[j], code = om[mat_old_index(j, skip1, skip2)];
                     if ((unsigned)sst < (unsigned)nsst && (unsigned)code < (unsigned)nf2) {
                         const size_t idx = (size_t)(sst * nf2 + code) * nsq + i * nsm + k;
@@ -412,18 +429,20 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
             }
         }
     };
-    // Everything about operator j that is the same for all lanes (time step, block size and offset, scalar decay) is
+    // Everything about an operator that is the same for all lanes (time step, block size and offset, scalar decay) is
     // worked out for 64 operators at once, lane jj for operator base + jj, and handed to the sequential loop with
     // v_readlane: the loop itself then waits for LDS only twice per operator (vector tile, eigenvalue of the lane's state).
-    double lacc = 0.0, tlast = 0.0;
+    double tlast = t0;
     int iexp = 0;                                   // common binary exponent taken out of the vectors
-    fetch(0);
-    for (int base = 0; base < n; base += 64) {
-        const int jm = base + lane;
+    if (cnt > 0) fetch(0);
+    for (int base = 0; base < cnt; base += 64) {
+        const int qm = base + lane;
         double my_dt = 0.0, my_sc = 0.0; int my_on = 0; bool my_bad = false;
-        if (jm < n) {
-            const int sst = tsst[jm], o = mat_old_index(jm, skip1, skip2);
-            const double tau = ot[o], tp = jm == 0 ? 0.0 : ot[mat_old_index(jm - 1, skip1, skip2)];
+        if (qm < cnt) {
+            const int jm = trial_index(qm), sst = tsst[jm], o = mat_old_index(jm, skip1, skip2);
+            const double tau = ot[o] + (jbeg + qm >= n ? beta : 0.0);
+            double tp = t0;
+            if (qm > 0) { const int jp = trial_index(qm - 1); tp = ot[mat_old_index(jp, skip1, skip2)] + (jbeg + qm - 1 >= n ? beta : 0.0); }
             my_dt = tau - tp;
             if ((unsigned)sst >= (unsigned)nsst) my_bad = true;
             else {
@@ -433,28 +452,28 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
                 my_on = off | (t_n[sst] << 16);
                 my_sc = (t_eval[off] - egs) * my_dt;
             }
-            if (jm == n - 1) tlast = tau;
+            if (qm == cnt - 1) tlast = tau;
         }
         if (__ballot(my_bad) != 0ull) return res;
         lacc -= wave_sum(my_sc);
-        const int cnt = min(64, n - base);
+        const int cntg = min(64, cnt - base);
         // eigenvalue difference of the lane's state in the block of the first operator of this group (prefetched one ahead)
         int on = __builtin_amdgcn_readlane(my_on, 0);
         double de = ((on >> 16) > 1 && mi < (on >> 16)) ? t_eval[(on & 0xffff) + mi] - t_eval[on & 0xffff] : 0.0;
-        for (int jj = 0; jj < cnt; ++jj) {
-            const int j = base + jj;
-            if ((j % MAT_CH) == 0) {                 // stage the next MAT_CH operator matrices
+        for (int jj = 0; jj < cntg; ++jj) {
+            const int q = base + jj;
+            if ((q % MAT_CH) == 0) {                 // stage the next MAT_CH operator matrices
                 lds_sync();
 #pragma unroll
-                for (int q = 0; q < NREG; ++q) { const int e = q * 64 + lane; if (e < MAT_CH * NT * NT) opbuf[e] = reg[q]; }
+                for (int r = 0; r < NREG; ++r) { const int e = r * 64 + lane; if (e < MAT_CH * NT * NT) opbuf[e] = reg[r]; }
                 lds_sync();
-                if (j + MAT_CH < n) fetch(j / MAT_CH + 1);
+                if (q + MAT_CH < cnt) fetch(q / MAT_CH + 1);
             }
-            const int jo = j % MAT_CH;
+            const int jo = q % MAT_CH;
             const int dlo = __builtin_amdgcn_readlane((int)__double2loint(my_dt), jj), dhi = __builtin_amdgcn_readlane(__double2hiint(my_dt), jj);
             const double dt = __hiloint2double(dhi, dlo);
             const double fdec = exp(-de * dt);
-            if (jj + 1 < cnt) {                      // next operator's eigenvalue difference: in flight during this product
+            if (jj + 1 < cntg) {                     // next operator's eigenvalue difference: in flight during this product
                 on = __builtin_amdgcn_readlane(my_on, jj + 1);
                 de = ((on >> 16) > 1 && mi < (on >> 16)) ? t_eval[(on & 0xffff) + mi] - t_eval[on & 0xffff] : 0.0;
             }
@@ -464,7 +483,7 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
             const double *row = opbuf + (jo * NT + (act ? mi : 0)) * NT;
 #pragma unroll
             for (int b = 0; b < MAT_NB; ++b) {
-                if (b * spb < nout) {                // uniform
+                if (b * spb < ncols) {               // uniform
                     const double *vr = vbuf + (valid[b] ? (b * spb + ms) : 0) * NT;
                     double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
@@ -473,7 +492,7 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
                 }
             }
             lds_sync();
-            if ((j & 3) == 3) {                      // keep the vectors near one: take out a power of two (exact)
+            if ((q & 3) == 3) {                      // keep the vectors near one: take out a power of two (exact)
                 double m = 0.0;
 #pragma unroll
                 for (int b = 0; b < MAT_NB; ++b) m = fmax(m, fabs(v[b]));
@@ -486,13 +505,30 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
             }
         }
     }
-    const double tprev = uni(wave_max(tlast));
+    const double tprev = cnt > 0 ? uni(wave_max(tlast)) : t0;
     lacc += (double)iexp * 0.6931471805599453;
-    {   // free evolution to beta inside the outer block
-        const int off = uni(t_off[outer]);
-        const double e0 = uni(t_eval[off]), dt = beta - tprev;
+    {   // free evolution to t1 inside the last block
+        const int off = uni(t_off[sst_end]), nend = uni(t_n[sst_end]);
+        const double e0 = uni(t_eval[off]), dt = t1 - tprev;
         lacc -= (e0 - egs) * dt;
-        const double fdec = (nout > 1 && mi < nout) ? exp(-(t_eval[off + mi] - e0) * dt) : 1.0;
+        const double fdec = (nend > 1 && mi < nend) ? exp(-(t_eval[off + mi] - e0) * dt) : 1.0;
+        if (has_pout) {                              // the vectors themselves are the result
+            double *pout = (double *)(lds_base + uni((int)a.pout));
+            double m = 0.0;
+#pragma unroll
+            for (int b = 0; b < MAT_NB; ++b) { v[b] = (valid[b] && mi < nend) ? v[b] * fdec : 0.0; m = fmax(m, fabs(v[b])); }
+            m = wave_max(m);
+            if (!(m > 0.0)) return res;
+            const int e2 = ilogb(m);
+            for (int e = lane; e < NT * NT; e += 64) pout[e] = 0.0;
+            lds_sync();
+#pragma unroll
+            for (int b = 0; b < MAT_NB; ++b) if (valid[b]) pout[(b * spb + ms) * NT + mi] = ldexp(v[b], -e2);
+            if (lane == 0) pout[NT * NT] = lacc + (double)e2 * 0.6931471805599453;
+            lds_sync();
+            res.x = 0.0; res.y = 1.0;
+            return res;
+        }
         double part = 0.0;
 #pragma unroll
         for (int b = 0; b < MAT_NB; ++b) part += diag[b] ? v[b] * fdec : 0.0;
@@ -510,7 +546,7 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
     return res;
 }
 
-__device__ __forceinline__ void mat_trace_seq(Ctx &x, const int *tsst, int n, int skip1, int skip2, double &tlog, double &tsign, double *ptout = nullptr)
+__device__ __forceinline__ MatSeqArgs mat_seq_args(Ctx &x, const int *tsst, int n, int skip1, int skip2)
 {
     extern __shared__ unsigned char lds_base[];
     const DevConst &C = x.C;
@@ -518,22 +554,87 @@ __device__ __forceinline__ void mat_trace_seq(Ctx &x, const int *tsst, int n, in
     MatSeqArgs a;
     a.tsst = off(tsst); a.om = off(x.om); a.ot = off(x.ot); a.conn = off(x.t_conn); a.tn = off(x.t_n); a.toff = off(x.t_off);
     a.teval = off(x.t_eval); a.opbuf = off(x.opbuf); a.top = x.t_op ? off(x.t_op) : 0xffffffffu;
-    a.ptout = ptout ? off(ptout) : 0xffffffffu;
+    a.ptout = a.pin = a.pout = 0xffffffffu;
     a.opmat = C.opmat;
     a.n = n; a.skip1 = skip1; a.skip2 = skip2; a.nsm = C.nsm; a.spb = x.spb_; a.nf2 = 2 * C.nflav; a.nsst = C.nsst;
     a.beta = C.beta; a.egs = C.egs;
-    wave_sync();
+    return a;
+}
+__device__ __forceinline__ double2 mat_seq_call(const DevConst &C, const MatSeqArgs &a)
+{
     const int nt = mat_seq_pad(C.nsm);
-    const double2 r = nt == 8 ? mat_trace_seq_core<8>(a) : (nt == 10 ? mat_trace_seq_core<10>(a) : mat_trace_seq_core<16>(a));
+    return nt == 8 ? mat_trace_seq_core<8>(a) : (nt == 10 ? mat_trace_seq_core<10>(a) : mat_trace_seq_core<16>(a));
+}
+
+__device__ __forceinline__ void mat_trace_seq(Ctx &x, const int *tsst, int n, int skip1, int skip2, double &tlog, double &tsign, double *ptout = nullptr)
+{
+    extern __shared__ unsigned char lds_base[];
+    const DevConst &C = x.C;
+    MatSeqArgs a = mat_seq_args(x, tsst, n, skip1, skip2);
+    a.ptout = ptout ? (unsigned)((const unsigned char *)ptout - lds_base) : 0xffffffffu;
+    wave_sync();
+    const int outer = uni(tsst[0]);
+    tlog = -HUGE_VAL; tsign = 0.0;
+    if ((unsigned)outer >= (unsigned)C.nsst || uni(tsst[n]) != outer) return;
+    a.jbeg = 0; a.cnt = n; a.sst_start = outer; a.sst_end = outer; a.ncols = uni(x.t_n[outer]); a.t0 = 0.0; a.t1 = C.beta;
+    const double2 r = mat_seq_call(C, a);
+    tlog = uni(r.x); tsign = uni(r.y);
+}
+
+// The same trace with everything outside the sliding window taken from a cache.  A pair move changes operators inside
+// [wmin, wmax] only, so the product of all operators from wmax over beta = 0 to wmin,
+//     P = (ops before wmin) (ops after wmax) : block at wmax -> block at wmin,
+// stays what it is until the window moves or a global move, a tau shift or a change of the outer block is accepted
+// (x.pvalid).  The trial trace is then  Tr[ (ops inside the window) P ] : the stored vectors P are propagated through the
+// operators inside the window only (the reference keeps bra / ket vectors outside the window for the same reason,
+// Trace.F90:5384-5522, 6109-6209).  Z-space sweep only: worm operators may sit anywhere.
+__device__ W2DYN_INLINE void mat_trace_seq_window(Ctx &x, const int *tsst, int n, int skip1, int skip2, double &tlog, double &tsign)
+{
+    extern __shared__ unsigned char lds_base[];
+    const DevConst &C = x.C;
+    tlog = -HUGE_VAL; tsign = 0.0;
+    wave_sync();
+    const int outer = uni(tsst[0]);
+    if ((unsigned)outer >= (unsigned)C.nsst || uni(tsst[n]) != outer) return;
+    // trial indices of the window: [jlo, jhi) - the operators left out (skip1, skip2) lie inside the window
+    int clo = 0, chi = 0;
+    const int nstored = n + (skip1 >= 0 ? 1 : 0) + (skip2 >= 0 ? 1 : 0);
+    for (int base = 0; base < nstored; base += 64) {
+        const int e = base + x.lane; const bool in = e < nstored;
+        const double t = in ? x.ot[e] : 0.0;
+        clo += count_pred(in && t < x.wmin); chi += count_pred(in && t <= x.wmax);
+    }
+    const int jlo = clo, jhi = chi - (nstored - n);
+    if (jhi < jlo || (skip1 >= 0 && (skip1 < clo || skip1 >= chi)) || (skip2 >= 0 && (skip2 < clo || skip2 >= chi))) {
+        mat_trace_seq(x, tsst, n, skip1, skip2, tlog, tsign);       // not a window-local change: the plain evaluation
+        return;
+    }
+    const int sst_lo = uni(tsst[jlo]), sst_hi = uni(tsst[jhi]);     // tsst[n] = outer covers jhi = n
+    if ((unsigned)sst_lo >= (unsigned)C.nsst || (unsigned)sst_hi >= (unsigned)C.nsst) return;
+    MatSeqArgs a = mat_seq_args(x, tsst, n, skip1, skip2);
+    const unsigned poff = (unsigned)((const unsigned char *)x.pmat - lds_base);
+    if (!x.pvalid || x.p_lo != sst_lo || x.p_hi != sst_hi) {
+        // operators jhi .. n-1, then 0 .. jlo-1, from wmax to beta + wmin, unit vectors on the block at wmax
+        a.jbeg = jhi; a.cnt = (n - jhi) + jlo; a.sst_start = sst_hi; a.sst_end = sst_lo; a.ncols = uni(x.t_n[sst_hi]);
+        a.t0 = x.wmax; a.t1 = C.beta + x.wmin; a.pout = poff;
+        const double2 r = mat_seq_call(C, a);
+        if (uni(r.y) == 0.0) { x.pvalid = 0; return; }
+        x.pvalid = 1; x.p_lo = sst_lo; x.p_hi = sst_hi;
+        a.pout = 0xffffffffu;
+    }
+    a.jbeg = jlo; a.cnt = jhi - jlo; a.sst_start = sst_lo; a.sst_end = sst_hi; a.ncols = uni(x.t_n[sst_hi]);
+    a.t0 = x.wmin; a.t1 = x.wmax; a.pin = poff;
+    const double2 r = mat_seq_call(C, a);
     tlog = uni(r.x); tsign = uni(r.y);
 }
 
 // trace of the trial sequence whose block sequence is in tsst: tree for small blocks (MATN = 2, 3, 4 = padded block
 // size the kernel was instantiated for), sequential walk otherwise (MATN = 9)
-template <int MATN>
+template <int MATN, bool WINDOW = false>
 __device__ W2DYN_INLINE void mat_trace_trial(Ctx &x, const int *tsst, int n, int skip1, int skip2, double &tlog, double &tsign)
 {
     if constexpr (MATN >= 2 && MATN <= 4) mat_trace_tree<MATN>(x, tsst, n, skip1, skip2, tlog, tsign);
+    else if constexpr (WINDOW) mat_trace_seq_window(x, tsst, n, skip1, skip2, tlog, tsign);
     else mat_trace_seq(x, tsst, n, skip1, skip2, tlog, tsign);
 }
 
@@ -716,6 +817,6 @@ __device__ W2DYN_INLINE void step_glob_mat(Ctx &x)
     x.det_log = logdet_new; x.det_sign = sign_new;
     x.tr_log = tl; x.tr_sign = ts;
     mat_commit_sst(x);
-    x.npairs = -1;
+    x.npairs = -1; x.pvalid = 0;
     x.count(C_ACCGLOB);
 }
