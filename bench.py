@@ -36,6 +36,9 @@ WORKLOADS = {
     "C2A": dict(config="C2", nftau=5001, overrides=dict(Nftau=5001, NCorr=200, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Nwarmups=0, Nmeas=1024, AccumGtau=2),
                 text="C2 + AccumGtau=2 (per-chain autocorrelation accumulator of G(tau), 10 levels)"),
     # the other single-GPU configurations (parity-test cases; selectable with --config for extra bench lines)
+    # BASELINE.json configs[0]: the reference's own CPU-runnable case (beta = 10: expansion order ~1.4 per flavour)
+    "C1": dict(config="C1", nftau=5001, overrides=dict(Nftau=5001, NCorr=100, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Nwarmups=0, Nmeas=1),
+               text="C1: 1-band Hubbard, Bethe D=1, U=2, beta=10, half filling, one window, NCorr=100, NLegMax=100, Ntau=1000"),
     "C3": dict(config="C3", nftau=5001, overrides=dict(Nftau=5001, NCorr=100, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Nwarmups=0, Nmeas=1),
                text="C3: 2-orbital density-density, U=2, J=0.25, beta=50, TaudiffMax=10, NCorr=100"),
     "C4": dict(config="C4", nftau=5001, overrides=dict(Nftau=5001, NCorr=100, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Nwarmups=0, Nmeas=1),
