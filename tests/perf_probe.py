@@ -34,6 +34,9 @@ def probe(cfg, nftau, over, nw, kmax=0, rounds=int(os.environ.get('PROBE_ROUNDS'
             c[1], c[16] / c[1], c[17] / c[1], c[18] / c[1], c[19] / c[1], c[4], c[20] / c[4], c[21] / c[4], c[22] / c[4], c[23] / c[4]), flush=True)
     if os.environ.get("PROBE_PICK") and len(c) >= 24:
         print("   pick: n=%d, LDS path (nw>64) %.4f, mean nw %.1f, register-path cycles per pick %.0f" % (c[3], c[21] / max(c[3], 1), c[22] / max(c[3], 1), c[23] / max(c[3] - c[21], 1)), flush=True)
+    if os.environ.get("PROBE_SEQ") and len(c) >= 24:
+        print("   cached-window trace: calls %d, mean operators %.1f, full evaluations %.4f, rebuilds of the outside product %.4f (%.1f operators, %.0f cycles each), window part %.1f operators, %.0f cycles" % (
+            c[16], c[23] / max(c[16], 1), c[22] / max(c[16], 1), c[17] / max(c[16], 1), c[18] / max(c[17], 1), c[20] / max(c[17], 1), c[19] / max(c[16] - c[22], 1), c[21] / max(c[16] - c[22], 1)), flush=True)
     if os.environ.get("PROBE_GLOB") and len(c) >= 24:
         print("   glob stages (cycles per global move): setup+qn %.0f invert %.0f parity %.0f logtrace %.0f install %.0f (acc=%d of %d)" % (
             c[16] / max(c[6], 1), c[17] / max(c[6], 1), c[18] / max(c[6], 1), c[19] / max(c[6], 1), c[20] / max(c[6], 1), c[7], c[6]), flush=True)

@@ -24,7 +24,7 @@
 // evaluating block 64*chunk+i, and handed out with v_readlane - the stream itself is unchanged.
 #pragma once
 #include <hip/hip_runtime.h>
-#if defined(W2DYN_STAMPS) && !defined(W2DYN_STAMPS_GLOB)
+#if defined(W2DYN_STAMPS) && !defined(W2DYN_STAMPS_GLOB) && !defined(W2DYN_STAMPS_SEQ)
 #define DBG_STAMP(x, c) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((x).lane == 0) (x).cnt[c] += t_ - (x).tstamp; (x).tstamp = t_; } while (0)
 #define DBG_START(x) (x).tstamp = __builtin_amdgcn_s_memtime()
 #else
@@ -135,6 +135,7 @@ struct DevConst {
     const int *sst_n, *sst_off, *conn, *sst_first, *sst_of_state, *dmoff;   // [nsst] [nsst] [nsst][nflav][2] [nsst] [nstates] [nsst+1]
     const double *sst_eval;       // [nstates] eigenvalues in block order
     const double *opmat;          // [nsst][nflav][2][nsm][nsm] operators in the eigenbasis, row = target state, zero padded
+    const double *opmat_pad;      // blocks of more than 4 states: the same with rows and columns padded to mat_seq_pad(nsm) (sequential evaluator)
     // worm sampling (CTQMC.F90:335-378, 434; ctqmc_measure arguments)
     int isector, icomponent, nwf, nwb, wormphconv, g4ph, g4pp;
     double p_wins, p_wrep, worm_eta;
@@ -162,7 +163,7 @@ __host__ __device__ inline size_t lds_bytes_per_wave(int nflav, int kmax, int wc
     size_t d = (size_t)2 * nflav * kmax + 2 * (size_t)kmax + ((mat ? u1 + u2 : (u1 > u2 ? u1 : u2)) + 7) / 8;
     size_t i = (size_t)MAXFLAV + kmax;                                         // K, piv
     if (mat) { d += wcap + 2; i += (size_t)3 * wcap + 8; }                     // ot; om, osst, tsst
-    if (mat > 4) { const size_t nt = mat <= 8 ? 8 : (mat <= 10 ? 10 : 16); d += 6 * nt * nt + 2; }   // stage of MAT_CH operator matrices + vector tile + product outside the window (sequential trace, mat = block size)
+    if (mat > 4) { const size_t nt = mat <= 8 ? 8 : (mat <= 10 ? 10 : 16); d += (16 + 64) * nt + nt * nt + 2; }   // vector tile + decay table (mat_seq_lds_doubles) + product outside the window (sequential trace, mat = block size)
     size_t b = d * sizeof(double) + C_NCOUNT * sizeof(unsigned long long) + i * sizeof(int);
     return (b + 15) & ~(size_t)15;
 }
@@ -278,7 +279,7 @@ struct Ctx {
     double wr_t; int wr_m, wr_c, wr_p;  // lane e: window-list entry e (tau, f|ca<<8|slot<<16, partner count, pairs before e) when nwin <= 64
     int wvalid;                      // window list (registers or LDS) matches the current configuration and window
     // matrix local-trace path
-    double *opbuf;                                   // stage of MAT_CH operator matrices (blocks of more than 4 states)
+    double *opbuf;                                   // sequential evaluator (blocks of more than 4 states): vector tile and decay table, mat_seq_lds_doubles()
     double *pmat; int pvalid, p_lo, p_hi;            // sequential trace: product of the operators outside the window (mat_trace_seq_window), its blocks
     double *ot; int *om, *osst, *tsst; int nops;     // time-ordered operator list, block sequence, trial block sequence (LDS)
     const short *t_conn, *t_shift;                   // 16-bit block numbers: the two tables are the bulk of the shared LDS (5 orbitals: 352 blocks x 20 operators)
@@ -1496,7 +1497,7 @@ __device__ __forceinline__ void ctx_setup(Ctx &x, unsigned char *smem)
         x.om = x.piv + C.kmax; x.osst = x.om + C.wcap; x.tsst = x.osst + C.wcap + 2;
         x.ot = (double *)(((size_t)(x.tsst + C.wcap + 2) + 7) & ~(size_t)7);
         x.opbuf = x.ot + C.wcap + 2;
-        { const int nt = C.nsm <= 8 ? 8 : (C.nsm <= 10 ? 10 : 16); x.pmat = x.opbuf + 5 * nt * nt; }
+        { const int nt = C.nsm <= 8 ? 8 : (C.nsm <= 10 ? 10 : 16); x.pmat = x.opbuf + (16 + 64) * nt; }
         const int nf2 = 2 * C.nflav;
         short *ti = (short *)smem;
         x.t_conn = ti; x.t_shift = ti + C.nsst * nf2; x.t_n = (const int *)(ti + 2 * C.nsst * nf2); x.t_off = x.t_n + C.nsst;

@@ -336,12 +336,22 @@ __device__ W2DYN_INLINE void mat_trace_tree(Ctx &x, const int *tsst, int n, int 
 }
 
 // Sequential evaluation of the trace of a trial sequence whose block sequence tsst is known (blocks of 5..16 states):
-// lane = (outer state of the batch, component), all batches of outer states advance together on one common scale and
-// share the operator rows.  The operator matrices live in global memory (L2): with the block sequence known their
-// addresses are known up front, so they are fetched MAT_CH operators ahead - all 64 lanes load the next chunk into
-// registers while the current chunk is applied out of the wave's LDS stage (one memory latency per chunk instead of one
-// per operator and batch).
-constexpr int MAT_CH = 4, MAT_NB = 4;
+// lane = (outer state of the batch, component), all batches of outer states advance together on one common scale.
+// A wave issues at most one vector instruction every four clocks whatever the occupancy, so the cost of one operator is
+// its instruction count, and the loop over the operators holds nothing but the product itself:
+//   * everything that is the same for all lanes (time step, block, scalar decay, position of the matrix) is worked out for
+//     64 operators at once, lane jj for operator base + jj;
+//   * the decay factors exp(-(E_i - E_0) dt) of the 64 operators are computed NT per lane and step into an LDS table (one
+//     exp per operator and state instead of one per operator and lane);
+//   * every lane reads ITS row of the operator matrix straight from global memory (L2; the table is padded to NT x NT by
+//     the host, so a row is NT / 2 aligned 16-byte loads from a scalar base), four operators ahead into registers: no
+//     staging through LDS, no index arithmetic per element;
+//   * the vectors are exchanged through a zero-padded LDS tile: rows of vectors that do not exist read as zero and rows of
+//     the matrix beyond the target block are zero, so no lane needs a mask inside the product.
+constexpr int MAT_NB = 4, MAT_AHEAD = 4, MAT_TILE_ROWS = 16;
+
+// doubles of LDS the evaluator needs per wave: vector tile [MAT_TILE_ROWS][NT], then the decay table [64][NT]
+__host__ __device__ inline int mat_seq_lds_doubles(int nt) { return (MAT_TILE_ROWS + 64) * nt; }
 
 // Everything the evaluator needs, by value: LDS locations as byte offsets into the dynamic LDS (so that the out-of-line
 // function below addresses LDS as LDS, not through generic pointers) and plain numbers.  The function is a REAL call on
@@ -349,10 +359,10 @@ constexpr int MAT_CH = 4, MAT_NB = 4;
 // allocator spills loop-carried values to scratch (measured: ~5000 cycles per operator, 0.5 M cycles per trace); as a
 // call the caller's state is saved once per trace and the loop runs out of registers.
 struct MatSeqArgs {
-    unsigned tsst, om, ot, conn, tn, toff, teval, opbuf, top;      // byte offsets; top = 0xffffffff: operators in global memory
+    unsigned tsst, om, ot, conn, tn, toff, teval, opbuf;           // byte offsets
     unsigned ptout;                                                // 0xffffffff or byte offset of nsm + 1 doubles: partial traces of the outer states, then their common log scale
     unsigned pin, pout;                                            // 0xffffffff or byte offset of NT * NT + 1 doubles: vectors to start from / to leave the result in ([vector][component], stride NT, then the log scale)
-    const double *opmat;
+    const double *opmat;                                           // [nsst][nf2][NT][NT] (DevConst::opmat_pad)
     int n, skip1, skip2, nsm, spb, nf2, nsst;
     // the stretch of the trial sequence to apply: cnt operators from trial index jbeg on (indices beyond n - 1 wrap around
     // to 0, their times count from beta), between the times t0 and t1 (same unwrapped scale), from block sst_start to
@@ -363,12 +373,12 @@ struct MatSeqArgs {
     double beta, egs;
 };
 
-// padded block size the evaluator is instantiated for (stage and vector exchange use this stride)
+// padded block size the evaluator is instantiated for (operator table, vector tile and vector exchange use this stride)
 __host__ __device__ inline int mat_seq_pad(int nsm) { return nsm <= 8 ? 8 : (nsm <= 10 ? 10 : 16); }
 
-// NT: padded block size.  The lane's vector components v[b] (one per batch of vectors) stay in registers; for the
-// matrix-vector product they are exchanged through a small LDS tile (V[vector][component], stride NT), so that one
-// operator costs a handful of wide LDS reads issued back to back instead of NT dependent cross-lane shuffles per batch.
+typedef double mat_d2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) mat_d2 *MatRowPtr;
+
 template <int NT>
 __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
 {
@@ -379,65 +389,44 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
     const short *t_conn = (const short *)(lds_base + uni((int)a.conn));
     const int *t_n = (const int *)(lds_base + uni((int)a.tn)), *t_off = (const int *)(lds_base + uni((int)a.toff));
     const double *t_eval = (const double *)(lds_base + uni((int)a.teval));
-    double *opbuf = (double *)(lds_base + uni((int)a.opbuf)), *vbuf = opbuf + MAT_CH * NT * NT;
-    const bool ops_lds = uni((int)a.top) != -1;
-    const double *ops_l = (const double *)(lds_base + (ops_lds ? uni((int)a.top) : 0));
-    const double *ops_g = (const double *)(((unsigned long long)(unsigned)uni((int)((unsigned long long)a.opmat >> 32)) << 32) | (unsigned long long)(unsigned)uni((int)(unsigned long long)a.opmat));
+    double *vbuf = (double *)(lds_base + uni((int)a.opbuf)), *fdt = vbuf + MAT_TILE_ROWS * NT;
+    const unsigned long long ops_bits = ((unsigned long long)(unsigned)uni((int)((unsigned long long)a.opmat >> 32)) << 32) | (unsigned long long)(unsigned)uni((int)(unsigned long long)a.opmat);
     const int n = uni(a.n), skip1 = uni(a.skip1), skip2 = uni(a.skip2), nsm = uni(a.nsm), spb = uni(a.spb), nf2 = uni(a.nf2), nsst = uni(a.nsst);
     const int jbeg = uni(a.jbeg), cnt = uni(a.cnt), sst_start = uni(a.sst_start), sst_end = uni(a.sst_end), ncols = uni(a.ncols);
     const double beta = uni(a.beta), egs = uni(a.egs), t0 = uni(a.t0), t1 = uni(a.t1);
     const bool has_pin = uni((int)a.pin) != -1, has_pout = uni((int)a.pout) != -1;
-    const int nsq = nsm * nsm, ms = lane / nsm, mi = lane - ms * nsm;
     double2 res = make_double2(-HUGE_VAL, 0.0);
     if ((unsigned)sst_start >= (unsigned)nsst || (unsigned)sst_end >= (unsigned)nsst) return res;
     if (cnt > 0 && uni(tsst[jbeg >= n ? jbeg - n : jbeg]) != sst_start) return res;
     if (cnt == 0 && sst_start != sst_end) return res;
+    // lanes beyond the last full vector repeat lane 0's arithmetic and never write
     const bool act = lane < spb * nsm;
-    bool diag[MAT_NB], valid[MAT_NB]; double v[MAT_NB];
+    const int ms = act ? lane / nsm : 0, mi = act ? lane - ms * nsm : 0;
+    const int nb = (ncols + spb - 1) / spb;         // batches of vectors in use
+    bool diag[MAT_NB], wr[MAT_NB]; double v[MAT_NB];
     double lacc = 0.0;
     {
         const double *pin = (const double *)(lds_base + (has_pin ? uni((int)a.pin) : 0));
 #pragma unroll
         for (int b = 0; b < MAT_NB; ++b) {
             const int st = b * spb + ms;
-            valid[b] = act && st < ncols;
-            diag[b] = valid[b] && st == mi;
-            v[b] = has_pin ? (valid[b] ? pin[st * NT + mi] : 0.0) : (diag[b] ? 1.0 : 0.0);
+            const bool inr = st < ncols;
+            wr[b] = act && inr;
+            diag[b] = wr[b] && st == mi;
+            v[b] = has_pin ? (inr ? pin[st * NT + mi] : 0.0) : ((inr && st == mi) ? 1.0 : 0.0);
         }
         if (has_pin) lacc = uni(pin[NT * NT]);
     }
     lds_sync();
-    for (int e = lane; e < NT * NT; e += 64) vbuf[e] = 0.0;      // the padding of the vector tile stays zero from here on
-    constexpr int NREG = (MAT_CH * NT * NT + 63) / 64;
-    double reg[NREG];
+    for (int e = lane; e < MAT_TILE_ROWS * NT; e += 64) vbuf[e] = 0.0;      // what no lane writes below stays zero
+    const MatRowPtr myrow = (MatRowPtr)(ops_bits + (unsigned long long)(mi * NT) * sizeof(double));
+    mat_d2 R[MAT_AHEAD][NT / 2];                    // the lane's rows of the next MAT_AHEAD operators
     auto trial_index = [&](int q) { const int j = jbeg + q; return j >= n ? j - n : j; };
-    auto fetch = [&](int c) {                       // operators c*MAT_CH .. of the stretch into registers
-#pragma unroll
-        for (int q = 0; q < NREG; ++q) {
-            const int e = q * 64 + lane;
-            reg[q] = 0.0;
-            if (e < MAT_CH * NT * NT) {              // stage layout (operator, row, column) with the padded stride NT: constant divisors
-                const int jo = e / (NT * NT), r = e - jo * (NT * NT), i = r / NT, k = r - i * NT, qq = c * MAT_CH + jo;
-                if (qq < cnt && i < nsm && k < nsm) {
-                    const int j = trial_index(qq);
-                    const int sst = tsst[j], code = om[mat_old_index(j, skip1, skip2)];
-                    if ((unsigned)sst < (unsigned)nsst && (unsigned)code < (unsigned)nf2) {
-                        const size_t idx = (size_t)(sst * nf2 + code) * nsq + i * nsm + k;
-                        reg[q] = ops_lds ? ops_l[idx] : ops_g[idx];
-                    }
-                }
-            }
-        }
-    };
-    // Everything about an operator that is the same for all lanes (time step, block size and offset, scalar decay) is
-    // worked out for 64 operators at once, lane jj for operator base + jj, and handed to the sequential loop with
-    // v_readlane: the loop itself then waits for LDS only twice per operator (vector tile, eigenvalue of the lane's state).
     double tlast = t0;
     int iexp = 0;                                   // common binary exponent taken out of the vectors
-    if (cnt > 0) fetch(0);
     for (int base = 0; base < cnt; base += 64) {
         const int qm = base + lane;
-        double my_dt = 0.0, my_sc = 0.0; int my_on = 0; bool my_bad = false;
+        double my_dt = 0.0, my_sc = 0.0; int my_on = 0, my_op = nsst * nf2; bool my_bad = false;      // beyond the stretch: the unit matrix the host appends to the table
         if (qm < cnt) {
             const int jm = trial_index(qm), sst = tsst[jm], o = mat_old_index(jm, skip1, skip2);
             const double tau = ot[o] + (jbeg + qm >= n ? beta : 0.0);
@@ -450,52 +439,62 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
                 my_bad = (unsigned)code >= (unsigned)nf2 || t_conn[sst * nf2 + code] < 0;
                 const int off = t_off[sst];
                 my_on = off | (t_n[sst] << 16);
+                if (!my_bad) my_op = sst * nf2 + code;
                 my_sc = (t_eval[off] - egs) * my_dt;
             }
             if (qm == cnt - 1) tlast = tau;
         }
         if (__ballot(my_bad) != 0ull) return res;
         lacc -= wave_sum(my_sc);
-        const int cntg = min(64, cnt - base);
-        // eigenvalue difference of the lane's state in the block of the first operator of this group (prefetched one ahead)
-        int on = __builtin_amdgcn_readlane(my_on, 0);
-        double de = ((on >> 16) > 1 && mi < (on >> 16)) ? t_eval[(on & 0xffff) + mi] - t_eval[on & 0xffff] : 0.0;
-        for (int jj = 0; jj < cntg; ++jj) {
-            const int q = base + jj;
-            if ((q % MAT_CH) == 0) {                 // stage the next MAT_CH operator matrices
+        // The group is filled up to a multiple of MAT_AHEAD with unit operators (decay factor one, unit matrix: the vectors
+        // pass unchanged, exactly), so that the loop below has no branch around its loads: the compiler's count of loads in
+        // flight stays exact and a product waits for ITS rows only, not for the ones requested after them.
+        const int cntg = min(64, cnt - base), cntp = (cntg + MAT_AHEAD - 1) / MAT_AHEAD * MAT_AHEAD;
+#pragma unroll
+        for (int u = 0; u < MAT_AHEAD; ++u) {        // rows of the first operators of the group: in flight while the decay table is made
+            const MatRowPtr p = myrow + (size_t)__builtin_amdgcn_readlane(my_op, u) * (NT * NT / 2);
+#pragma unroll
+            for (int k = 0; k < NT / 2; ++k) R[u][k] = p[k];
+        }
+        lds_sync();                                 // the table of the group before is not read any more
+        for (int e0 = 0; e0 < cntp * NT; e0 += 64) {      // all lanes stay in the loop: the values are fetched from other lanes
+            const int e = e0 + lane, jj = e / NT, i = e - jj * NT;
+            const double dtj = __shfl(my_dt, jj & 63, 64);
+            const int onj = __shfl(my_on, jj & 63, 64), nj = onj >> 16, off = onj & 0xffff;
+            const double f = (jj < cntg && i < nj) ? exp(-(t_eval[off + i] - t_eval[off]) * dtj) : 0.0;
+            if (e < cntp * NT) fdt[e] = jj >= cntg ? 1.0 : f;
+        }
+        lds_sync();
+        for (int jj0 = 0; jj0 < cntp; jj0 += MAT_AHEAD) {
+#pragma unroll
+            for (int u = 0; u < MAT_AHEAD; ++u) {
+                const int jj = jj0 + u;
+                const double fd = fdt[jj * NT + mi];
+                // vectors that do not exist are zero and stay zero; lanes beyond the last full vector write what lane 0 writes
+#pragma unroll
+                for (int b = 0; b < MAT_NB; ++b) if (b < nb) vbuf[(b * spb + ms) * NT + mi] = v[b] * fd;
                 lds_sync();
 #pragma unroll
-                for (int r = 0; r < NREG; ++r) { const int e = r * 64 + lane; if (e < MAT_CH * NT * NT) opbuf[e] = reg[r]; }
+                for (int b = 0; b < MAT_NB; ++b) {
+                    if (b < nb) {                    // uniform
+                        const double *vr = vbuf + (b * spb + ms) * NT;
+                        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                        for (int k = 0; k < NT / 2; ++k) { acc0 = fma(R[u][k].x, vr[2 * k], acc0); acc1 = fma(R[u][k].y, vr[2 * k + 1], acc1); }
+                        v[b] = acc0 + acc1;
+                    }
+                }
                 lds_sync();
-                if (q + MAT_CH < cnt) fetch(q / MAT_CH + 1);
-            }
-            const int jo = q % MAT_CH;
-            const int dlo = __builtin_amdgcn_readlane((int)__double2loint(my_dt), jj), dhi = __builtin_amdgcn_readlane(__double2hiint(my_dt), jj);
-            const double dt = __hiloint2double(dhi, dlo);
-            const double fdec = exp(-de * dt);
-            if (jj + 1 < cntg) {                     // next operator's eigenvalue difference: in flight during this product
-                on = __builtin_amdgcn_readlane(my_on, jj + 1);
-                de = ((on >> 16) > 1 && mi < (on >> 16)) ? t_eval[(on & 0xffff) + mi] - t_eval[on & 0xffff] : 0.0;
-            }
+                {   // the operator MAT_AHEAD further on (beyond the group: a row that is never used)
+                    const MatRowPtr p = myrow + (size_t)__builtin_amdgcn_readlane(my_op, (jj + MAT_AHEAD) & 63) * (NT * NT / 2);
 #pragma unroll
-            for (int b = 0; b < MAT_NB; ++b) if (valid[b]) vbuf[(b * spb + ms) * NT + mi] = v[b] * fdec;
-            lds_sync();
-            const double *row = opbuf + (jo * NT + (act ? mi : 0)) * NT;
-#pragma unroll
-            for (int b = 0; b < MAT_NB; ++b) {
-                if (b * spb < ncols) {               // uniform
-                    const double *vr = vbuf + (valid[b] ? (b * spb + ms) : 0) * NT;
-                    double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-                    for (int k = 0; k < NT; k += 2) { acc0 = fma(row[k], vr[k], acc0); acc1 = fma(row[k + 1], vr[k + 1], acc1); }
-                    v[b] = valid[b] ? acc0 + acc1 : 0.0;
+                    for (int k = 0; k < NT / 2; ++k) R[u][k] = p[k];
                 }
             }
-            lds_sync();
-            if ((q & 3) == 3) {                      // keep the vectors near one: take out a power of two (exact)
+            {   // keep the vectors near one: take out a power of two (exact)
                 double m = 0.0;
 #pragma unroll
-                for (int b = 0; b < MAT_NB; ++b) m = fmax(m, fabs(v[b]));
+                for (int b = 0; b < MAT_NB; ++b) if (b < nb) m = fmax(m, fabs(v[b]));
                 m = wave_max(m);
                 if (!(m > 0.0)) return res;
                 const int e2 = ilogb(m);
@@ -516,14 +515,14 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
             double *pout = (double *)(lds_base + uni((int)a.pout));
             double m = 0.0;
 #pragma unroll
-            for (int b = 0; b < MAT_NB; ++b) { v[b] = (valid[b] && mi < nend) ? v[b] * fdec : 0.0; m = fmax(m, fabs(v[b])); }
+            for (int b = 0; b < MAT_NB; ++b) { v[b] = (wr[b] && mi < nend) ? v[b] * fdec : 0.0; m = fmax(m, fabs(v[b])); }
             m = wave_max(m);
             if (!(m > 0.0)) return res;
             const int e2 = ilogb(m);
             for (int e = lane; e < NT * NT; e += 64) pout[e] = 0.0;
             lds_sync();
 #pragma unroll
-            for (int b = 0; b < MAT_NB; ++b) if (valid[b]) pout[(b * spb + ms) * NT + mi] = ldexp(v[b], -e2);
+            for (int b = 0; b < MAT_NB; ++b) if (wr[b]) pout[(b * spb + ms) * NT + mi] = ldexp(v[b], -e2);
             if (lane == 0) pout[NT * NT] = lacc + (double)e2 * 0.6931471805599453;
             lds_sync();
             res.x = 0.0; res.y = 1.0;
@@ -534,6 +533,7 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
         for (int b = 0; b < MAT_NB; ++b) part += diag[b] ? v[b] * fdec : 0.0;
         if (uni((int)a.ptout) != -1) {               // estimator pass only: hand the partial traces to the caller
             double *pto = (double *)(lds_base + uni((int)a.ptout));
+            lds_sync();
 #pragma unroll
             for (int b = 0; b < MAT_NB; ++b) if (diag[b]) pto[b * spb + ms] = v[b] * fdec;
             if (lane == 0) pto[nsm] = lacc;
@@ -553,9 +553,9 @@ __device__ __forceinline__ MatSeqArgs mat_seq_args(Ctx &x, const int *tsst, int 
     auto off = [&](const void *p) { return (unsigned)((const unsigned char *)p - lds_base); };
     MatSeqArgs a;
     a.tsst = off(tsst); a.om = off(x.om); a.ot = off(x.ot); a.conn = off(x.t_conn); a.tn = off(x.t_n); a.toff = off(x.t_off);
-    a.teval = off(x.t_eval); a.opbuf = off(x.opbuf); a.top = x.t_op ? off(x.t_op) : 0xffffffffu;
+    a.teval = off(x.t_eval); a.opbuf = off(x.opbuf);
     a.ptout = a.pin = a.pout = 0xffffffffu;
-    a.opmat = C.opmat;
+    a.opmat = C.opmat_pad;
     a.n = n; a.skip1 = skip1; a.skip2 = skip2; a.nsm = C.nsm; a.spb = x.spb_; a.nf2 = 2 * C.nflav; a.nsst = C.nsst;
     a.beta = C.beta; a.egs = C.egs;
     return a;
@@ -588,6 +588,15 @@ __device__ __forceinline__ void mat_trace_seq(Ctx &x, const int *tsst, int n, in
 // (x.pvalid).  The trial trace is then  Tr[ (ops inside the window) P ] : the stored vectors P are propagated through the
 // operators inside the window only (the reference keeps bra / ket vectors outside the window for the same reason,
 // Trace.F90:5384-5522, 6109-6209).  Z-space sweep only: worm operators may sit anywhere.
+#ifdef W2DYN_STAMPS_SEQ     // diagnostic build: counts and cycles of the cached-window evaluation in the DBG slots
+#define SEQ_COUNT(x, c, v) do { if ((x).lane == 0) (x).cnt[c] += (unsigned long long)(v); } while (0)
+#define SEQ_T0() const unsigned long long tq0_ = __builtin_amdgcn_s_memtime()
+#define SEQ_T1(x, c) do { if ((x).lane == 0) (x).cnt[c] += __builtin_amdgcn_s_memtime() - tq0_; } while (0)
+#else
+#define SEQ_COUNT(x, c, v)
+#define SEQ_T0()
+#define SEQ_T1(x, c)
+#endif
 __device__ W2DYN_INLINE void mat_trace_seq_window(Ctx &x, const int *tsst, int n, int skip1, int skip2, double &tlog, double &tsign)
 {
     extern __shared__ unsigned char lds_base[];
@@ -605,7 +614,9 @@ __device__ W2DYN_INLINE void mat_trace_seq_window(Ctx &x, const int *tsst, int n
         clo += count_pred(in && t < x.wmin); chi += count_pred(in && t <= x.wmax);
     }
     const int jlo = clo, jhi = chi - (nstored - n);
+    SEQ_COUNT(x, C_DBG0, 1); SEQ_COUNT(x, C_DBG7, n);
     if (jhi < jlo || (skip1 >= 0 && (skip1 < clo || skip1 >= chi)) || (skip2 >= 0 && (skip2 < clo || skip2 >= chi))) {
+        SEQ_COUNT(x, C_DBG6, 1);
         mat_trace_seq(x, tsst, n, skip1, skip2, tlog, tsign);       // not a window-local change: the plain evaluation
         return;
     }
@@ -617,14 +628,18 @@ __device__ W2DYN_INLINE void mat_trace_seq_window(Ctx &x, const int *tsst, int n
         // operators jhi .. n-1, then 0 .. jlo-1, from wmax to beta + wmin, unit vectors on the block at wmax
         a.jbeg = jhi; a.cnt = (n - jhi) + jlo; a.sst_start = sst_hi; a.sst_end = sst_lo; a.ncols = uni(x.t_n[sst_hi]);
         a.t0 = x.wmax; a.t1 = C.beta + x.wmin; a.pout = poff;
+        SEQ_COUNT(x, C_DBG1, 1); SEQ_COUNT(x, C_DBG2, a.cnt); SEQ_T0();
         const double2 r = mat_seq_call(C, a);
+        SEQ_T1(x, C_DBG4);
         if (uni(r.y) == 0.0) { x.pvalid = 0; return; }
         x.pvalid = 1; x.p_lo = sst_lo; x.p_hi = sst_hi;
         a.pout = 0xffffffffu;
     }
     a.jbeg = jlo; a.cnt = jhi - jlo; a.sst_start = sst_lo; a.sst_end = sst_hi; a.ncols = uni(x.t_n[sst_hi]);
     a.t0 = x.wmin; a.t1 = x.wmax; a.pin = poff;
+    SEQ_COUNT(x, C_DBG3, a.cnt); SEQ_T0();
     const double2 r = mat_seq_call(C, a);
+    SEQ_T1(x, C_DBG5);
     tlog = uni(r.x); tsign = uni(r.y);
 }
 

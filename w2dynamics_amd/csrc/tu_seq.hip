@@ -1,4 +1,5 @@
 // translation unit: Z-space sweep and misc estimators on the matrix trace path, blocks of 5..16 states (sequential propagation)
+#define W2DYN_WPE_MAT 1     // 407 registers when left alone: at 256 the kernel spilled 650 and still ran one wave per SIMD
 #include "launch.hpp"
 namespace w2dyn {
 void launch_sweep_seq(bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count, int resume)

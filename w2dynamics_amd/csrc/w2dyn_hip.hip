@@ -671,6 +671,15 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
         }
         if (lp.nsst > 32767) return fail(s, W2DYN_EUNSUPPORTED, "%d blocks: more than the 16-bit block tables hold", lp.nsst);
     }
+    std::vector<double> opmat_pad;
+    if (s->mat && C.nsm > 4) {          // the sequential evaluator reads whole rows of a fixed length: stride mat_seq_pad(nsm)
+        const int nt = mat_seq_pad(C.nsm);
+        opmat_pad.assign(((size_t)lp.nsst * nf * 2 + 1) * nt * nt, 0.0);       // one more: the unit matrix (fills groups of operators, mat_trace_seq_core)
+        for (int i = 0; i < nt; ++i) opmat_pad[((size_t)lp.nsst * nf * 2 * nt + i) * nt + i] = 1.0;
+        for (size_t m = 0; m < (size_t)lp.nsst * nf * 2; ++m)
+            for (int i = 0; i < C.nsm; ++i) for (int j = 0; j < C.nsm; ++j)
+                opmat_pad[(m * nt + i) * nt + j] = opmat[(m * C.nsm + i) * C.nsm + j];
+    }
     { int rc0 = configure_kmax(s, kmax); if (rc0) return rc0; }
     C.beta = s->beta; C.rbeta = 1.0 / s->beta; C.p_glob = s->p_glob; C.p_shift = s->p_shift; C.egs = s->egs;
     C.seed = (unsigned long long)s->seed; C.first_walker = (unsigned long long)s->first_walker;
@@ -696,6 +705,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
         if ((rc = dev_upload(s, C.sst_first, first))) return rc;
     }
     if (s->mat) { if ((rc = dev_upload(s, C.opmat, opmat))) return rc; }
+    if (!opmat_pad.empty()) { if ((rc = dev_upload(s, C.opmat_pad, opmat_pad))) return rc; }
     const size_t W = s->nwalkers;
     if ((rc = dev_alloc(s, C.ws, W))) return rc;
     if ((rc = dev_alloc(s, C.K, W * nf))) return rc;
