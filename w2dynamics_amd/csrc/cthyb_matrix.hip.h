@@ -379,7 +379,9 @@ __host__ __device__ inline int mat_seq_pad(int nsm) { return nsm <= 8 ? 8 : (nsm
 typedef double mat_d2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) mat_d2 *MatRowPtr;
 
-template <int NT>
+// NB: batches of vectors in use, ceil(ncols / spb) (compile-time, so that the loop has no branches at all: a taken branch costs
+// a single wave more than the dozen instructions it skips)
+template <int NT, int NB>
 __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
 {
     extern __shared__ unsigned char lds_base[];
@@ -402,13 +404,12 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
     // lanes beyond the last full vector repeat lane 0's arithmetic and never write
     const bool act = lane < spb * nsm;
     const int ms = act ? lane / nsm : 0, mi = act ? lane - ms * nsm : 0;
-    const int nb = (ncols + spb - 1) / spb;         // batches of vectors in use
-    bool diag[MAT_NB], wr[MAT_NB]; double v[MAT_NB];
+    bool diag[NB], wr[NB]; double v[NB];
     double lacc = 0.0;
     {
         const double *pin = (const double *)(lds_base + (has_pin ? uni((int)a.pin) : 0));
 #pragma unroll
-        for (int b = 0; b < MAT_NB; ++b) {
+        for (int b = 0; b < NB; ++b) {
             const int st = b * spb + ms;
             const bool inr = st < ncols;
             wr[b] = act && inr;
@@ -465,25 +466,24 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
             if (e < cntp * NT) fdt[e] = jj >= cntg ? 1.0 : f;
         }
         lds_sync();
+        double fd = fdt[mi];
         for (int jj0 = 0; jj0 < cntp; jj0 += MAT_AHEAD) {
 #pragma unroll
             for (int u = 0; u < MAT_AHEAD; ++u) {
                 const int jj = jj0 + u;
-                const double fd = fdt[jj * NT + mi];
                 // vectors that do not exist are zero and stay zero; lanes beyond the last full vector write what lane 0 writes
 #pragma unroll
-                for (int b = 0; b < MAT_NB; ++b) if (b < nb) vbuf[(b * spb + ms) * NT + mi] = v[b] * fd;
+                for (int b = 0; b < NB; ++b) vbuf[(b * spb + ms) * NT + mi] = v[b] * fd;
                 lds_sync();
 #pragma unroll
-                for (int b = 0; b < MAT_NB; ++b) {
-                    if (b < nb) {                    // uniform
-                        const double *vr = vbuf + (b * spb + ms) * NT;
-                        double acc0 = 0.0, acc1 = 0.0;
+                for (int b = 0; b < NB; ++b) {
+                    const double *vr = vbuf + (b * spb + ms) * NT;
+                    double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-                        for (int k = 0; k < NT / 2; ++k) { acc0 = fma(R[u][k].x, vr[2 * k], acc0); acc1 = fma(R[u][k].y, vr[2 * k + 1], acc1); }
-                        v[b] = acc0 + acc1;
-                    }
+                    for (int k = 0; k < NT / 2; ++k) { acc0 = fma(R[u][k].x, vr[2 * k], acc0); acc1 = fma(R[u][k].y, vr[2 * k + 1], acc1); }
+                    v[b] = acc0 + acc1;
                 }
+                fd = fdt[(jj + 1) * NT + mi];        // the next operator's factor travels with the vector reads (beyond the group: never used)
                 lds_sync();
                 {   // the operator MAT_AHEAD further on (beyond the group: a row that is never used)
                     const MatRowPtr p = myrow + (size_t)__builtin_amdgcn_readlane(my_op, (jj + MAT_AHEAD) & 63) * (NT * NT / 2);
@@ -494,12 +494,12 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
             {   // keep the vectors near one: take out a power of two (exact)
                 double m = 0.0;
 #pragma unroll
-                for (int b = 0; b < MAT_NB; ++b) if (b < nb) m = fmax(m, fabs(v[b]));
+                for (int b = 0; b < NB; ++b) m = fmax(m, fabs(v[b]));
                 m = wave_max(m);
                 if (!(m > 0.0)) return res;
                 const int e2 = ilogb(m);
 #pragma unroll
-                for (int b = 0; b < MAT_NB; ++b) v[b] = ldexp(v[b], -e2);
+                for (int b = 0; b < NB; ++b) v[b] = ldexp(v[b], -e2);
                 iexp += e2;
             }
         }
@@ -515,14 +515,14 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
             double *pout = (double *)(lds_base + uni((int)a.pout));
             double m = 0.0;
 #pragma unroll
-            for (int b = 0; b < MAT_NB; ++b) { v[b] = (wr[b] && mi < nend) ? v[b] * fdec : 0.0; m = fmax(m, fabs(v[b])); }
+            for (int b = 0; b < NB; ++b) { v[b] = (wr[b] && mi < nend) ? v[b] * fdec : 0.0; m = fmax(m, fabs(v[b])); }
             m = wave_max(m);
             if (!(m > 0.0)) return res;
             const int e2 = ilogb(m);
             for (int e = lane; e < NT * NT; e += 64) pout[e] = 0.0;
             lds_sync();
 #pragma unroll
-            for (int b = 0; b < MAT_NB; ++b) if (wr[b]) pout[(b * spb + ms) * NT + mi] = ldexp(v[b], -e2);
+            for (int b = 0; b < NB; ++b) if (wr[b]) pout[(b * spb + ms) * NT + mi] = ldexp(v[b], -e2);
             if (lane == 0) pout[NT * NT] = lacc + (double)e2 * 0.6931471805599453;
             lds_sync();
             res.x = 0.0; res.y = 1.0;
@@ -530,12 +530,12 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
         }
         double part = 0.0;
 #pragma unroll
-        for (int b = 0; b < MAT_NB; ++b) part += diag[b] ? v[b] * fdec : 0.0;
+        for (int b = 0; b < NB; ++b) part += diag[b] ? v[b] * fdec : 0.0;
         if (uni((int)a.ptout) != -1) {               // estimator pass only: hand the partial traces to the caller
             double *pto = (double *)(lds_base + uni((int)a.ptout));
             lds_sync();
 #pragma unroll
-            for (int b = 0; b < MAT_NB; ++b) if (diag[b]) pto[b * spb + ms] = v[b] * fdec;
+            for (int b = 0; b < NB; ++b) if (diag[b]) pto[b * spb + ms] = v[b] * fdec;
             if (lane == 0) pto[nsm] = lacc;
             lds_sync();
         }
@@ -560,11 +560,16 @@ __device__ __forceinline__ MatSeqArgs mat_seq_args(Ctx &x, const int *tsst, int 
     a.beta = C.beta; a.egs = C.egs;
     return a;
 }
-__device__ __forceinline__ double2 mat_seq_call(const DevConst &C, const MatSeqArgs &a)
+// The choice among the instances is made inline at the call site: a second out-of-line level (kernel -> dispatcher ->
+// evaluator) hung the GPU in one of the diagnostic builds (nested calls; not understood, not used).
+__device__ __forceinline__ double2 mat_seq_dispatch(const MatSeqArgs &a, int nt)
 {
-    const int nt = mat_seq_pad(C.nsm);
-    return nt == 8 ? mat_trace_seq_core<8>(a) : (nt == 10 ? mat_trace_seq_core<10>(a) : mat_trace_seq_core<16>(a));
+    const int nb = uni((a.ncols + a.spb - 1) / a.spb);
+    if (nt == 8) return mat_trace_seq_core<8, 1>(a);                  // up to 8 states: all vectors in one batch
+    if (nt == 10) return nb <= 1 ? mat_trace_seq_core<10, 1>(a) : mat_trace_seq_core<10, 2>(a);
+    return nb <= 1 ? mat_trace_seq_core<16, 1>(a) : (nb == 2 ? mat_trace_seq_core<16, 2>(a) : (nb == 3 ? mat_trace_seq_core<16, 3>(a) : mat_trace_seq_core<16, 4>(a)));
 }
+__device__ __forceinline__ double2 mat_seq_call(const DevConst &C, const MatSeqArgs &a) { return mat_seq_dispatch(a, mat_seq_pad(C.nsm)); }
 
 __device__ __forceinline__ void mat_trace_seq(Ctx &x, const int *tsst, int n, int skip1, int skip2, double &tlog, double &tsign, double *ptout = nullptr)
 {
