@@ -1769,7 +1769,9 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
     ctx_setup(x, smem);
     if (x.w >= C.nwalkers) return;
     ctx_load(x);
-    if constexpr (MAT != 0) mat_trace_current<MAT>(x);
+    double pt_ = 0.0, lsc_ = 0.0; int sk_ = 0;          // blocks of more than 4 states: partial traces and the block at beta/2 (mat_halves)
+    if constexpr (MAT > 4) mat_halves(x, pt_, lsc_, sk_);
+    else if constexpr (MAT != 0) mat_trace_current<MAT>(x);
     const int nf = C.nflav, nd = C.nd;
     int par = 0;
     // every lane takes one operator (f, type, slot) of the flat list of all flavours' operators (so the lanes stay busy
@@ -1842,37 +1844,7 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
         // MeasDensityMatrix_beta_half (CTQMC.F90:3088-3151): kets from 0 to beta/2 through the operators with
         // tau <= beta/2, bras from beta down to beta/2, for all states of the outer block at once
         if constexpr (MAT >= 2 && MAT <= 4) mat_dm_tree<MAT>(x, cfgsign, bin);
-        else {
-        const double b2 = 0.5 * C.beta;
-        const int nsm = C.nsm, nout = uni(x.t_n[x.outer]);
-        const int nk = mat_lower_eq(x, b2);
-        for (int s0 = 0; s0 < nout; s0 += x.spb_) {            // batches of outer states (one batch for blocks of up to 8 states)
-        const bool dg = x.lane < x.spb_ * nsm && s0 + x.ms_ == x.mi_ && s0 + x.ms_ < nout;
-        double ket = dg ? 1.0 : 0.0, lk = 0.0, tp = 0.0;
-        int sk = x.outer;
-        for (int i = 0; i < nk; ++i) {
-            const double tau = uni(x.ot[i]);
-            sk = mat_apply(x, sk, uni(x.om[i]), tau - tp, ket, lk); tp = tau;
-            if ((i & 3) == 3) mat_rescale(ket, lk);
-        }
-        mat_evolve(x, sk, b2 - tp, ket, lk);
-        double bra = dg ? 1.0 : 0.0, lb = 0.0;
-        int sb = x.outer; tp = C.beta;
-        for (int i = x.nops - 1; i >= nk; --i) {          // the bra sees the operator of the other type (Trace.F90:5927)
-            const double tau = uni(x.ot[i]);
-            sb = mat_apply(x, sb, uni(x.om[i]) ^ 1, tp - tau, bra, lb); tp = tau;
-            if ((i & 3) == 3) mat_rescale(bra, lb);
-        }
-        mat_evolve(x, sb, tp - b2, bra, lb);
-        const int n = uni(x.t_n[sk]);
-        const double fac = -cfgsign * x.tr_sign * exp(lk + lb - x.tr_log);
-        double *dmb = C.acc_dm + (size_t)bin * C.dmsize + C.dmoff[sk];
-        for (int j = 0; j < n; ++j) {                    // rho(i1 = bra index, i2 = ket index)
-            const double kj = __shfl(ket, x.ms_ * nsm + j, 64);
-            if (x.lane < x.spb_ * nsm && s0 + x.ms_ < nout && x.mi_ < n && sb == sk) atomicAdd(&dmb[x.mi_ * n + j], bra * fac * kj);
-        }
-        }
-        }
+        else if (x.tr_sign != 0.0) mat_dm_from_halves(x, sk_, -cfgsign * x.tr_sign / fabs(wave_sum(pt_)), bin);
     } else {
     // state alive at beta/2 (Trace.F90:6334: operators with tau <= beta/2 have acted)
     int sb2 = x.outer;
@@ -1894,8 +1866,8 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
             atomicAdd(&C.acc_signstate[(size_t)bin * C.nstates + x.outer], cfgsign);
         }
     } else {
-        double pt = 0.0, lsc = 0.0;                        // lane i < n: partial trace of outer state i on the common scale exp(lsc)
-        mat_part_traces<MAT>(x, pt, lsc);
+        double pt = pt_, lsc = lsc_;                       // lane i < n: partial trace of outer state i on the common scale exp(lsc)
+        if constexpr (MAT <= 4) mat_part_traces<MAT>(x, pt, lsc);
         const int n = uni(x.t_n[x.outer]), off = uni(x.t_off[x.outer]);
         if (x.lane < n) {
             atomicAdd(&C.acc_tcstate[(size_t)bin * C.nstates + off + x.lane], fabs(pt) * exp(lsc));

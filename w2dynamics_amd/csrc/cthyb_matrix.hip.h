@@ -715,6 +715,68 @@ __device__ W2DYN_INLINE void mat_part_traces(Ctx &x, double &pt, double &lsc)
     }
 }
 
+// Blocks of more than 4 states: everything the Z-space estimators need from the propagated states comes out of ONE walk
+// over the operators, cut at beta/2 (two stretches of the sequential evaluator):
+//   K(i, s) = <i| (operators with tau <= beta/2, evolution to beta/2) |s>     s: states of the outer block, i: block at beta/2
+//   A(s, i) = <s| (evolution to beta, operators with tau > beta/2) |i>
+// The partial trace of outer state s is sum_i A(s,i) K(i,s) (parttrace, Trace.F90:6029-6031), the trace their sum, and the
+// density matrix at beta/2 is rho(i1,i2) = sum_s A(s,i1) K(i2,s) / trace (MeasDensityMatrix_beta_half, CTQMC.F90:3088-3151).
+// Leaves A in x.pmat ([i][s], stride NT) and K in x.opbuf ([s][i]), their log scales behind them; sets x.tr_log / x.tr_sign;
+// lane s < n(outer) receives the partial trace pt on the scale exp(lsc).  sk: block at beta/2.
+__device__ W2DYN_INLINE void mat_halves(Ctx &x, double &pt, double &lsc, int &sk)
+{
+    extern __shared__ unsigned char lds_base[];
+    const DevConst &C = x.C;
+    const int nt = mat_seq_pad(C.nsm), n = x.nops;
+    pt = 0.0; lsc = 0.0; sk = x.outer;
+    x.tr_log = -HUGE_VAL; x.tr_sign = 0.0;
+    wave_sync();
+    if (!(uni(x.osst[n]) == x.outer)) return;
+    const double b2 = 0.5 * C.beta;
+    const int nk = mat_lower_eq(x, b2);
+    sk = uni(x.osst[nk]);                                  // osst[n] = outer covers nk = n
+    if ((unsigned)sk >= (unsigned)C.nsst) return;
+    const int nout = uni(x.t_n[x.outer]), nmid = uni(x.t_n[sk]);
+    MatSeqArgs a = mat_seq_args(x, x.osst, n, -1, -1);
+    a.pout = (unsigned)((const unsigned char *)x.pmat - lds_base);
+    a.jbeg = 0; a.cnt = nk; a.sst_start = x.outer; a.sst_end = sk; a.ncols = nout; a.t0 = 0.0; a.t1 = b2;
+    double2 r = mat_seq_call(C, a);
+    if (uni(r.y) == 0.0) return;
+    wave_sync();
+    double keep[5];                                        // NT * NT + 1 <= 257 doubles
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { const int e = q * 64 + x.lane; keep[q] = e <= nt * nt ? x.pmat[e] : 0.0; }
+    wave_sync();
+    a.jbeg = nk; a.cnt = n - nk; a.sst_start = sk; a.sst_end = x.outer; a.ncols = nmid; a.t0 = b2; a.t1 = C.beta;
+    r = mat_seq_call(C, a);
+    if (uni(r.y) == 0.0) return;
+    wave_sync();
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { const int e = q * 64 + x.lane; if (e <= nt * nt) x.opbuf[e] = keep[q]; }     // the evaluator's own space is free again
+    wave_sync();
+    const double *A = x.pmat, *K = x.opbuf;
+    if (x.lane < nout) for (int i = 0; i < nmid; ++i) pt = fma(A[i * nt + x.lane], K[x.lane * nt + i], pt);
+    lsc = uni(A[nt * nt]) + uni(K[nt * nt]);
+    const double tot = wave_sum(pt);
+    if (tot == 0.0 || !(fabs(tot) > 0.0)) { pt = 0.0; return; }
+    x.tr_log = lsc + log(fabs(tot)); x.tr_sign = tot < 0.0 ? -1.0 : 1.0;
+}
+
+// density matrix at beta/2 from the two halves left by mat_halves: fac = -cfgsign * sign(trace) / |sum of the partial traces|
+__device__ W2DYN_INLINE void mat_dm_from_halves(Ctx &x, int sk, double fac, int bin)
+{
+    const DevConst &C = x.C;
+    const int nt = mat_seq_pad(C.nsm), nout = uni(x.t_n[x.outer]), n = uni(x.t_n[sk]);
+    const double *A = x.pmat, *K = x.opbuf;
+    double *dmb = C.acc_dm + (size_t)bin * C.dmsize + C.dmoff[sk];
+    for (int e = x.lane; e < n * n; e += 64) {             // rho(i1 = bra index, i2 = ket index)
+        const int i1 = e / n, i2 = e - i1 * n;
+        double acc = 0.0;
+        for (int s = 0; s < nout; ++s) acc = fma(A[i1 * nt + s], K[s * nt + i2], acc);
+        atomicAdd(&dmb[i1 * n + i2], fac * acc);
+    }
+}
+
 // check_qn_all_ssts (Trace.F90:1402-1433): number of outer blocks for which the operator sequence is allowed;
 // with select > 0 returns instead the index of the select-th allowed block.
 __device__ W2DYN_INLINE int mat_possible(Ctx &x, int select)
