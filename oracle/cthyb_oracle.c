@@ -1864,6 +1864,60 @@ static double dm_expect(const ora_walker *w, int nop, const int *fl, const int *
     return tot;
 }
 
+/* MeasSsquare: S^2 = 1/2 (S+S- + S-S+) + Sz^2 written as the reference writes it (init_S2alt2, Operator.F90:548-633): a sum
+ * of strings c+_{b3 s4} c_{b3 s3} c+_{b1 s2} c_{b1 s1} with the coefficients sm1(s2,s1) sm2(s4,s3) of the three terms
+ * (Spm / PauliSM, AngularMomentum.F90:46-50), here applied with the operators of the eigenbasis: S[row * n + col] of block b. */
+static void s2_block_eig(const ora_walker *w, int b, double *S)
+{
+    const ora_locprob *lp = w->lp; const int n = lp->sst_n[b], nd = w->p.nd;
+    for (int i = 0; i < n * n; ++i) S[i] = 0.0;
+    for (int xyz = 0; xyz < 3; ++xyz)
+        for (int b1 = 0; b1 < nd; ++b1) for (int s1 = 0; s1 < 2; ++s1) for (int s2 = 0; s2 < 2; ++s2) {
+            double c1 = xyz == 0 ? ((s2 == 1 && s1 == 0) ? 1.0 : 0.0) : (xyz == 1 ? ((s2 == 0 && s1 == 1) ? 1.0 : 0.0) : (s1 == s2 ? (s1 == 0 ? 1.0 : -1.0) : 0.0));
+            if (c1 == 0.0) continue;
+            for (int b3 = 0; b3 < nd; ++b3) for (int s3 = 0; s3 < 2; ++s3) for (int s4 = 0; s4 < 2; ++s4) {
+                double c2 = xyz == 0 ? ((s4 == 0 && s3 == 1) ? 0.5 : 0.0) : (xyz == 1 ? ((s4 == 1 && s3 == 0) ? 0.5 : 0.0) : (s3 == s4 ? (s3 == 0 ? 0.25 : -0.25) : 0.0));
+                if (c2 == 0.0) continue;
+                const int fl[4] = {2 * b1 + s1, 2 * b1 + s2, 2 * b3 + s3, 2 * b3 + s4}, ca[4] = {2, 1, 2, 1};
+                for (int col = 0; col < n; ++col) {
+                    double v[64], out[64]; int s = b, ok = 1;
+                    for (int i = 0; i < n; ++i) v[i] = (i == col) ? 1.0 : 0.0;
+                    for (int q = 0; q < 4 && ok; ++q) {
+                        int t = connect(w, s, fl[q], ca[q]);
+                        if (t < 0) { ok = 0; break; }
+                        int ns = lp->sst_n[s], nt = lp->sst_n[t]; const double *O = ora_lp_op(lp, s, fl[q], ca[q]);
+                        for (int i = 0; i < nt; ++i) { double a = 0.0; for (int j = 0; j < ns; ++j) a += O[i + nt * j] * v[j]; out[i] = a; }
+                        for (int i = 0; i < nt; ++i) v[i] = out[i];
+                        s = t;
+                    }
+                    if (!ok || s != b) continue;           /* a string that leaves the block: undefined in the reference, left out */
+                    for (int row = 0; row < n; ++row) S[row * n + col] += c1 * c2 * v[row];
+                }
+            }
+        }
+}
+
+/* ssq[0 .. 2 Nd]: tr(rho S^2) over the blocks with N electrons (MeasureS2_from_densitymatrix, CTQMC.F90:2810-2840);
+ * sop (4^Nd)^2 row major: S^2 in the occupation basis, block order (create_ssquare_full, CTQMC.F90:2769-2806) */
+void ora_get_ssquare(const ora_walker *w, double *ssq, double *sop)
+{
+    const ora_locprob *lp = w->lp; size_t N = (size_t)w->nstates;
+    double S[64 * 64];
+    for (int i = 0; i <= 2 * w->p.nd; ++i) ssq[i] = 0.0;
+    memset(sop, 0, sizeof(double) * N * N);
+    for (int b = 0; b < lp->nsst; ++b) {
+        int n = lp->sst_n[b], off = lp->sst_off[b]; const double *V = lp->evec[b];
+        int nel = __builtin_popcount((unsigned)lp->states[off]);
+        s2_block_eig(w, b, S);
+        for (int col = 0; col < n; ++col) for (int row = 0; row < n; ++row) ssq[nel] += w->dmblk[w->dmoff[b] + col * n + row] * S[row * n + col];
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) {
+            double a = 0.0;
+            for (int k = 0; k < n; ++k) for (int l = 0; l < n; ++l) a += V[i + n * k] * S[k * n + l] * V[j + n * l];
+            sop[(size_t)(off + i) * N + off + j] = a;
+        }
+    }
+}
+
 void ora_get_occ(const ora_walker *w, double *occ, double *rho1, double *rho2)
 {
     int nf = w->nflav;

@@ -131,6 +131,7 @@ void ora_get_outer_histograms(const ora_walker *w, double *sign_sst, double *tco
 int ora_nsst(const ora_walker *w);
 int ora_nsmax(const ora_walker *w);
 void ora_get_blocks(const ora_walker *w, int *sst_n, int *sst_off, int *states);  /* [nsst],[nsst],[4^Nd] */
+void ora_get_ssquare(const ora_walker *w, double *ssq, double *sop);   /* (2Nd+1), (4^Nd)^2: MeasSsquare, CTQMC.F90:2769-2840 */
 void ora_get_occ(const ora_walker *w, double *occ, double *rho1, double *rho2);   /* (Nd,2,Nd,2), (2Nd)^2, (2Nd)^4: CTQMC.F90:2884-3060 */
 void ora_get_accpair(const ora_walker *w, int64_t *out);  /* (Nd,2,Ntau) */
 void ora_get_energies(const ora_walker *w, double *out);  /* 4^Nd eigenstate energies */

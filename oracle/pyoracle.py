@@ -83,6 +83,7 @@ def lib():
     L.ora_get_giw_worm.argtypes = [vp, dp]; L.ora_get_giw_worm.restype = C.c_int
     L.ora_get_gtau_blocks.argtypes = [vp, C.c_void_p]; L.ora_get_gtau_blocks.restype = C.c_int
     L.ora_get_ntau_n0.argtypes = [vp, C.c_void_p]; L.ora_get_ntau_n0.restype = C.c_int
+    L.ora_get_ssquare.argtypes = [vp, dp, dp]
     L.ora_get_gtau_worm.argtypes = [vp, dp]; L.ora_get_gtau_worm.restype = C.c_int
     L.ora_get_hashybs.argtypes = [vp, ip]
     L.ora_get_g2iw.argtypes = [vp, dp]; L.ora_get_g2iw.restype = C.c_int
@@ -130,6 +131,7 @@ class OracleWalker:
     def __init__(self, problem, pset, rng=("std", 0), fourpnt=0):
         self.L = lib()
         self.p = params_from_pstring(pset, problem.nd, problem.beta, fourpnt)
+        self.meas_ssq = pset.get_int("MeasSsquare") != 0
         assert self.p.nftau == problem.nftau, "Nftau in the parameter string must match the F(tau) array"
         if rng[0] == "std":
             self.rng = self.L.ora_rng_std(int(rng[1]))
@@ -229,6 +231,9 @@ class OracleWalker:
                 a = np.zeros((2 * p.n4iwf, 2 * p.n4iwf, 2 * p.n4iwb + 1, 2))
                 if self.L.ora_get_g4iw_worm(self.h, a, pp):
                     r[key] = a[..., 0] + 1j * a[..., 1]
+        if nd <= 5 and self.meas_ssq:
+            ssq = np.zeros(2 * nd + 1); sop = np.zeros((4 ** nd, 4 ** nd)); self.L.ora_get_ssquare(self.h, ssq, sop)
+            r["ssquare"] = ssq; r["ssquare_operator"] = sop
         a = np.zeros((nd, 2, nd, 2, p.ntau + 1))
         if self.L.ora_get_ntau_n0(self.h, a.ctypes.data):
             r["ntau_n0"] = a

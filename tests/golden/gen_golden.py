@@ -265,7 +265,7 @@ def gen_worm(only=None):
         print("worm", name, "steps(worm, Z) of the eta search", steps, "cntsampling", r["cntsampling"][[0, sector - 1]], "nops", len(c_end["taus"]))
 
 
-KINDS = ("traj", "stat", "g4", "worm", "calib", "accum", "g4leg", "susz")
+KINDS = ("traj", "stat", "g4", "worm", "calib", "accum", "g4leg", "susz", "ssq")
 
 ACCUM = {   # AccumGtau = 2 (autocorrelation accumulator: gtau_blocks) and 0 (G(tau), G(l) not measured), one seeded chain
     # name: (config, nftau, overrides, seed)
@@ -352,6 +352,32 @@ def gen_susz(only=None):
         print("susz", name, r["ntau_n0"].shape, "n(0)n(0) diag", [float(r["ntau_n0"][b, 0, b, 0, 0]) for b in range(p.nd)], "occ", np.einsum("bsbs->bs", r["occ"]).ravel())
 
 
+SSQ = ("C4", "C4N", "C5K")
+
+
+def gen_ssq(only=None):
+    """MeasSsquare: <S^2> per electron number from the density matrix at beta/2 of one recorded configuration, and the S^2
+    operator in the occupation basis (CTQMC.F90:2769-2840, Operator.F90:548-633)."""
+    for name in SSQ:
+        if only and name not in only:
+            continue
+        cfg, nftau, over, seed = TRAJ[name]
+        g = np.load(os.path.join(OUT, "traj_%s.npz" % name), allow_pickle=False)
+        c_end = {k[4:]: g[k] for k in g.files if k.startswith("end_")}
+        c_end["outer_sst"] = int(c_end["outer_sst"]); c_end["outer_state"] = int(c_end["outer_state"])
+        over1 = dict(over); over1.update(Nmeas=1, NCorr=0, Nwarmups=0, MeasSsquare=1, MeasDensityMatrix=1)
+        p, ps1 = pstring_for(cfg, nftau, over1)
+        s = refdrive.RefSolver(p, ps1, seed)
+        s.set_taudiffmax(over["TaudiffMax"])
+        s.set_config(c_end)
+        s.measure()
+        r = s.results(("ssquare", "ssquare_operator", "densitymatrix", "mean_sign", "occ"))
+        s.close()
+        np.savez_compressed(os.path.join(OUT, "ssq_%s.npz" % name), config=cfg, nftau=nftau, seed=seed, overrides=repr(over1),
+                            **{"cfg_" + k: v for k, v in c_end.items()}, **{"res_" + k: v for k, v in r.items()})
+        print("ssq", name, "S^2 per N:", r["ssquare"], "tr S2op", float(np.trace(r["ssquare_operator"])))
+
+
 if __name__ == "__main__":
     if not refdrive.available():
         raise SystemExit("oracle/_ref is not built: run oracle/build_ref.sh in the build container")
@@ -373,3 +399,5 @@ if __name__ == "__main__":
         gen_g4leg(only)
     if "susz" in which:
         gen_susz(only)
+    if "ssq" in which:
+        gen_ssq(only)

@@ -910,6 +910,38 @@ def test_susceptibility_recorded_configuration_vs_reference_golden(name):
     q.dest_ctqmc(); q.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["C4", "C4N", "C5K"])
+def test_ssquare_recorded_configuration_vs_reference_golden(name):
+    """f-3, MeasSsquare = 1 (CTQMC.F90:2769-2840): <S^2> per electron number and the S^2 operator of the occupation basis ==
+    what the REFERENCE printed for the same recorded configuration (tree path: C4; sequential path: C4N, C5K)."""
+    g = util.load_golden("ssq_%s.npz" % name)
+    over = g["overrides"]
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    q = make_gpu(p, ps, int(g["seed"]), 4, wpb=4)
+    q.set_taudiffmax(over["TaudiffMax"])
+    c = util.cfg_from(g, "cfg_")
+    q.set_mc_config(len(c["taus"]), c["taus"], c["orbs"], c["spins"], c["cas"], c["hashybs"], c["outer_sst"], c["outer_state"])
+    q.ctqmc_measure(1, 1)
+    assert q.ssquare.shape == g["res_ssquare"].shape and q.ssquare_operator.shape == g["res_ssquare_operator"].shape
+    assert rel(q.ssquare, g["res_ssquare"]) < TOL
+    assert np.abs(q.ssquare_operator - g["res_ssquare_operator"]).max() < 1e-12
+    assert rel(q.densitymatrix, g["res_densitymatrix"]) < TOL
+    q.dest_ctqmc(); q.close()
+
+
+@pytest.mark.gpu
+def test_ssquare_is_refused_when_the_blocks_do_not_conserve_the_spin():
+    """One-state blocks (Nt Szt Azt): the spin-flip terms of S^2 leave the block, the reference adds them to the wrong
+    element - refused, not imitated."""
+    p, ps, pset = util.setup("C3", 501, dict(BASE, MeasSsquare=1))
+    q = MCTQMC(nwalkers=4)
+    q.init_rnd(1); q.init_paras(ps)
+    with pytest.raises(W2DynError, match="MeasSsquare"):
+        q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+    q.close()
+
+
 @pytest.mark.parametrize("budget", [None, 100000], ids=["bin-per-chain", "folded-bins"])
 def test_susceptibility_chains_vs_oracle(monkeypatch, budget):
     """MeasSusz in a sampled run (window shifts, global and tau-shift moves): every chain's <n(tau) n(0)> agrees with the

@@ -115,6 +115,25 @@ def test_oracle_susceptibility_on_recorded_configuration(name):
     w.close()
 
 
+@pytest.mark.parametrize("name", ["C4", "C4N", "C5K"])
+def test_oracle_ssquare_on_recorded_configuration(name):
+    """MeasSsquare = 1 (CTQMC.F90:2769-2840, Operator.F90:548-633): <S^2> per electron number from the density matrix at
+    beta/2 of one recorded configuration, and the S^2 operator in the occupation basis, against the reference's - blocks of up
+    to 3 (C4), 9 (C4N) and 10 states (C5K)."""
+    g = util.load_golden("ssq_%s.npz" % name)
+    over = g["overrides"]
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    w = pyoracle.OracleWalker(p, pset, ("std", int(g["seed"])))
+    w.set_taudiffmax(over["TaudiffMax"])
+    assert w.set_config(util.cfg_from(g, "cfg_")) == 0
+    w.measure()
+    r = w.results()
+    assert np.abs(g["res_ssquare"]).max() > 0.5
+    assert rel(r["ssquare"], g["res_ssquare"]) < 1e-10
+    assert np.abs(r["ssquare_operator"] - g["res_ssquare_operator"]).max() < 1e-12
+    w.close()
+
+
 def test_matrix_update_primitives_against_exact_inverse(oracle_lib):
     """MatrixUpdate.F90:489-631 (the reference's disabled self-test) idea: fast updates vs a fresh inverse."""
     L = oracle_lib

@@ -266,6 +266,41 @@ struct LocalProblem {
         }
     }
 
+    // S^2 = 1/2 (S+S- + S-S+) + Sz^2 in the occupation basis, block by block (init_S2alt2, Operator.F90:548-633: strings
+    // c+_{b3 s4} c_{b3 s3} c+_{b1 s2} c_{b1 s1} with the coefficients sm1(s2,s1) sm2(s4,s3) of the three terms), column major
+    // n x n per block.  Returns false when a string leaves the block it started from: the reference then adds the element
+    // to a position of the wrong block (or outside it), so there is nothing defined to reproduce.
+    std::vector<std::vector<double>> s2_occ;
+    bool build_s2()
+    {
+        s2_occ.assign(nsst, {});
+        bool closed = true;
+        auto apply = [&](int &st, double &sg, int f, int ca) {
+            const int b = bit(f);
+            if ((ca == 1) == (bool)(st >> b & 1)) return false;
+            sg *= fsign(st, b); st ^= 1 << b;
+            return true;
+        };
+        for (int blk = 0; blk < nsst; ++blk) {
+            const int n = sst_n[blk];
+            s2_occ[blk].assign((size_t)n * n, 0.0);
+            for (int i1 = 0; i1 < n; ++i1) for (int xyz = 0; xyz < 3; ++xyz)
+                for (int b1 = 0; b1 < nd; ++b1) for (int s1 = 0; s1 < 2; ++s1) for (int s2 = 0; s2 < 2; ++s2) {
+                    const double c1 = xyz == 0 ? ((s2 == 1 && s1 == 0) ? 1.0 : 0.0) : (xyz == 1 ? ((s2 == 0 && s1 == 1) ? 1.0 : 0.0) : (s1 == s2 ? (s1 == 0 ? 1.0 : -1.0) : 0.0));
+                    if (c1 == 0.0) continue;
+                    for (int b3 = 0; b3 < nd; ++b3) for (int s3 = 0; s3 < 2; ++s3) for (int s4 = 0; s4 < 2; ++s4) {
+                        const double c2 = xyz == 0 ? ((s4 == 0 && s3 == 1) ? 0.5 : 0.0) : (xyz == 1 ? ((s4 == 1 && s3 == 0) ? 0.5 : 0.0) : (s3 == s4 ? (s3 == 0 ? 0.25 : -0.25) : 0.0));
+                        if (c2 == 0.0) continue;
+                        int st = states[sst_off[blk] + i1]; double sg = 1.0;
+                        if (!apply(st, sg, 2 * b1 + s1, 2) || !apply(st, sg, 2 * b1 + s2, 1) || !apply(st, sg, 2 * b3 + s3, 2) || !apply(st, sg, 2 * b3 + s4, 1)) continue;
+                        if (sst_of_state[st] != blk) { closed = false; continue; }
+                        s2_occ[blk][idx_in_block[st] + (size_t)n * i1] += c1 * c2 * sg;
+                    }
+                }
+        }
+        return closed;
+    }
+
     // <A> = sum_b tr(rho_b A_bb), A = product of operators applied right to left: (fl[0],ca[0]) acts first.
     // rho: block-diagonal density matrix in the eigenbasis, block b at dmoff[b], [bra][ket] row major (CTQMC.F90:2842-3060)
     double expect(const double *rho, const std::vector<int> &dmoff, int nop, const int *fl, const int *ca) const

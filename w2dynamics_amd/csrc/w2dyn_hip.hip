@@ -111,6 +111,7 @@ struct w2dyn_solver {
     double p_wins = 0, p_wrep = 0, worm_eta = 0;
     int worm_meas_g4iw = 0, g4ph = 0, g4pp = 0, wormphconv = 0, nbw = 0, cur_isector = 1;
     // G(tau) accumulator (AccumGtau, CTQMC.F90:492-500): 0 = G(tau)/G(l) not measured, 1 = mean, 2 = per-chain autocorrelation stack
+    bool meas_ssq = false;                                               // MeasSsquare: <S^2> per electron number from the density matrix
     bool meas_susz = false; int nbs = 0; double *acc_susz = nullptr;     // MeasSusz: <n(tau) n(0)>, accumulator bins [nbs][nflav][nflav][Ntau]
     int accum_gtau = 1, ac_lev = 0; long long ac_n = 0; double *ac_dat = nullptr, *ac_out = nullptr;
     int res_isector = 1;                             // sector of the run the result table was made from
@@ -528,7 +529,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     struct { const char *key; long long allowed; } zero_int[] = {
         {"segment", 0}, {"offdiag", 0}, {"full_offdiag", 0}, {"statesampling", 0}, {"flavourchange_moves", 0}, {"Phonon", 0},
         {"Screening", 0}, {"Uw", 0}, {"MeasGtauDetRat", 0},
-        {"MeasExpResDensityMatrix", 0}, {"MeasSsquare", 0}, {"Gtau_mean_step", 0}, {"Gtau_mid_step", 0}, {"sign_step", 0},
+        {"MeasExpResDensityMatrix", 0}, {"Gtau_mean_step", 0}, {"Gtau_mid_step", 0}, {"sign_step", 0},
         {"NSymMove", 0}, {"MeasDensityMatrix", 1}, {"Eigenbasis", 1}};
     for (auto &z : zero_int) {
         if (!get_int(s, z.key, iv)) return W2DYN_EINVAL;
@@ -585,6 +586,8 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if (!get_int(s, "AccumGtau", iv)) return W2DYN_EINVAL;
     if (iv < 0 || iv > 2) return fail(s, W2DYN_EINVAL, "invalid value %lld for AccumGtau (0, 1, 2)", iv);     // CTQMC.F90:502
     s->accum_gtau = (int)iv;
+    if (!get_int(s, "MeasSsquare", iv)) return W2DYN_EINVAL;
+    s->meas_ssq = iv != 0;               // CTQMC.F90:8009-8010
     if (!get_int(s, "MeasSusz", iv)) return W2DYN_EINVAL;
     s->meas_susz = iv == 1;              // CTQMC.F90:534-540 (matrix solver: b_meas_susz_mat)
     if (!get_int(s, "MaxHisto", iv)) return W2DYN_EINVAL; s->maxhisto = (int)iv;
@@ -763,6 +766,9 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
         if ((rc = dev_alloc(s, s->ac_out, B * (size_t)nf * lev * s->ntau))) return rc;
     }
     s->acc_susz = nullptr; s->nbs = 0;
+    if (s->meas_ssq && !s->lp.build_s2())
+        return fail(s, W2DYN_EUNSUPPORTED, "MeasSsquare = 1 needs blocks that S^2 does not leave (quantum numbers '%s' do not conserve the total spin: "
+                                           "the reference's result is undefined there)", qns.c_str());
     if (s->meas_susz) {
         // meas_ntau_n0 walks stored bra / ket vectors of the eigenbasis (Trace.F90:6472-6835); with one state per block the
         // densities are numbers and the estimator is an occupation count, which is what k_meas_susz does
@@ -1271,6 +1277,23 @@ int w2dyn_measure_finish(w2dyn_solver *s)
             }
         }
         R["densitymatrix"] = full;
+    }
+    if (s->meas_ssq) {   // MeasureS2_from_densitymatrix, create_ssquare_full (CTQMC.F90:2769-2840)
+        std::vector<double> ssq(2 * nd + 1, 0.0), sop((size_t)ns * ns, 0.0);
+        const double *blk = R["dmblocks"].data();
+        for (int b = 0; b < no; ++b) {
+            const int n = lp.sst_n[b], off = lp.sst_off[b]; const std::vector<double> &V = lp.evec[b], &S = lp.s2_occ[b];
+            const int nel = __builtin_popcount((unsigned)lp.states[off]);
+            for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) sop[(size_t)(off + i) * ns + off + j] = S[i + (size_t)n * j];
+            std::vector<double> T((size_t)n * n, 0.0);              // T = S V, then S_eig = V^T T
+            for (int i = 0; i < n; ++i) for (int l = 0; l < n; ++l) { double a = 0.0; for (int j = 0; j < n; ++j) a += S[i + (size_t)n * j] * V[j + (size_t)n * l]; T[i + (size_t)n * l] = a; }
+            const double *Rb = blk + s->dmoff[b];
+            for (int k = 0; k < n; ++k) for (int l = 0; l < n; ++l) {
+                double se = 0.0; for (int i = 0; i < n; ++i) se += V[i + (size_t)n * k] * T[i + (size_t)n * l];
+                ssq[nel] += Rb[k * n + l] * se;                       // tr(rho S^2): S^2 is symmetric
+            }
+        }
+        R["ssquare"] = ssq; R["ssquare_operator"] = sop;
     }
     s->res_isector = s->cur_isector;
     if (s->ac_dat) {     // gtau_blocks (CTQMC.F90:8733-8739, unscaled): per accumulator bin and averaged over the bins' chains

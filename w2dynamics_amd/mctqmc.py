@@ -386,6 +386,10 @@ class MCTQMC:
             return self.result("rho2").reshape(nf, nf, nf, nf)
         if name == "densitymatrix":
             return self.result("densitymatrix").reshape(4 ** nd, 4 ** nd)
+        if name == "ssquare":                           # MeasSsquare: Ssquare(0:2*NBands), CTQMC.F90:161, 734
+            return self.result("ssquare")
+        if name == "ssquare_operator":                  # Ssquare_operator(NStates, NStates), occupation basis, CTQMC.F90:162, 746
+            return self.result("ssquare_operator").reshape(4 ** nd, 4 ** nd)
         if name in ("outersuperstatehisto", "outerstatehisto", "signhistosuperstates", "signhistostates",
                     "tracecontribsuperstates", "tracecontribstates", "eigenstatesenergies", "accadd", "accrem",
                     "lhisto", "rhisto"):

@@ -48,6 +48,8 @@ RESULTSET_CONDITIONAL = (      # (key, module variable, condition on the QMC con
     ("g4tau", "g4tau", lambda c, fp: fp & 1), ("g4leg", "g4leg", lambda c, fp: fp & 2), ("g4iw", "g4iw", lambda c, fp: fp & 4),
     ("g4iw-pp", "g4iw_pp", lambda c, fp: fp & 4 and c["MeasG4iwPP"] != 0),
     ("ntau-n0", "ntau_n0", lambda c, fp: c["segment"] == 0 and c["MeasSusz"] != 0),
+    ("ssquare-operator", "ssquare_operator", lambda c, fp: c["MeasSsquare"] != 0),
+    ("s2", "ssquare", lambda c, fp: c["MeasSsquare"] != 0 and (c["MeasDensityMatrix"] != 0 or c["Eigenbasis"] != 0)),
     ("gtau-blocks", "gtau_blocks", lambda c, fp: c["AccumGtau"] == 2),
 )
 # quantities with one observation per accumulator bin (their error bar comes from the bins): key -> "<variable>_bins"
