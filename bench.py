@@ -165,7 +165,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--walkers", type=int, default=int(os.environ.get("W2DYN_WALKERS", 65536)), help="chains per GPU")
+    ap.add_argument("--walkers", type=int, default=int(os.environ.get("W2DYN_WALKERS", 131072)), help="chains per GPU")
     ap.add_argument("--walkers-per-bin", type=int, default=int(os.environ.get("W2DYN_WPB", 8)))
     ap.add_argument("--thermal", type=int, default=20000, help="untimed thermalisation MC steps per chain")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -68,13 +68,13 @@ def test_chains_retrace_oracle(cfg, nftau, over, seed):
 
 
 def test_full_size_run_properties():
-    """BASELINE.json's bench configuration at full size (C2, 16384 chains, NCorr = 200, Ntau = 1000, NLegMax = 100,
+    """BASELINE.json's bench configuration at full size (C2, 131072 chains, NCorr = 200, Ntau = 1000, NLegMax = 100,
     Nftau = 5001) through size-independent properties: a chain's trajectory depends on (seed, chain number) only - the
     same chains come out of a 64-chain context at the right offset and of the CPU oracle; the pooled results are the
     means of the bins; histograms are normalised; half filling and the sign come out right."""
     over = dict(Nwarmups=2000, Nmeas=3, NCorr=200, TaudiffMax=10.0, Ntau=1000, NLegMax=100, Niw=8, Nftau=5001)
     p, ps, pset = util.setup("C2", 5001, over)
-    W = 16384
+    W = 131072
 
     def run(nw, first):
         q = MCTQMC(nwalkers=nw, first_walker=first, walkers_per_bin=8)
