@@ -1083,15 +1083,22 @@ __device__ W2DYN_INLINE void step_shift(Ctx &x)
         }
         if constexpr (!MAT) { if ((wcnt + wacnt) & 1) outer ^= 1 << flav_bit(f, C.nd); }
         if (!((wcnt == 0 && wacnt == 0) || (wcnt == k && wacnt == k))) {
-            for (int j0 = 0; j0 < k; j0 += 64) {
-                int j = j0 + x.lane;
-                if (j < k) {
-                    double sj = (tap[j] < dt) ? -1.0 : 1.0;
-                    for (int i = 0; i < k; ++i) {
-                        double s = ((tcp[i] < dt) ? -1.0 : 1.0) * sj;
-                        if (s < 0.0) Mf[(size_t)i * kmax + j] = -Mf[(size_t)i * kmax + j];
-                    }
+            // rows of creators and columns of annihilators that wrap change sign: flat element loop, four loads of M in
+            // flight per lane (M lives in HBM: a row-by-row loop pays one memory round trip per row)
+            const int kk = k * k;
+            const unsigned magic = (1u << 24) / (unsigned)k + 1u;      // e / k == (e * magic) >> 24 for e < 65536
+            for (int e0 = 0; e0 < kk; e0 += 256) {
+                double mv[4]; size_t at[4]; bool flip[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * 64 + x.lane, ec = e < kk ? e : kk - 1;
+                    const int i = (int)(((unsigned)ec * magic) >> 24), j = ec - i * k;
+                    at[u] = (size_t)i * kmax + j;
+                    flip[u] = e < kk && ((tcp[i] < dt) != (tap[j] < dt));
+                    mv[u] = Mf[at[u]];
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (flip[u]) Mf[at[u]] = -mv[u];
             }
         }
         if ((k & 1) && ((wcnt + wacnt) & 1)) detrat = -detrat;
