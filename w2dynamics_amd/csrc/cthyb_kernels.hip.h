@@ -1158,6 +1158,8 @@ __device__ W2DYN_INLINE void build_and_invert(Ctx &x, int f, int k, const double
     int *piv = x.piv;                // kmax entries of LDS
     if (in_lds) {
         const bool lv = x.lane < k;
+        const int rpt = 64 / k, gr = (int)(((unsigned)x.lane * magic) >> 24), gc = x.lane - gr * k;   // rows per group; the lane's row in it, its column
+        const bool gact = gr < rpt;
         int pstep = -1, sig = 0;     // lane r: step at which row r was eliminated; lane p: sigma(p)
         double dreg = 1.0;           // lane p: pivot of step p
         for (int p = 0; p < k; ++p) {
@@ -1173,10 +1175,18 @@ __device__ W2DYN_INLINE void build_and_invert(Ctx &x, int f, int k, const double
             if (x.lane == p) { dreg = d; sig = bi; }
             if (lv) { x.RM[x.lane] = (x.lane == p) ? id : rowv * id; x.MQ[x.lane] = a; }   // scaled pivot row, pivot column
             wave_sync();
-            for (int e = x.lane; e < kk; e += 64) {
-                int r = (int)(((unsigned)e * magic) >> 24), c = e - r * k;
-                double rp = x.RM[c];
-                x.gj[e] = (r == bi) ? rp : (((c == p) ? 0.0 : x.gj[e]) - x.MQ[r] * rp);
+            // lane = (row inside a group of 64 / k rows, column): the column, its pivot-row element and the test against p are
+            // the same for every group of rows, only the row moves on
+            {
+                const double rp = gact ? x.RM[gc] : 0.0;
+                const bool cp = gc == p;
+                for (int r = gr; r < k; r += rpt) {
+                    if (gact) {
+                        const int e = r * k + gc;
+                        const double g = x.gj[e];
+                        x.gj[e] = (r == bi) ? rp : ((cp ? 0.0 : g) - x.MQ[r] * rp);
+                    }
+                }
             }
             wave_sync();
         }
