@@ -53,8 +53,8 @@ TRAJ = [
     ("C4SQ", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=3.0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 4245),
     ("C4A", 1001, dict(BASE, Nwarmups=4000, Nmeas=10, NCorr=100, TaudiffMax=10.0, NLegMax=20, Ntau=200), 32),
     # blocks of 9 and 10 states: outer states propagated in batches
-    ("C4N", 501, dict(BASE, Nwarmups=3000, Nmeas=20, NCorr=30, TaudiffMax=3.0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 4251),
-    ("C5K", 501, dict(BASE, Nwarmups=3000, Nmeas=10, NCorr=50, TaudiffMax=3.0, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 4252),
+    ("C4N", 501, dict(BASE, Nwarmups=3000, Nmeas=20, NCorr=30, TaudiffMax=3.0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1, MeasSsquare=1), 4251),
+    ("C5K", 501, dict(BASE, Nwarmups=3000, Nmeas=10, NCorr=50, TaudiffMax=3.0, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05, MeasSsquare=1), 4252),
 ]
 
 
@@ -153,7 +153,7 @@ def _retrace(cfg, nftau, over, seed):
     hbins = {k: getattr(q, k + "_bins") for k in HIST}
     bins = {k: getattr(q, k + "_bins") for k in ("gleg", "gtau", "giw", "histo", "occ")}
     tot = {k: 0.0 for k in bins}
-    msign = 0.0; dm = 0.0; rho1 = 0.0
+    msign = 0.0; dm = 0.0; rho1 = 0.0; ssq = None
     for w, o in enumerate(oracles):
         o.measure(); r = o.results()
         for k in bins:
@@ -166,6 +166,9 @@ def _retrace(cfg, nftau, over, seed):
         # every chain has the same number of measurements, so sign-weighted chain results average like this
         if "densitymatrix" in r:
             dm = dm + r["densitymatrix"] * r["mean_sign"]; rho1 = rho1 + r["rho1"] * r["mean_sign"]
+        if "ssquare" in r:       # MeasSsquare: linear in the density matrix, pools like it
+            ssq = (0.0 if ssq is None else ssq) + r["ssquare"] * r["mean_sign"]
+            sop = r["ssquare_operator"]
         o.close()
     assert q.mean_sign == pytest.approx(msign, abs=1e-12)
     if msign == -1.0:
@@ -173,6 +176,9 @@ def _retrace(cfg, nftau, over, seed):
             assert rel(getattr(q, k), tot[k]) < TOL, k
     assert rel(q.densitymatrix, dm / nw / msign) < TOL
     assert rel(q.rho1, rho1 / nw / msign) < TOL
+    if ssq is not None:
+        assert np.abs(ssq).max() > 0.1 and rel(q.ssquare, ssq / nw / msign) < TOL
+        assert np.abs(q.ssquare_operator - sop).max() < 1e-12
     assert np.all(np.isnan(q.lhisto)) and np.all(q.rhisto == 0.0)       # what the reference returns (CTQMC.F90:8698-8699)
     assert np.abs(q.eigenstatesenergies - r["eigenstatesenergies"]).max() < 1e-12
     q.dest_ctqmc(); q.close()
