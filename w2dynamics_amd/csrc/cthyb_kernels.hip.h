@@ -135,6 +135,7 @@ struct DevConst {
     const int *sst_n, *sst_off, *conn, *sst_first, *sst_of_state, *dmoff;   // [nsst] [nsst] [nsst][nflav][2] [nsst] [nstates] [nsst+1]
     const double *sst_eval;       // [nstates] eigenvalues in block order
     const double *opmat;          // [nsst][nflav][2][nsm][nsm] operators in the eigenbasis, row = target state, zero padded
+    double *kcache;               // blocks of more than 4 states: [nwalkers][MAT_CK_ENTRIES][NT*NT+1] checkpoints of the window part (mat_trace_seq_window)
     const double *opmat_pad;      // blocks of more than 4 states: the same with rows and columns padded to mat_seq_pad(nsm) (sequential evaluator)
     // worm sampling (CTQMC.F90:335-378, 434; ctqmc_measure arguments)
     int isector, icomponent, nwf, nwb, wormphconv, g4ph, g4pp;
@@ -281,6 +282,7 @@ struct Ctx {
     // matrix local-trace path
     double *opbuf;                                   // sequential evaluator (blocks of more than 4 states): vector tile and decay table, mat_seq_lds_doubles()
     double *pmat; int pvalid, p_lo, p_hi;            // sequential trace: product of the operators outside the window (mat_trace_seq_window), its blocks
+    double *kc; int kval, k_i1, k_first;             // its checkpoints inside the window (global memory): window operators covered, of the last trial, first changed trial index
     double *ot; int *om, *osst, *tsst; int nops;     // time-ordered operator list, block sequence, trial block sequence (LDS)
     const short *t_conn, *t_shift;                   // 16-bit block numbers: the two tables are the bulk of the shared LDS (5 orbitals: 352 blocks x 20 operators)
     const int *t_n, *t_off; const double *t_eval, *t_op;   // block-shared tables (LDS); t_op null: operators stay in global memory
@@ -704,6 +706,7 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
             else if (j >= p_hi + 2) x.tsst[j] = x.osst[j - 2];
         }
         mat_insert(x, p_lo, lo, code_lo); mat_insert(x, p_hi + 1, hi, code_hi);
+        x.k_first = p_lo;
         mat_trace_trial<MAT, (MAT > 4 && WORM == 0)>(x, x.tsst, x.nops, -1, -1, tl_new, ts_new);
         dlogtr = tl_new - x.tr_log;
     } else {
@@ -956,6 +959,7 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
             else if (j >= i2 - 1) x.tsst[j] = x.osst[j + 2];
         }
         wave_sync();
+        x.k_first = i1;
         mat_trace_trial<MAT, (MAT > 4 && WORM == 0)>(x, x.tsst, x.nops - 2, i1, i2, tl_new, ts_new);
         dlogtr = tl_new - x.tr_log;
     } else {
@@ -1509,12 +1513,14 @@ __device__ __forceinline__ void ctx_setup(Ctx &x, unsigned char *smem)
     x.K = (int *)(x.cnt + C_NCOUNT); x.piv = x.K + MAXFLAV;
     x.nops = 0; x.tr_log = 0.0; x.tr_sign = 1.0; x.ms_ = 0; x.mi_ = 0; x.spb_ = 1;
     x.pmat = nullptr; x.pvalid = 0; x.p_lo = x.p_hi = -1;
+    x.kc = nullptr; x.kval = 0; x.k_i1 = 0; x.k_first = 0;
     if (C.mat) {
         // per-wave list arrays behind the common slice; block-shared tables at the start of the dynamic LDS
         x.om = x.piv + C.kmax; x.osst = x.om + C.wcap; x.tsst = x.osst + C.wcap + 2;
         x.ot = (double *)(((size_t)(x.tsst + C.wcap + 2) + 7) & ~(size_t)7);
         x.opbuf = x.ot + C.wcap + 2;
-        { const int nt = C.nsm <= 8 ? 8 : (C.nsm <= 10 ? 10 : 16); x.pmat = x.opbuf + (16 + 64) * nt; }
+        { const int nt = C.nsm <= 8 ? 8 : (C.nsm <= 10 ? 10 : 16); x.pmat = x.opbuf + (16 + 64) * nt;
+          if (C.kcache) x.kc = C.kcache + (size_t)x.w * 131 * (nt * nt + 1); }
         const int nf2 = 2 * C.nflav;
         short *ti = (short *)smem;
         x.t_conn = ti; x.t_shift = ti + C.nsst * nf2; x.t_n = (const int *)(ti + 2 * C.nsst * nf2); x.t_off = x.t_n + C.nsst;

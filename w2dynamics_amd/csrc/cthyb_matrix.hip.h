@@ -107,6 +107,7 @@ __device__ __forceinline__ bool mat_walk_sst(Ctx &x) { return mat_walk_into(x, x
 __device__ __forceinline__ void mat_commit_sst(Ctx &x)      // osst <- tsst after an accepted move
 {
     for (int e = x.lane; e <= x.nops; e += 64) x.osst[e] = x.tsst[e];
+    x.kval = min(x.kval, x.k_i1);            // checkpoints of the window part: valid up to the first operator that changed
     wave_sync();
 }
 
@@ -349,6 +350,10 @@ __device__ W2DYN_INLINE void mat_trace_tree(Ctx &x, const int *tsst, int n, int 
 //   * the vectors are exchanged through a zero-padded LDS tile: rows of vectors that do not exist read as zero and rows of
 //     the matrix beyond the target block are zero, so no lane needs a mask inside the product.
 constexpr int MAT_NB = 4, MAT_AHEAD = 4, MAT_TILE_ROWS = 16;
+// checkpoints of the window part (mat_trace_seq_window): entry size in doubles, entries per chain (window operators / 2 at
+// most 128, plus two scratch entries that take the stores nobody wants: 2 * 65 >= 128 doubles, one slot per lane and kind)
+__host__ __device__ inline int mat_ck_doubles(int nt) { return nt * nt + 1; }
+constexpr int MAT_CK_ENTRIES = 131;
 
 // doubles of LDS the evaluator needs per wave: vector tile [MAT_TILE_ROWS][NT], then the decay table [64][NT]
 __host__ __device__ inline int mat_seq_lds_doubles(int nt) { return (MAT_TILE_ROWS + 64) * nt; }
@@ -363,6 +368,10 @@ struct MatSeqArgs {
     unsigned ptout;                                                // 0xffffffff or byte offset of nsm + 1 doubles: partial traces of the outer states, then their common log scale
     unsigned pin, pout;                                            // 0xffffffff or byte offset of NT * NT + 1 doubles: vectors to start from / to leave the result in ([vector][component], stride NT, then the log scale)
     const double *opmat;                                           // [nsst][nf2][NT][NT] (DevConst::opmat_pad)
+    // checkpoints in global memory (mat_trace_seq_window): gin = vectors to start from (same format as pin) or null;
+    // gout = where the vectors after the 2nd, 4th, ... operator of the stretch go (entries of MAT_CK_DOUBLES(NT) doubles,
+    // the first nstore / 2 of them are kept, the rest lands in the scratch entry gdump); STORE instances only
+    const double *gin; double *gout, *gdump; int nstore;
     int n, skip1, skip2, nsm, spb, nf2, nsst;
     // the stretch of the trial sequence to apply: cnt operators from trial index jbeg on (indices beyond n - 1 wrap around
     // to 0, their times count from beta), between the times t0 and t1 (same unwrapped scale), from block sst_start to
@@ -376,14 +385,51 @@ struct MatSeqArgs {
 // padded block size the evaluator is instantiated for (operator table, vector tile and vector exchange use this stride)
 __host__ __device__ inline int mat_seq_pad(int nsm) { return nsm <= 8 ? 8 : (nsm <= 10 ? 10 : 16); }
 
+// What actually travels to the out-of-line evaluator: the same, packed into 29 dwords.  A function's arguments beyond 32
+// dwords are passed on the stack, and with part of MatSeqArgs there the sweep kernel went wrong (trajectories off with 40
+// dwords; fine again with everything in registers) - LDS offsets and the small integers are 16-bit here.
+struct MatSeqPacked {
+    unsigned h[13];                // halves: 11 LDS offsets in dwords (0xffff: none), then 13 small integers (skip + 1), 2 spare
+    const double *opmat, *gin; double *gout, *gdump;
+    double t0, t1, beta, egs;
+};
+__device__ __forceinline__ MatSeqPacked mat_seq_pack(const MatSeqArgs &a)
+{
+    MatSeqPacked p;
+    auto off = [](unsigned b) { return b == 0xffffffffu ? 0xffffu : (b >> 2); };
+    const unsigned v[26] = {off(a.tsst), off(a.om), off(a.ot), off(a.conn), off(a.tn), off(a.toff), off(a.teval), off(a.opbuf), off(a.ptout), off(a.pin), off(a.pout),
+                            (unsigned)a.n, (unsigned)(a.skip1 + 1), (unsigned)(a.skip2 + 1), (unsigned)a.nsm, (unsigned)a.spb, (unsigned)a.nf2, (unsigned)a.nsst,
+                            (unsigned)a.jbeg, (unsigned)a.cnt, (unsigned)a.sst_start, (unsigned)a.sst_end, (unsigned)a.ncols, (unsigned)a.nstore, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 13; ++i) p.h[i] = (v[2 * i] & 0xffffu) | (v[2 * i + 1] << 16);
+    p.opmat = a.opmat; p.gin = a.gin; p.gout = a.gout; p.gdump = a.gdump;
+    p.t0 = a.t0; p.t1 = a.t1; p.beta = a.beta; p.egs = a.egs;
+    return p;
+}
+__device__ __forceinline__ MatSeqArgs mat_seq_unpack(const MatSeqPacked &p)
+{
+    MatSeqArgs a;
+    auto half = [&](int i) { const unsigned w = (unsigned)uni((int)p.h[i >> 1]); return (i & 1) ? (w >> 16) : (w & 0xffffu); };
+    auto off = [&](int i) { const unsigned v = half(i); return v == 0xffffu ? 0xffffffffu : (v << 2); };
+    a.tsst = off(0); a.om = off(1); a.ot = off(2); a.conn = off(3); a.tn = off(4); a.toff = off(5); a.teval = off(6); a.opbuf = off(7);
+    a.ptout = off(8); a.pin = off(9); a.pout = off(10);
+    a.n = (int)half(11); a.skip1 = (int)half(12) - 1; a.skip2 = (int)half(13) - 1; a.nsm = (int)half(14); a.spb = (int)half(15); a.nf2 = (int)half(16);
+    a.nsst = (int)half(17); a.jbeg = (int)half(18); a.cnt = (int)half(19);
+    a.sst_start = (int)(short)half(20); a.sst_end = (int)(short)half(21); a.ncols = (int)half(22); a.nstore = (int)half(23);
+    a.opmat = p.opmat; a.gin = p.gin; a.gout = p.gout; a.gdump = p.gdump;
+    a.t0 = p.t0; a.t1 = p.t1; a.beta = p.beta; a.egs = p.egs;
+    return a;
+}
+
 typedef double mat_d2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) mat_d2 *MatRowPtr;
 
 // NB: batches of vectors in use, ceil(ncols / spb) (compile-time, so that the loop has no branches at all: a taken branch costs
 // a single wave more than the dozen instructions it skips)
-template <int NT, int NB>
-__device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
+template <int NT, int NB, bool STORE = false>
+__device__ __noinline__ double2 mat_trace_seq_core(MatSeqPacked packed)
 {
+    const MatSeqArgs a = mat_seq_unpack(packed);
     extern __shared__ unsigned char lds_base[];
     const int lane = (int)__lane_id();
     const int *tsst = (const int *)(lds_base + uni((int)a.tsst)), *om = (const int *)(lds_base + uni((int)a.om));
@@ -397,6 +443,12 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
     const int jbeg = uni(a.jbeg), cnt = uni(a.cnt), sst_start = uni(a.sst_start), sst_end = uni(a.sst_end), ncols = uni(a.ncols);
     const double beta = uni(a.beta), egs = uni(a.egs), t0 = uni(a.t0), t1 = uni(a.t1);
     const bool has_pin = uni((int)a.pin) != -1, has_pout = uni((int)a.pout) != -1;
+    typedef const __attribute__((address_space(1))) double *GInPtr;
+    typedef __attribute__((address_space(1))) double *GOutPtr;
+    auto uni_ptr = [](const void *p) { const unsigned long long b = (unsigned long long)p; return ((unsigned long long)(unsigned)uni((int)(b >> 32)) << 32) | (unsigned long long)(unsigned)uni((int)b); };
+    const GInPtr gin = (GInPtr)uni_ptr(a.gin);
+    const unsigned long long gout_b = uni_ptr(a.gout), gdump_b = uni_ptr(a.gdump);
+    const int nstore = uni(a.nstore);
     double2 res = make_double2(-HUGE_VAL, 0.0);
     if ((unsigned)sst_start >= (unsigned)nsst || (unsigned)sst_end >= (unsigned)nsst) return res;
     if (cnt > 0 && uni(tsst[jbeg >= n ? jbeg - n : jbeg]) != sst_start) return res;
@@ -414,9 +466,11 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
             const bool inr = st < ncols;
             wr[b] = act && inr;
             diag[b] = wr[b] && st == mi;
-            v[b] = has_pin ? (inr ? pin[st * NT + mi] : 0.0) : ((inr && st == mi) ? 1.0 : 0.0);
+            if (STORE && gin) v[b] = inr ? gin[st * NT + mi] : 0.0;
+            else v[b] = has_pin ? (inr ? pin[st * NT + mi] : 0.0) : ((inr && st == mi) ? 1.0 : 0.0);
         }
-        if (has_pin) lacc = uni(pin[NT * NT]);
+        if (STORE && gin) lacc = uni(gin[NT * NT]);
+        else if (has_pin) lacc = uni(pin[NT * NT]);
     }
     lds_sync();
     for (int e = lane; e < MAT_TILE_ROWS * NT; e += 64) vbuf[e] = 0.0;      // what no lane writes below stays zero
@@ -446,6 +500,12 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
             if (qm == cnt - 1) tlast = tau;
         }
         if (__ballot(my_bad) != 0ull) return res;
+        const double lacc_g0 = lacc;
+        double sc_pre = my_sc;                      // STORE: lane jj = scalar decay of the group's operators up to and including jj
+        if constexpr (STORE) {
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(sc_pre, o, 64); if (lane >= o) sc_pre += t; }
+        }
         lacc -= wave_sum(my_sc);
         // The group is filled up to a multiple of MAT_AHEAD with unit operators (decay factor one, unit matrix: the vectors
         // pass unchanged, exactly), so that the loop below has no branch around its loads: the compiler's count of loads in
@@ -485,6 +545,25 @@ __device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
                 }
                 fd = fdt[(jj + 1) * NT + mi];        // the next operator's factor travels with the vector reads (beyond the group: never used)
                 lds_sync();
+                if constexpr (STORE) {
+                    // checkpoint after every second operator: all lanes store, always (a store under a branch or a lane mask
+                    // would blur the compiler's count of accesses in flight); what nobody wants goes to the scratch entry
+                    if ((u & 1) == 1) {        // constant after unrolling
+                        const int qa = base + jj;                                  // this was operator qa of the stretch
+                        const bool keep = qa < nstore && jj < cntg;
+                        const unsigned long long dst = keep ? gout_b + (unsigned long long)(qa >> 1) * (NT * NT + 1) * sizeof(double) : gdump_b;
+#pragma unroll
+                        for (int b = 0; b < NB; ++b) {
+                            const unsigned long long at = (keep && wr[b]) ? dst + (unsigned long long)((b * spb + ms) * NT + mi) * sizeof(double)
+                                                                           : gdump_b + (unsigned long long)lane * sizeof(double);
+                            *(GOutPtr)at = v[b];
+                        }
+                        const double lsc = lacc_g0 - readlane_d(sc_pre, jj & 63) + (double)iexp * 0.6931471805599453;
+                        const unsigned long long at = (keep && lane == 0) ? dst + (unsigned long long)(NT * NT) * sizeof(double)
+                                                                          : gdump_b + (unsigned long long)(65 + lane) * sizeof(double);
+                        *(GOutPtr)at = lsc;
+                    }
+                }
                 {   // the operator MAT_AHEAD further on (beyond the group: a row that is never used)
                     const MatRowPtr p = myrow + (size_t)__builtin_amdgcn_readlane(my_op, (jj + MAT_AHEAD) & 63) * (NT * NT / 2);
 #pragma unroll
@@ -555,6 +634,7 @@ __device__ __forceinline__ MatSeqArgs mat_seq_args(Ctx &x, const int *tsst, int 
     a.tsst = off(tsst); a.om = off(x.om); a.ot = off(x.ot); a.conn = off(x.t_conn); a.tn = off(x.t_n); a.toff = off(x.t_off);
     a.teval = off(x.t_eval); a.opbuf = off(x.opbuf);
     a.ptout = a.pin = a.pout = 0xffffffffu;
+    a.gin = nullptr; a.gout = a.gdump = nullptr; a.nstore = 0;
     a.opmat = C.opmat_pad;
     a.n = n; a.skip1 = skip1; a.skip2 = skip2; a.nsm = C.nsm; a.spb = x.spb_; a.nf2 = 2 * C.nflav; a.nsst = C.nsst;
     a.beta = C.beta; a.egs = C.egs;
@@ -562,14 +642,17 @@ __device__ __forceinline__ MatSeqArgs mat_seq_args(Ctx &x, const int *tsst, int 
 }
 // The choice among the instances is made inline at the call site: a second out-of-line level (kernel -> dispatcher ->
 // evaluator) hung the GPU in one of the diagnostic builds (nested calls; not understood, not used).
-__device__ __forceinline__ double2 mat_seq_dispatch(const MatSeqArgs &a, int nt)
+template <bool STORE = false>
+__device__ __forceinline__ double2 mat_seq_dispatch(const MatSeqArgs &args, int nt)
 {
-    const int nb = uni((a.ncols + a.spb - 1) / a.spb);
-    if (nt == 8) return mat_trace_seq_core<8, 1>(a);                  // up to 8 states: all vectors in one batch
-    if (nt == 10) return nb <= 1 ? mat_trace_seq_core<10, 1>(a) : mat_trace_seq_core<10, 2>(a);
-    return nb <= 1 ? mat_trace_seq_core<16, 1>(a) : (nb == 2 ? mat_trace_seq_core<16, 2>(a) : (nb == 3 ? mat_trace_seq_core<16, 3>(a) : mat_trace_seq_core<16, 4>(a)));
+    const int nb = uni((args.ncols + args.spb - 1) / args.spb);
+    const MatSeqPacked a = mat_seq_pack(args);
+    if (nt == 8) return mat_trace_seq_core<8, 1, STORE>(a);                  // up to 8 states: all vectors in one batch
+    if (nt == 10) return nb <= 1 ? mat_trace_seq_core<10, 1, STORE>(a) : mat_trace_seq_core<10, 2, STORE>(a);
+    return nb <= 1 ? mat_trace_seq_core<16, 1, STORE>(a) : (nb == 2 ? mat_trace_seq_core<16, 2, STORE>(a) : (nb == 3 ? mat_trace_seq_core<16, 3, STORE>(a) : mat_trace_seq_core<16, 4, STORE>(a)));
 }
-__device__ __forceinline__ double2 mat_seq_call(const DevConst &C, const MatSeqArgs &a) { return mat_seq_dispatch(a, mat_seq_pad(C.nsm)); }
+template <bool STORE = false>
+__device__ __forceinline__ double2 mat_seq_call(const DevConst &C, const MatSeqArgs &a) { return mat_seq_dispatch<STORE>(a, mat_seq_pad(C.nsm)); }
 
 __device__ __forceinline__ void mat_trace_seq(Ctx &x, const int *tsst, int n, int skip1, int skip2, double &tlog, double &tsign, double *ptout = nullptr)
 {
@@ -636,14 +719,29 @@ __device__ W2DYN_INLINE void mat_trace_seq_window(Ctx &x, const int *tsst, int n
         SEQ_COUNT(x, C_DBG1, 1); SEQ_COUNT(x, C_DBG2, a.cnt); SEQ_T0();
         const double2 r = mat_seq_call(C, a);
         SEQ_T1(x, C_DBG4);
+        x.kval = 0;
         if (uni(r.y) == 0.0) { x.pvalid = 0; return; }
         x.pvalid = 1; x.p_lo = sst_lo; x.p_hi = sst_hi;
         a.pout = 0xffffffffu;
     }
-    a.jbeg = jlo; a.cnt = jhi - jlo; a.sst_start = sst_lo; a.sst_end = sst_hi; a.ncols = uni(x.t_n[sst_hi]);
-    a.t0 = x.wmin; a.t1 = x.wmax; a.pin = poff;
+    // Checkpoints inside the window (global memory, per chain): the vectors after every second window operator of the
+    // CURRENT configuration.  The operators in front of the first one a proposal changes (x.k_first) are the current ones,
+    // so the walk starts at the last checkpoint not beyond it and leaves new checkpoints up to it on the way; an accepted
+    // move cuts the valid checkpoints back to its first operator (mat_commit_sst), a new outside product drops them all.
+    const int i1 = max(min(x.k_first, jhi) - jlo, 0) & ~1;       // window operators (even) known to be unchanged
+    const int s = x.kc ? min(i1, x.kval) : 0;
+    x.k_i1 = i1;
+    const int stride = mat_ck_doubles(mat_seq_pad(C.nsm));
+    a.jbeg = jlo + s; a.cnt = (jhi - jlo) - s; a.sst_start = s ? uni(tsst[jlo + s]) : sst_lo; a.sst_end = sst_hi; a.ncols = uni(x.t_n[sst_hi]);
+    a.t0 = s ? uni(x.ot[jlo + s - 1]) : x.wmin; a.t1 = x.wmax; a.pin = poff;
     SEQ_COUNT(x, C_DBG3, a.cnt); SEQ_T0();
-    const double2 r = mat_seq_call(C, a);
+    double2 r;
+    if (x.kc) {
+        a.gin = s ? x.kc + (size_t)(s / 2 - 1) * stride : nullptr;
+        a.gout = x.kc + (size_t)(s / 2) * stride; a.gdump = x.kc + (size_t)(MAT_CK_ENTRIES - 3) * stride; a.nstore = i1 - s;
+        r = mat_seq_call<true>(C, a);
+        x.kval = uni(r.y) != 0.0 ? max(x.kval, i1) : s;
+    } else r = mat_seq_call(C, a);
     SEQ_T1(x, C_DBG5);
     tlog = uni(r.x); tsign = uni(r.y);
 }

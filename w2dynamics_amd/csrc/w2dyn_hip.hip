@@ -709,6 +709,10 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     }
     if (s->mat) { if ((rc = dev_upload(s, C.opmat, opmat))) return rc; }
     if (!opmat_pad.empty()) { if ((rc = dev_upload(s, C.opmat_pad, opmat_pad))) return rc; }
+    if (!opmat_pad.empty() && !getenv("W2DYN_NO_CHECKPOINTS")) {      // checkpoints of the window part of the sequential trace
+        const int nt = mat_seq_pad(C.nsm);
+        if ((rc = dev_alloc(s, C.kcache, (size_t)s->nwalkers * MAT_CK_ENTRIES * mat_ck_doubles(nt)))) return rc;
+    }
     const size_t W = s->nwalkers;
     if ((rc = dev_alloc(s, C.ws, W))) return rc;
     if ((rc = dev_alloc(s, C.K, W * nf))) return rc;
