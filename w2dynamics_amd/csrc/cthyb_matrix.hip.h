@@ -676,6 +676,9 @@ __device__ __forceinline__ void mat_trace_seq(Ctx &x, const int *tsst, int n, in
 // (x.pvalid).  The trial trace is then  Tr[ (ops inside the window) P ] : the stored vectors P are propagated through the
 // operators inside the window only (the reference keeps bra / ket vectors outside the window for the same reason,
 // Trace.F90:5384-5522, 6109-6209).  Z-space sweep only: worm operators may sit anywhere.
+// CAUTION: a -DW2DYN_STAMPS -DW2DYN_STAMPS_SEQ build of the state with window checkpoints faulted the GPU (the production
+// build of the same source passes every parity test); the numbers quoted in DESIGN.md come from the state before them.  Do not
+// run such a build on a shared machine without finding out why first.
 #ifdef W2DYN_STAMPS_SEQ     // diagnostic build: counts and cycles of the cached-window evaluation in the DBG slots
 #define SEQ_COUNT(x, c, v) do { if ((x).lane == 0) (x).cnt[c] += (unsigned long long)(v); } while (0)
 #define SEQ_T0() const unsigned long long tq0_ = __builtin_amdgcn_s_memtime()
