@@ -148,6 +148,7 @@ int w2dyn_get_walker_state(w2dyn_solver *s, int walker, double *out6);
 /* name: "gtau" (Nd,2,Ntau) | "gleg" (Nd,2,NLegMax) | "giw" (Nd,2,2Niw) complex | "occ" (Nd,2,Nd,2) |
  *       "histo" (Nd,2,MaxHisto+1) | "densitymatrix" (4^Nd,4^Nd) | "rho1" ((2Nd)^2) | "rho2" ((2Nd)^4) |
  *       "ssquare" (2Nd+1) | "ssquare_operator" (4^Nd,4^Nd) with MeasSsquare (CTQMC.F90:161-162, 2769-2840) |
+ *       "gtau_mean_step", "gtau_mid_step" (Nd,2,Nmeas) | "sign_step" (Nmeas): chain-mean series (CTQMC.F90:43-44, 2394-2402) |
  *       "outersuperstatehisto" | "outerstatehisto" | "signhistosuperstates" | "signhistostates" | "tracecontribsuperstates" |
  *       "tracecontribstates" | "statessuperstates" (int32) | "eigenstatesenergies" | "occbasismapping" (4^Nd,Nd,2) int32 |
  *       "accadd" (16) | "accrem" (16) | "accpair" (Nd,2,Ntau) int64 | "cntsampling" (16) int64 | "lhisto" | "rhisto" |

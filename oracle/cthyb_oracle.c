@@ -72,6 +72,7 @@ struct ora_walker {
     /* accumulators */
     double *gleg, *gtau, *giw, *histo, *dm, *outer_histo;
     double *ntau_n0;                      /* [nflav][nflav][ntau+1], MeasSusz */
+    double *gms, *gmid, *sstep;           /* [nflav][nmeas] x2, [nmeas]: Gtau_mean_step, Gtau_mid_step, sign_step */
     /* MeasOuterHistograms (CTQMC.F90:3285-3339): per block [nsst] and per eigenstate [nstates], block order */
     double *sign_sst, *tcontrib_sst, *outer_state_histo, *sign_state, *tcontrib_state;
     double *g2iw, *g4iw, *g4iwpp;    /* complex interleaved, NULL when not measured */
@@ -1120,6 +1121,11 @@ ora_walker *ora_create(const ora_params *p, const double *U, const double *ftau_
     w->gleg = (double *)calloc((size_t)w->nflav * p->nlegmax, sizeof(double));
     w->gtau = (double *)calloc((size_t)w->nflav * p->ntau, sizeof(double));
     w->ntau_n0 = p->meas_susz ? (double *)calloc((size_t)w->nflav * w->nflav * (p->ntau + 1), sizeof(double)) : NULL;
+    w->gms = w->gmid = w->sstep = NULL;
+    if (p->step_series && p->nmeas > 0) {
+        w->gms = (double *)calloc((size_t)w->nflav * p->nmeas, sizeof(double)); w->gmid = (double *)calloc((size_t)w->nflav * p->nmeas, sizeof(double));
+        w->sstep = (double *)calloc((size_t)p->nmeas, sizeof(double));
+    }
     w->giw = (double *)calloc((size_t)w->nflav * 2 * p->niw * 2, sizeof(double));
     w->histo = (double *)calloc((size_t)w->nflav * (p->maxhisto + 1), sizeof(double));
     w->dm = (double *)calloc((size_t)w->nstates, sizeof(double));
@@ -1171,7 +1177,7 @@ void ora_destroy(ora_walker *w)
 {
     if (!w) return;
     for (int f = 0; f < w->nflav; ++f) free(w->M[f]);
-    free(w->ops); free(w->ftab); ora_locprob_free(w->lp); free(w->ptr); free(w->dmblk); free(w->dmoff); free(w->accpair); free(w->accpairtau); free(w->gleg); free(w->gtau); free(w->giw); free(w->ntau_n0);
+    free(w->ops); free(w->ftab); ora_locprob_free(w->lp); free(w->ptr); free(w->dmblk); free(w->dmoff); free(w->accpair); free(w->accpairtau); free(w->gleg); free(w->gtau); free(w->giw); free(w->ntau_n0); free(w->gms); free(w->gmid); free(w->sstep);
     free(w->histo); free(w->dm); free(w->outer_histo); free(w->sign_sst); free(w->tcontrib_sst); free(w->outer_state_histo); free(w->sign_state); free(w->tcontrib_state); free(w->g2iw); free(w->g4iw); free(w->g4iwpp); free(w->g4w); free(w->g4wpp); free(w->g4tau); free(w->g4leg); free(w->giww); free(w->gtauw); free(w->acbuf); free(w->acdat); free(w);
 }
 
@@ -1553,6 +1559,20 @@ void ora_measure_once(ora_walker *w)
         ora_meas_flavour(w->M[f], k, tc, ta, w->p.beta, w->cfgsign, w->p.nlegmax, acc ? w->gleg + (size_t)f * w->p.nlegmax : NULL,
                          w->p.ntau, acc == 0 ? NULL : (acc == 2 ? w->acbuf : w->gtau) + (size_t)f * w->p.ntau, 2 * w->p.niw,
                          w->p.meas_giw ? w->giw + (size_t)f * 4 * w->p.niw : NULL);
+        /* per-measurement series (CTQMC.F90:2394-2402, inside MeasGtauRem: not with AccumGtau = 0): the element as it went into
+         * G(tau), times the configuration sign once more; entry g_inmeas = number of this measurement */
+        if (w->gms && acc && (long long)w->cnt_meas <= (long long)w->p.nmeas) {
+            const size_t at = (size_t)f * w->p.nmeas + (size_t)w->cnt_meas - 1;
+            for (int ia = 0; ia < k; ++ia) for (int ic = 0; ic < k; ++ic) {
+                double m = w->M[f][ic * k + ia];
+                if (!(ta[ia] - tc[ic] > 0.0)) m = -m;
+                m = m * w->cfgsign;
+                if (w->p.step_series & 1) w->gms[at] += m * w->cfgsign;
+                const double r = fabs(ta[ia] - tc[ic]) / w->p.beta;
+                if ((w->p.step_series & 2) && r >= 0.4 && r <= 0.6) w->gmid[at] += m * w->cfgsign;
+                if (w->p.step_series & 4) w->sstep[(size_t)w->cnt_meas - 1] = w->cfgsign;
+            }
+        }
         free(tc); free(ta);
     }
     if (w->p.accum_gtau == 2) autocorr_add(w);                          /* gtau_accum%add(), CTQMC.F90:2439 */
@@ -1597,6 +1617,7 @@ void ora_measure_finish(ora_walker *w)
     for (size_t i = 0; i < (size_t)nf * w->p.ntau; ++i)                                 /* 8726-8731 */
         w->gtau[i] = -(w->gtau[i] / w->cnt_meas) / (-w->mean_sign) * (double)w->p.ntau / (beta * beta);
     for (size_t i = 0; i < (size_t)nf * (w->p.maxhisto + 1); ++i) w->histo[i] /= w->cnt_meas;   /* 8755 */
+    if (w->gms) for (size_t i = 0; i < (size_t)nf * w->p.nmeas; ++i) { w->gms[i] /= beta * beta; w->gmid[i] /= beta * beta; }   /* 8741-8742 */
     if (w->ntau_n0)                                                                     /* 8744-8746 */
         for (int ff = 0; ff < nf * nf; ++ff) {
             double *r = w->ntau_n0 + (size_t)ff * (w->p.ntau + 1);
@@ -1784,6 +1805,13 @@ int ora_get_g4iw_worm(const ora_walker *w, double *o, int pp)
 }
 /* autocorracc_blocks (Accumulators.F90:343-361): sqdiff / (n - 1) per level, n halved from level to level;
  * out (Nd,2,Ntau,nlevels) C order; returns nlevels (0 if AccumGtau != 2); out may be NULL */
+int ora_get_step_series(const ora_walker *w, double *mean, double *mid, double *sign)
+{
+    if (!w->gms) return 0;
+    memcpy(mean, w->gms, sizeof(double) * (size_t)w->nflav * w->p.nmeas); memcpy(mid, w->gmid, sizeof(double) * (size_t)w->nflav * w->p.nmeas);
+    memcpy(sign, w->sstep, sizeof(double) * (size_t)w->p.nmeas);
+    return w->p.nmeas;
+}
 int ora_get_ntau_n0(const ora_walker *w, double *o)
 {
     if (!w->ntau_n0) return 0;

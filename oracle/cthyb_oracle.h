@@ -54,6 +54,7 @@ typedef struct ora_params {
     double epsblock;        /* EPSBLOCK: threshold of the automatic block partitioning, QuantumNumbers = All (CTQMC.F90:7972) */
     int accum_gtau;         /* AccumGtau: 0 = G(tau)/G(l) not measured, 1 = running mean, 2 = autocorrelation accumulator (CTQMC.F90:492-500) */
     int meas_susz;          /* MeasSusz (matrix solver): <n(tau) n(0)>, meas_ntau_n0 (CTQMC.F90:534-540, Trace.F90:6472-6835) */
+    int step_series;        /* bit 0: Gtau_mean_step, bit 1: Gtau_mid_step, bit 2: sign_step - per-measurement series (CTQMC.F90:43-45, 2394-2402) */
 } ora_params;
 
 typedef struct ora_walker ora_walker;
@@ -131,6 +132,7 @@ void ora_get_outer_histograms(const ora_walker *w, double *sign_sst, double *tco
 int ora_nsst(const ora_walker *w);
 int ora_nsmax(const ora_walker *w);
 void ora_get_blocks(const ora_walker *w, int *sst_n, int *sst_off, int *states);  /* [nsst],[nsst],[4^Nd] */
+int ora_get_step_series(const ora_walker *w, double *mean, double *mid, double *sign);   /* (2Nd, Nmeas) x2, (Nmeas); returns Nmeas or 0 */
 void ora_get_ssquare(const ora_walker *w, double *ssq, double *sop);   /* (2Nd+1), (4^Nd)^2: MeasSsquare, CTQMC.F90:2769-2840 */
 void ora_get_occ(const ora_walker *w, double *occ, double *rho1, double *rho2);   /* (Nd,2,Nd,2), (2Nd)^2, (2Nd)^4: CTQMC.F90:2884-3060 */
 void ora_get_accpair(const ora_walker *w, int64_t *out);  /* (Nd,2,Ntau) */

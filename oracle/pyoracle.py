@@ -24,7 +24,7 @@ class OraParams(C.Structure):
                 ("p_worm_ins", C.c_double), ("p_worm_rep", C.c_double), ("worm_eta", C.c_double),
                 ("worm_meas_g4iw", C.c_int), ("g4ph", C.c_int), ("g4pp", C.c_int), ("wormphconv", C.c_int),
                 ("worm_meas_giw", C.c_int), ("worm_meas_gtau", C.c_int), ("epsblock", C.c_double), ("accum_gtau", C.c_int),
-                ("meas_susz", C.c_int)]
+                ("meas_susz", C.c_int), ("step_series", C.c_int)]
 
 
 def build():
@@ -84,6 +84,7 @@ def lib():
     L.ora_get_gtau_blocks.argtypes = [vp, C.c_void_p]; L.ora_get_gtau_blocks.restype = C.c_int
     L.ora_get_ntau_n0.argtypes = [vp, C.c_void_p]; L.ora_get_ntau_n0.restype = C.c_int
     L.ora_get_ssquare.argtypes = [vp, dp, dp]
+    L.ora_get_step_series.argtypes = [vp, dp, dp, dp]; L.ora_get_step_series.restype = C.c_int
     L.ora_get_gtau_worm.argtypes = [vp, dp]; L.ora_get_gtau_worm.restype = C.c_int
     L.ora_get_hashybs.argtypes = [vp, ip]
     L.ora_get_g2iw.argtypes = [vp, dp]; L.ora_get_g2iw.restype = C.c_int
@@ -122,7 +123,8 @@ def params_from_pstring(ps, nd, beta, fourpnt=0):
                      wormphconv=int(ps.get_int("WormPHConvention") != 0),
                      worm_meas_giw=int(ps.get_int("WormMeasGiw") != 0), worm_meas_gtau=int(ps.get_int("WormMeasGtau") != 0),
                      epsblock=ps.get_real("EPSBLOCK"), accum_gtau=ps.get_int("AccumGtau"),
-                     meas_susz=int(ps.get_int("MeasSusz") == 1 and ps.get_int("segment") == 0))
+                     meas_susz=int(ps.get_int("MeasSusz") == 1 and ps.get_int("segment") == 0),
+                     step_series=(1 if ps.get_int("Gtau_mean_step") else 0) | (2 if ps.get_int("Gtau_mid_step") else 0) | (4 if ps.get_int("sign_step") else 0))
 
 
 class OracleWalker:
@@ -234,6 +236,12 @@ class OracleWalker:
         if nd <= 5 and self.meas_ssq:
             ssq = np.zeros(2 * nd + 1); sop = np.zeros((4 ** nd, 4 ** nd)); self.L.ora_get_ssquare(self.h, ssq, sop)
             r["ssquare"] = ssq; r["ssquare_operator"] = sop
+        if p.step_series and p.nmeas > 0:
+            gm = np.zeros((nd, 2, p.nmeas)); gi = np.zeros((nd, 2, p.nmeas)); ss = np.zeros(p.nmeas)
+            if self.L.ora_get_step_series(self.h, gm, gi, ss):
+                if p.step_series & 1: r["gtau_mean_step"] = gm
+                if p.step_series & 2: r["gtau_mid_step"] = gi
+                if p.step_series & 4: r["sign_step"] = ss
         a = np.zeros((nd, 2, nd, 2, p.ntau + 1))
         if self.L.ora_get_ntau_n0(self.h, a.ctypes.data):
             r["ntau_n0"] = a

@@ -265,7 +265,7 @@ def gen_worm(only=None):
         print("worm", name, "steps(worm, Z) of the eta search", steps, "cntsampling", r["cntsampling"][[0, sector - 1]], "nops", len(c_end["taus"]))
 
 
-KINDS = ("traj", "stat", "g4", "worm", "calib", "accum", "g4leg", "susz", "ssq")
+KINDS = ("traj", "stat", "g4", "worm", "calib", "accum", "g4leg", "susz", "ssq", "steps")
 
 ACCUM = {   # AccumGtau = 2 (autocorrelation accumulator: gtau_blocks) and 0 (G(tau), G(l) not measured), one seeded chain
     # name: (config, nftau, overrides, seed)
@@ -378,6 +378,29 @@ def gen_ssq(only=None):
         print("ssq", name, "S^2 per N:", r["ssquare"], "tr S2op", float(np.trace(r["ssquare_operator"])))
 
 
+STEPS = ("C1", "C3", "C4S")
+
+
+def gen_steps(only=None):
+    """Gtau_mean_step, Gtau_mid_step, sign_step: per-measurement series of a seeded reference run (CTQMC.F90:2394-2402); the
+    oracle with the same generator retraces the chain, so the series must agree entry by entry."""
+    for name in STEPS:
+        if only and name not in only:
+            continue
+        cfg, nftau, over, seed = TRAJ[name]
+        over1 = dict(over); over1.update(Gtau_mean_step=1, Gtau_mid_step=1, sign_step=1)
+        p, ps = pstring_for(cfg, nftau, over1)
+        s = refdrive.RefSolver(p, ps, seed)
+        s.set_taudiffmax(over["TaudiffMax"])
+        s.warmup(over["Nwarmups"])
+        s.measure()
+        r = s.results(("gtau_mean_step", "gtau_mid_step", "sign_step", "gtau", "mean_sign"))
+        s.close()
+        np.savez_compressed(os.path.join(OUT, "steps_%s.npz" % name), config=cfg, nftau=nftau, seed=seed, overrides=repr(over1),
+                            **{"res_" + k: v for k, v in r.items()})
+        print("steps", name, r["gtau_mean_step"].shape, r["gtau_mean_step"][0, 0, :4], r["gtau_mid_step"][0, 0, :4], r["sign_step"][:4])
+
+
 if __name__ == "__main__":
     if not refdrive.available():
         raise SystemExit("oracle/_ref is not built: run oracle/build_ref.sh in the build container")
@@ -401,3 +424,5 @@ if __name__ == "__main__":
         gen_susz(only)
     if "ssq" in which:
         gen_ssq(only)
+    if "steps" in which:
+        gen_steps(only)

@@ -917,6 +917,35 @@ def test_susceptibility_recorded_configuration_vs_reference_golden(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["C1", "C3", "C4S"])
+def test_step_series_are_the_chain_means_of_the_oracle_series(cfg):
+    """Gtau_mean_step, Gtau_mid_step, sign_step (CTQMC.F90:2394-2402): entry m of the HIP series is the mean over the chains of
+    what every chain's oracle twin (same stream) records at its m-th measurement; C1 has empty configurations (sign entry 0),
+    C4S runs on the matrix trace path."""
+    over = dict(BASE, Nwarmups=2000, Nmeas=12, NCorr=30, TaudiffMax=3.0 if cfg == "C4S" else 6.0, PercentageGlobalMove=0.1,
+                PercentageTauShiftMove=0.1, Gtau_mean_step=1, Gtau_mid_step=1, sign_step=1)
+    p, ps, pset = util.setup(cfg, 501, over)
+    nw = 6
+    q = make_gpu(p, ps, 57, nw, wpb=1)
+    q.set_taudiffmax(over["TaudiffMax"])
+    q.ctqmc_warmup(over["Nwarmups"])
+    q.ctqmc_measure(1, 1)
+    tot = {}
+    for w in range(nw):
+        o = pyoracle.OracleWalker(p, pset, ("philox", 57, w))
+        o.set_taudiffmax(over["TaudiffMax"]); o.warmup(over["Nwarmups"]); o.measure()
+        r = o.results()
+        for k in ("gtau_mean_step", "gtau_mid_step", "sign_step"):
+            tot[k] = tot.get(k, 0.0) + r[k] / nw
+        o.close()
+    for k in tot:
+        a = getattr(q, k)
+        assert a.shape == tot[k].shape and np.abs(tot[k]).max() > 0, k
+        assert np.abs(a - tot[k]).max() < 1e-10 * np.abs(tot[k]).max(), k
+    q.dest_ctqmc(); q.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["C4", "C4N", "C5K"])
 def test_ssquare_recorded_configuration_vs_reference_golden(name):
     """f-3, MeasSsquare = 1 (CTQMC.F90:2769-2840): <S^2> per electron number and the S^2 operator of the occupation basis ==

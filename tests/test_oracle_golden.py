@@ -134,6 +134,26 @@ def test_oracle_ssquare_on_recorded_configuration(name):
     w.close()
 
 
+@pytest.mark.parametrize("name", ["C1", "C3", "C4S"])
+def test_oracle_step_series_retrace_reference_chain(name):
+    """Gtau_mean_step, Gtau_mid_step, sign_step (CTQMC.F90:2394-2402, 8741-8742): the per-measurement series of a seeded
+    reference run, entry by entry (the oracle with the same generator walks the same chain) - including the entries of empty
+    configurations, where the reference leaves the sign at zero."""
+    g = util.load_golden("steps_%s.npz" % name)
+    over = g["overrides"]
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    w = pyoracle.OracleWalker(p, pset, ("std", int(g["seed"])))
+    w.set_taudiffmax(over["TaudiffMax"])
+    w.warmup(over["Nwarmups"])
+    w.measure()
+    r = w.results()
+    for k in ("gtau_mean_step", "gtau_mid_step", "sign_step"):
+        assert r[k].shape == g["res_" + k].shape and np.abs(g["res_" + k]).max() > 0
+        assert np.abs(r[k] - g["res_" + k]).max() < 1e-10 * np.abs(g["res_" + k]).max(), k
+    assert rel(r["gtau"], g["res_gtau"]) < 1e-10
+    w.close()
+
+
 def test_matrix_update_primitives_against_exact_inverse(oracle_lib):
     """MatrixUpdate.F90:489-631 (the reference's disabled self-test) idea: fast updates vs a fresh inverse."""
     L = oracle_lib

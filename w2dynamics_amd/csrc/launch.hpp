@@ -37,6 +37,7 @@ void launch_meas_gtau_ac(const DevConst &C, hipStream_t st, double *dat, int nle
 void launch_gtau_blocks(const DevConst &C, hipStream_t st, const double *dat, int nlev, long long n, double *out);
 void launch_meas_giw(const DevConst &C, hipStream_t st);
 void launch_meas_susz(const DevConst &C, hipStream_t st, double *acc, int nbs);
+void launch_meas_steps(const DevConst &C, hipStream_t st, double *ser, int nmeas, int m, int what);
 void launch_meas_g4leg(const DevConst &C, hipStream_t st, double *acc_tau, double *acc_leg, int nbl, int nt, int nl, int nwb);
 size_t g4leg_fact_lds(const DevConst &C, int nl);
 void launch_meas_g4leg_fact(const DevConst &C, hipStream_t st, double *acc_leg, int nbl, int nl, int nwb);

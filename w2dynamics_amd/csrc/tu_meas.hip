@@ -151,6 +151,49 @@ __global__ void __launch_bounds__(256) k_meas_susz(DevConst C, double *__restric
             }
     }
 }
+// Gtau_mean_step, Gtau_mid_step, sign_step (CTQMC.F90:2394-2402): per-measurement series.  The reference keeps one chain's
+// series per rank; here entry m is the MEAN over the chains of this process (independent chains: the normalised
+// autocorrelation of the mean is that of one chain).  One wave per (chain, flavour): sum of the elements as they go into G(tau)
+// (sign of the wrap; the configuration sign enters twice, i.e. not at all), and of those with |tau_a - tau_c| / beta in
+// [0.4, 0.6]; the sign entry is the configuration sign of chains that hold at least one pair (the reference sets it inside
+// the pair loop).  ser = [mean: nflav x nmeas | mid: nflav x nmeas | sign: nmeas].
+__global__ void __launch_bounds__(256) k_meas_steps(DevConst C, double *__restrict__ ser, int nmeas, int m, int what)
+{
+    const int wv = (int)((blockIdx.x * 256u + threadIdx.x) >> 6), lane = threadIdx.x & 63, nf = C.nflav;
+    if (wv >= C.nwalkers * nf) return;
+    const int w = wv / nf, f = wv - w * nf;
+    const int k = C.K[(size_t)w * nf + f];
+    if (k == 0) return;
+    const size_t wf = (size_t)w * nf + f;
+    const double *tc = C.TC + wf * C.kmax, *ta = C.TA + wf * C.kmax, *M = C.M + wf * C.kmax * C.kmax;
+    double sm = 0.0, smid = 0.0;
+    for (int e = lane; e < k * k; e += 64) {
+        const int ic = e / k, ia = e - ic * k;
+        double v = M[(size_t)ic * C.kmax + ia];
+        const double d = ta[ia] - tc[ic];
+        if (!(d > 0.0)) v = -v;
+        sm += v;
+        const double r = fabs(d) / C.beta;
+        if (r >= 0.4 && r <= 0.6) smid += v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sm += __shfl_xor(sm, o, 64); smid += __shfl_xor(smid, o, 64); }
+    if (lane != 0) return;
+    const double inv = 1.0 / (double)C.nwalkers;
+    if (what & 1) atomicAdd(&ser[(size_t)f * nmeas + m], sm * inv);
+    if (what & 2) atomicAdd(&ser[(size_t)(nf + f) * nmeas + m], smid * inv);
+    if (what & 4) {
+        bool first = true;
+        for (int g = 0; g < f; ++g) first = first && C.K[(size_t)w * nf + g] == 0;
+        if (first) atomicAdd(&ser[(size_t)2 * nf * nmeas + m], C.cfgsign[w] * inv);
+    }
+}
+void launch_meas_steps(const DevConst &C, hipStream_t st, double *ser, int nmeas, int m, int what)
+{
+    const unsigned waves = (unsigned)C.nwalkers * (unsigned)C.nflav;
+    hipLaunchKernelGGL(k_meas_steps, dim3((waves + 3) / 4), dim3(256), 0, st, C, ser, nmeas, m, what);
+}
+
 void launch_meas_susz(const DevConst &C, hipStream_t st, double *acc, int nbs)
 {
     const size_t lds = (size_t)2 * C.nflav * C.kmax * sizeof(double);

@@ -112,6 +112,7 @@ struct w2dyn_solver {
     int worm_meas_g4iw = 0, g4ph = 0, g4pp = 0, wormphconv = 0, nbw = 0, cur_isector = 1;
     // G(tau) accumulator (AccumGtau, CTQMC.F90:492-500): 0 = G(tau)/G(l) not measured, 1 = mean, 2 = per-chain autocorrelation stack
     bool meas_ssq = false;                                               // MeasSsquare: <S^2> per electron number from the density matrix
+    int step_series = 0; double *ser = nullptr;                          // Gtau_mean_step (1) | Gtau_mid_step (2) | sign_step (4): [2 nflav + 1][Nmeas] chain-mean series
     bool meas_susz = false; int nbs = 0; double *acc_susz = nullptr;     // MeasSusz: <n(tau) n(0)>, accumulator bins [nbs][nflav][nflav][Ntau]
     int accum_gtau = 1, ac_lev = 0; long long ac_n = 0; double *ac_dat = nullptr, *ac_out = nullptr;
     int res_isector = 1;                             // sector of the run the result table was made from
@@ -529,7 +530,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     struct { const char *key; long long allowed; } zero_int[] = {
         {"segment", 0}, {"offdiag", 0}, {"full_offdiag", 0}, {"statesampling", 0}, {"flavourchange_moves", 0}, {"Phonon", 0},
         {"Screening", 0}, {"Uw", 0}, {"MeasGtauDetRat", 0},
-        {"MeasExpResDensityMatrix", 0}, {"Gtau_mean_step", 0}, {"Gtau_mid_step", 0}, {"sign_step", 0},
+        {"MeasExpResDensityMatrix", 0},
         {"NSymMove", 0}, {"MeasDensityMatrix", 1}, {"Eigenbasis", 1}};
     for (auto &z : zero_int) {
         if (!get_int(s, z.key, iv)) return W2DYN_EINVAL;
@@ -586,6 +587,10 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if (!get_int(s, "AccumGtau", iv)) return W2DYN_EINVAL;
     if (iv < 0 || iv > 2) return fail(s, W2DYN_EINVAL, "invalid value %lld for AccumGtau (0, 1, 2)", iv);     // CTQMC.F90:502
     s->accum_gtau = (int)iv;
+    s->step_series = 0;                  // CTQMC.F90:510-512
+    if (!get_int(s, "Gtau_mean_step", iv)) return W2DYN_EINVAL; if (iv != 0) s->step_series |= 1;
+    if (!get_int(s, "Gtau_mid_step", iv)) return W2DYN_EINVAL; if (iv != 0) s->step_series |= 2;
+    if (!get_int(s, "sign_step", iv)) return W2DYN_EINVAL; if (iv != 0) s->step_series |= 4;
     if (!get_int(s, "MeasSsquare", iv)) return W2DYN_EINVAL;
     s->meas_ssq = iv != 0;               // CTQMC.F90:8009-8010
     if (!get_int(s, "MeasSusz", iv)) return W2DYN_EINVAL;
@@ -770,6 +775,8 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
         if ((rc = dev_alloc(s, s->ac_out, B * (size_t)nf * lev * s->ntau))) return rc;
     }
     s->acc_susz = nullptr; s->nbs = 0;
+    s->ser = nullptr;
+    if (s->step_series && s->nmeas > 0) { if ((rc = dev_alloc(s, s->ser, (size_t)(2 * nf + 1) * (size_t)s->nmeas))) return rc; }
     if (s->meas_ssq && !s->lp.build_s2())
         return fail(s, W2DYN_EUNSUPPORTED, "MeasSsquare = 1 needs blocks that S^2 does not leave (quantum numbers '%s' do not conserve the total spin: "
                                            "the reference's result is undefined there)", qns.c_str());
@@ -1007,6 +1014,7 @@ int w2dyn_measure_begin(w2dyn_solver *s)
     if (C.acc_giww) HIPCHK(hipMemsetAsync(C.acc_giww, 0, sizeof(double) * B * C.niw2 * 2, s->stream));
     if (C.acc_gtauw) HIPCHK(hipMemsetAsync(C.acc_gtauw, 0, sizeof(double) * B * s->ntau, s->stream));
     if (s->acc_susz) HIPCHK(hipMemsetAsync(s->acc_susz, 0, sizeof(double) * (size_t)s->nbs * nf * nf * s->ntau, s->stream));
+    if (s->ser) HIPCHK(hipMemsetAsync(s->ser, 0, sizeof(double) * (size_t)(2 * nf + 1) * (size_t)s->nmeas, s->stream));
     if (s->fourpnt & 4) {
         const size_t n2 = 2 * (size_t)(s->n4iwf + s->n4iwb), n4 = (size_t)nf * nf * 4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1), ng2 = (size_t)nf * n2 * n2;
         HIPCHK(hipMemsetAsync(s->acc4, 0, sizeof(double2) * s->nb4 * n4, s->stream));
@@ -1050,6 +1058,10 @@ static int measure_once_impl(w2dyn_solver *s, double2 *g2buf)
     launch_meas_gleg(s->C, s->stream, s->gleg_segpre, s->ncu);
     HIPCHK(hipGetLastError());
     if ((rc = time_end(s, "meas_gleg"))) return rc;
+    }
+    if (s->ser && s->accum_gtau != 0 && s->meas_done < s->nmeas) {     // entry g_inmeas of the series (CTQMC.F90:2394-2402, 8424)
+        launch_meas_steps(s->C, s->stream, s->ser, (int)s->nmeas, (int)s->meas_done, s->step_series);
+        HIPCHK(hipGetLastError());
     }
     if (s->accum_gtau == 2) {
         if ((rc = time_begin(s))) return rc;
@@ -1315,6 +1327,18 @@ int w2dyn_measure_finish(w2dyn_solver *s)
         }
         for (size_t i = 0; i < per; ++i) tot[i] /= wtot;
         R["gtau_blocks"] = tot; R["gtau_blocks_bins"] = bins;
+    }
+    if (s->ser) {        // CTQMC.F90:8741-8742
+        const size_t nm = (size_t)s->nmeas;
+        std::vector<double> all((size_t)(2 * nf + 1) * nm);
+        HIPCHK(hipMemcpy(all.data(), s->ser, all.size() * sizeof(double), hipMemcpyDeviceToHost));
+        const double b2 = s->beta * s->beta;
+        std::vector<double> gm(all.begin(), all.begin() + nf * nm), gi(all.begin() + nf * nm, all.begin() + 2 * nf * nm), ss(all.begin() + 2 * nf * nm, all.end());
+        for (auto &v : gm) v /= b2;
+        for (auto &v : gi) v /= b2;
+        if (s->step_series & 1) R["gtau_mean_step"] = gm;
+        if (s->step_series & 2) R["gtau_mid_step"] = gi;
+        if (s->step_series & 4) R["sign_step"] = ss;
     }
     {   // acceptance ratios (CTQMC.F90:8680-8695); 16 sectors, Z = index 0
         std::vector<double> aa(16, 0.0), ar(16, 0.0);

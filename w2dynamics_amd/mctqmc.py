@@ -386,6 +386,10 @@ class MCTQMC:
             return self.result("rho2").reshape(nf, nf, nf, nf)
         if name == "densitymatrix":
             return self.result("densitymatrix").reshape(4 ** nd, 4 ** nd)
+        if name in ("gtau_mean_step", "gtau_mid_step"):  # (Nd, 2, Nmeas): chain-mean series, CTQMC.F90:43, 510-511
+            return self.result(name).reshape(nd, 2, -1)
+        if name == "sign_step":
+            return self.result(name)
         if name == "ssquare":                           # MeasSsquare: Ssquare(0:2*NBands), CTQMC.F90:161, 734
             return self.result("ssquare")
         if name == "ssquare_operator":                  # Ssquare_operator(NStates, NStates), occupation basis, CTQMC.F90:162, 746

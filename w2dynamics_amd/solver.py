@@ -49,6 +49,9 @@ RESULTSET_CONDITIONAL = (      # (key, module variable, condition on the QMC con
     ("g4iw-pp", "g4iw_pp", lambda c, fp: fp & 4 and c["MeasG4iwPP"] != 0),
     ("ntau-n0", "ntau_n0", lambda c, fp: c["segment"] == 0 and c["MeasSusz"] != 0),
     ("ssquare-operator", "ssquare_operator", lambda c, fp: c["MeasSsquare"] != 0),
+    ("gtau-mean-step", "gtau_mean_step", lambda c, fp: c["Gtau_mean_step"] != 0),
+    ("gtau-mid-step", "gtau_mid_step", lambda c, fp: c["Gtau_mid_step"] != 0),
+    ("sign-step", "sign_step", lambda c, fp: c["sign_step"] != 0),
     ("s2", "ssquare", lambda c, fp: c["MeasSsquare"] != 0 and (c["MeasDensityMatrix"] != 0 or c["Eigenbasis"] != 0)),
     ("gtau-blocks", "gtau_blocks", lambda c, fp: c["AccumGtau"] == 2),
 )
