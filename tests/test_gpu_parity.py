@@ -109,6 +109,40 @@ def test_full_size_run_properties():
     big.dest_ctqmc(); big.close()
 
 
+def test_full_size_run_properties_sequential_trace():
+    """The 5-orbital Kanamori bench workload (C5K: blocks of up to 10 states, sequential trace with the cached outside product
+    and the window checkpoints in global memory) at 16384 chains: a chain's trajectory depends on (seed, chain number) only,
+    so the chains at both ends of the full-size context come out of a 64-chain context at the same offset - same
+    configurations, same per-bin estimators - whatever else shares the GPU and wherever their checkpoint slots lie."""
+    over = dict(Nwarmups=400, Nmeas=2, NCorr=100, TaudiffMax=10.0, Ntau=200, NLegMax=40, Niw=8, Nftau=5001)
+    p, ps, pset = util.setup("C5KB", 5001, over)
+    W = 16384
+
+    def run(nw, first):
+        q = MCTQMC(nwalkers=nw, first_walker=first, walkers_per_bin=8)
+        q.init_rnd(4321); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+        q.set_taudiffmax(over["TaudiffMax"]); q.ctqmc_warmup(over["Nwarmups"]); q.ctqmc_measure(1, 1)
+        return q
+
+    big = run(W, 0)
+    glb, occb = big.gleg_bins, big.occ_bins
+    assert np.abs(big.histo.sum(axis=-1) - 1.0).max() < 1e-12
+    for first in (0, W - 64):
+        small = run(64, first)
+        for w in (0, 31, 63):
+            n, osst, _ = small.get_mc_config_scalars(w)
+            nb, osb, _ = big.get_mc_config_scalars(first + w)
+            assert n == nb and osst == osb and n > 0
+            assert np.array_equal(small.get_mc_config(n, w)[0], big.get_mc_config(n, first + w)[0])
+        # per-bin results are divided by the mean sign of their own context, and this problem has a (mild) sign problem:
+        # about one chain in 10^4 carries the opposite sign (checked against the oracle: tests/zero_sign_probe.py)
+        assert rel(small.gleg_bins * small.mean_sign, glb[first // 8: first // 8 + 8] * big.mean_sign) < 1e-12
+        assert rel(small.occ_bins * small.mean_sign, occb[first // 8: first // 8 + 8] * big.mean_sign) < 1e-12
+        small.dest_ctqmc(); small.close()
+    assert -1.0 <= big.mean_sign < -0.99
+    big.dest_ctqmc(); big.close()
+
+
 @pytest.mark.parametrize("in_lds", ["1", "0"])
 def test_matrix_path_lds_layouts_retrace_oracle(monkeypatch, in_lds):
     """The matrix path has two LDS layouts (operator matrices staged in LDS at one workgroup per CU, or left in global
