@@ -393,6 +393,7 @@ struct MatSeqPacked {
     const double *opmat, *gin; double *gout, *gdump;
     double t0, t1, beta, egs;
 };
+static_assert(sizeof(MatSeqPacked) <= 32 * sizeof(unsigned), "the evaluator's arguments must fit into the 32 argument registers");
 __device__ __forceinline__ MatSeqPacked mat_seq_pack(const MatSeqArgs &a)
 {
     MatSeqPacked p;
