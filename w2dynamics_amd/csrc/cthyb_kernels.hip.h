@@ -1830,11 +1830,11 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
             const bool wtr = act && !MAT && bitj < biti, wbl = act && fj < fi, wsame = act && (fj == fi) && ci;
             if (!__ballot(wtr || wbl || wsame)) continue;
             const double *cj = x.tc(fj), *aj = x.ta(fj);
-            int below = 0, above = 0;
-            for (int lj = 0; lj < kj; ++lj) {
-                double t1 = cj[lj], t2 = aj[lj];
-                below += (t1 < ti) + (t2 < ti); above += (t1 > ti) + (t2 > ti);
-            }
+            // operators of flavour fj at earlier times; the later ones are the rest (times are distinct; the operator itself
+            // is neither)
+            int below = 0;
+            for (int lj = 0; lj < kj; ++lj) below += (cj[lj] < ti) + (aj[lj] < ti);
+            const int above = 2 * kj - below - ((act && fj == fi) ? 1 : 0);
             if (wtr) par ^= below & 1;
             if (wbl) par ^= above & 1;
             if (wsame) par ^= above & 1;
