@@ -1333,7 +1333,10 @@ __device__ W2DYN_INLINE void glob_logtraces(Ctx &x, const int *gmap, bool flip, 
 
 // log of the scalar local trace of the current configuration as the reference carries it (Trace%Trace%log,
 // Trace.F90:5595-5724: energies relative to the ground level): the `old` half of glob_logtraces plus Egs * beta
-__device__ W2DYN_INLINE double scalar_logtrace(Ctx &x)
+// pairs != nullptr: sum_{f<g} U_fg D_fg comes from the caller (k_meas_misc gets it out of its sign scan, which visits the
+// same operator pairs: D_fg = sum_z s_z (beta - t_z) P(t_z), z over the operators of f and g, P = creators minus annihilators
+// of the other flavour at earlier times)
+__device__ W2DYN_INLINE double scalar_logtrace(Ctx &x, const double *pairs = nullptr)
 {
     const DevConst &C = x.C;
     const int nf = C.nflav, nd = C.nd;
@@ -1361,7 +1364,7 @@ __device__ W2DYN_INLINE double scalar_logtrace(Ctx &x)
             const double ng0 = (double)((x.outer >> flav_bit(g, nd)) & 1);
             uo += u * (nf0 * ng0 * beta + nf0 * sg + ng0 * sf);
             const int kg = x.order(g);
-            if (kf == 0 || kg == 0) continue;
+            if (pairs || kf == 0 || kg == 0) continue;
             const double *cg = x.tc(g), *ag = x.ta(g);
             for (int base = 0; base < 2 * kg; base += 64) {
                 const int iy = base + x.lane;
@@ -1374,7 +1377,7 @@ __device__ W2DYN_INLINE double scalar_logtrace(Ctx &x)
             }
         }
     }
-    return C.egs * beta - (uo + wave_sum(po));
+    return C.egs * beta - (uo + (pairs ? *pairs : wave_sum(po)));
 }
 
 __device__ W2DYN_INLINE void step_glob(Ctx &x)
@@ -1797,6 +1800,7 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
     else if constexpr (MAT != 0) mat_trace_current<MAT>(x);
     const int nf = C.nflav, nd = C.nd;
     int par = 0;
+    double pairsum = 0.0;            // one-state blocks: this lane's part of sum_{f<g} U_fg D_fg (scalar_logtrace)
     // every lane takes one operator (f, type, slot) of the flat list of all flavours' operators (so the lanes stay busy
     // whatever the orders of the single flavours are) and scans the operators that can contribute a transposition
     int N = 0;
@@ -1824,21 +1828,25 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
                 par ^= (ti > tw) ? 1 : 0;
             }
         }
+        double uacc = 0.0;           // one-state blocks: sum_g U(fi, g) (creators - annihilators of g before ti), for the log trace
         for (int fj = 0; fj < nf; ++fj) {
             const int kj = x.order(fj);
             const int bitj = flav_bit(fj, nd);
             const bool wtr = act && !MAT && bitj < biti, wbl = act && fj < fi, wsame = act && (fj == fi) && ci;
-            if (!__ballot(wtr || wbl || wsame)) continue;
+            if (MAT && !__ballot(wtr || wbl || wsame)) continue;
             const double *cj = x.tc(fj), *aj = x.ta(fj);
             // operators of flavour fj at earlier times; the later ones are the rest (times are distinct; the operator itself
             // is neither)
-            int below = 0;
-            for (int lj = 0; lj < kj; ++lj) below += (cj[lj] < ti) + (aj[lj] < ti);
+            int cb = 0, ab = 0;
+            for (int lj = 0; lj < kj; ++lj) { cb += cj[lj] < ti; ab += aj[lj] < ti; }
+            const int below = cb + ab;
             const int above = 2 * kj - below - ((act && fj == fi) ? 1 : 0);
             if (wtr) par ^= below & 1;
             if (wbl) par ^= above & 1;
             if (wsame) par ^= above & 1;
+            if constexpr (!MAT) { if (act && fj != fi && cb != ab) uacc = fma(C.udd[fi * nf + fj], (double)(cb - ab), uacc); }
         }
+        if constexpr (!MAT) { if (act) pairsum += (ci ? 1.0 : -1.0) * (C.beta - ti) * uacc; }
     }
     const bool worm = x.sector != 1;
     if (worm && x.lane == 0) {
@@ -1883,7 +1891,8 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
     }
     // MeasOuterHistograms (CTQMC.F90:3285-3339): sign and weight exp(log|partial trace|) of every state of the outer block
     if constexpr (MAT == 0) {
-        const double c = exp(scalar_logtrace(x));          // one state per block: the partial trace is the trace
+        const double ptot = wave_sum(pairsum);
+        const double c = exp(scalar_logtrace(x, &ptot));   // one state per block: the partial trace is the trace
         if (x.lane == 0) {
             atomicAdd(&C.acc_tcstate[(size_t)bin * C.nstates + x.outer], c);
             atomicAdd(&C.acc_signstate[(size_t)bin * C.nstates + x.outer], cfgsign);
