@@ -1796,8 +1796,10 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
     if (x.w >= C.nwalkers) return;
     ctx_load(x);
     double pt_ = 0.0, lsc_ = 0.0; int sk_ = 0;          // blocks of more than 4 states: partial traces and the block at beta/2 (mat_halves)
+    constexpr int NT2 = (MAT >= 2 && MAT <= 4) ? MAT * MAT : 1;
+    double Kt_[NT2], At_[NT2];                          // blocks of up to 4 states: the two halves as matrices (lane 0; mat_halves_tree), sk_ = operators up to beta/2
     if constexpr (MAT > 4) mat_halves(x, pt_, lsc_, sk_);
-    else if constexpr (MAT != 0) mat_trace_current<MAT>(x);
+    else if constexpr (MAT != 0) mat_halves_tree<MAT>(x, Kt_, At_, pt_, lsc_, sk_);
     const int nf = C.nflav, nd = C.nd;
     int par = 0;
     double pairsum = 0.0;            // one-state blocks: this lane's part of sum_{f<g} U_fg D_fg (scalar_logtrace)
@@ -1874,7 +1876,7 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
     if constexpr (MAT) {
         // MeasDensityMatrix_beta_half (CTQMC.F90:3088-3151): kets from 0 to beta/2 through the operators with
         // tau <= beta/2, bras from beta down to beta/2, for all states of the outer block at once
-        if constexpr (MAT >= 2 && MAT <= 4) mat_dm_tree<MAT>(x, cfgsign, bin);
+        if constexpr (MAT >= 2 && MAT <= 4) { if (x.tr_sign != 0.0) mat_dm_tree_from<MAT>(x, Kt_, At_, sk_, -cfgsign * x.tr_sign * exp(lsc_ - x.tr_log), bin); }
         else if (x.tr_sign != 0.0) mat_dm_from_halves(x, sk_, -cfgsign * x.tr_sign / fabs(wave_sum(pt_)), bin);
     } else {
     // state alive at beta/2 (Trace.F90:6334: operators with tau <= beta/2 have acted)
@@ -1898,8 +1900,7 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
             atomicAdd(&C.acc_signstate[(size_t)bin * C.nstates + x.outer], cfgsign);
         }
     } else {
-        double pt = pt_, lsc = lsc_;                       // lane i < n: partial trace of outer state i on the common scale exp(lsc)
-        if constexpr (MAT <= 4) mat_part_traces<MAT>(x, pt, lsc);
+        const double pt = pt_, lsc = lsc_;                 // lane i < n: partial trace of outer state i on the common scale exp(lsc)
         const int n = uni(x.t_n[x.outer]), off = uni(x.t_off[x.outer]);
         if (x.lane < n) {
             atomicAdd(&C.acc_tcstate[(size_t)bin * C.nstates + off + x.lane], fabs(pt) * exp(lsc));

@@ -785,6 +785,57 @@ __device__ W2DYN_INLINE void mat_dm_tree(Ctx &x, double cfgsign, int bin)
     }
 }
 
+// Blocks of up to 4 states: the same two halves as tree products (lane 0 holds K and A), from which the estimator kernel
+// takes the trace (sum of the diagonal of A K), the partial traces of the outer states (that diagonal) and the density
+// matrix at beta/2 - two tree products per measurement instead of four.  Sets x.tr_log / x.tr_sign; lane s < n(outer)
+// receives the partial trace pt on the scale exp(lsc); nk = operators up to beta/2.
+template <int NSM>
+__device__ W2DYN_INLINE void mat_halves_tree(Ctx &x, double (&K)[NSM * NSM], double (&A)[NSM * NSM], double &pt, double &lsc, int &nk)
+{
+    const DevConst &C = x.C;
+    const double b2 = 0.5 * C.beta;
+    pt = 0.0; lsc = 0.0; nk = 0;
+    x.tr_log = -HUGE_VAL; x.tr_sign = 0.0;
+#pragma unroll
+    for (int i = 0; i < NSM * NSM; ++i) { K[i] = 0.0; A[i] = 0.0; }
+    if (!(uni(x.osst[x.nops]) == x.outer)) return;
+    nk = mat_lower_eq(x, b2);
+    int exk, exa; double lk, la;
+    mat_tree_product<NSM>(x, x.osst, nk, -1, -1, 0, nk, 0.0, b2, K, exk, lk);
+    mat_tree_product<NSM>(x, x.osst, x.nops, -1, -1, nk, x.nops, b2, C.beta, A, exa, la);
+    lsc = lk + la + (double)(uni(exk) + uni(exa)) * 0.6931471805599453;
+    double tot = 0.0;
+#pragma unroll
+    for (int sidx = 0; sidx < NSM; ++sidx) {
+        double d = 0.0;
+#pragma unroll
+        for (int i = 0; i < NSM; ++i) d = fma(A[sidx * NSM + i], K[i * NSM + sidx], d);
+        d = uni(d);                                           // lane 0 holds the products
+        tot += d;
+        if (x.lane == sidx) pt = d;
+    }
+    if (tot == 0.0 || !(fabs(tot) > 0.0)) { pt = 0.0; return; }
+    x.tr_log = lsc + log(fabs(tot)); x.tr_sign = tot < 0.0 ? -1.0 : 1.0;
+}
+
+// density matrix at beta/2 from those halves: rho(i1,i2) += fac (K A)(i2,i1), fac = -cfgsign sign(trace) exp(lsc - log|trace|)
+template <int NSM>
+__device__ W2DYN_INLINE void mat_dm_tree_from(Ctx &x, const double (&K)[NSM * NSM], const double (&A)[NSM * NSM], int nk, double fac, int bin)
+{
+    const DevConst &C = x.C;
+    if (x.lane == 0) {
+        double R[NSM * NSM];
+        mat_matmul<NSM>(K, A, R);
+        const int sb = x.osst[nk], n = x.t_n[sb];
+        double *dmb = C.acc_dm + (size_t)bin * C.dmsize + C.dmoff[sb];
+#pragma unroll
+        for (int i1 = 0; i1 < NSM; ++i1)
+#pragma unroll
+            for (int i2 = 0; i2 < NSM; ++i2)
+                if (i1 < n && i2 < n) atomicAdd(&dmb[i1 * n + i2], fac * R[i2 * NSM + i1]);
+    }
+}
+
 // trace of the stored configuration (osst must be current)
 template <int MATN>
 __device__ W2DYN_INLINE void mat_trace_current(Ctx &x)
