@@ -238,6 +238,35 @@ def test_recorded_configuration_vs_reference_golden(name):
     q.dest_ctqmc(); q.close()
 
 
+@pytest.mark.parametrize("cfg,niw,nwarm", [("C2L", 2100, 30000), ("C1", 2000, 3000), ("C5Z", 300, 4000)], ids=["C2L-two-frequency-blocks", "C1-default-Niw", "C5Z-10-flavours"])
+def test_giw_production_frequency_counts_vs_oracle(cfg, niw, nwarm):
+    """k_meas_giw at the reference's default Niw = 2000 and beyond one frequency block of the kernel (2048 positive
+    frequencies per workgroup: Niw = 2100 gives a second, ragged block), with orders beyond one register tile of 24
+    annihilators (C2L, beta = 200: k ~ 35) - chain by chain against the oracle's exact sums, element by
+    element: |a - b| <= 1e-10 |b| + 1e-13 max|b| (the phases come from three table entries per frequency instead of one
+    sincos per element; G(iw) falls off as 1/w, so a max-norm alone would not see the tail)."""
+    over = dict(Ntau=100, NLegMax=12, Niw=niw, MeasGiw=1, Nwarmups=nwarm, Nmeas=2, NCorr=50, TaudiffMax=10.0)
+    p, ps, pset = util.setup(cfg, 501, over)
+    nw = 5
+    q = make_gpu(p, ps, 808, nw, wpb=2)
+    q.set_taudiffmax(10.0); q.ctqmc_warmup(nwarm); q.ctqmc_measure(1, 1)
+    gb = q.giw_bins
+    assert gb.shape == (3, p.nd, 2, 2 * niw)
+    tot = 0.0; kmaxseen = 0
+    for w in range(nw):
+        o = pyoracle.OracleWalker(p, pset, ("philox", 808, w))
+        o.set_taudiffmax(10.0); o.warmup(nwarm); o.measure()
+        r = o.results(); tot = tot + r["giw"] / nw
+        kmaxseen = max(kmaxseen, max(o.minv(orb, sp).shape[0] for orb in range(1, p.nd + 1) for sp in (1, 2)))
+        o.close()
+    a, b = q.giw, tot
+    assert np.all(np.abs(a - b) <= 1e-10 * np.abs(b) + 1e-13 * np.abs(b).max())
+    assert np.abs(a - np.conj(a[..., ::-1])).max() == 0.0          # G(-iw) = conj G(iw), exactly
+    if cfg == "C2L":
+        assert kmaxseen > 24
+    q.dest_ctqmc(); q.close()
+
+
 @pytest.mark.parametrize("atomics", ["", "1"], ids=["factorised", "atomics"])
 @pytest.mark.parametrize("name", ["C1", "C3", "C4S"])
 def test_two_particle_legendre_and_tau_vs_reference_golden(monkeypatch, name, atomics):

@@ -2452,35 +2452,103 @@ __global__ __launch_bounds__(256) void k_meas_g4leg_fact(DevConst C, double *acc
 }
 
 // Matsubara estimator (measure_giw_nfft + naive get_giw, CTQMC.F90:1015-1056, Nfft_z.F90:376-414):
-// giw(n) += sum_ij M(c_j,a_i) exp(-i w_n tau_c_j) exp(+i w_n tau_a_i), no configuration sign.
-// One wave per (bin, flavour, frequency chunk of 64): lane = frequency; the pair loop is wave-uniform, so M and the
-// taus are broadcast loads.  u_i = sum_c M(c,a) e^{-i w tau_c} first (k^2 complex MACs), then sum_a u_a e^{i w tau_a}.
-__global__ __launch_bounds__(64) void k_meas_giw(DevConst C)
+// giw(n) += sum_ij M(c_j,a_i) exp(-i w_n tau_c_j) exp(+i w_n tau_a_i), no configuration sign, w_n = (2n+1) pi/beta.
+// M is real, so giw(-w) = conj(giw(w)): only the Niw positive frequencies are computed, the mirror entry is written with
+// them.  Two-step transform  giw(n) = sum_c conj(T_c(n)) U_c(n),  U_c(n) = sum_a M(c,a) T_a(n),  T_o(n) = e^{i w_n tau_o}:
+// a complex x real multiply-add (two FMAs) per element and frequency, a complex multiply-add per creator and frequency.
+// One workgroup per (accumulator bin, flavour, block of 256 * GIW_NP frequencies), thread = frequency (GIW_NP of them,
+// 256 apart), the bin's chains looped; everything about a chain is workgroup-uniform: the row of M comes through scalar
+// loads, the FMAs take it from SGPRs, and the phases T_a(n) of GIW_TS annihilators stay in registers while the creators
+// are looped.  No sincos per element: with n = nbase + 256 p + 16 h + l the phase is the product of three table entries,
+// P3[p] = e^{i pi (2 (nbase + 256 p) + 1) x}, P2[h] = e^{2 pi i 16 h x}, P1[l] = e^{2 pi i l x}, x = tau/beta (sincospi:
+// the argument reduction is exact), 16 + 16 + GIW_NP sincos per operator and chain instead of 2 k per element.
+constexpr int GIW_TS = 24, GIW_NP = 8, GIW_TAB = 32 + GIW_NP;
+__device__ __forceinline__ void giw_fill(double2 *tab, int nops, const double *tau, double rbeta, int nbase, int tid)
 {
-    const int bin = blockIdx.x, f = blockIdx.y, ifr = blockIdx.z * 64 + threadIdx.x;   // 0-based frequency index
-    if (ifr >= C.niw2) return;
-    const int kmax = C.kmax;
-    const double freq = M_PI / C.beta * (double)(2 * (ifr + 1) - C.niw2 - 1);
-    double re = 0.0, im = 0.0;
-    int w0 = bin * C.walkers_per_bin, w1 = min(w0 + C.walkers_per_bin, C.nwalkers);
+    for (int e = tid; e < nops * GIW_TAB; e += 256) {
+        const int o = e / GIW_TAB, j = e - o * GIW_TAB;
+        const double x = tau[o] * rbeta;
+        const double arg = j < 16 ? (double)(2 * j) * x : (j < 32 ? (double)(32 * (j - 16)) * x : (double)(2 * (nbase + 256 * (j - 32)) + 1) * x);
+        double sn, cs; sincospi(arg, &sn, &cs);
+        tab[e] = make_double2(cs, sn);
+    }
+}
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// one frequency pass over one annihilator tile of 4 NG entries (na of them exist) and nc creators.  The row segments of M
+// are read unconditionally, 4 NG doubles as aligned scalar loads: entries beyond na - finite stale numbers of the
+// zero-initialised arrays, at the far end up to 184 B past the last row into the allocation's padding (dev_alloc) - meet
+// phases that are set to zero
+template <int NG>
+__device__ __forceinline__ void giw_pass(const double2 *tA, const double2 *tC, const double *Mrow0, int kmax, int na, int nc, int p, int h, int l, double &sr, double &si)
+{
+    double er[4 * NG], ei[4 * NG];
+#pragma unroll
+    for (int a = 0; a < 4 * NG; ++a) {
+        const int ac = a < na ? a : 0;
+        const double2 e = cmul(tA[ac * GIW_TAB + 32 + p], cmul(tA[ac * GIW_TAB + 16 + h], tA[ac * GIW_TAB + l]));
+        er[a] = a < na ? e.x : 0.0; ei[a] = a < na ? e.y : 0.0;
+    }
+    for (int c = 0; c < nc; ++c) {
+        const double4 *row = (const double4 *)(Mrow0 + (size_t)c * kmax);
+        double ur = 0.0, ui = 0.0;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const double4 m = row[g];
+            ur = fma(m.x, er[4 * g], ur); ui = fma(m.x, ei[4 * g], ui);
+            ur = fma(m.y, er[4 * g + 1], ur); ui = fma(m.y, ei[4 * g + 1], ui);
+            ur = fma(m.z, er[4 * g + 2], ur); ui = fma(m.z, ei[4 * g + 2], ui);
+            ur = fma(m.w, er[4 * g + 3], ur); ui = fma(m.w, ei[4 * g + 3], ui);
+        }
+        const double2 t = cmul(tC[c * GIW_TAB + 32 + p], cmul(tC[c * GIW_TAB + 16 + h], tC[c * GIW_TAB + l]));
+        sr += t.x * ur + t.y * ui; si += t.x * ui - t.y * ur;       // conj(T_c) U_c
+    }
+}
+__global__ __launch_bounds__(256) void k_meas_giw(DevConst C, const double *__restrict__ Mall, const double *__restrict__ TCall,
+                                                  const double *__restrict__ TAall, const int *__restrict__ Kall, int ccap)
+{
+    extern __shared__ double2 giw_lds[];
+    double2 *tA = giw_lds, *tC = giw_lds + GIW_TS * GIW_TAB;        // phase tables of the current annihilator tile / creator chunk
+    const int bin = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, l = tid & 15, h = tid >> 4;
+    const int niw = C.niw2 >> 1, nbase = blockIdx.z * 256 * GIW_NP, kmax = C.kmax, nf = C.nflav;
+    double are[GIW_NP], aim[GIW_NP];
+#pragma unroll
+    for (int p = 0; p < GIW_NP; ++p) { are[p] = 0.0; aim[p] = 0.0; }
+    const int w0 = bin * C.walkers_per_bin, w1 = min(w0 + C.walkers_per_bin, C.nwalkers);
     for (int w = w0; w < w1; ++w) {
-        int k = C.K[(size_t)w * C.nflav + f];
-        const double *tcp = C.TC + ((size_t)w * C.nflav + f) * kmax, *tap = C.TA + ((size_t)w * C.nflav + f) * kmax;
-        const double *Mf = C.M + ((size_t)w * C.nflav + f) * kmax * kmax;
-        for (int ic = 0; ic < k; ++ic) {
-            double sc, cc; sincos(-freq * tcp[ic], &sc, &cc);
-            double ur = 0.0, ui = 0.0;
-            for (int ia = 0; ia < k; ++ia) {
-                double sa, ca; sincos(freq * tap[ia], &sa, &ca);
-                double m = Mf[ic * kmax + ia];
-                ur += m * ca; ui += m * sa;
+        const int k = Kall[(size_t)w * nf + f];
+        if (k == 0) continue;
+        const double *tcp = TCall + ((size_t)w * nf + f) * kmax, *tap = TAall + ((size_t)w * nf + f) * kmax;
+        const double *Mf = Mall + ((size_t)w * nf + f) * kmax * kmax;
+        for (int c0 = 0; c0 < k; c0 += ccap) {
+            const int nc = min(ccap, k - c0);
+            for (int a0 = 0; a0 < k; a0 += GIW_TS) {
+                const int na = min(GIW_TS, k - a0);
+                __syncthreads();                                     // the tables' readers of the previous round are done
+                if (a0 == 0) giw_fill(tC, nc, tcp + c0, C.rbeta, nbase, tid);
+                giw_fill(tA, na, tap + a0, C.rbeta, nbase, tid);
+                __syncthreads();
+                const double *Mrow0 = Mf + (size_t)c0 * kmax + a0;
+#pragma unroll
+                for (int p = 0; p < GIW_NP; ++p) {
+                    if (nbase + 256 * p >= niw) continue;            // uniform
+                    double sr = 0.0, si = 0.0;
+                    if (na <= 8) giw_pass<2>(tA, tC, Mrow0, kmax, na, nc, p, h, l, sr, si);
+                    else if (na <= 16) giw_pass<4>(tA, tC, Mrow0, kmax, na, nc, p, h, l, sr, si);
+                    else giw_pass<GIW_TS / 4>(tA, tC, Mrow0, kmax, na, nc, p, h, l, sr, si);
+                    are[p] += sr; aim[p] += si;
+                }
             }
-            re += cc * ur - sc * ui;
-            im += cc * ui + sc * ur;
         }
     }
-    double *g = C.acc_giw + (((size_t)bin * C.nflav + f) * C.niw2 + ifr) * 2;
-    g[0] += re; g[1] += im;
+    double *g = C.acc_giw + ((size_t)bin * nf + f) * C.niw2 * 2;
+#pragma unroll
+    for (int p = 0; p < GIW_NP; ++p) {
+        const int n = nbase + 256 * p + tid;
+        if (n < niw) {
+            double *gp = g + (size_t)(niw + n) * 2, *gm = g + (size_t)(niw - 1 - n) * 2;
+            gp[0] += are[p]; gp[1] += aim[p]; gm[0] += are[p]; gm[1] -= aim[p];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -39,7 +39,10 @@ void launch_gtau_blocks(const DevConst &C, hipStream_t st, const double *dat, in
 }
 void launch_meas_giw(const DevConst &C, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_meas_giw, dim3(C.nbins, C.nflav, (C.niw2 + 63) / 64), dim3(64), 0, st, C);
+    // creators in chunks of ccap operators (phase tables in LDS: 640 B per operator), one chunk in practice
+    const int ccap = std::min(C.kmax, 104), niw = C.niw2 / 2, per = 256 * GIW_NP;
+    const size_t lds = (size_t)(GIW_TS + ccap) * GIW_TAB * sizeof(double2);
+    hipLaunchKernelGGL(k_meas_giw, dim3(C.nbins, C.nflav, (niw + per - 1) / per), dim3(256), lds, st, C, C.M, C.TC, C.TA, C.K, ccap);
 }
 void launch_meas_g4leg(const DevConst &C, hipStream_t st, double *acc_tau, double *acc_leg, int nbl, int nt, int nl, int nwb)
 {

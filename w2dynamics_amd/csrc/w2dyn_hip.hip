@@ -192,7 +192,9 @@ bool get_str(w2dyn_solver *s, const char *id, std::string &out)
 template <class T> int dev_alloc(w2dyn_solver *s, T *&ptr, size_t count)
 {
     void *p = nullptr;
-    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    // 256 bytes of zeroed padding behind every array: k_meas_giw reads rows of M in aligned segments of 4 doubles per
+    // scalar load and may run up to 184 bytes past the last row (the values meet zero phases)
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T) + 256;
     HIPCHK(hipMalloc(&p, bytes));
     HIPCHK(hipMemsetAsync(p, 0, bytes, s->stream));
     s->allocs.push_back(p);

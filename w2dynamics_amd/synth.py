@@ -125,6 +125,8 @@ def config(name: str, nftau: int = 5001) -> Problem:
         return make_problem(1, 10.0, 2.0, nftau=nftau)
     if name == "C2":
         return make_problem(1, 100.0, 2.0, nftau=nftau)
+    if name == "C2L":      # C2 at half the temperature: orders of 30-40 per flavour (estimator kernels: more than one register tile)
+        return make_problem(1, 200.0, 2.0, nftau=nftau)
     if name == "C3":
         return make_problem(2, 50.0, 2.0, j=0.25, nftau=nftau)
     if name == "C4":
