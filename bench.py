@@ -370,7 +370,10 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
             gb4 = by4 / (g4_ms * 1e-3) / 1e9 if g4_ms > 0 else 0.0
             tr2, _ = pmc_traffic("k_meas_g2iw", W, wname); tr4, _ = pmc_traffic("k_meas_g4iw", W, wname)
             out["roofline_g2iw"] = {"kernel": "k_meas_g2iw", "bound": "mfma", "achieved": tf2, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": tf2 / FP64_PEAK_TFLOPS, "traffic": tr2, "avg_launch_ms": g2_ms, "launches": ng2, "algorithmic_flops_per_launch": fl2}
+                                    "frac": tf2 / FP64_PEAK_TFLOPS, "traffic": tr2, "avg_launch_ms": g2_ms, "launches": ng2, "algorithmic_flops_per_launch": fl2,
+                                    # what bounds it at production boxes (n2 >> k): every chain's n2 x n2 table is written once
+                                    "hbm_bytes_written_per_launch": float(W) * nflav * n2 * n2 * 16.0,
+                                    "hbm_write_gbs": float(W) * nflav * n2 * n2 * 16.0 / (g2_ms * 1e-3) / 1e9 if g2_ms > 0 else 0.0}
             out["roofline_g4iw"] = {"kernel": "k_meas_g4iw", "bound": "hbm", "achieved": gb4, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": gb4 / HBM_PEAK_GBS, "traffic": tr4, "avg_launch_ms": g4_ms, "launches": ng4,
                                     "algorithmic_bytes_per_launch": by4, "complex_macs_per_launch": float(W) * n4,

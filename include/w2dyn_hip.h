@@ -30,7 +30,8 @@ enum {
     W2DYN_EUNSUPPORTED = -2, /* a mode of the reference this build refuses loudly             */
     W2DYN_EHIP = -3,         /* HIP runtime error                                            */
     W2DYN_EOVERFLOW = -4,    /* a walker exceeded the configured expansion-order capacity    */
-    W2DYN_ENUMERIC = -5      /* reference would `stop` (e.g. "DetRat too small in removal")  */
+    W2DYN_ENUMERIC = -5,     /* reference would `stop` (e.g. "DetRat too small in removal")  */
+    W2DYN_EINTERRUPTED = -6  /* stepping call after SIGINT / SIGTERM / SIGUSR1: nothing launched (the ctqmc_* loops end softly instead: `aborted`) */
 };
 
 /* lifetime -------------------------------------------------------------------------------------------------- */
@@ -166,7 +167,8 @@ int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out);
 
 /* timing of the last w2dyn_sweep / w2dyn_measure_once launches, measured with HIP events on the context's own
  * stream: average kernel duration in ms and number of launches since the last reset (bench.py roofline leg) */
-/* timing: off by default (launches are asynchronous); on: every launch is bracketed by HIP events and the host waits for it */
+/* timing: off by default; on: every launch is bracketed by a pair of HIP events on the context's stream.  Launches stay
+ * asynchronous - the pairs are read out when the stream is waited for anyway (w2dyn_sync, w2dyn_kernel_time) */
 int w2dyn_set_timing(w2dyn_solver *s, int on);
 int w2dyn_kernel_time(w2dyn_solver *s, const char *kernel /* "sweep" | "sweep_worm" | "sweep_calibrate" | "meas_gleg" | "meas_misc" | "meas_giw" | "meas_g2iw" | "meas_g4iw" | "meas_g4w" | "meas_gw" | "meas_gtau_ac" | "meas_g4leg" */,
                       double *avg_ms, int64_t *launches, int reset);

@@ -10,7 +10,7 @@
 #define W2DYN_RNG_H
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define W2DYN_HD __host__ __device__ inline
 #else
 #define W2DYN_HD static inline

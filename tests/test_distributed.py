@@ -67,6 +67,25 @@ def _worker(rank, world, port, out):
                                                                        "cplx": (ra.size, (rb.size - 1) // 3, cplx.shape[1:], True)}, comm).allreduce()
         res["pm_mean"] = pm.sample("real").mean(); res["pm_stderr"] = pm.sample("real").stderr()
         res["pm_cmean"] = pm.sample("cplx", 0.5).mean(); res["pm_cstderr"] = pm.sample("cplx", 0.5).stderr(); res["pm_n"] = pm.sample("cplx").ntotal
+        # one observation per rank (sign, acceptance rates, rho1 ...): the error bar is the between-rank term alone.  Mean 1,
+        # spread 1e-9: squaring before the shift would lose it in the rounding of n |m|^2
+        tiny = np.array([[1.0 + (1e-9 if rank else -1e-9), 5.0 + 3e-9 * rank]])
+        st = DistributedSample(tiny, comm)
+        res["tiny_mean"] = st.mean(); res["tiny_stderr"] = st.stderr(); res["tiny_n"] = st.ntotal
+        # a moments-only sample says so when asked for what it cannot give
+        mo = pm.sample("real")
+        msgs = []
+        for call in (lambda: mo.apply(lambda x: x), lambda: join(mo, mo), lambda: mo.cov()):
+            try:
+                call(); msgs.append("")
+            except ValueError as e:
+                msgs.append(str(e))
+        from w2dynamics_amd.postproc import DistributedJackknife
+        try:
+            DistributedJackknife(mo); msgs.append("")
+        except ValueError as e:
+            msgs.append(str(e))
+        res["moments_only_msgs"] = np.array(msgs)
         comm.Barrier()
         # chain sharding: rank r owns chains [r*W, (r+1)*W) of one global family; no chain belongs to two ranks
         W = 5
@@ -110,6 +129,11 @@ def test_two_rank_statistics_and_packed_allreduce(tmp_path):
     np.testing.assert_allclose(r["pm_cmean"], 0.5 * cplx.mean(0), rtol=1e-13)
     np.testing.assert_allclose(r["pm_cstderr"], 0.5 * cplx.std(0, ddof=1) / np.sqrt(n), rtol=1e-12)
     assert int(r["pm_n"]) == n
+    tiny = np.array([[1.0 - 1e-9, 5.0], [1.0 + 1e-9, 5.0 + 3e-9]])
+    assert int(r["tiny_n"]) == 2
+    np.testing.assert_allclose(r["tiny_mean"], tiny.mean(0), rtol=1e-15)
+    np.testing.assert_allclose(r["tiny_stderr"], tiny.std(0, ddof=1) / np.sqrt(2), rtol=1e-6)      # 1e-9 and 1.5e-9, not 0
+    assert all("moments only" in m for m in r["moments_only_msgs"])
 
 
 def test_single_process_comm_is_identity():
@@ -122,3 +146,8 @@ def test_single_process_comm_is_identity():
     np.testing.assert_allclose(s.stderr(), x.std(0, ddof=1) / 2.0)
     with pytest.raises(ValueError):
         DistributedSample(x, TorchComm(), ntotal=3)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                  # a single observation: NaN error bar, no division warning
+        one = DistributedSample(x[:1], TorchComm())
+        assert np.all(np.isnan(one.stderr())) and np.array_equal(one.mean(), x[0])

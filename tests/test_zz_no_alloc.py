@@ -23,13 +23,19 @@ def _run(noalloc, nw, nwf, nwb, seed):
     q.init_rnd(seed); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
     q.set_taudiffmax(4.0); q.ctqmc_warmup(over["Nwarmups"])
     q.set_sector(1, 1); q.measure_begin()
+    import torch
+    q.sync(); torch.cuda.mem_get_info()                 # first call sets up torch's own context: not part of the comparison
+    free0 = torch.cuda.mem_get_info()[0]                # hipMemGetInfo: free bytes of the device
     for _ in range(over["Nmeas"]):
         q.sweep(over["NCorr"])
         if noalloc:
             q.measure_once_noalloc()
         else:
             q.measure_once()
-    q.sync(); q.measure_finish()
+    q.sync()
+    if noalloc:                                         # the property itself: not a byte of device memory taken or given back
+        assert torch.cuda.mem_get_info()[0] == free0
+    q.measure_finish()
     res = {k: np.array(getattr(q, k)) for k in ("g4iw", "g4iw_pp", "g2iw", "gleg", "gtau", "giw", "occ", "histo")}
     res["g4iw_bins"] = np.array(q.g4iw_bins)
     q.dest_ctqmc(); q.close()

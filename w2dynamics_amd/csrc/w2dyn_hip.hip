@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -36,26 +37,33 @@ struct KTimer {
 constexpr size_t W2DYN_SCRATCH_BYTES = (size_t)32 << 20;
 constexpr int W2DYN_MAX_DEVICES = 64;
 void *g_scratch_ptr[W2DYN_MAX_DEVICES] = {nullptr};
+std::mutex g_scratch_mutex;
 
 // Soft abort (Signals.F90:117-137): SIGTERM / SIGINT / SIGUSR1 are trapped from init_solver to the end of ctqmc_measure
 // (CTQMC.F90:8076-8078, 9352-9355); the handler only raises this flag, the sampling loops look at it between launches.
+// The handlers are process-wide, the contexts are not: every context that has a solver holds one reference, the first
+// one installs the handlers, the last one puts the previous ones back (acquire_traps / release_traps below, which also
+// run on every error exit of ctqmc_measure and in w2dyn_destroy).  The stepping entry points (w2dyn_sweep,
+// w2dyn_measure_once[_noalloc]) have no loop of their own to leave early: they return W2DYN_EINTERRUPTED once the flag is up.
 volatile sig_atomic_t g_signal_fired = 0;
-bool g_traps_installed = false;
+int g_trap_users = 0;
+std::mutex g_trap_mutex;
 struct sigaction g_prev_term, g_prev_int, g_prev_usr1;
 void trap_notify(int) { g_signal_fired = 1; }
 void install_traps()
 {
-    if (g_traps_installed) return;
+    std::lock_guard<std::mutex> lock(g_trap_mutex);
+    if (g_trap_users++ > 0) return;
     struct sigaction sa; memset(&sa, 0, sizeof sa);
     sa.sa_handler = trap_notify; sigemptyset(&sa.sa_mask);
     sigaction(SIGTERM, &sa, &g_prev_term); sigaction(SIGINT, &sa, &g_prev_int); sigaction(SIGUSR1, &sa, &g_prev_usr1);
-    g_traps_installed = true;
 }
 void clear_traps()      // reset_notify + clear_trap, CTQMC.F90:9352-9355
 {
-    if (!g_traps_installed) return;
+    std::lock_guard<std::mutex> lock(g_trap_mutex);
+    if (g_trap_users == 0 || --g_trap_users > 0) return;
     sigaction(SIGTERM, &g_prev_term, nullptr); sigaction(SIGINT, &g_prev_int, nullptr); sigaction(SIGUSR1, &g_prev_usr1, nullptr);
-    g_traps_installed = false; g_signal_fired = 0;
+    g_signal_fired = 0;
 }
 
 }  // namespace
@@ -66,6 +74,7 @@ static __device__ __align__(256) unsigned char w2dyn_scratch[W2DYN_SCRATCH_BYTES
 static hipError_t scratch_address(int device, void **out)
 {
     if (device < 0 || device >= W2DYN_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (!g_scratch_ptr[device]) {
         void *p = nullptr;
         hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(w2dyn_scratch));
@@ -93,6 +102,7 @@ struct w2dyn_solver {
     int fourpnt = 0;
     std::vector<Param> paras;
     bool have_paras = false, have_solver = false;
+    bool has_traps = false;                          // this context holds a reference on the signal handlers
     // parameters picked up at init_solver
     int nd = 0, nflav = 0, nstates = 0, nftau = 0, ntau = 0, nleg = 0, niw = 0, meas_giw = 0, ncorr = 0, maxhisto = 0;
     int64_t nmeas = 0;
@@ -147,6 +157,8 @@ struct w2dyn_solver {
 };
 
 namespace {
+void acquire_traps(w2dyn_solver *s) { if (!s->has_traps) { install_traps(); s->has_traps = true; } }
+void release_traps(w2dyn_solver *s) { if (s->has_traps) { clear_traps(); s->has_traps = false; } }
 
 int fail(w2dyn_solver *s, int code, const char *fmt, ...)
 {
@@ -452,7 +464,7 @@ int w2dyn_create(w2dyn_solver **out, int device)
     w2dyn_solver *s = new w2dyn_solver();
     s->device = device;
     if (hipSetDevice(device) != hipSuccess || scratch_address(device, &s->scratch) != hipSuccess || hipStreamCreate(&s->stream) != hipSuccess ||
-        hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { delete s; return W2DYN_EHIP; }
+        hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { w2dyn_destroy(s); return W2DYN_EHIP; }      // frees what exists
     if (hipDeviceGetAttribute(&s->ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || s->ncu <= 0) s->ncu = 256;
     *out = s;
     return 0;
@@ -463,6 +475,7 @@ int w2dyn_destroy(w2dyn_solver *s)
     if (!s) return 0;
     (void)hipSetDevice(s->device);
     free_device(s);
+    release_traps(s);
     if (s->packbuf) (void)hipFree(s->packbuf);
     if (s->packscale) (void)hipFree(s->packscale);
     for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
@@ -845,7 +858,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     HIPCHK(hipStreamSynchronize(s->stream));
     s->have_solver = true; s->aborted = 0; s->meas_done = 0; s->steps_done = 0;
     s->res.clear(); s->counters.assign(C_NCOUNT, 0.0);
-    install_traps();                                                                  // CTQMC.F90:8076-8078
+    acquire_traps(s);                                                                 // CTQMC.F90:8076-8078
     return 0;
 }
 
@@ -881,9 +894,20 @@ static void accpair_to_default(w2dyn_solver *s)
     s->C.accpair = s->accpair_default; s->C.naccpair = s->ntau; s->C.accpair_max = s->beta; s->C.calib = 0;
 }
 
+static int interrupted_call(w2dyn_solver *s, const char *what)
+{
+    return fail(s, W2DYN_EINTERRUPTED, "%s: a signal (SIGINT / SIGTERM / SIGUSR1) arrived while this context's solver exists; nothing was launched", what);
+}
+
+static int sweep_impl(w2dyn_solver *s, int64_t nsteps, int count_as_sampling);
 int w2dyn_sweep(w2dyn_solver *s, int64_t nsteps, int count_as_sampling)
 {
     if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "sweep before init_solver");
+    if (g_signal_fired) return interrupted_call(s, "w2dyn_sweep");
+    return sweep_impl(s, nsteps, count_as_sampling);
+}
+static int sweep_impl(w2dyn_solver *s, int64_t nsteps, int count_as_sampling)
+{
     if (nsteps <= 0) return 0;
     HIPCHK(hipSetDevice(s->device));
     LaunchCfg l = walker_launch(s);
@@ -978,7 +1002,7 @@ int w2dyn_ctqmc_warmup(w2dyn_solver *s, int64_t n)
     // and a signal (CTQMC.F90:8214) is noticed between two of them
     const int64_t WARMUP_CHUNK = 200000;
     for (int64_t done = 0; done < n && !g_signal_fired; done += WARMUP_CHUNK) {
-        if ((rc = w2dyn_sweep(s, std::min<int64_t>(WARMUP_CHUNK, n - done), 0))) return rc;
+        if ((rc = sweep_impl(s, std::min<int64_t>(WARMUP_CHUNK, n - done), 0))) return rc;
         if ((rc = finish_paused(s, 0))) return rc;
     }
     if ((rc = grow_if_close(s))) return rc;
@@ -1113,6 +1137,7 @@ static int measure_once_impl(w2dyn_solver *s, double2 *g2buf)
 int w2dyn_measure_once(w2dyn_solver *s)
 {
     if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "measure before init_solver");
+    if (g_signal_fired) return interrupted_call(s, "w2dyn_measure_once");
     return measure_once_impl(s, s->G2);
 }
 
@@ -1124,6 +1149,7 @@ int w2dyn_measure_once_noalloc(w2dyn_solver *s)
     if (need > W2DYN_SCRATCH_BYTES)
         return fail(s, W2DYN_EINVAL, "measure_once_noalloc: %zu bytes of per-chain g2 tables (chains x flavours x (2 (N4iwf + N4iwb))^2 x 16) exceed the static scratch of %zu bytes", need, (size_t)W2DYN_SCRATCH_BYTES);
     if (!s->scratch) return fail(s, W2DYN_EHIP, "measure_once_noalloc: no scratch address for device %d", s->device);
+    if (g_signal_fired) return interrupted_call(s, "w2dyn_measure_once_noalloc");
     // nothing below allocates, frees or waits for the GPU: kernel launches on the context's stream only (timing is
     // skipped).  k_meas_g2iw writes every entry of every chain's table, so the array's old contents never matter.
     const bool timing = s->timing;
@@ -1528,6 +1554,12 @@ static int enter_sector(w2dyn_solver *s, int isector, int icomponent)
 int w2dyn_ctqmc_measure(w2dyn_solver *s, int isector, int icomponent)
 {
     if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "ctqmc_measure before init_solver");
+    // whatever way this call ends - result, soft abort, error - the context is back in Z space and gives up its reference
+    // on the signal handlers (CTQMC.F90:9352-9355)
+    struct Leave {
+        w2dyn_solver *s;
+        ~Leave() { s->cur_isector = 1; s->C.isector = 1; s->C.p_wins = 0.0; release_traps(s); }
+    } leave{s};
     int rc;
     if ((rc = enter_sector(s, isector, icomponent))) return rc;
     if ((rc = w2dyn_measure_begin(s))) return rc;
@@ -1541,17 +1573,15 @@ int w2dyn_ctqmc_measure(w2dyn_solver *s, int isector, int icomponent)
     for (int64_t m = 0; m < s->nmeas && !s->no_sampling; ++m) {
         if (g_signal_fired) { interrupted = true; break; }
         double a = now_s();
-        if ((rc = w2dyn_sweep(s, s->ncorr, 1))) return rc;
+        if ((rc = sweep_impl(s, s->ncorr, 1))) return rc;
         tsteps += now_s() - a;
-        if ((rc = w2dyn_measure_once(s))) return rc;
+        if ((rc = measure_once_impl(s, s->G2))) return rc;
         if ((m % MEAS_SYNC) == MEAS_SYNC - 1) { if ((rc = grow_if_close(s))) return rc; }
     }
     if ((rc = w2dyn_sync(s))) return rc;
     s->time_sim = now_s() - t0; s->time_sim_steps = tsteps;
     rc = w2dyn_measure_finish(s);
     if (interrupted && rc == 0) s->aborted = s->meas_done == 0 ? 2 : 1;
-    s->cur_isector = 1; s->C.isector = 1; s->C.p_wins = 0.0;
-    clear_traps();                                                                    // CTQMC.F90:9352-9355
     return rc;
 }
 
@@ -1590,7 +1620,7 @@ int w2dyn_count_steps(w2dyn_solver *s, int isector, int icomponent, int64_t nfix
     HIPCHK(hipMemcpy(TC0.data(), C.TC, TC0.size() * sizeof(double), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(TA0.data(), C.TA, TA0.size() * sizeof(double), hipMemcpyDeviceToHost));
     const int kmax0 = C.kmax;
-    if ((rc = w2dyn_sweep(s, nfix, 1))) return rc;
+    if ((rc = sweep_impl(s, nfix, 1))) return rc;      // a signal is left pending for ctqmc_measure, as in the reference
     if ((rc = finish_paused(s, 2))) return rc;
     if ((rc = check_walker_errors(s))) return rc;
     HIPCHK(hipMemcpy(ws1.data(), C.ws, W * sizeof(WalkerScalars), hipMemcpyDeviceToHost));
@@ -1630,7 +1660,7 @@ int w2dyn_dest_ctqmc(w2dyn_solver *s)
     if (!s) return W2DYN_EINVAL;
     (void)hipSetDevice(s->device);
     free_device(s);
-    clear_traps();
+    release_traps(s);
     return 0;
 }
 

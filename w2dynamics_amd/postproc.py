@@ -109,6 +109,7 @@ class DistributedJackknife:
     cached moments); the replicas of this rank are formed in one vector operation."""
 
     def __init__(self, sample):
+        sample._need_observations("DistributedJackknife")
         self.comm = sample.comm
         self.nlocal, self.ntotal = sample.nlocal, sample.ntotal
         self._mean = sample.mean()

@@ -41,7 +41,7 @@ RESULTSET_ALWAYS = {
 }
 RESULTSET_CONDITIONAL = (      # (key, module variable, condition on the QMC configuration and FourPnt)
     ("giw-meas", "giw", lambda c, fp: c["MeasGiw"] != 0 and c["offdiag"] == 0),
-    ("g2iw", "g2iw", lambda c, fp: c["MeasG2iw"] != 0 and fp & 4),
+    ("g2iw", "g2iw", lambda c, fp: c["MeasG2iw"] != 0),
     ("densitymatrix", "densitymatrix", lambda c, fp: c["MeasDensityMatrix"] != 0 and c["segment"] == 0),
     ("rho2", "rho2", lambda c, fp: c["MeasDensityMatrix"] != 0 and c["segment"] == 0),
     ("rho1", "rho1", lambda c, fp: c["MeasDensityMatrix"] != 0 and c["segment"] == 0),
@@ -87,6 +87,7 @@ class HipCtHybSolver:
         self.ctqmc.init_rnd(seed)
         self.ctqmc.fancy_prog = False
         self.fttype = "legendre"         # [General] FTType of the reference's configuration (impurity.py:1054)
+        self.last_local = {}             # this rank's own values of quantities that are averaged over the ranks (eta, window)
 
     def set_problem(self, problem, compute_fourpoint=0):
         """problem: w2dynamics_amd.synth.Problem (arrays already in init_solver layout, muimp negated)."""
@@ -148,6 +149,9 @@ class HipCtHybSolver:
         result = {}
         for key, var in names.items():
             if key in ("g4iw", "g4iw-pp", "g2iw"):
+                if key == "g2iw" and not fp & 4:        # allocated and zeroed, but only measured along with g4iw (CTQMC.F90:838-840, 2157)
+                    n2 = 2 * (int(c["N4iwf"]) + int(c["N4iwb"]))
+                    result[key] = DistributedSample(np.zeros((1, nd, 2, n2, n2), dtype=complex), self.comm)
                 continue                                # device-made moments (solve)
             if key in RESULTSET_BINNED:
                 local = np.asarray(getattr(q, RESULTSET_BINNED[key]))
@@ -201,39 +205,36 @@ class HipCtHybSolver:
         if worm_warmups < 0:
             worm_warmups = int(0.1 * self.qmc["Nwarmups"])
 
-        def balance(eta):
+        def imbalance(eta):
+            """(steps in worm space - steps in Z space) / all steps of a count_steps run at this eta."""
             q.wormeta[:] = eta
             sw, sz = q.count_steps(isector, icomponent, worm_warmups)
             if sw + sz != worm_warmups:
                 raise ValueError("%d steps in worm, %d steps in Z, some steps missing!" % (sw, sz))
-            return sw, sz
+            return float(sw - sz) / float(sw + sz), sw, sz
 
-        search = int(self.qmc["WormSearchEta"])
-        if search == 1:            # rescaling search, impurity.py:717-742
-            q.wormeta[:] = float(self.qmc["WormEta"])
-            for i_try in range(50):
-                sw, sz = balance(q.wormeta[0])
-                if abs(float(sw - sz)) / float(sw + sz) > 0.1:
-                    if i_try == 49 or sw == 0:
-                        q.wormeta[:] = 0.0
-                        break
-                    q.wormeta[:] = q.wormeta[:] * float(sz) / float(sw)
-                else:
+        # what the reference's two searches do (impurity.py:717-779), as one table: mode 1 rescales eta by the ratio of the
+        # step counts until the two spaces are balanced within 10 % (50 rounds, eta = 0 when worm space is never reached);
+        # mode 2 looks for the root of the imbalance on [1e-4, 1e2], then on [1e-6, 1e4]; otherwise eta = WormEta
+        mode = int(self.qmc["WormSearchEta"])
+        eta = float(self.qmc["WormEta"])
+        if mode == 1:
+            for round_ in range(50):
+                d, sw, sz = imbalance(eta)
+                if abs(d) <= 0.1:
                     break
-            eta = float(q.wormeta[0])
-        elif search == 2:          # root finding, impurity.py:744-779
-            def eta_root(eta):
-                sw, sz = balance(eta)
-                return float(sw - sz) / float(sw + sz)
-            try:
-                eta = opt.brentq(eta_root, 1e-4, 1e2, xtol=0.001, rtol=0.001, maxiter=50, disp=True)
-            except ValueError:
+                eta = 0.0 if (sw == 0 or round_ == 49) else eta * float(sz) / float(sw)
+                if eta == 0.0:
+                    break
+        elif mode == 2:
+            eta = 0.0
+            for lo, hi in ((1e-4, 1e2), (1e-6, 1e4)):
                 try:
-                    eta = opt.brentq(eta_root, 1e-6, 1e4, xtol=0.001, rtol=0.001, maxiter=50, disp=True)
-                except ValueError:
-                    eta = 0.0
-        else:
-            eta = float(self.qmc["WormEta"])
+                    eta = opt.brentq(lambda e: imbalance(e)[0], lo, hi, xtol=0.001, rtol=0.001, maxiter=50, disp=True)
+                    break
+                except ValueError:      # no sign change on this bracket
+                    continue
+        self.last_local["eta"] = float(eta)               # this rank's own value; all ranks go on with the mean
         eta_stat = DistributedSample([np.array([eta])], self.comm)
         eta_mean = float(np.asarray(eta_stat.mean()).ravel()[0])
         q.wormeta[:] = eta_mean
@@ -301,31 +302,32 @@ class HipCtHybSolver:
         return result
 
     def calibrate_taudiff_max(self, phase1pairnum=1000, phase2taugrid=100, phase2pairnum=1000, nprogress=100000):
-        """Two-phase window calibration in the call order of `CtHybSolver.calibrate_taudiff_max`
-        (`impurity.py:1150-1172`): the 99.5th percentile of the accepted pair distances sets a provisional window,
-        then the distance histogram on that window is fitted (`estimate_taudiff_max`)."""
-        q = self.ctqmc
-        q.init_counters()
-        q.ctqmc_calibrate(True, phase1pairnum, phase2taugrid, phase2pairnum, nprogress)
-        acctaulist = q.accpairtau
-        acctaulist.sort()
-        taudiffmax = DistributedSample([np.array((acctaulist[int(0.995 * phase1pairnum)],))], self.comm).mean()
-        taudiffmax = float(np.asarray(taudiffmax).ravel()[0])
-        q.set_taudiffmax(taudiffmax)
-        q.init_counters()
-        q.ctqmc_calibrate(False, phase1pairnum, phase2taugrid, phase2pairnum, nprogress)
-        return self.estimate_taudiff_max(self.comm, q.accpair, taudiffmax, phase2taugrid)
-
-    @staticmethod
-    def estimate_taudiff_max(comm, accept_pair, taudiffmax, phase2taugrid):
-        """Distance at which the fitted exponential decay of the pair acceptance has dropped to 1 %, largest over the
-        flavours (`impurity.py:1174-1195`)."""
+        """Window calibration with the library's two calibration phases (`ctqmc_calibrate`), the protocol of
+        `CtHybSolver.calibrate_taudiff_max` / `estimate_taudiff_max` (`impurity.py:1150-1195`): phase 1 collects accepted
+        pair distances with one window, their 99.5 % quantile - averaged over the ranks - is the provisional window; phase 2
+        histograms the accepted distances on it, and the distance at which an exponential fitted to a flavour's histogram
+        has dropped to 1 % is that flavour's estimate; the largest one is returned."""
         import scipy.optimize as opt
-        accept_pair = np.asarray(DistributedSample([np.asarray(accept_pair, dtype=np.float64)], comm).mean())
-        taus = (np.arange(phase2taugrid) + 0.5) * taudiffmax / phase2taugrid          # transform.tau_bins(..., "centre")
-        estimates = np.empty(accept_pair.shape[:2])
-        for b in range(accept_pair.shape[0]):
-            for s in range(accept_pair.shape[1]):
-                fit = opt.leastsq(lambda p, t, acc: acc - p[0] * np.exp(p[1] * t), (accept_pair[b, s, 0], -1), (taus, accept_pair[b, s]))
-                estimates[b, s] = np.log(1 - 0.99) / fit[0][1]
-        return float(np.amax(estimates))
+        q = self.ctqmc
+
+        def phase(first):
+            q.init_counters()
+            q.ctqmc_calibrate(first, phase1pairnum, phase2taugrid, phase2pairnum, nprogress)
+
+        def over_ranks(x):
+            return np.asarray(DistributedSample([np.asarray(x, dtype=np.float64)], self.comm).mean())
+
+        phase(True)
+        quantile = float(np.sort(q.accpairtau)[int(0.995 * phase1pairnum)])
+        window = float(over_ranks([quantile]).ravel()[0])
+        self.last_local.update(taudiffmax_phase1=quantile, taudiffmax_phase1_mean=window)
+        q.set_taudiffmax(window)
+        phase(False)
+        histo = over_ranks(q.accpair)                                            # (band, spin, distance bin)
+        centres = (np.arange(phase2taugrid) + 0.5) * window / phase2taugrid      # transform.tau_bins(..., "centre")
+
+        def decay_length(acc):
+            amp_rate = opt.leastsq(lambda p: acc - p[0] * np.exp(p[1] * centres), (acc[0], -1.0))[0]
+            return np.log(1.0 - 0.99) / amp_rate[1]
+
+        return float(max(decay_length(acc) for acc in histo.reshape(-1, phase2taugrid)))

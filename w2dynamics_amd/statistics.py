@@ -6,9 +6,11 @@ the reference's driver and result writer use: `mean`, `stderr`, `var`, `sum`, `a
 differently:
 
   * every sample is reduced to its moments once - per rank the count n_r, the sum, and the squared deviations from the
-    rank's own mean - and ONE packed fp64 all-reduce combines (n_r, n_r m_r, M2_r, n_r |m_r|^2) of all ranks; mean,
-    variance and standard error are then read off the cached moments (between-rank part by the parallel-axis formula).
-    On xGMI a ring all-reduce is bound by one link, so one bucket instead of two or three collectives per quantity;
+    rank's own mean - and ONE packed fp64 all-reduce combines (n_r, n_r m_r, M2_r) of all ranks; with more than one rank
+    a second, equally packed all-reduce adds the between-rank part n_r |m_r - m|^2 about the GLOBAL mean m (two-pass:
+    squaring after the shift, so a rank-to-rank spread of 1e-9 of the mean survives - samples with one observation per
+    rank consist of this term alone); mean, variance and standard error are then read off the cached moments.
+    On xGMI a ring all-reduce is bound by one link, so one bucket per pass instead of one collective per quantity and statistic;
   * the moments can also come straight from the GPU (`from_moments`, fed by `MCTQMC.reduce_pack`): the per-bin results
     are summed and squared by a kernel and the packed device buffer goes into `torch.distributed.all_reduce` (RCCL) as it
     is - no numpy round trip of data that already sits in HBM.
@@ -132,7 +134,10 @@ class DistributedSample:
     def from_moments(cls, n, s1, m2, between, comm=None, reduced=True):
         """Sample known only through its moments - count, sum, squared deviations from the rank means and
         n_r |m_r|^2 - e.g. one record of `PackedMoments` (made on the GPU, all-reduced there).  `reduced=False`: the
-        moments are this rank's and are all-reduced here.  `local` is not available for such a sample."""
+        moments are this rank's and are all-reduced here.  `local` is not available for such a sample.  The
+        between-rank part between - n |m|^2 is a difference of large numbers: it is left out on a single rank (where it
+        is zero by construction) and only trusted down to ~1e-15 n |m|^2 across ranks, which is far below the scatter of
+        the accumulator bins these records are made of."""
         self = cls.__new__(cls)
         self.comm = comm if comm is not None else TorchComm()
         self.local = None; self.nlocal = int(round(float(n)))
@@ -142,8 +147,15 @@ class DistributedSample:
             n = nn[0]
         n = float(n)
         self._ntotal = int(round(n))
-        self._moments = (n, s1, m2 + np.maximum(between - n * np.abs(s1 / n) ** 2, 0.0))
+        if self.comm.Get_size() > 1:
+            m2 = m2 + np.maximum(between - n * np.abs(s1 / n) ** 2, 0.0)
+        self._moments = (n, s1, m2)
         return self
+
+    def _need_observations(self, what):
+        if self.local is None:
+            raise ValueError("%s needs the observations, but this sample holds moments only (count, sum, squared deviations: a record "
+                             "of MCTQMC.reduce_pack / PackedMoments); take mean(), var(), stderr() from it" % what)
 
     def _reduce(self):
         if self._moments is None:
@@ -155,13 +167,15 @@ class DistributedSample:
                 m2_r = (dev.real ** 2 + dev.imag ** 2).sum(axis=0) if np.iscomplexobj(x) else (dev ** 2).sum(axis=0)
             else:
                 m_r = np.zeros(x.shape[1:], x.dtype); m2_r = np.zeros(x.shape[1:])
-            n, s1, m2, between = self.comm.allreduce_packed([np.array([n_r]), n_r * m_r, m2_r, n_r * np.abs(m_r) ** 2])
+            n, s1, m2 = self.comm.allreduce_packed([np.array([n_r]), n_r * m_r, m2_r])
             n = float(n[0])
             if self._ntotal is not None and self._ntotal != int(round(n)):
                 raise ValueError("ntotal = %d given, but the ranks hold %d observations" % (self._ntotal, int(round(n))))
             self._ntotal = int(round(n))
-            # parallel-axis formula: sum_i |x_i - m|^2 = sum_r [ M2_r + n_r |m_r - m|^2 ]
-            m2 = m2 + np.maximum(between - n * np.abs(s1 / n) ** 2, 0.0) if self.comm.Get_size() > 1 else m2
+            if self.comm.Get_size() > 1:
+                # parallel-axis formula: sum_i |x_i - m|^2 = sum_r [ M2_r + n_r |m_r - m|^2 ], the shift done before squaring
+                between, = self.comm.allreduce_packed([n_r * np.abs(m_r - s1 / n) ** 2])
+                m2 = m2 + between
             self._moments = (n, s1, m2)
         return self._moments
 
@@ -182,6 +196,8 @@ class DistributedSample:
         n, s1, m2 = self._reduce()
         if mean is not None:      # second moment about a caller-supplied point
             m2 = m2 + n * np.abs(np.asarray(mean) - s1 / n) ** 2
+        if n - ddof <= 0:         # a single observation has no spread to speak of: NaN, quietly (the reference divides by zero)
+            return np.full(np.shape(m2), np.nan)
         return m2 / (n - ddof)
 
     def stddev(self, var=None, ddof=1):
@@ -193,8 +209,7 @@ class DistributedSample:
 
     def cov(self, mean=None, ddof=1):
         """Covariance matrix of the flattened observation, shape = shape + shape (second factor conjugated)."""
-        if self.local is None:
-            raise ValueError("covariances need the observations, not only their moments")
+        self._need_observations("cov()")
         n, s1, _ = self._reduce()
         centre = (s1 / n if mean is None else np.asarray(mean)).ravel()
         d = self.local.reshape(self.nlocal, -1) - centre
@@ -206,8 +221,7 @@ class DistributedSample:
 
     def apply(self, func, inplace=False):
         """Sample of func(x_i)."""
-        if self.local is None:
-            raise ValueError("apply needs the observations, not only their moments")
+        self._need_observations("apply()")
         mapped = np.array([func(obs) for obs in self.local])
         if inplace:
             self.local = mapped; self._moments = None
@@ -219,6 +233,8 @@ def join(*samples):
     """One sample holding the observations of all arguments (each rank concatenates its local blocks)."""
     if not samples:
         raise ValueError("join() needs at least one sample")
+    for smp in samples:
+        smp._need_observations("join()")
     return DistributedSample(np.concatenate([s.local for s in samples], axis=0), samples[0].comm, sum(s.ntotal for s in samples))
 
 
@@ -227,14 +243,23 @@ class PackedMoments:
     buffer is all-reduced where it lives (RCCL) and only the reduced moments are copied to the host."""
 
     def __init__(self, tensor, layout, comm=None):
-        self.tensor = tensor            # 1-d float64 torch tensor on the GPU, aliasing the library's buffer
+        self.tensor = tensor            # 1-d float64 torch tensor on the GPU, aliasing the library's buffer until allreduce()
         self.layout = layout            # name -> (offset, doubles per bin, shape, is complex)
         self.comm = comm if comm is not None else TorchComm()
         self._host = None
 
     def allreduce(self):
-        self.comm.allreduce_tensor(self.tensor)
-        self._host = self.tensor.cpu().numpy()
+        """Reduce over the ranks and copy the result to the host.  With RCCL the device buffer is reduced where it lies;
+        any other backend (the gloo groups of the CPU tests and of one-GPU rehearsals) gets a host copy.  The alias of the
+        library's buffer is dropped afterwards: the next `reduce_pack` or `w2dyn_destroy` may free that memory."""
+        if self.tensor is None:
+            raise RuntimeError("PackedMoments.allreduce called twice")
+        if self.comm.active and self.comm.backend != "nccl":
+            self._host = self.comm._reduce_flat(self.tensor.cpu().numpy())
+        else:
+            self.comm.allreduce_tensor(self.tensor)
+            self._host = self.tensor.cpu().numpy()
+        self.tensor = None
         return self
 
     def sample(self, name, scale=1.0):
