@@ -115,6 +115,8 @@ STAT = {
     "C2": ("C2", 2001, dict(Nwarmups=100000, Nmeas=10000, NCorr=200, TaudiffMax=10.0, Ntau=100, NLegMax=30), 8),
     "C3": ("C3", 1001, dict(Nwarmups=100000, Nmeas=10000, NCorr=100, TaudiffMax=10.0, Ntau=100, NLegMax=30), 8),
     "C4": ("C4", 1001, dict(Nwarmups=50000, Nmeas=5000, NCorr=100, TaudiffMax=10.0, Ntau=100, NLegMax=30), 8),
+    # BASELINE.json configs[4], Z-space part: 5 orbitals, beta = 100 (round 3)
+    "C5Z": ("C5Z", 1001, dict(Nwarmups=50000, Nmeas=5000, NCorr=100, TaudiffMax=10.0, Ntau=100, NLegMax=30), 8),
 }
 
 
@@ -265,7 +267,44 @@ def gen_worm(only=None):
         print("worm", name, "steps(worm, Z) of the eta search", steps, "cntsampling", r["cntsampling"][[0, sector - 1]], "nops", len(c_end["taus"]))
 
 
-KINDS = ("traj", "stat", "g4", "worm", "calib", "accum", "g4leg", "susz", "ssq", "steps")
+# worm estimator over independent seeds (mean and standard error of g4iw_worm): the statistical reference for BASELINE.json
+# configs[4] (worm_C5a's parameters with ten times the measurements); seeds 2000 ... 2000 + nseeds - 1, one chain each
+WORMSTAT = {"C5a": ("C5a", 16, 2000)}
+
+
+def _wormstat_chain(args):
+    name, seed, nmeas = args
+    cfg, nftau, over, _, comp = WORM[name]
+    over = dict(over, Nmeas=nmeas)
+    p, ps = pstring_for(cfg, nftau, over)
+    s = refdrive.RefSolver(p, ps, seed, fourpnt=8)
+    s.set_taudiffmax(over["TaudiffMax"])
+    s.warmup(over["Nwarmups"])
+    s.worm_warmup(0, 4, comp)
+    s.measure(4, comp)
+    r = s.results(("g4iw_worm", "mean_sign", "cntsampling", "occ"))
+    s.close()
+    return r
+
+
+def gen_wormstat(only=None):
+    import multiprocessing as mp
+    for out, (name, nseeds, nmeas) in WORMSTAT.items():
+        if only and out not in only:
+            continue
+        with mp.get_context("spawn").Pool(8) as pool:
+            rs = pool.map(_wormstat_chain, [(name, 2000 + i, nmeas) for i in range(nseeds)])
+        g = np.array([r["g4iw_worm"] for r in rs]); occ = np.array([r["occ"] for r in rs])
+        cfg, nftau, over, _, comp = WORM[name]
+        np.savez_compressed(os.path.join(OUT, "wormstat_%s.npz" % out), config=cfg, nftau=nftau, nseeds=nseeds, component=comp,
+                            overrides=repr(dict(over, Nmeas=nmeas)), g4iw_worm_mean=g.mean(axis=0),
+                            g4iw_worm_err=np.sqrt(g.real.var(axis=0, ddof=1) + g.imag.var(axis=0, ddof=1)) / np.sqrt(nseeds),
+                            occ_mean=occ.mean(axis=0), occ_err=occ.std(axis=0, ddof=1) / np.sqrt(nseeds),
+                            cntsampling=np.array([r["cntsampling"] for r in rs]))
+        print("wormstat", out, "max |g4iw_worm|", np.abs(g.mean(axis=0)).max(), "max err", (np.sqrt(g.real.var(axis=0, ddof=1) + g.imag.var(axis=0, ddof=1)) / np.sqrt(nseeds)).max())
+
+
+KINDS = ("traj", "stat", "g4", "worm", "calib", "accum", "g4leg", "susz", "ssq", "steps", "wormstat")
 
 ACCUM = {   # AccumGtau = 2 (autocorrelation accumulator: gtau_blocks) and 0 (G(tau), G(l) not measured), one seeded chain
     # name: (config, nftau, overrides, seed)
@@ -426,3 +465,5 @@ if __name__ == "__main__":
         gen_ssq(only)
     if "steps" in which:
         gen_steps(only)
+    if "wormstat" in which:
+        gen_wormstat(only)

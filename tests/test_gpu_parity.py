@@ -19,6 +19,13 @@ def rel(a, b):
     return np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300)
 
 
+def close_elementwise(a, b):
+    """|a - b| <= 1e-10 |b| + 1e-14 max|b| for every element: next to rel(), whose max-norm pins small entries (Legendre
+    coefficients of high order are 1e-4 ... 1e-6 of the first one) to 1e-10 of the scale only."""
+    a, b = np.asarray(a), np.asarray(b)
+    return bool(np.all(np.abs(a - b) <= 1e-10 * np.abs(b) + 1e-14 * np.abs(b).max()))
+
+
 def rel_nan(a, b):
     """rel() for arrays with 0/0 = NaN entries (outer blocks never visited, CTQMC.F90:8757-8758): same NaN pattern required."""
     a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
@@ -195,6 +202,8 @@ def _retrace(cfg, nftau, over, seed):
         o.measure(); r = o.results()
         for k in bins:
             assert rel(bins[k][w], r[k]) < TOL, (k, w)
+            if k == "gleg":      # Chebyshev moments turned into Legendre coefficients once per run: every order on its own scale
+                assert close_elementwise(bins[k][w], r[k]), (k, w)
             tot[k] = tot[k] + r[k] / nw
         msign += r["mean_sign"] / nw
         for k in HIST:      # trace contributions: exp of a log trace of magnitude ~ beta * U, hence 1e-9
@@ -234,6 +243,7 @@ def test_recorded_configuration_vs_reference_golden(name):
     q.ctqmc_measure(1, 1)
     for k in ("gleg", "gtau", "giw", "occ", "histo"):
         assert rel(getattr(q, k), g["res_" + k]) < TOL, k
+    assert close_elementwise(q.gleg, g["res_gleg"])
     assert q.mean_sign == float(g["res_mean_sign"])
     q.dest_ctqmc(); q.close()
 
@@ -589,7 +599,7 @@ def test_unsupported_modes_are_refused():
     q.close()
 
 
-@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4", "C5Z"])
 def test_full_run_statistics_vs_reference(name):
     """Full-run observables agree with long REFERENCE runs (8 seeds, tests/golden/stat_*.npz) within error bars.
 
@@ -702,6 +712,40 @@ def test_worm_sampling_vs_reference_statistics(name):
         assert np.abs(getattr(q, k) - m).max() < 0.3 * sig.max()
     assert abs(q.accwormadd[2] - float(g["res_accwormadd"][2])) < 0.05
     assert abs(q.accwormrep[2] - float(g["res_accwormrep"][2])) < 0.1
+    q.dest_ctqmc(); q.close()
+
+
+def test_worm_sampling_vs_reference_seeds():
+    """BASELINE.json configs[4] (5 orbitals, beta = 100, sector 4, component 0011, N4iwf = 10, N4iwb = 5): the worm estimator
+    of a GPU run against mean +- standard error over 16 seeded REFERENCE chains (tests/golden/wormstat_C5a.npz, 2000
+    measurements each): element by element within 5 sigma of the combined error, reduced chi^2 below 2 over the elements
+    with a signal; the Z-space occupations sampled along with it likewise."""
+    g = util.load_golden("wormstat_C5a.npz")
+    # chains of the reference's own length (2000 measurements after the same warm-up): a chain starts in Z space and moves
+    # between the two spaces every few thousand steps, so the ratio estimator N_worm / N_Z of a much shorter chain would carry a
+    # start-up bias the reference's chains do not have
+    comp = int(g["component"]); nw = 128
+    over = dict(g["overrides"])
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    q = MCTQMC(nwalkers=nw, walkers_per_bin=4)
+    q.fourpnt = 8
+    q.init_rnd(6); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+    q.set_taudiffmax(over["TaudiffMax"]); q.ctqmc_warmup(over["Nwarmups"])
+    q.ctqmc_measure(4, comp)
+    b = q.g4iw_worm_bins; nb = b.shape[0]
+    mean = q.g4iw_worm
+    err = np.sqrt(b.real.var(axis=0, ddof=1) + b.imag.var(axis=0, ddof=1)) / np.sqrt(nb)
+    ref, referr = g["g4iw_worm_mean"], g["g4iw_worm_err"]
+    sig = np.sqrt(err ** 2 + referr ** 2)
+    z = np.abs(mean - ref) / sig
+    assert z.max() < 5.0, z.max()
+    strong = np.abs(ref) > 5 * referr                   # elements where the reference sees a signal at all
+    assert strong.sum() > 20
+    assert (z[strong] ** 2).mean() / 2.0 < 2.0, (z[strong] ** 2).mean()       # complex: two degrees of freedom per element
+    assert np.abs(mean[strong] - ref[strong]).max() < 0.5 * np.abs(ref).max()
+    ob = q.occ_bins
+    zo = np.abs(ob.mean(axis=0) - g["occ_mean"]) / np.sqrt(ob.var(axis=0, ddof=1) / nb + g["occ_err"] ** 2 + 1e-30)
+    assert zo.max() < 5.0, zo.max()
     q.dest_ctqmc(); q.close()
 
 

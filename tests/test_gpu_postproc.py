@@ -42,7 +42,7 @@ def test_noninteracting_self_energy_vanishes():
     assert np.abs(d(r["smom"].mean())).max() < 1e-12       # no interaction, no moments
 
 
-@pytest.mark.parametrize("name", ["C1", "C3"])
+@pytest.mark.parametrize("name", ["C1", "C2", "C3", "C4"])
 def test_self_energy_vs_reference_runs(name):
     """Sigma(iw) from the HIP run against Sigma(iw) from the reference's 8-seed mean G(l), within combined errors; its
     high-frequency limit against the moments from rho1 / rho2 (Hartree term U <n> for the half-filled model)."""

@@ -45,7 +45,7 @@ def main():
     res["w_occ_mean"] = np.asarray(rw["occ"].mean()); res["w_occ_err"] = np.asarray(rw["occ"].stderr())
     # 3. eta search and window calibration: every rank finds its own value, all use the mean over ranks
     #    (impurity.py:739-740, 1161-1163); the rank's own values are kept in last_local
-    s.qmc.update(WormSearchEta=1, WormEta=1.0, TaudiffMax=-1.0, Nmeas=5)
+    s.qmc.update(WormSearchEta=1, WormEta=1e-6, TaudiffMax=-1.0, Nmeas=5)
     s.set_problem(prob, compute_fourpoint=8)
     rs = s.solve_component(0, 4, 16, [])
     loc = dict(s.last_local)

@@ -427,10 +427,16 @@ typedef const __attribute__((address_space(1))) mat_d2 *MatRowPtr;
 
 // NB: batches of vectors in use, ceil(ncols / spb) (compile-time, so that the loop has no branches at all: a taken branch costs
 // a single wave more than the dozen instructions it skips)
+#ifdef W2DYN_SEQ_UNPACKED      // ISA study only (tools/vgpr.sh tu_seq -DW2DYN_SEQ_UNPACKED): the 42-dword structure by value
+template <int NT, int NB, bool STORE = false>
+__device__ __noinline__ double2 mat_trace_seq_core(MatSeqArgs a)
+{
+#else
 template <int NT, int NB, bool STORE = false>
 __device__ __noinline__ double2 mat_trace_seq_core(MatSeqPacked packed)
 {
     const MatSeqArgs a = mat_seq_unpack(packed);
+#endif
     extern __shared__ unsigned char lds_base[];
     const int lane = (int)__lane_id();
     const int *tsst = (const int *)(lds_base + uni((int)a.tsst)), *om = (const int *)(lds_base + uni((int)a.om));
@@ -647,7 +653,11 @@ template <bool STORE = false>
 __device__ __forceinline__ double2 mat_seq_dispatch(const MatSeqArgs &args, int nt)
 {
     const int nb = uni((args.ncols + args.spb - 1) / args.spb);
+#ifdef W2DYN_SEQ_UNPACKED
+    const MatSeqArgs &a = args;
+#else
     const MatSeqPacked a = mat_seq_pack(args);
+#endif
     if (nt == 8) return mat_trace_seq_core<8, 1, STORE>(a);                  // up to 8 states: all vectors in one batch
     if (nt == 10) return nb <= 1 ? mat_trace_seq_core<10, 1, STORE>(a) : mat_trace_seq_core<10, 2, STORE>(a);
     return nb <= 1 ? mat_trace_seq_core<16, 1, STORE>(a) : (nb == 2 ? mat_trace_seq_core<16, 2, STORE>(a) : (nb == 3 ? mat_trace_seq_core<16, 3, STORE>(a) : mat_trace_seq_core<16, 4, STORE>(a)));
