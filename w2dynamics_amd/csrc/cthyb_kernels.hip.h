@@ -24,7 +24,7 @@
 // evaluating block 64*chunk+i, and handed out with v_readlane - the stream itself is unchanged.
 #pragma once
 #include <hip/hip_runtime.h>
-#if defined(W2DYN_STAMPS) && !defined(W2DYN_STAMPS_GLOB) && !defined(W2DYN_STAMPS_SEQ)
+#if defined(W2DYN_STAMPS) && !defined(W2DYN_STAMPS_GLOB) && !defined(W2DYN_STAMPS_SEQ) && !defined(W2DYN_STAMPS_ACC)
 #define DBG_STAMP(x, c) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((x).lane == 0) (x).cnt[c] += t_ - (x).tstamp; (x).tstamp = t_; } while (0)
 #define DBG_START(x) (x).tstamp = __builtin_amdgcn_s_memtime()
 #else

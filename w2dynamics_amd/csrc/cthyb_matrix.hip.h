@@ -385,15 +385,25 @@ struct MatSeqArgs {
 // padded block size the evaluator is instantiated for (operator table, vector tile and vector exchange use this stride)
 __host__ __device__ inline int mat_seq_pad(int nsm) { return nsm <= 8 ? 8 : (nsm <= 10 ? 10 : 16); }
 
-// What actually travels to the out-of-line evaluator: the same, packed into 29 dwords.  A function's arguments beyond 32
-// dwords are passed on the stack, and with part of MatSeqArgs there the sweep kernel went wrong (trajectories off with 40
-// dwords; fine again with everything in registers) - LDS offsets and the small integers are 16-bit here.
+// What actually travels to the out-of-line evaluator: the same, packed into 29 dwords (LDS offsets and the small integers
+// as 16-bit halves).  How it travels (read off the ISA of tu_seq, round 3; `tools/vgpr.sh tu_seq [-DW2DYN_SEQ_UNPACKED]`):
+// clang passes an aggregate of more than 16 dwords INDIRECTLY whatever its size - the caller writes a copy to offset 0 of
+// its own private segment (scratch_store_dwordx4 off, v[..], off offset:0..104) and hands over the private address in v0;
+// the callee reads it back with scratch_load_dwordx4 v[..], v0, off and makes everything wave-uniform with
+// v_readfirstlane.  That holds for this structure and for the 42-dword MatSeqArgs alike; in both builds the kernel sets
+// s32 to its own frame size (0x500 / 0x660 for k_sweep<9, false>) and its descriptor asks for that plus the deepest callee's
+// 12 bytes (private_segment_fixed_size 1292 / 1644, uses_dynamic_stack 0).  So the earlier explanation of the wrong
+// trajectories seen once with the unpacked structure - "arguments beyond 32 dwords go on the stack" - was wrong: nothing of
+// either structure is passed in argument registers, and the ISA of the two builds differs in frame offsets only.  That
+// intermediate state also carried the first, unfinished version of the window checkpoints (same commit), which is where the
+// fault must have been; it cannot be rebuilt from the history.  The packing stays because it is cheaper (120 instead of
+// 168 bytes written and read per trace); the size check below documents the layout, it protects nothing.
 struct MatSeqPacked {
     unsigned h[13];                // halves: 11 LDS offsets in dwords (0xffff: none), then 13 small integers (skip + 1), 2 spare
     const double *opmat, *gin; double *gout, *gdump;
     double t0, t1, beta, egs;
 };
-static_assert(sizeof(MatSeqPacked) <= 32 * sizeof(unsigned), "the evaluator's arguments must fit into the 32 argument registers");
+static_assert(sizeof(MatSeqPacked) == 120, "layout of the evaluator's packed arguments (29 dwords and one of padding)");
 __device__ __forceinline__ MatSeqPacked mat_seq_pack(const MatSeqArgs &a)
 {
     MatSeqPacked p;
@@ -647,8 +657,10 @@ __device__ __forceinline__ MatSeqArgs mat_seq_args(Ctx &x, const int *tsst, int 
     a.beta = C.beta; a.egs = C.egs;
     return a;
 }
-// The choice among the instances is made inline at the call site: a second out-of-line level (kernel -> dispatcher ->
-// evaluator) hung the GPU in one of the diagnostic builds (nested calls; not understood, not used).
+// The choice among the instances is made inline at the call site.  A second out-of-line level (kernel -> dispatcher ->
+// evaluator, the dispatcher taking the arguments by reference, i.e. as a generic pointer into the kernel's private
+// segment) hung the GPU in one diagnostic build of round 2 and is not used: one call level, arguments by value.  The cause
+// of that hang is NOT established (the build no longer exists; it is not to be re-created on a shared machine).
 template <bool STORE = false>
 __device__ __forceinline__ double2 mat_seq_dispatch(const MatSeqArgs &args, int nt)
 {
@@ -691,6 +703,9 @@ __device__ __forceinline__ void mat_trace_seq(Ctx &x, const int *tsst, int n, in
 // build of the same source passes every parity test); the numbers quoted in DESIGN.md come from the state before them.  Do not
 // run such a build on a shared machine without finding out why first.
 #ifdef W2DYN_STAMPS_SEQ     // diagnostic build: counts and cycles of the cached-window evaluation in the DBG slots
+#ifndef W2DYN_STAMPS_SEQ_ISA_ONLY
+#error "W2DYN_STAMPS_SEQ: a build of this kind faulted the GPU in round 2 and the cause is not known (see CAUTION above); compile it to ISA only (-DW2DYN_STAMPS_SEQ_ISA_ONLY with hipcc -S), do not run it"
+#endif
 #define SEQ_COUNT(x, c, v) do { if ((x).lane == 0) (x).cnt[c] += (unsigned long long)(v); } while (0)
 #define SEQ_T0() const unsigned long long tq0_ = __builtin_amdgcn_s_memtime()
 #define SEQ_T1(x, c) do { if ((x).lane == 0) (x).cnt[c] += __builtin_amdgcn_s_memtime() - tq0_; } while (0)
