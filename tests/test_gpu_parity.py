@@ -1009,10 +1009,11 @@ def test_solver_worm_component_with_eta_search():
     assert 0.3 < st[3] / st[0] < 3.0
 
 
-@pytest.mark.parametrize("name", ["C1", "C3"])
+@pytest.mark.parametrize("name", ["C1", "C3", "C4"])
 def test_susceptibility_recorded_configuration_vs_reference_golden(name):
     """f-3, MeasSusz = 1 (matrix solver, meas_ntau_n0, Trace.F90:6472-6835): <n(tau) n(0)> of a recorded configuration ==
-    what the REFERENCE printed - one window (C1: reference time beta) and several windows (C3)."""
+    what the REFERENCE printed - one window (C1: reference time beta), several windows (C3), and blocks of several states
+    (C4, 3-orbital Kanamori: densities inserted into the bra / ket vectors of the matrix trace path, k_meas_susz_mat)."""
     g = util.load_golden("susz_%s.npz" % name)
     over = g["overrides"]
     p, ps, pset = util.setup(g["config"], g["nftau"], over)
@@ -1120,8 +1121,33 @@ def test_susceptibility_chains_vs_oracle(monkeypatch, budget):
     q.dest_ctqmc(); q.close()
 
 
-def test_susceptibility_is_refused_on_the_matrix_trace_path():
-    p, ps, pset = util.setup("C4", 501, dict(BASE, Nwarmups=0, Nmeas=1, NCorr=1, TaudiffMax=6.0, MeasSusz=1))
+@pytest.mark.parametrize("cfg,tdm", [("C4S", 3.0), ("C3Q", 5.0)], ids=["C4S-kanamori", "C3Q-coarse-blocks"])
+def test_susceptibility_matrix_path_chains_vs_oracle(cfg, tdm):
+    """MeasSusz on the matrix trace path in a sampled run (window shifts, global and tau-shift moves, several windows): every
+    chain's <n(tau) n(0)> agrees with the oracle chain of the same stream, which takes every one of the nflav^2 Ntau traces
+    from scratch with the four density operators in the list."""
+    over = dict(BASE, Nwarmups=2000, Nmeas=6, NCorr=30, TaudiffMax=tdm, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1, MeasSusz=1, Ntau=70)
+    p, ps, pset = util.setup(cfg, 501, over)
+    nw = 5
+    q = make_gpu(p, ps, 43, nw, wpb=1)
+    q.set_taudiffmax(tdm)
+    q.ctqmc_warmup(over["Nwarmups"])
+    q.ctqmc_measure(1, 1)
+    res = []
+    for w in range(nw):
+        o = pyoracle.OracleWalker(p, pset, ("philox", 43, w))
+        o.set_taudiffmax(tdm); o.warmup(over["Nwarmups"]); o.measure()
+        res.append(o.results()["ntau_n0"]); o.close()
+    res = np.array(res)
+    assert np.abs(res).max() > 0.1
+    for w in range(nw):
+        assert rel(q.ntau_n0_bins[w], res[w]) < TOL, w
+    assert rel(q.ntau_n0, res.mean(axis=0)) < TOL
+    q.dest_ctqmc(); q.close()
+
+
+def test_susceptibility_is_refused_beyond_blocks_of_eight_states():
+    p, ps, pset = util.setup("C4N", 501, dict(BASE, Nwarmups=0, Nmeas=1, NCorr=1, TaudiffMax=3.0, MeasSusz=1))      # blocks of up to 9 states
     q = MCTQMC(nwalkers=4, walkers_per_bin=1)
     q.init_rnd(1); q.init_paras(ps)
     with pytest.raises(W2DynError) as e:

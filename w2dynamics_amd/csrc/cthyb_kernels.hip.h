@@ -1920,6 +1920,213 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// MeasSusz on the matrix trace path: <n_1(tauref) n_2(tauref + t beta/Ntau)> with the densities inserted into the operator
+// sequence (meas_ntau_n0, Trace.F90:6472-6835: densities applied to the stored bra / ket vectors of the outer states).
+// tauref is the upper edge of the chain's window; points beyond beta are taken at tauref - (Ntau - t) beta/Ntau as there.
+// One wave per chain, lane = (outer state s, component i) as in mat_apply (blocks of up to 8 states).  Per chain:
+//   1. kets K_s[j] right after operator j-1 and bras B_s[j] right in front of operator j, j = 0 .. n (each set of vectors
+//      scaled to a largest element of one, the log of the scale kept with it), to the chain's slice of a global work area;
+//   2. for every flavour f1: the kets with n_f1 inserted at tauref for the positions behind it (K'_s[j], j > jr, and the
+//      vectors at tauref itself in slot jr) and the bras with n_f1 inserted for the positions in front of it;
+//   3. lane = tau point: the point's interval j is found by bisection over the operator times, ket and bra of that interval are
+//      brought to the point with the interval's decay factors, and  sum_s B_s n_f2 K_s  is formed for every f2 with the
+//      density matrices N[block][f2] = Op(c+_f2) Op(c_f2) of the eigenbasis (host-made table `dens`):
+//          ntau_n0[f1][f2][t] -= cfgsign * Tr[... n_f2 ... n_f1 ...] / Tr[...]
+// Cost per chain: O(nflav (n + Ntau) nsm^2 n_outer) instead of nflav^2 Ntau traces from scratch.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void susz_store(double *arr, int ent, int j, int slot, bool act, double v, double l, int lane)
+{
+    if (act) arr[(size_t)j * ent + slot] = v;
+    if (lane == 0) arr[(size_t)j * ent + ent - 1] = l;
+}
+// v <- N v inside block sst (N = density matrix of flavour f in the block's eigenbasis, row-major [target][source])
+__device__ __forceinline__ double susz_dens_ket(Ctx &x, const double *dens, int sst, int f, double v)
+{
+    const int nsm = x.C.nsm;
+    const double *N = dens + (size_t)(sst * x.C.nflav + f) * nsm * nsm;
+    const bool act = x.lane < nsm * nsm;
+    double nv = 0.0;
+    for (int j = 0; j < nsm; ++j) {
+        const double vj = __shfl(v, x.ms_ * nsm + j, 64);
+        nv = fma(act ? N[x.mi_ * nsm + j] : 0.0, vj, nv);
+    }
+    return nv;
+}
+// b <- b N (bra side)
+__device__ __forceinline__ double susz_dens_bra(Ctx &x, const double *dens, int sst, int f, double b)
+{
+    const int nsm = x.C.nsm;
+    const double *N = dens + (size_t)(sst * x.C.nflav + f) * nsm * nsm;
+    const bool act = x.lane < nsm * nsm;
+    double nb = 0.0;
+    for (int i = 0; i < nsm; ++i) {
+        const double bi = __shfl(b, x.ms_ * nsm + i, 64);
+        nb = fma(act ? N[i * nsm + x.mi_] : 0.0, bi, nb);
+    }
+    return nb;
+}
+// one step of the bras towards earlier times: decay over dt inside block `src` (the block behind operator `code`), then the
+// operator from the right: b[m] <- sum_i b[i] e^{-(E_i - E_0) dt} Op[i][m], Op taking block `sst` into `src`
+__device__ __forceinline__ void susz_bra_step(Ctx &x, int sst, int code, int src, double dt, double &b, double &lb)
+{
+    const DevConst &C = x.C;
+    const int nsm = C.nsm, nf2 = 2 * C.nflav;
+    const int n = uni(x.t_n[src]), off = uni(x.t_off[src]);
+    const double e0 = uni(x.t_eval[off]);
+    if (n > 1) b *= exp(-(((x.mi_ < n) ? x.t_eval[off + x.mi_] : e0) - e0) * dt);
+    lb -= (e0 - C.egs) * dt;
+    const size_t base = (size_t)(sst * nf2 + code) * nsm * nsm;
+    const bool act = x.lane < nsm * nsm;
+    double nb = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const double bi = __shfl(b, x.ms_ * nsm + i, 64);
+        const double o = act ? (x.t_op ? x.t_op[base + i * nsm + x.mi_] : C.opmat[base + i * nsm + x.mi_]) : 0.0;
+        nb = fma(o, bi, nb);
+    }
+    b = nb;
+}
+template <int NSMT>
+__global__ __launch_bounds__(256) void k_meas_susz_mat(DevConst C, double *__restrict__ acc, int nbs, double *__restrict__ work, const double *__restrict__ dens)
+{
+    extern __shared__ unsigned char smem[];
+    stage_shared_tables(C, smem);
+    Ctx x(C);
+    ctx_setup(x, smem);
+    if (x.w >= C.nwalkers) return;
+    ctx_load(x);
+    if (x.sector != 1 || (x.err & (ERR_WCAP | ERR_BLOCKSEQ))) return;      // chains in worm space measure no Z-space estimator
+    const int nsm = C.nsm, nf = C.nflav, n = x.nops, ntau = C.ntau, ent = nsm * nsm + 1;
+    const int outer = x.outer, nout = uni(x.t_n[outer]);
+    const double beta = C.beta, tauD = beta / (double)ntau, tauref = x.wmax;
+    double *SK = work + (size_t)x.w * 4 * (C.wcap + 1) * ent, *SB = SK + (size_t)(C.wcap + 1) * ent, *SX = SB + (size_t)(C.wcap + 1) * ent, *SY = SX + (size_t)(C.wcap + 1) * ent;
+    const bool act = x.lane < nsm * nsm;
+    const int slot = x.lane;
+    const bool diag = act && x.ms_ == x.mi_ && x.ms_ < nout;
+    if (uni(x.osst[n]) != outer) return;                                     // not a closed sequence: nothing to measure
+    // 1a. kets
+    double v = diag ? 1.0 : 0.0, lacc = 0.0, tprev = 0.0;
+    susz_store(SK, ent, 0, slot, act, v, lacc, x.lane);
+    for (int j = 0; j < n; ++j) {
+        const double tau = uni(x.ot[j]);
+        if (mat_apply(x, uni(x.osst[j]), uni(x.om[j]), tau - tprev, v, lacc) < 0) return;
+        if (!mat_rescale(v, lacc)) return;                                   // the trace vanishes
+        susz_store(SK, ent, j + 1, slot, act, v, lacc, x.lane);
+        tprev = tau;
+    }
+    double ltr0, sign0;
+    {
+        double vf = v, lf = lacc;
+        mat_evolve(x, outer, beta - tprev, vf, lf);
+        const double tot = wave_sum(diag ? vf : 0.0);
+        if (tot == 0.0 || !(fabs(tot) > 0.0)) return;
+        ltr0 = lf + log(fabs(tot)); sign0 = tot < 0.0 ? -1.0 : 1.0;
+    }
+    // 1b. bras
+    {
+        double b = diag ? 1.0 : 0.0, lb = 0.0, tnext = beta;
+        susz_store(SB, ent, n, slot, act, b, lb, x.lane);
+        for (int j = n - 1; j >= 0; --j) {
+            const double tau = uni(x.ot[j]);
+            susz_bra_step(x, uni(x.osst[j]), uni(x.om[j]), uni(x.osst[j + 1]), tnext - tau, b, lb);
+            if (!mat_rescale(b, lb)) return;
+            susz_store(SB, ent, j, slot, act, b, lb, x.lane);
+            tnext = tau;
+        }
+    }
+    int jr = 0;                                                              // operators in front of tauref
+    for (int base = 0; base < n; base += 64) { const int e = base + x.lane; jr += count_pred(e < n && x.ot[e] < tauref); }
+    const int br = uni(x.osst[jr]);
+    const double t_before = jr > 0 ? uni(x.ot[jr - 1]) : 0.0, t_after = jr < n ? uni(x.ot[jr]) : beta;
+    const double cfg = C.cfgsign[x.w];
+    const int ab = (x.w / C.walkers_per_bin) % nbs;
+    double *out = acc + (size_t)ab * nf * nf * ntau;
+    wave_sync();
+    for (int f1 = 0; f1 < nf; ++f1) {
+        // 2a. kets with n_f1 at tauref: slot jr holds the vectors AT tauref, slots j > jr those right after operator j-1
+        bool kets_ok = true, bras_ok = true;
+        {
+            double k1 = act ? SK[(size_t)jr * ent + slot] : 0.0, lk = uni(SK[(size_t)jr * ent + ent - 1]);
+            mat_evolve(x, br, tauref - t_before, k1, lk);
+            k1 = susz_dens_ket(x, dens, br, f1, k1);
+            kets_ok = mat_rescale(k1, lk);
+            if (kets_ok) {
+                susz_store(SX, ent, jr, slot, act, k1, lk, x.lane);
+                double tp = tauref;
+                for (int j = jr; j < n && kets_ok; ++j) {
+                    const double tau = uni(x.ot[j]);
+                    if (mat_apply(x, uni(x.osst[j]), uni(x.om[j]), tau - tp, k1, lk) < 0) { kets_ok = false; break; }
+                    kets_ok = mat_rescale(k1, lk);
+                    if (kets_ok) susz_store(SX, ent, j + 1, slot, act, k1, lk, x.lane);
+                    tp = tau;
+                }
+            }
+        }
+        // 2b. bras with n_f1 at tauref: slot jr holds the bras AT tauref, slots j < jr those right in front of operator j
+        {
+            double b1 = act ? SB[(size_t)jr * ent + slot] : 0.0, lb = uni(SB[(size_t)jr * ent + ent - 1]);
+            mat_evolve(x, br, t_after - tauref, b1, lb);
+            b1 = susz_dens_bra(x, dens, br, f1, b1);
+            bras_ok = mat_rescale(b1, lb);
+            if (bras_ok) {
+                susz_store(SY, ent, jr, slot, act, b1, lb, x.lane);
+                double tn = tauref;
+                for (int j = jr - 1; j >= 0 && bras_ok; --j) {
+                    const double tau = uni(x.ot[j]);
+                    susz_bra_step(x, uni(x.osst[j]), uni(x.om[j]), uni(x.osst[j + 1]), tn - tau, b1, lb);
+                    bras_ok = mat_rescale(b1, lb);
+                    if (bras_ok) susz_store(SY, ent, j, slot, act, b1, lb, x.lane);
+                    tn = tau;
+                }
+            }
+        }
+        wave_sync();
+        // 3. lane = tau point
+        for (int tb = 0; tb < ntau; tb += 64) {
+            const int t = tb + x.lane;
+            if (t < ntau) {
+                double tauint = tauref + (double)t * tauD;
+                const bool wrapped = tauint > beta;
+                if (wrapped) tauint = tauref - (double)(ntau - t) * tauD;
+                if (wrapped ? bras_ok : kets_ok) {
+                    int lo = 0, hi = n;                                      // j = operators with time < tauint
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (x.ot[mid] < tauint) lo = mid + 1; else hi = mid; }
+                    const int j = lo;
+                    const double *Kp, *Bp; double tk, tbra;
+                    if (!wrapped) { Kp = SX + (size_t)j * ent; tk = j == jr ? tauref : x.ot[j - 1]; Bp = SB + (size_t)j * ent; tbra = j < n ? x.ot[j] : beta; }
+                    else { Kp = SK + (size_t)j * ent; tk = j > 0 ? x.ot[j - 1] : 0.0; Bp = SY + (size_t)j * ent; tbra = j == jr ? tauref : x.ot[j]; }
+                    const int b = x.osst[j], nst = x.t_n[b], off = x.t_off[b];
+                    const double e0 = x.t_eval[off];
+                    double dk[NSMT], db[NSMT];
+#pragma unroll
+                    for (int i = 0; i < NSMT; ++i) {
+                        const double de = i < nst ? x.t_eval[off + i] - e0 : 0.0;
+                        dk[i] = i < nst ? exp(-de * (tauint - tk)) : 0.0; db[i] = i < nst ? exp(-de * (tbra - tauint)) : 0.0;
+                    }
+                    const double pref = -cfg * sign0 * exp(Kp[ent - 1] + Bp[ent - 1] - (e0 - C.egs) * (tbra - tk) - ltr0);
+                    for (int f2 = 0; f2 < nf; ++f2) {
+                        const double *N = dens + (size_t)(b * nf + f2) * nsm * nsm;
+                        double val = 0.0;
+                        for (int sI = 0; sI < nout; ++sI) {
+#pragma unroll
+                            for (int i = 0; i < NSMT; ++i) {
+                                if (i < nst) {
+                                    double r = 0.0;
+#pragma unroll
+                                    for (int m = 0; m < NSMT; ++m) if (m < nst) r = fma(N[i * nsm + m], Kp[sI * nsm + m] * dk[m], r);
+                                    val = fma(Bp[sI * nsm + i] * db[i], r, val);
+                                }
+                            }
+                        }
+                        if (val != 0.0) atomicAdd(&out[((size_t)f1 * nf + f2) * ntau + t], pref * val);
+                    }
+                }
+            }
+        }
+        wave_sync();
+    }
+}
+
 #ifdef W2DYN_TU_MEAS
 // Legendre and tau-bin estimators (MeasGtauRem, CTQMC.F90:2252-2440): THE data-parallel kernel.
 // One wave per (bin, flavour).  The wave walks the chains of its bin; lanes take (creator, annihilator) pairs; every

@@ -27,6 +27,7 @@ void launch_sweep_worm_seq(int nworm, const LaunchCfg &l, const DevConst &C, lon
 void launch_meas_misc_scalar(const LaunchCfg &l, const DevConst &C);
 void launch_meas_misc_tree(int mat, const LaunchCfg &l, const DevConst &C);
 void launch_meas_misc_seq(const LaunchCfg &l, const DevConst &C);
+void launch_meas_susz_mat(const LaunchCfg &l, const DevConst &C, double *acc, int nbs, double *work, const double *dens);   // tu_tree.hip
 
 // estimators (tu_meas.hip); grids and LDS sizes are worked out here from the DevConst
 // segpre: nbins * nflav + 1 element counts (work list, made by the launch itself); ncu: compute units of the device

@@ -16,4 +16,10 @@ void launch_meas_misc_tree(int mat, const LaunchCfg &l, const DevConst &C)
     else if (mat == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_misc<3>), l.grid, l.block, l.lds, l.stream, C);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_misc<4>), l.grid, l.block, l.lds, l.stream, C);
 }
+// MeasSusz on the matrix trace path (blocks of up to 8 states); work: 4 (wcap + 1) (nsm^2 + 1) doubles per chain
+void launch_meas_susz_mat(const LaunchCfg &l, const DevConst &C, double *acc, int nbs, double *work, const double *dens)
+{
+    if (C.nsm <= 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_susz_mat<4>), l.grid, l.block, l.lds, l.stream, C, acc, nbs, work, dens);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_susz_mat<8>), l.grid, l.block, l.lds, l.stream, C, acc, nbs, work, dens);
+}
 }  // namespace w2dyn

@@ -124,6 +124,7 @@ struct w2dyn_solver {
     bool meas_ssq = false;                                               // MeasSsquare: <S^2> per electron number from the density matrix
     int step_series = 0; double *ser = nullptr;                          // Gtau_mean_step (1) | Gtau_mid_step (2) | sign_step (4): [2 nflav + 1][Nmeas] chain-mean series
     bool meas_susz = false; int nbs = 0; double *acc_susz = nullptr;     // MeasSusz: <n(tau) n(0)>, accumulator bins [nbs][nflav][nflav][Ntau]
+    double *susz_work = nullptr; const double *susz_dens = nullptr;                   // matrix trace path: per-chain bra / ket vectors, density matrices of the eigenbasis
     int accum_gtau = 1, ac_lev = 0; long long ac_n = 0; double *ac_dat = nullptr, *ac_out = nullptr;
     int res_isector = 1;                             // sector of the run the result table was made from
     int worm_meas_giw = 0, worm_meas_gtau = 0;       // sector 2: WormMeasGiw, WormMeasGtau (CTQMC.F90:597-612)
@@ -798,11 +799,30 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if (s->meas_susz) {
         // meas_ntau_n0 walks stored bra / ket vectors of the eigenbasis (Trace.F90:6472-6835); with one state per block the
         // densities are numbers and the estimator is an occupation count, which is what k_meas_susz does
-        if (s->mat) return fail(s, W2DYN_EUNSUPPORTED, "MeasSusz = 1 is only supported when every block of H_loc holds one state (density-density interaction with Nt Szt Azt)");
+        // the matrix trace path (k_meas_susz_mat) inserts the densities into kets and bras kept per operator position
+        if (s->mat && lp.nsmax > 8) return fail(s, W2DYN_EUNSUPPORTED, "MeasSusz = 1 on the matrix trace path handles blocks of up to 8 states (largest block here: %d)", lp.nsmax);
         if (s->ntau > 2048) return fail(s, W2DYN_EUNSUPPORTED, "MeasSusz = 1: Ntau = %d too large (at most 2048)", s->ntau);
         const size_t per = (size_t)nf * nf * s->ntau * sizeof(double);
         s->nbs = (int)std::max<size_t>(1, std::min<size_t>(B, acc_budget() / per));
         if ((rc = dev_alloc(s, s->acc_susz, (size_t)s->nbs * nf * nf * s->ntau))) return rc;
+        s->susz_work = nullptr; s->susz_dens = nullptr;
+        if (s->mat) {
+            // N[block][f] = Op(c+_f : block' -> block) Op(c_f : block -> block') in the eigenbasis, zero where c_f annihilates the block
+            const int nsm = C.nsm;
+            std::vector<double> dens((size_t)lp.nsst * nf * nsm * nsm, 0.0);
+            for (int b = 0; b < lp.nsst; ++b) for (int f = 0; f < nf; ++f) {
+                const int tb = lp.connect(b, f, 2);
+                if (tb < 0 || lp.connect(tb, f, 1) != b) continue;
+                const double *A = &opmat[((size_t)(b * nf + f) * 2 + 1) * nsm * nsm];        // c_f : b -> tb, [target][source]
+                const double *Cr = &opmat[((size_t)(tb * nf + f) * 2 + 0) * nsm * nsm];      // c+_f : tb -> b
+                double *N = &dens[(size_t)(b * nf + f) * nsm * nsm];
+                for (int i = 0; i < nsm; ++i) for (int m = 0; m < nsm; ++m) { double a = 0.0; for (int k = 0; k < nsm; ++k) a += Cr[i * nsm + k] * A[k * nsm + m]; N[i * nsm + m] = a; }
+            }
+            if ((rc = dev_upload(s, s->susz_dens, dens))) return rc;
+            const size_t wdoubles = (size_t)W * 4 * (C.wcap + 1) * (nsm * nsm + 1);
+            if (wdoubles * sizeof(double) > ((size_t)32 << 30)) return fail(s, W2DYN_EUNSUPPORTED, "MeasSusz = 1 on the matrix trace path: %zu bytes of per-chain bra / ket vectors; use fewer chains", wdoubles * sizeof(double));
+            if ((rc = dev_alloc(s, s->susz_work, wdoubles))) return rc;
+        }
     }
     s->acc_g4tau = s->acc_g4leg = nullptr; s->nbl = 0;
     if (s->fourpnt & 3) {
@@ -1098,7 +1118,8 @@ static int measure_once_impl(w2dyn_solver *s, double2 *g2buf)
     }
     if (s->acc_susz) {                // CTQMC.F90:8556-8560
         if ((rc = time_begin(s))) return rc;
-        launch_meas_susz(s->C, s->stream, s->acc_susz, s->nbs);
+        if (s->mat) launch_meas_susz_mat(l, s->C, s->acc_susz, s->nbs, s->susz_work, s->susz_dens);
+        else launch_meas_susz(s->C, s->stream, s->acc_susz, s->nbs);
         HIPCHK(hipGetLastError());
         if ((rc = time_end(s, "meas_susz"))) return rc;
     }
