@@ -105,7 +105,7 @@ int w2dyn_measure_finish(w2dyn_solver *s);
  * context's accumulators) as w2dyn_measure_once in a Z-space run with FourPnt & 4, but the per-chain g2(nu, nu') tables
  * that k_meas_g2iw hands to k_meas_g4iw live in a static __device__ array of 32 MiB (one copy per GPU, held until the process
  * ends) instead of the buffer init_solver allocates; the call does no hipMalloc / hipFree / synchronisation and skips the
- * event timing.  chains x flavours x (2 (N4iwf + N4iwb))^2 x 16 bytes beyond 32 MiB -> W2DYN_EINVAL.  All contexts of a GPU
+ * event timing.  chains x flavours x n2 (n2 + 2 N4iwb + 1) x 16 bytes, n2 = 2 (N4iwf + N4iwb), beyond 32 MiB -> W2DYN_EINVAL.  All contexts of a GPU
  * share the array: calls that overlap on one GPU (two contexts, two streams) race. */
 int w2dyn_measure_once_noalloc(w2dyn_solver *s);
 

@@ -23,9 +23,15 @@ def _run(noalloc, nw, nwf, nwb, seed):
     q.init_rnd(seed); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
     q.set_taudiffmax(4.0); q.ctqmc_warmup(over["Nwarmups"])
     q.set_sector(1, 1); q.measure_begin()
-    import torch
-    q.sync(); torch.cuda.mem_get_info()                 # first call sets up torch's own context: not part of the comparison
-    free0 = torch.cuda.mem_get_info()[0]                # hipMemGetInfo: free bytes of the device
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")                 # the runtime the library itself is linked against
+
+    def free_bytes():                                   # hipMemGetInfo: free bytes of the device
+        f, t = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+        return f.value
+    q.sync()
+    free0 = free_bytes()
     for _ in range(over["Nmeas"]):
         q.sweep(over["NCorr"])
         if noalloc:
@@ -34,7 +40,7 @@ def _run(noalloc, nw, nwf, nwb, seed):
             q.measure_once()
     q.sync()
     if noalloc:                                         # the property itself: not a byte of device memory taken or given back
-        assert torch.cuda.mem_get_info()[0] == free0
+        assert free_bytes() == free0
     q.measure_finish()
     res = {k: np.array(getattr(q, k)) for k in ("g4iw", "g4iw_pp", "g2iw", "gleg", "gtau", "giw", "occ", "histo")}
     res["g4iw_bins"] = np.array(q.g4iw_bins)
@@ -58,7 +64,7 @@ def test_noalloc_measurement_equals_measure_once_twice_in_a_row():
 def test_noalloc_measurement_rejects_oversized_and_wrong_mode():
     over = dict(Ntau=100, NLegMax=12, Niw=8, Nwarmups=0, Nmeas=1, NCorr=1, TaudiffMax=4.0, N4iwf=20, N4iwb=10)
     p, ps, pset = util.setup("C3", 501, over)
-    q = MCTQMC(nwalkers=512, walkers_per_bin=8)       # 512 chains x 4 flavours x 60^2 x 16 B = 118 MB > 32 MiB
+    q = MCTQMC(nwalkers=512, walkers_per_bin=8)       # 512 chains x 4 flavours x 60 (60 + 21) x 16 B = 159 MB > 32 MiB
     q.fourpnt = 4
     q.init_rnd(1); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
     q.set_taudiffmax(4.0); q.set_sector(1, 1); q.measure_begin()

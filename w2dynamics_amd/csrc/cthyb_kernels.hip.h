@@ -69,6 +69,8 @@ constexpr int KMAX_LIMIT = 256;
 constexpr int GLEG_SEG_BLOCK = 4096;     // k_gleg_segments: segments (bin, flavour) per workgroup
 constexpr int GLEG_RED_ROWS = 8, GLEG_RED_STRIDE = 65;      // k_meas_gleg: LDS transpose tile of the end-of-segment reduction
 constexpr int G2_FC = 32;                                    // k_meas_g2iw: frequency chunk of the two-step transform
+// entries of a (chain, flavour)'s g2 table: n2 x n2, then its 2 nwb + 1 central diagonals as rows (k_meas_g2iw)
+__host__ __device__ inline size_t g2_stride(int n2, int nwb) { return (size_t)n2 * (size_t)(n2 + 2 * nwb + 1); }
 
 enum Counter { C_TRYADD, C_ACCADD, C_QNADD, C_TRYREM, C_ACCREM, C_QNREM, C_TRYGLOB, C_ACCGLOB, C_QNGLOB,
                C_TRYSHIFT, C_ACCSHIFT, C_SAMPLING,
@@ -2767,13 +2769,16 @@ __global__ __launch_bounds__(256) void k_meas_giw(DevConst C, const double *__re
 // U(ic,wa) = sum_ia M(ic,ia) Ea(ia,wa) followed by g2(wa,wc) = sum_ic Ec(ic,wc) U(ic,wa): 8 k n2 (k + n2) flop
 // instead of 8 k^2 n2^2.  grid (chains, flavours), 256 threads; LDS 3 * kmax * G2_FC complex.
 // G2 layout [chain][flavour][wa][wc], frequencies nu_n = (2n+1) pi/beta, n = -n2/2 .. n2/2-1.
-__global__ __launch_bounds__(256) void k_meas_g2iw(DevConst C, int n2, double2 *G2)
+// Behind the n2 x n2 table of a (chain, flavour) lie its 2 nwb + 1 central diagonals once more, as rows:
+// diag[(a - c + nwb) n2 + c] = g2(a, c) for |a - c| <= nwb - the operands A(w1) = g2(w1 + wb, w1), B(w2) = g2(w2, w2 + wb) of the
+// matrix product in k_meas_g4iw, which would otherwise be gathered one 16-byte element per cache line.
+__global__ __launch_bounds__(256) void k_meas_g2iw(DevConst C, int n2, int nwb, double2 *G2)
 {
     extern __shared__ double2 g2s[];
     const int w = blockIdx.x, f = blockIdx.y, tid = threadIdx.x, kmax = C.kmax;
     const int k = C.K[(size_t)w * C.nflav + f];
-    double2 *out = G2 + ((size_t)w * C.nflav + f) * n2 * n2;
-    if (k == 0) { for (int e = tid; e < n2 * n2; e += 256) out[e] = make_double2(0.0, 0.0); return; }
+    double2 *out = G2 + ((size_t)w * C.nflav + f) * g2_stride(n2, nwb);
+    if (k == 0) { for (int e = tid; e < (int)g2_stride(n2, nwb); e += 256) out[e] = make_double2(0.0, 0.0); return; }
     double2 *Ea = g2s, *Ec = g2s + (size_t)kmax * G2_FC, *U = Ec + (size_t)kmax * G2_FC;
     const double *tcp = C.TC + ((size_t)w * C.nflav + f) * kmax, *tap = C.TA + ((size_t)w * C.nflav + f) * kmax;
     const double *Mf = C.M + ((size_t)w * C.nflav + f) * kmax * kmax;
@@ -2809,68 +2814,199 @@ __global__ __launch_bounds__(256) void k_meas_g2iw(DevConst C, int n2, double2 *
                     re += a.x * b.x - a.y * b.y; im += a.x * b.y + a.y * b.x;
                 }
                 out[(size_t)(a0 + wa) * n2 + (c0 + wc)] = make_double2(re, im);
+                const int dd = (a0 + wa) - (c0 + wc);
+                if (dd >= -nwb && dd <= nwb) out[(size_t)n2 * n2 + (size_t)(dd + nwb) * n2 + (c0 + wc)] = make_double2(re, im);
             }
         }
         __syncthreads();
     }
 }
 
-// Assembly of the two-particle Green's function from products of two g2 (CTQMC.F90:2175-2222) and accumulation of g2
-// itself.  One thread per output element and accumulator bin, looping over the chains of the bin: every accumulator
-// element is read and written once per launch (HBM streaming), the g2 values of a chain come from L2.
-// acc4 / acc4pp layout [nb4][f1][f2][w1][w2][wb] (complex), acc2 [nb4][f][wa][wc]; chains of sample bin b go to b % nb4.
-__global__ __launch_bounds__(256) void k_meas_g4iw(DevConst C, int nwf, int nwb, int zph, int nb4, const double2 *G2,
-                                                    double2 *acc4, double2 *acc4pp, double2 *acc2)
+// Assembly of the two-particle Green's function from products of two g2 (CTQMC.F90:2175-2222) and accumulation of g2.
+// acc4 / acc4pp layout [nb4][f1][f2][wb][w1][w2] (complex; the host turns it into the reference's (w1, w2, wb) order),
+// acc2 [nb4][f][wa][wc]; chains of sample bin b go to b % nb4.
+//
+// The direct term of the particle-hole channel factorises for fixed (f1, f2, wb): with A_ch(w1) = g2_ch[f1](w1 + wb, w1)
+// and B_ch(w2) = g2_ch[f2](w2, w2 + wb) it is  sum_ch A_ch(w1) B_ch(w2)  - a complex matrix product over the CHAINS of the
+// accumulator bin, (2 N4iwf) x chains times chains x (2 N4iwf).  That is a real fp64 contraction of a size the matrix
+// cores take: four v_mfma_f64_16x16x4_f64 per 16 x 16 tile and four chains (Re += Ar Br - Ai Bi, Im += Ar Bi + Ai Br),
+// instead of four FMAs and two gathered loads per element and chain.  One workgroup = (f1, f2, wb, accumulator bin), its
+// four waves cover a 64 x 64 region of (w1, w2) in 2 x 2 tiles of 16 x 16 each (16 accumulator registers of 4 doubles per
+// lane); the operands A (lane = (w1, chain)) and B (lane = (chain, w2)) come straight from the chains' g2 tables (L2).
+// The exchange term (equal flavours) and the particle-particle channel do not factorise - both of their factors depend on
+// w1 and w2 - and stay element-wise on the same register layout (C/D of the f64 MFMA: column = lane & 15, row = (lane >> 4)
+// + 4 reg).  The accumulators cross HBM once per launch.
+typedef double g4_d4 __attribute__((ext_vector_type(4)));
+// PP = false: particle-hole channel into acc (MFMA direct term, element-wise exchange term for equal flavours);
+// PP = true: particle-particle channel into acc (element-wise)
+template <bool PP>
+__global__ __launch_bounds__(256, PP ? 1 : 2) void k_meas_g4iw(DevConst C, int nwf, int nwb, int zph, int nb4, const double2 *__restrict__ G2, double2 *__restrict__ acc)
 {
     const int nf = C.nflav, n2 = 2 * (nwf + nwb), h = n2 / 2, nw = 2 * nwf, nb = 2 * nwb + 1;
-    const size_t n4 = (size_t)nf * nf * nw * nw * nb, ng2 = (size_t)nf * n2 * n2;
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int b4 = blockIdx.y;
-    if (e < n4) {
-        size_t r = e;
-        const int wb = (int)(r % nb) - nwb; r /= nb;
-        const int w2 = (int)(r % nw) - nwf; r /= nw;
-        const int w1 = (int)(r % nw) - nwf; r /= nw;
-        const int f2 = (int)(r % nf), f1 = (int)(r / nf);
-        int a1, c1, a2, c2, a3, c3, a4, c4;           // (annihilator, creator) frequency indices of the four factors
-        if (zph == 0) { a1 = w1 + wb; c1 = w1; a2 = w2; c2 = w2 + wb; a3 = w2; c3 = w1; a4 = w1 + wb; c4 = w2 + wb; }
-        else { a1 = w1; c1 = w1 - wb; a2 = w2 - wb; c2 = w2; a3 = w1; c3 = w2; a4 = w2 - wb; c4 = w1 - wb; }
-        const int p1a = wb - w2 - 1, p1c = w1, p2a = w2, p2c = wb - w1 - 1, p3a = w2, p3c = w1, p4a = wb - w2 - 1, p4c = wb - w1 - 1;
-        double re = 0.0, im = 0.0, pre = 0.0, pim = 0.0;
-        for (int bin = b4; bin < C.nbins; bin += nb4) {
-            const int w0 = bin * C.walkers_per_bin, w1e = min(w0 + C.walkers_per_bin, C.nwalkers);
-            for (int w = w0; w < w1e; ++w) {
-                const double2 *g1 = G2 + ((size_t)w * nf + f1) * n2 * n2, *g2p = G2 + ((size_t)w * nf + f2) * n2 * n2;
-                if (acc4) {
-                    double2 x = g1[(size_t)(a1 + h) * n2 + (c1 + h)], y = g2p[(size_t)(a2 + h) * n2 + (c2 + h)];
-                    re += x.x * y.x - x.y * y.y; im += x.x * y.y + x.y * y.x;
-                    if (f1 == f2) {
-                        double2 u = g1[(size_t)(a3 + h) * n2 + (c3 + h)], v = g1[(size_t)(a4 + h) * n2 + (c4 + h)];
-                        re -= u.x * v.x - u.y * v.y; im -= u.x * v.y + u.y * v.x;
-                    }
+    const size_t n4 = (size_t)nf * nf * nw * nw * nb, g2sz = g2_stride(n2, nwb);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nreg = (nw + 63) / 64;                               // 64 x 64 regions per direction
+    const int reg_i = blockIdx.x / nreg, reg_j = blockIdx.x - reg_i * nreg;
+    int r = blockIdx.y;
+    const int wbi = r % nb; r /= nb;
+    const int f2 = r % nf, f1 = r / nf;
+    const int wb = wbi - nwb, b4 = blockIdx.z;
+    const int r0 = reg_i * 64 + (wv >> 1) * 32, c0 = reg_j * 64 + (wv & 1) * 32;      // first row / column index (0-based) of this wave
+    if (r0 >= nw || c0 >= nw) return;
+    const int li = lane & 15, lk = lane >> 4;
+    const bool same = f1 == f2;
+    // operand positions inside a chain's g2 table: A of row tile t at w1 = r0 + 16 t + li, B of column tile t at w2 = c0 + 16 t + li
+    unsigned offA[2], offB[2]; bool okA[2], okB[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int i1 = r0 + 16 * t + li, i2 = c0 + 16 * t + li, w1 = i1 - nwf, w2 = i2 - nwf;
+        okA[t] = i1 < nw; okB[t] = i2 < nw;
+        // A = g2(a1, c1) with a1 - c1 = wb, B = g2(a2, c2) with a2 - c2 = -wb, both conventions: rows wb + nwb and -wb + nwb of the diagonals
+        const int c1 = zph == 0 ? w1 : w1 - wb, c2 = zph == 0 ? w2 + wb : w2;
+        offA[t] = okA[t] ? (unsigned)(n2 * n2 + (wb + nwb) * n2 + (c1 + h)) : 0u; offB[t] = okB[t] ? (unsigned)(n2 * n2 + (nwb - wb) * n2 + (c2 + h)) : 0u;
+    }
+    // element-wise part: the lane's element q of tile (ti, tj) is (w1, w2) = (r0 + 16 ti + lk + 4 q, c0 + 16 tj + li) - nwf.
+    // A factor g(row, col) whose ROW runs with w2 (the lane-fast index) would be a gather of 16-byte pieces from 64
+    // different cache lines per load; it is read the other way round instead - row with lk + 4 q, column with li: whole
+    // lines - into a 16 x 16 tile of LDS and picked up transposed (stage_t).
+    __shared__ double2 g4_tile[4][4][16 * 17];                     // per wave: one tile per (ti, tj) (particle-hole) or per factor (particle-particle)
+    double2 (*tl)[16 * 17] = g4_tile[wv];
+    // out[q] = g[(rbase + sr li) n2 + cbase + sc (lk + 4 q)]; rows belong to w2 indices c0 + 16 tj + .., columns to w1 indices r0 + 16 ti + ..
+    auto stage_t_load = [&](const double2 *g, double2 *tile, int ti, int tj, int rbase, int sr, int cbase, int sc) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rl = lk + 4 * q;                                         // row of the tile this lane fills, column li
+            const bool ok = c0 + 16 * tj + rl < nw && r0 + 16 * ti + li < nw;
+            tile[rl * 17 + li] = ok ? g[(unsigned)((rbase + sr * rl) * n2 + (cbase + sc * li))] : make_double2(0.0, 0.0);
+        }
+    };
+    g4_d4 re[2][2], im[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { re[a][b] = (g4_d4)(0.0); im[a][b] = (g4_d4)(0.0); }
+    for (int bin = b4; bin < C.nbins; bin += nb4) {
+        const int w0 = bin * C.walkers_per_bin, w1e = min(w0 + C.walkers_per_bin, C.nwalkers);
+        for (int w4 = w0; w4 < w1e; w4 += 4) {
+            if constexpr (!PP) {
+                const int wl = w4 + lk;
+                const bool wok = wl < w1e;
+                const double2 *g1 = G2 + ((size_t)(wok ? wl : w0) * nf + f1) * g2sz, *g2p = G2 + ((size_t)(wok ? wl : w0) * nf + f2) * g2sz;
+                double ar[2], ai[2], br[2], bi[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const double2 a = g1[offA[t]], b = g2p[offB[t]];
+                    ar[t] = (wok && okA[t]) ? a.x : 0.0; ai[t] = (wok && okA[t]) ? a.y : 0.0;
+                    br[t] = (wok && okB[t]) ? b.x : 0.0; bi[t] = (wok && okB[t]) ? b.y : 0.0;
                 }
-                if (acc4pp) {
-                    double2 x = g1[(size_t)(p1a + h) * n2 + (p1c + h)], y = g2p[(size_t)(p2a + h) * n2 + (p2c + h)];
-                    pre += x.x * y.x - x.y * y.y; pim += x.x * y.y + x.y * y.x;
-                    if (f1 == f2) {
-                        double2 u = g1[(size_t)(p3a + h) * n2 + (p3c + h)], v = g1[(size_t)(p4a + h) * n2 + (p4c + h)];
-                        pre -= u.x * v.x - u.y * v.y; pim -= u.x * v.y + u.y * v.x;
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj) {
+                        re[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[ti], br[tj], re[ti][tj], 0, 0, 0);
+                        re[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai[ti], bi[tj], re[ti][tj], 0, 0, 0);
+                        im[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[ti], bi[tj], im[ti][tj], 0, 0, 0);
+                        im[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[ti], br[tj], im[ti][tj], 0, 0, 0);
+                    }
+            }
+            if (PP || same) {
+                const int wend = min(w4 + 4, w1e);
+                for (int w = w4; w < wend; ++w) {
+                    const double2 *g1 = G2 + ((size_t)w * nf + f1) * g2sz, *g2p = G2 + ((size_t)w * nf + f2) * g2sz;      // uniform bases
+                    if constexpr (!PP) {
+                        // exchange term  - g1(a3, c3) g1(a4, c4):  zph = 0: (w2, w1) (w1 + wb, w2 + wb);  zph = 1: (w1, w2) (w2 - wb, w1 - wb).
+                        // All four tiles of the chain at once: sixteen line-wise loads into the LDS tiles, sixteen direct ones into
+                        // registers, ONE hand-off - a tile at a time the wave waited for two memory round trips per tile
+                        double2 dir[2][2][4];
+#pragma unroll
+                        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                            for (int tj = 0; tj < 2; ++tj) {
+                                const int R = r0 + 16 * ti - nwf + h, Cc = c0 + 16 * tj - nwf + h;     // w1 + h = R + (lk + 4 q), w2 + h = Cc + li
+                                if (zph == 0) stage_t_load(g1, tl[2 * ti + tj], ti, tj, Cc, 1, R, 1); else stage_t_load(g1, tl[2 * ti + tj], ti, tj, Cc - wb, 1, R - wb, 1);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const int rl = lk + 4 * q;
+                                    const bool ok = r0 + 16 * ti + rl < nw && c0 + 16 * tj + li < nw;
+                                    dir[ti][tj][q] = g1[ok ? (unsigned)(zph == 0 ? (R + wb + rl) * n2 + (Cc + wb + li) : (R + rl) * n2 + (Cc + li)) : 0u];
+                                }
+                            }
+                        lds_sync();
+#pragma unroll
+                        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const int rl = lk + 4 * q;
+                                    const bool ok = r0 + 16 * ti + rl < nw && c0 + 16 * tj + li < nw;
+                                    const double2 t = tl[2 * ti + tj][li * 17 + rl], d = dir[ti][tj][q];
+                                    if (ok) { re[ti][tj][q] -= t.x * d.x - t.y * d.y; im[ti][tj][q] -= t.x * d.y + t.y * d.x; }
+                                }
+                        lds_sync();
+                    } else {
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                        for (int tj = 0; tj < 2; ++tj) {
+                            const int R = r0 + 16 * ti - nwf + h, Cc = c0 + 16 * tj - nwf + h;     // w1 + h = R + (lk + 4 q), w2 + h = Cc + li
+                            {
+                                // direct: g1(wb - w2 - 1, w1) g2(w2, wb - w1 - 1); exchange (equal flavours): - g1(w2, w1) g1(wb - w2 - 1, wb - w1 - 1)
+                                const int Rm = wb - 1 + 2 * h - Cc, Cm = wb - 1 + 2 * h - R;       // (wb - w2 - 1) + h = Rm - li, (wb - w1 - 1) + h = Cm - (lk + 4 q)
+                                stage_t_load(g1, tl[0], ti, tj, Rm, -1, R, 1);
+                                stage_t_load(g2p, tl[1], ti, tj, Cc, 1, Cm, -1);
+                                if (same) { stage_t_load(g1, tl[2], ti, tj, Cc, 1, R, 1); stage_t_load(g1, tl[3], ti, tj, Rm, -1, Cm, -1); }
+                                lds_sync();
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const int rl = lk + 4 * q;
+                                    const bool ok = r0 + 16 * ti + rl < nw && c0 + 16 * tj + li < nw;
+                                    const double2 xx = tl[0][li * 17 + rl], yy = tl[1][li * 17 + rl];
+                                    if (ok) { re[ti][tj][q] += xx.x * yy.x - xx.y * yy.y; im[ti][tj][q] += xx.x * yy.y + xx.y * yy.x; }
+                                    if (same) {
+                                        const double2 u = tl[2][li * 17 + rl], v = tl[3][li * 17 + rl];
+                                        if (ok) { re[ti][tj][q] -= u.x * v.x - u.y * v.y; im[ti][tj][q] -= u.x * v.y + u.y * v.x; }
+                                    }
+                                }
+                                lds_sync();
+                            }
+                        }
                     }
                 }
             }
         }
-        if (acc4) { double2 *d = acc4 + (size_t)b4 * n4 + e; double2 o = *d; o.x += re; o.y += im; *d = o; }
-        if (acc4pp) { double2 *d = acc4pp + (size_t)b4 * n4 + e; double2 o = *d; o.x += pre; o.y += pim; *d = o; }
     }
-    if (acc2 && e < ng2) {
-        const int f = (int)(e / ((size_t)n2 * n2)); const size_t q = e % ((size_t)n2 * n2);
-        double re = 0.0, im = 0.0;
-        for (int bin = b4; bin < C.nbins; bin += nb4) {
-            const int w0 = bin * C.walkers_per_bin, w1e = min(w0 + C.walkers_per_bin, C.nwalkers);
-            for (int w = w0; w < w1e; ++w) { double2 x = G2[((size_t)w * nf + f) * n2 * n2 + q]; re += x.x; im += x.y; }
-        }
-        double2 *d = acc2 + (size_t)b4 * ng2 + e; double2 o = *d; o.x += re; o.y += im; *d = o;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i1 = r0 + 16 * ti + lk + 4 * q, i2 = c0 + 16 * tj + li;
+                if (i1 >= nw || i2 >= nw) continue;
+                const size_t e = ((((size_t)f1 * nf + f2) * nb + wbi) * nw + i1) * nw + i2;      // w2 fastest: the wave writes runs of 16 elements
+                double2 *d = acc + (size_t)b4 * n4 + e; double2 o = *d; o.x += re[ti][tj][q]; o.y += im[ti][tj][q]; *d = o;
+            }
+}
+// g2 itself (MeasG2iw): thread = element, workgroup = (256 elements, accumulator bin, chunk of G2ACC_CHUNK sample bins of that
+// accumulator bin); the chunk's chains are summed in registers (reads: unit stride across the wave) and added with one
+// return-less atomic per element - a thread per element alone leaves the GPU to 25600 threads that each walk all chains
+constexpr int G2ACC_CHUNK = 16;
+__global__ __launch_bounds__(256) void k_meas_g2acc(DevConst C, int n2, int nwb, int nb4, const double2 *__restrict__ G2, double2 *__restrict__ acc2)
+{
+    const int nf = C.nflav;
+    const size_t ng2 = (size_t)nf * n2 * n2, e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int b4 = blockIdx.y;
+    if (e >= ng2) return;
+    const int f = (int)(e / ((size_t)n2 * n2)); const size_t q = e % ((size_t)n2 * n2);
+    double re = 0.0, im = 0.0;
+    const int first = b4 + (int)blockIdx.z * G2ACC_CHUNK * nb4;
+    for (int c = 0, bin = first; c < G2ACC_CHUNK && bin < C.nbins; ++c, bin += nb4) {
+        const int w0 = bin * C.walkers_per_bin, w1e = min(w0 + C.walkers_per_bin, C.nwalkers);
+        for (int w = w0; w < w1e; ++w) { const double2 x = G2[((size_t)w * nf + f) * g2_stride(n2, nwb) + q]; re += x.x; im += x.y; }
     }
+    double *d = (double *)(acc2 + (size_t)b4 * ng2 + e);
+    atomicAdd(d, re); atomicAdd(d + 1, im);
 }
 #endif  // W2DYN_TU_MEAS
 

@@ -42,7 +42,7 @@ void launch_meas_steps(const DevConst &C, hipStream_t st, double *ser, int nmeas
 void launch_meas_g4leg(const DevConst &C, hipStream_t st, double *acc_tau, double *acc_leg, int nbl, int nt, int nl, int nwb);
 size_t g4leg_fact_lds(const DevConst &C, int nl);
 void launch_meas_g4leg_fact(const DevConst &C, hipStream_t st, double *acc_leg, int nbl, int nl, int nwb);
-void launch_meas_g2iw(const DevConst &C, hipStream_t st, int n2, double2 *G2);
+void launch_meas_g2iw(const DevConst &C, hipStream_t st, int n2, int nwb, double2 *G2);     // G2: g2_stride(n2, nwb) entries per chain and flavour
 void launch_meas_g4iw(const DevConst &C, hipStream_t st, int nwf, int nwb, int zph, int nb4, const double2 *G2, double2 *acc4, double2 *acc4pp, double2 *acc2);
 void launch_meas_g4w(const DevConst &C, hipStream_t st, int pp, int nbw);
 void launch_meas_gw(const DevConst &C, hipStream_t st);

@@ -59,15 +59,21 @@ void launch_meas_g4leg_fact(const DevConst &C, hipStream_t st, double *acc_leg, 
     else if (nwb < 12) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_g4leg_fact<12, 1>), grid, dim3(256), lds, st, C, acc_leg, nbl, nl, nwb);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_g4leg_fact<24, 1>), grid, dim3(256), lds, st, C, acc_leg, nbl, nl, nwb);
 }
-void launch_meas_g2iw(const DevConst &C, hipStream_t st, int n2, double2 *G2)
+void launch_meas_g2iw(const DevConst &C, hipStream_t st, int n2, int nwb, double2 *G2)
 {
-    hipLaunchKernelGGL(k_meas_g2iw, dim3(C.nwalkers, C.nflav), dim3(256), (size_t)3 * C.kmax * G2_FC * sizeof(double2), st, C, n2, G2);
+    hipLaunchKernelGGL(k_meas_g2iw, dim3(C.nwalkers, C.nflav), dim3(256), (size_t)3 * C.kmax * G2_FC * sizeof(double2), st, C, n2, nwb, G2);
 }
 void launch_meas_g4iw(const DevConst &C, hipStream_t st, int nwf, int nwb, int zph, int nb4, const double2 *G2, double2 *acc4, double2 *acc4pp, double2 *acc2)
 {
-    const int n2 = 2 * (nwf + nwb);
-    const size_t n4 = (size_t)C.nflav * C.nflav * 4 * nwf * nwf * (2 * nwb + 1), ng2 = (size_t)C.nflav * n2 * n2;
-    hipLaunchKernelGGL(k_meas_g4iw, dim3((unsigned)(((n4 > ng2 ? n4 : ng2) + 255) / 256), nb4), dim3(256), 0, st, C, nwf, nwb, zph, nb4, G2, acc4, acc4pp, acc2);
+    const int n2 = 2 * (nwf + nwb), nw = 2 * nwf, nreg = (nw + 63) / 64;
+    const dim3 grid(nreg * nreg, C.nflav * C.nflav * (2 * nwb + 1), nb4);
+    if (acc4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_g4iw<false>), grid, dim3(256), 0, st, C, nwf, nwb, zph, nb4, G2, acc4);
+    if (acc4pp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_g4iw<true>), grid, dim3(256), 0, st, C, nwf, nwb, zph, nb4, G2, acc4pp);
+    if (acc2) {
+        const size_t ng2 = (size_t)C.nflav * n2 * n2;
+        const int per_b4 = (C.nbins + nb4 - 1) / nb4;                  // sample bins per accumulator bin
+        hipLaunchKernelGGL(k_meas_g2acc, dim3((unsigned)((ng2 + 255) / 256), nb4, (per_b4 + G2ACC_CHUNK - 1) / G2ACC_CHUNK), dim3(256), 0, st, C, n2, nwb, nb4, G2, acc2);
+    }
 }
 void launch_meas_g4w(const DevConst &C, hipStream_t st, int pp, int nbw)
 {

@@ -849,11 +849,12 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     s->G2 = s->acc4 = s->acc4pp = s->acc2 = nullptr; s->nb4 = 0;
     if (s->fourpnt & 4) {
         const size_t n2 = 2 * (size_t)(s->n4iwf + s->n4iwb), n4 = (size_t)nf * nf * 4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1), ng2 = (size_t)nf * n2 * n2;
-        const size_t g2bytes = W * ng2 * sizeof(double2);
+        const size_t g2all = W * nf * g2_stride((int)n2, s->n4iwb);          // per chain and flavour: the n2 x n2 table, then its 2 N4iwb + 1 central diagonals as rows
+        const size_t g2bytes = g2all * sizeof(double2);
         if (g2bytes > ((size_t)32 << 30)) return fail(s, W2DYN_EUNSUPPORTED, "two-particle measurement: %zu bytes of per-chain g2 scratch; use fewer chains or frequencies", g2bytes);
         const size_t per = (n4 * (1 + (s->meas_g4iwpp ? 1 : 0)) + (s->meas_g2iw ? ng2 : 0)) * sizeof(double2);
         s->nb4 = (int)std::max<size_t>(1, std::min<size_t>(B, acc_budget() / std::max<size_t>(per, 1)));
-        if ((rc = dev_alloc(s, s->G2, W * ng2))) return rc;
+        if ((rc = dev_alloc(s, s->G2, g2all))) return rc;
         if ((rc = dev_alloc(s, s->acc4, (size_t)s->nb4 * n4))) return rc;
         if (s->meas_g4iwpp) { if ((rc = dev_alloc(s, s->acc4pp, (size_t)s->nb4 * n4))) return rc; }
         if (s->meas_g2iw) { if ((rc = dev_alloc(s, s->acc2, (size_t)s->nb4 * ng2))) return rc; }
@@ -1143,7 +1144,7 @@ static int measure_once_impl(w2dyn_solver *s, double2 *g2buf)
     if (s->fourpnt & 4) {           // CTQMC.F90:8579
         const int n2 = 2 * (s->n4iwf + s->n4iwb);
         if ((rc = time_begin(s))) return rc;
-        launch_meas_g2iw(s->C, s->stream, n2, g2buf);
+        launch_meas_g2iw(s->C, s->stream, n2, s->n4iwb, g2buf);
         HIPCHK(hipGetLastError());
         if ((rc = time_end(s, "meas_g2iw"))) return rc;
         if ((rc = time_begin(s))) return rc;
@@ -1166,9 +1167,9 @@ int w2dyn_measure_once_noalloc(w2dyn_solver *s)
 {
     if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "measure before init_solver");
     if (!(s->fourpnt & 4) || s->cur_isector != 1) return fail(s, W2DYN_EINVAL, "measure_once_noalloc: a Z-space run with FourPnt & 4 (Matsubara two-particle estimators) is required");
-    const size_t n2 = 2 * (size_t)(s->n4iwf + s->n4iwb), need = (size_t)s->nwalkers * s->nflav * n2 * n2 * sizeof(double2);
+    const size_t n2 = 2 * (size_t)(s->n4iwf + s->n4iwb), need = (size_t)s->nwalkers * s->nflav * g2_stride((int)n2, s->n4iwb) * sizeof(double2);
     if (need > W2DYN_SCRATCH_BYTES)
-        return fail(s, W2DYN_EINVAL, "measure_once_noalloc: %zu bytes of per-chain g2 tables (chains x flavours x (2 (N4iwf + N4iwb))^2 x 16) exceed the static scratch of %zu bytes", need, (size_t)W2DYN_SCRATCH_BYTES);
+        return fail(s, W2DYN_EINVAL, "measure_once_noalloc: %zu bytes of per-chain g2 tables (chains x flavours x n2 (n2 + 2 N4iwb + 1) x 16, n2 = 2 (N4iwf + N4iwb)) exceed the static scratch of %zu bytes", need, (size_t)W2DYN_SCRATCH_BYTES);
     if (!s->scratch) return fail(s, W2DYN_EHIP, "measure_once_noalloc: no scratch address for device %d", s->device);
     if (g_signal_fired) return interrupted_call(s, "w2dyn_measure_once_noalloc");
     // nothing below allocates, frees or waits for the GPU: kernel launches on the context's stream only (timing is
@@ -1456,7 +1457,7 @@ int w2dyn_measure_finish(w2dyn_solver *s)
     }
     if (s->fourpnt & 4) {     // CTQMC.F90:8790-8800: G4iw * zScaling / beta^2, G2iw * zScaling / beta, zScaling = -1/(N mean_sign)
         const size_t n2 = 2 * (size_t)(s->n4iwf + s->n4iwb), n4 = (size_t)nf * nf * 4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1), ng2 = (size_t)nf * n2 * n2;
-        auto reduce4 = [&](const double2 *dev, size_t per, const char *name, double extra) {
+        auto reduce4 = [&](const double2 *dev, size_t per, const char *name, double extra, bool wb_first) {
             std::vector<double> raw((size_t)s->nb4 * per * 2), bins((size_t)s->nb4 * per * 2), tot(per * 2, 0.0);
             (void)hipMemcpy(raw.data(), dev, raw.size() * sizeof(double), hipMemcpyDeviceToHost);
             PackDesc d{(const double *)dev, s->nb4, per * 2, std::vector<double>(s->nb4), 0};
@@ -1467,11 +1468,23 @@ int w2dyn_measure_finish(w2dyn_solver *s)
                 for (size_t i = 0; i < per * 2; ++i) { double v = raw[(size_t)b * per * 2 + i]; tot[i] += v; bins[(size_t)b * per * 2 + i] = v * (-1.0 / (nb * ms)) * extra; }
             }
             for (size_t i = 0; i < per * 2; ++i) tot[i] *= (-1.0 / (nmeas_tot * ms)) * extra;
+            if (wb_first) {      // device order [f1][f2][wb][w1][w2] -> the reference's G4iw(.., w1, w2, wb) (the packed moments stay in device order)
+                const size_t nw = 2 * (size_t)s->n4iwf, nbq = 2 * (size_t)s->n4iwb + 1, ff = (size_t)nf * nf;
+                auto turn = [&](std::vector<double> &v, size_t lead) {
+                    std::vector<double> o(v.size());
+                    for (size_t a = 0; a < lead * ff; ++a) for (size_t q = 0; q < nbq; ++q) for (size_t i = 0; i < nw * nw; ++i) {
+                        const size_t src = ((a * nbq + q) * nw * nw + i) * 2, dst = ((a * nw * nw + i) * nbq + q) * 2;
+                        o[dst] = v[src]; o[dst + 1] = v[src + 1];
+                    }
+                    v.swap(o);
+                };
+                turn(tot, 1); turn(bins, (size_t)s->nb4);
+            }
             R[name] = tot; R[std::string(name) + "_bins"] = bins; s->pack[name] = d;
         };
-        reduce4(s->acc4, n4, "g4iw", 1.0 / (beta * beta));
-        if (s->acc4pp) reduce4(s->acc4pp, n4, "g4iw_pp", 1.0 / (beta * beta));
-        if (s->acc2) reduce4(s->acc2, ng2, "g2iw", 1.0 / beta);
+        reduce4(s->acc4, n4, "g4iw", 1.0 / (beta * beta), true);
+        if (s->acc4pp) reduce4(s->acc4pp, n4, "g4iw_pp", 1.0 / (beta * beta), true);
+        if (s->acc2) reduce4(s->acc2, ng2, "g2iw", 1.0 / beta, false);
     }
     if (s->cur_isector == 4 && (C.acc_g4w || C.acc_g4wpp)) {
         // wormScaling(SectorG4) = CntSampling(G4) / (CntMeas(G4) CntSampling(Z)) * 16/beta^2 / mean_sign (CTQMC.F90:8825-8849,

@@ -229,8 +229,8 @@ class MCTQMC:
             cplx = name not in ("gleg", "gtau", "histo", "gtau_worm")
             if name in ("gleg", "gtau", "histo", "giw"):
                 shape = (nd, 2, per // (2 * nd * (2 if cplx else 1)))
-            elif name in ("g4iw", "g4iw_pp"):
-                shape = (nd, 2, nd, 2, 2 * nwf, 2 * nwf, 2 * nwb + 1)
+            elif name in ("g4iw", "g4iw_pp"):      # device order: bosonic frequency in front of the two fermionic ones
+                shape = (nd, 2, nd, 2, 2 * nwb + 1, 2 * nwf, 2 * nwf)
             elif name == "g2iw":
                 shape = (nd, 2, 2 * (nwf + nwb), 2 * (nwf + nwb))
             elif name in ("g4iw_worm", "g4iwpp_worm"):
@@ -238,7 +238,7 @@ class MCTQMC:
             else:
                 shape = (per // (2 if cplx else 1),)
             assert int(np.prod(shape)) * (2 if cplx else 1) == per, (name, shape, per)
-            layout[name] = (offs[i], per, shape, cplx)
+            layout[name] = (offs[i], per, shape, cplx) + (((4, -1),) if name in ("g4iw", "g4iw_pp") else ())      # -> (.., w1, w2, wb) as the reference
         return PackedMoments(tensor, layout, comm)
 
     def kernel_time(self, name, reset=False):

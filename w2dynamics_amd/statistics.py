@@ -266,9 +266,11 @@ class PackedMoments:
         """DistributedSample (moments only) of `scale` times one packed result; call after `allreduce`."""
         if self._host is None:
             raise RuntimeError("PackedMoments.sample before allreduce")
-        off, per, shape, cplx = self.layout[name]
+        off, per, shape, cplx = self.layout[name][:4]
+        move = self.layout[name][4] if len(self.layout[name]) > 4 else None       # (axis of the device order, where it belongs)
         rec = self._host[off:off + 1 + 3 * per]
         n, s1, m2, bt = rec[0], rec[1:1 + per], rec[1 + per:1 + 2 * per], rec[1 + 2 * per:]
         if cplx:
             s1 = s1[0::2] + 1j * s1[1::2]; m2 = m2[0::2] + m2[1::2]; bt = bt[0::2] + bt[1::2]
-        return DistributedSample.from_moments(n, scale * s1.reshape(shape), scale ** 2 * m2.reshape(shape), scale ** 2 * bt.reshape(shape), self.comm)
+        s1, m2, bt = (np.moveaxis(a.reshape(shape), *move) if move else a.reshape(shape) for a in (s1, m2, bt))
+        return DistributedSample.from_moments(n, scale * s1, scale ** 2 * m2, scale ** 2 * bt, self.comm)
