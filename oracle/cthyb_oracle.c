@@ -64,6 +64,7 @@ struct ora_walker {
     double *acbuf, *acdat; int aclev; int64_t acn;
     double *g4tau, *g4leg;                    /* FourPnt & 1: G4tau (Nd,2,Nd,2,N4tau^3); FourPnt & 2: G4leg (Nd,2,Nd,2,N4tau,N4tau,2N4iwb+1) complex */
     double *giww, *gtauw;                     /* giw_worm (2Niw complex), gtau_worm (Ntau) accumulators (sector 2) */
+    double *weq[6]; size_t weq_n[6];          /* p2iw, p2iwpp, p2tau, p2taupp, p3iw, p3iwpp worm accumulators (sectors 6 - 9) */
     double try_add, acc_add, accqn_add, try_rem, acc_rem, accqn_rem, try_glob, acc_glob, accqn_glob;
     double try_shift, acc_shift, cnt_sampling, cnt_meas;
     int64_t *accpair;
@@ -523,6 +524,8 @@ static int count_pairs(const ora_walker *w, int pick, int *i1, int *i2)
 static inline double U01(ora_walker *w) { return w->rng->uniform(w->rng->state); }
 static inline int RINT(ora_walker *w, int lo, int hi) { return w->rng->randint(w->rng->state, lo, hi); }
 
+static int check_equal_time(const ora_walker *w, int sector);
+
 static void accpair_add(ora_walker *w, int f, double dt)
 {
     int n = w->naccpair;
@@ -565,7 +568,7 @@ static void step_add(ora_walker *w)
         if (w->ops[i].tau == tau2 && w->ops[i].flav == f && w->ops[i].ca == 1) ic = i;
     }
 
-    if (!sequence_valid(w, w->outer_sst)) {
+    if ((w->sector != 1 && !check_equal_time(w, w->sector)) || !sequence_valid(w, w->outer_sst)) {      /* CTQMC.F90:3455 */
         list_remove(w, ia > ic ? ia : ic); list_remove(w, ia > ic ? ic : ia);
         w->accqn_add += 1;
         return;
@@ -894,8 +897,33 @@ static void step_shift(ora_walker *w)
 
 static int worm_nops(const ora_walker *w) { return w->isector == 2 ? 2 : 4; }
 
-/* get_Proposal for SectorG / SectorG4 (CTQMC.F90:5677-5684) */
-static double worm_prefact(const ora_walker *w) { return pow(w->p.beta * (double)w->p.nd, (double)worm_nops(w)) * w->eta; }
+/* get_Proposal (CTQMC.F90:5677-5719): SectorG / SectorG4 (beta Nd)^n eta; P2 / P2pp beta^2 Nd^4 eta; P3 / P3pp beta^3 Nd^4 eta */
+static double worm_prefact(const ora_walker *w)
+{
+    const double b = w->p.beta, nd = (double)w->p.nd, nd4 = nd * nd * nd * nd;
+    if (w->isector == 6 || w->isector == 7) return b * b * nd4 * w->eta;
+    if (w->isector == 8 || w->isector == 9) return b * b * b * nd4 * w->eta;
+    return pow(b * nd, (double)worm_nops(w)) * w->eta;
+}
+
+/* check_EqualTime (Trace.F90:4184-4269): the operators of an equal-time pair must be neighbours in the list, the one named
+ * second right in front of the one named first.  wid = 1-based index in wormContainer */
+static int worm_index(const ora_walker *w, int wid)
+{
+    for (int i = 0; i < w->nops; ++i) if (w->ops[i].wid == wid) return i;
+    return -1;
+}
+static int prev_is(const ora_walker *w, int wid, int wid_prev) { const int i = worm_index(w, wid); return i > 0 && w->ops[i - 1].wid == wid_prev; }
+static int check_equal_time(const ora_walker *w, int sector)
+{
+    switch (sector) {
+    case 6: return prev_is(w, 1, 2) && prev_is(w, 3, 4);
+    case 7: return prev_is(w, 1, 3) && prev_is(w, 2, 4);
+    case 8: return prev_is(w, 3, 4);
+    case 9: return prev_is(w, 2, 4);
+    default: return 1;
+    }
+}
 
 /* StepWormAdd, CTQMC.F90:4992-5140 */
 static void step_worm_add(ora_walker *w)
@@ -909,14 +937,29 @@ static void step_worm_add(ora_walker *w)
     /* set_OperFlavor (Trace.F90:3804-3826): digits of comp-1 in base 2Nd, most significant first; CA = mod(i,2)+1 */
     op_t o[4]; int rest = comp - 1, base = ncomp / nf;
     for (int i = 0; i < nw; ++i) { int bs = rest / base; rest -= bs * base; base /= nf; o[i].flav = bs; o[i].ca = ((i + 1) % 2) + 1; o[i].wid = i + 1; }
-    /* set_OperTime (Trace.F90:3942-3967) */
+    /* set_OperTime (Trace.F90:3942-4020) */
+    const double beta = w->p.beta, eqoff = beta * 1e-14;       /* equal_time_offset, Trace.F90:398 */
+    if (w->isector >= 6 && w->isector <= 9) {
+        o[0].tau = U01(w) * beta;
+        o[3].tau = U01(w) * beta;
+        if (w->isector <= 7) {                                  /* two random times */
+            if (o[0].tau < eqoff) o[0].tau = eqoff;
+            if (o[3].tau > beta - eqoff) o[3].tau = beta - eqoff;
+            if (w->isector == 6) { o[1].tau = o[0].tau - eqoff; o[2].tau = o[3].tau + eqoff; }
+            else { o[1].tau = o[3].tau + eqoff; o[2].tau = o[0].tau - eqoff; }
+        } else {                                                /* three random times */
+            if (o[3].tau > beta - eqoff) o[3].tau = beta - eqoff;
+            if (w->isector == 8) { o[1].tau = U01(w) * beta; o[2].tau = o[3].tau + eqoff; }
+            else { o[1].tau = o[3].tau + eqoff; o[2].tau = U01(w) * beta; }
+        }
+    } else
     for (int i = 0; i < nw; ++i) {
         o[i].tau = U01(w) * w->p.beta;
         if (i > 0 && o[i - 1].tau == o[i].tau) o[i].tau += w->p.beta * 1e-14;
     }
     for (int i = 0; i < nw; ++i) list_insert(w, o[i]);
     double prefact = worm_prefact(w);
-    if (prefact == 0.0 || !sequence_valid(w, w->outer_sst)) {
+    if (!check_equal_time(w, w->isector) || prefact == 0.0 || !sequence_valid(w, w->outer_sst)) {
         for (int i = w->nops - 1; i >= 0; --i) if (w->ops[i].wid) list_remove(w, i);
         w->accqn_wadd += 1; w->sector = 1;
         return;
@@ -958,12 +1001,27 @@ static void step_worm_rem(ora_walker *w)
     }
 }
 
-/* StepWormReplace for SectorG / SectorG4 (CTQMC.F90:5809-6297) with propose_WormReplace / do_WormReplace (Trace.F90:3054-3478):
- * a worm operator and a hybridising operator of the same flavour and type exchange their roles */
+/* StepWormReplace (CTQMC.F90:5809-6297) with propose_WormReplace / do_WormReplace (Trace.F90:3054-3478): a worm operator
+ * and a hybridising operator of the same flavour and type exchange their roles.  If the worm operator belongs to an
+ * equal-time pair (sectors 6 - 9), its partner moves along to the hybridising operator's time (`multimove`, 6068-6127,
+ * 6183-6249): the pair then sits at (tau_h, tau_h + offset) in the order it had, the local trace changes. */
 static void step_worm_replace(ora_walker *w)
 {
     w->try_wrep += 1;
     int r = RINT(w, 1, worm_nops(w));
+    /* partner that moves along and the place (1 = first, 2 = second in time) of the partner / of the new worm operator */
+    int partner = 0, pos_partner = 0, pos_new = 0;
+    {
+        static const int p2[4] = {2, 1, 4, 3}, p2pp[4] = {3, 4, 1, 2};
+        switch (w->sector) {
+        case 6: partner = p2[r - 1]; pos_partner = (r & 1) ? 1 : 2; break;
+        case 7: partner = p2pp[r - 1]; pos_partner = (r <= 2) ? 1 : 2; break;
+        case 8: if (r > 2) { partner = p2[r - 1]; pos_partner = (r == 3) ? 1 : 2; } break;
+        case 9: if ((r & 1) == 0) { partner = p2pp[r - 1]; pos_partner = (r == 2) ? 1 : 2; } break;
+        default: break;
+        }
+        pos_new = 3 - pos_partner;
+    }
     int iw = -1;
     for (int i = 0; i < w->nops; ++i) if (w->ops[i].wid == r) iw = i;
     const int f = w->ops[iw].flav, ca = w->ops[iw].ca, k = w->k[f];
@@ -1004,8 +1062,35 @@ static void step_worm_replace(ora_walker *w)
     for (int c = 0; c < k; ++c) { double a = 0.0; for (int j = 0; j < k; ++j) a += M[c * k + j] * u[j]; x[c] = a; }
     double detrat = 1.0;
     for (int c = 0; c < k; ++c) detrat += v[c] * x[c];
-    double rnd = U01(w);
-    if (rnd < fabs(detrat)) {
+    double prob = fabs(detrat);
+    logval trnew = w->tr;
+    op_t old_partner, old_hyb;
+    if (partner) {
+        const double eqoff = w->p.beta * 1e-14;
+        const int ip = worm_index(w, partner);
+        old_partner = w->ops[ip]; old_hyb = w->ops[ih];
+        list_remove(w, ip > ih ? ip : ih); list_remove(w, ip > ih ? ih : ip);
+        w->ops[worm_index(w, r)].wid = 0;                       /* stays where it is, as a hybridising operator if accepted */
+        op_t np = old_partner, nh = old_hyb;
+        np.tau = th + (pos_partner == 2 ? eqoff : 0.0);
+        nh.tau = th + (pos_new == 2 ? eqoff : 0.0); nh.wid = r;
+        if (pos_partner == 1) { list_insert(w, np); list_insert(w, nh); } else { list_insert(w, nh); list_insert(w, np); }
+        int ok = check_equal_time(w, w->sector) && sequence_valid(w, w->outer_sst);
+        if (ok) {
+            trnew = full_trace(w, w->outer_sst);
+            prob = fabs(detrat * trnew.sign * w->tr.sign * exp(trnew.log - w->tr.log));
+        }
+        if (!ok || !(U01(w) < prob)) {
+            /* back to the old operators (6224-6234, 6281-6290); a failed check consumes no random number */
+            list_remove(w, worm_index(w, partner)); list_remove(w, worm_index(w, r));
+            for (int i = 0; i < w->nops; ++i)
+                if (w->ops[i].wid == 0 && w->ops[i].flav == f && w->ops[i].ca == ca && w->ops[i].tau == tw) w->ops[i].wid = r;
+            list_insert(w, old_hyb); list_insert(w, old_partner);
+            free(u); free(v); free(x); free(y);
+            return;
+        }
+    }
+    if (partner || U01(w) < prob) {
         for (int j = 0; j < k; ++j) { double a = 0.0; for (int c = 0; c < k; ++c) a += M[c * k + j] * v[c]; y[j] = a; }
         double *Mn = (double *)malloc(sizeof(double) * (size_t)k * k);
         for (int c = 0; c < k; ++c) for (int j = 0; j < k; ++j) Mn[c * k + j] = M[c * k + j] - x[c] * y[j] / detrat;
@@ -1025,7 +1110,8 @@ static void step_worm_replace(ora_walker *w)
         free(w->M[f]); w->M[f] = Mn;
         w->det.log += log(fabs(detrat));
         w->det.sign *= (detrat < 0.0 ? -1.0 : 1.0) * ((ncnt & 1) ? -1.0 : 1.0);
-        w->ops[ih].wid = r; w->ops[iw].wid = 0;
+        if (!partner) { w->ops[ih].wid = r; w->ops[iw].wid = 0; }
+        w->tr = trnew;
         w->cfgsign = -get_sign(w);
         w->acc_wrep += 1;
     }
@@ -1154,6 +1240,12 @@ ora_walker *ora_create(const ora_params *p, const double *U, const double *ftau_
     }
     if (p->worm_meas_giw) w->giww = (double *)calloc((size_t)4 * p->niw, sizeof(double));      /* CTQMC.F90:597-599 */
     if (p->worm_meas_gtau) w->gtauw = (double *)calloc((size_t)p->ntau, sizeof(double));        /* CTQMC.F90:609-612 */
+    for (int q = 0; q < 6; ++q) {                                                   /* CTQMC.F90:654-726 */
+        w->weq[q] = NULL; w->weq_n[q] = 0;
+        if (!p->worm_meas_eq[q]) continue;
+        w->weq_n[q] = q < 2 ? (size_t)2 * (2 * p->n2iwb + 1) : (q < 4 ? (size_t)p->ntau : (size_t)2 * 2 * p->n3iwf * (2 * p->n3iwb + 1));
+        w->weq[q] = (double *)calloc(w->weq_n[q], sizeof(double));
+    }
     if ((p->fourpnt & 8) && p->worm_meas_g4iw) {                                    /* CTQMC.F90:339-361 */
         size_t n = (size_t)4 * p->n4iwf * p->n4iwf * (2 * p->n4iwb + 1) * 2;
         if (p->g4ph) w->g4w = (double *)calloc(n, sizeof(double));
@@ -1178,7 +1270,7 @@ void ora_destroy(ora_walker *w)
     if (!w) return;
     for (int f = 0; f < w->nflav; ++f) free(w->M[f]);
     free(w->ops); free(w->ftab); ora_locprob_free(w->lp); free(w->ptr); free(w->dmblk); free(w->dmoff); free(w->accpair); free(w->accpairtau); free(w->gleg); free(w->gtau); free(w->giw); free(w->ntau_n0); free(w->gms); free(w->gmid); free(w->sstep);
-    free(w->histo); free(w->dm); free(w->outer_histo); free(w->sign_sst); free(w->tcontrib_sst); free(w->outer_state_histo); free(w->sign_state); free(w->tcontrib_state); free(w->g2iw); free(w->g4iw); free(w->g4iwpp); free(w->g4w); free(w->g4wpp); free(w->g4tau); free(w->g4leg); free(w->giww); free(w->gtauw); free(w->acbuf); free(w->acdat); free(w);
+    free(w->histo); free(w->dm); free(w->outer_histo); free(w->sign_sst); free(w->tcontrib_sst); free(w->outer_state_histo); free(w->sign_state); free(w->tcontrib_state); free(w->g2iw); free(w->g4iw); free(w->g4iwpp); free(w->g4w); free(w->g4wpp); free(w->g4tau); free(w->g4leg); free(w->giww); free(w->gtauw); for (int q = 0; q < 6; ++q) free(w->weq[q]); free(w->acbuf); free(w->acdat); free(w);
 }
 
 void ora_set_taudiffmax(ora_walker *w, double x) { init_window(w, x); }
@@ -1459,6 +1551,42 @@ static void meas_g_worm(ora_walker *w)
 
 /* autocorracc_add (Accumulators.F90:283-331): Welford update of level 0 with the buffer; whenever the lowest bits of the
  * count are ones, the mean of the two last lower-level values rolls over into the next level */
+/* measure_p2iw_worm / p2tau / p2iwpp / p2taupp / p3iw / p3iwpp (CTQMC.F90:1297-1507) with the exact transform (Nfft_worm.F90:94-137):
+ * the picked entries of the (4 N + 3)-point transform of x = dtau / (2 beta) are the bosonic frequencies 2 pi j / beta, j = -N..N,
+ * those of the 4 N3iwf-point one the fermionic frequencies (2 i + 1) pi / beta, i = -N3iwf..N3iwf-1 */
+static void meas_eq_worm(ora_walker *w)
+{
+    double t[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < w->nops; ++i) if (w->ops[i].wid) t[w->ops[i].wid] = w->ops[i].tau;
+    const double val = w->cfgsign / w->eta, beta = w->p.beta, pib = M_PI / beta;
+    const int sec = w->sector;
+    if (sec == 6 || sec == 7) {
+        const double dt = sec == 6 ? t[1] - t[3] : t[1] - t[2];
+        double *giw = w->weq[sec - 6], *gt = w->weq[sec - 4];
+        if (giw) {
+            const int nb = w->p.n2iwb;
+            for (int j = -nb; j <= nb; ++j) { const double ph = pib * (double)(2 * j) * dt; giw[2 * (j + nb)] += val * cos(ph); giw[2 * (j + nb) + 1] += val * sin(ph); }
+        }
+        if (gt) {                                   /* no sign change when the difference is wrapped (1340-1344) */
+            double tau = dt; if (tau < 0.0) tau += beta;
+            int itau = (int)((double)w->p.ntau * tau / beta) + 1;
+            if (itau > w->p.ntau) itau = w->p.ntau;
+            gt[itau - 1] += val;
+        }
+    } else if (sec == 8 || sec == 9) {
+        double *g = w->weq[sec - 4];
+        if (!g) return;
+        const double x1 = sec == 8 ? t[1] - t[2] : t[1] - t[3], x2 = sec == 8 ? t[2] - t[3] : t[3] - t[2];
+        const int nf3 = w->p.n3iwf, nb3 = w->p.n3iwb, nb = 2 * nb3 + 1;
+        for (int i = -nf3; i < nf3; ++i)
+            for (int j = -nb3; j <= nb3; ++j) {
+                const double ph = pib * ((double)(2 * i + 1) * x1 + (double)(2 * j) * x2);
+                double *o = g + 2 * ((size_t)(i + nf3) * nb + (j + nb3));
+                o[0] += val * cos(ph); o[1] += val * sin(ph);
+            }
+    }
+}
+
 static void autocorr_add(ora_walker *w)
 {
     const size_t nc = (size_t)w->nflav * w->p.ntau;
@@ -1521,6 +1649,8 @@ void ora_measure_once(ora_walker *w)
     int nf = w->nflav;
     if (w->sector != 1) {                                               /* CTQMC.F90:8586-8593 */
         if (w->sector == 2) { w->cnt_meas_w += 1; meas_g_worm(w); }
+        else if (w->sector == 6 || w->sector == 7) { w->cnt_meas_w += 1; meas_eq_worm(w); }              /* 8603-8610 */
+        else if (w->sector == 8 || w->sector == 9) { if (w->weq[w->sector - 4]) { w->cnt_meas_w += 1; meas_eq_worm(w); } }   /* 8611-8616 */
         else if (w->g4w || w->g4wpp) { w->cnt_meas_w += 1; meas_g4iw_worm(w); }
         return;
     }
@@ -1661,7 +1791,16 @@ void ora_measure_finish(ora_walker *w)
         if (w->giww) for (int i = 0; i < 4 * w->p.niw; ++i) w->giww[i] = -w->giww[i] * scal / nf2;
         if (w->gtauw) for (int i = 0; i < w->p.ntau; ++i) w->gtauw[i] = w->gtauw[i] * scal * ((double)w->p.ntau / beta) / nf2;
     }
-    if (w->isector != 2 && (w->g4w || w->g4wpp)) {   /* wormScaling(SectorG4), CTQMC.F90:8833-8849, 8883-8915 */
+    if (w->isector >= 6 && w->isector <= 9) {        /* wormNorm 16 / beta (P2) or 16 / beta^2 (P3), CTQMC.F90:8830-8849, 9116-9130, 9215-9224, 9229-9313 */
+        const double norm = w->isector <= 7 ? 16.0 / beta : 16.0 / (beta * beta);
+        const double scal = (w->cnt_meas_w != 0) ? w->cnt_sampling_w / (w->cnt_meas_w * w->cnt_sampling) * norm / w->mean_sign : 0.0;
+        for (int q = 0; q < 6; ++q) {
+            if (!w->weq[q]) continue;
+            const double fac = (q == 2 || q == 3) ? scal * ((double)w->p.ntau / beta) : scal;
+            for (size_t i = 0; i < w->weq_n[q]; ++i) w->weq[q][i] *= fac;
+        }
+    }
+    if ((w->isector == 4 || w->isector == 1) && (w->g4w || w->g4wpp)) {   /* wormScaling(SectorG4), CTQMC.F90:8833-8849, 8883-8915 */
         double scal = (w->cnt_meas_w != 0) ? w->cnt_sampling_w / (w->cnt_meas_w * w->cnt_sampling) * 16.0 / (beta * beta) / w->mean_sign : 0.0;
         size_t n = (size_t)4 * w->p.n4iwf * w->p.n4iwf * (2 * w->p.n4iwb + 1) * 2;
         if (w->g4w) for (size_t i = 0; i < n; ++i) w->g4w[i] *= scal;
@@ -1835,6 +1974,12 @@ int ora_get_giw_worm(const ora_walker *w, double *o)
     if (!w->giww) return 0;
     memcpy(o, w->giww, sizeof(double) * (size_t)4 * w->p.niw);
     return 1;
+}
+int ora_get_worm_eq(const ora_walker *w, int which, double *o)
+{
+    if (which < 0 || which > 5 || !w->weq[which]) return 0;
+    memcpy(o, w->weq[which], sizeof(double) * w->weq_n[which]);
+    return (int)w->weq_n[which];
 }
 int ora_get_gtau_worm(const ora_walker *w, double *o)
 {

@@ -55,6 +55,9 @@ typedef struct ora_params {
     int accum_gtau;         /* AccumGtau: 0 = G(tau)/G(l) not measured, 1 = running mean, 2 = autocorrelation accumulator (CTQMC.F90:492-500) */
     int meas_susz;          /* MeasSusz (matrix solver): <n(tau) n(0)>, meas_ntau_n0 (CTQMC.F90:534-540, Trace.F90:6472-6835) */
     int step_series;        /* bit 0: Gtau_mean_step, bit 1: Gtau_mid_step, bit 2: sign_step - per-measurement series (CTQMC.F90:43-45, 2394-2402) */
+    /* worm sampling with equal-time pairs, sectors 6 / 7 (P2 ph / pp) and 8 / 9 (P3 ph / pp) (CTQMC.F90:654-726) */
+    int n2iwb, n3iwf, n3iwb;                       /* N2iwb, N3iwf, N3iwb */
+    int worm_meas_eq[6];                           /* WormMeasP2iwPH, WormMeasP2iwPP, WormMeasP2tauPH, WormMeasP2tauPP, WormMeasP3iwPH, WormMeasP3iwPP */
 } ora_params;
 
 typedef struct ora_walker ora_walker;
@@ -69,7 +72,7 @@ void ora_destroy(ora_walker *w);
 void ora_set_taudiffmax(ora_walker *w, double x);        /* CTQMC.F90:8180 */
 void ora_warmup(ora_walker *w, int64_t n);               /* CTQMC.F90:8188 */
 int ora_measure(ora_walker *w);                          /* CTQMC.F90:8355 sector Z; returns `aborted` */
-/* ctqmc_measure(isector, icomponent) with isector = 2 (G worm), 4 (G4 worm) or 1 (CTQMC.F90:8355-8849); returns `aborted` */
+/* ctqmc_measure(isector, icomponent) with isector = 2 (G worm), 4 (G4 worm), 6 - 9 (P2 / P2pp / P3 / P3pp worms) or 1 (CTQMC.F90:8355-8849); returns `aborted` */
 int ora_measure_sector(ora_walker *w, int isector, int icomponent);
 void ora_set_wormeta(ora_walker *w, double eta);
 void ora_set_sector(ora_walker *w, int isector, int icomponent);   /* sector of the following ora_sweep calls */         /* module variable wormeta(isector) (impurity.py:719) */
@@ -82,6 +85,9 @@ int ora_get_g4iw_worm(const ora_walker *w, double *out_reim, int pp);
 int ora_get_ntau_n0(const ora_walker *w, double *out);       /* ntau_n0 (Nd,2,Nd,2,Ntau+1), MeasSusz = 1; returns 0 if not measured */
 int ora_get_gtau_blocks(const ora_walker *w, double *out);   /* gtau_blocks (Nd,2,Ntau,nlevels), AccumGtau = 2; returns nlevels */
 int ora_get_giw_worm(const ora_walker *w, double *out_reim);
+/* which = 0 p2iw_worm, 1 p2iwpp_worm (2N2iwb+1 complex interleaved), 2 p2tau_worm, 3 p2taupp_worm (Ntau),
+ * 4 p3iw_worm, 5 p3iwpp_worm (2N3iwf, 2N3iwb+1 complex interleaved); returns the number of doubles copied, 0 if not measured */
+int ora_get_worm_eq(const ora_walker *w, int which, double *out);
 int ora_get_gtau_worm(const ora_walker *w, double *out);
 /* [0]TryWormAdd [1]AccWormAdd [2]AccQNWormAdd [3]TryWormRem [4]AccWormRem [5]AccQNWormRem [6]TryWormRep [7]AccWormRep
  * [8]CntSampling(worm) [9]CntMeas(worm) [10]TryAdd(worm) [11]AccAdd(worm) [12]TryRem(worm) [13]AccRem(worm) [14]sector now */

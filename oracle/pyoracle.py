@@ -24,7 +24,11 @@ class OraParams(C.Structure):
                 ("p_worm_ins", C.c_double), ("p_worm_rep", C.c_double), ("worm_eta", C.c_double),
                 ("worm_meas_g4iw", C.c_int), ("g4ph", C.c_int), ("g4pp", C.c_int), ("wormphconv", C.c_int),
                 ("worm_meas_giw", C.c_int), ("worm_meas_gtau", C.c_int), ("epsblock", C.c_double), ("accum_gtau", C.c_int),
-                ("meas_susz", C.c_int), ("step_series", C.c_int)]
+                ("meas_susz", C.c_int), ("step_series", C.c_int),
+                ("n2iwb", C.c_int), ("n3iwf", C.c_int), ("n3iwb", C.c_int), ("worm_meas_eq", C.c_int * 6)]
+
+WORM_EQ_KEYS = ("WormMeasP2iwPH", "WormMeasP2iwPP", "WormMeasP2tauPH", "WormMeasP2tauPP", "WormMeasP3iwPH", "WormMeasP3iwPP")
+WORM_EQ_NAMES = ("p2iw_worm", "p2iwpp_worm", "p2tau_worm", "p2taupp_worm", "p3iw_worm", "p3iwpp_worm")
 
 
 def build():
@@ -86,6 +90,7 @@ def lib():
     L.ora_get_ssquare.argtypes = [vp, dp, dp]
     L.ora_get_step_series.argtypes = [vp, dp, dp, dp]; L.ora_get_step_series.restype = C.c_int
     L.ora_get_gtau_worm.argtypes = [vp, dp]; L.ora_get_gtau_worm.restype = C.c_int
+    L.ora_get_worm_eq.argtypes = [vp, C.c_int, dp]; L.ora_get_worm_eq.restype = C.c_int
     L.ora_get_hashybs.argtypes = [vp, ip]
     L.ora_get_g2iw.argtypes = [vp, dp]; L.ora_get_g2iw.restype = C.c_int
     L.ora_get_g4iw.argtypes = [vp, dp, C.c_int]; L.ora_get_g4iw.restype = C.c_int
@@ -124,7 +129,9 @@ def params_from_pstring(ps, nd, beta, fourpnt=0):
                      worm_meas_giw=int(ps.get_int("WormMeasGiw") != 0), worm_meas_gtau=int(ps.get_int("WormMeasGtau") != 0),
                      epsblock=ps.get_real("EPSBLOCK"), accum_gtau=ps.get_int("AccumGtau"),
                      meas_susz=int(ps.get_int("MeasSusz") == 1 and ps.get_int("segment") == 0),
-                     step_series=(1 if ps.get_int("Gtau_mean_step") else 0) | (2 if ps.get_int("Gtau_mid_step") else 0) | (4 if ps.get_int("sign_step") else 0))
+                     step_series=(1 if ps.get_int("Gtau_mean_step") else 0) | (2 if ps.get_int("Gtau_mid_step") else 0) | (4 if ps.get_int("sign_step") else 0),
+                     n2iwb=ps.get_int("N2iwb"), n3iwf=ps.get_int("N3iwf"), n3iwb=ps.get_int("N3iwb"),
+                     worm_meas_eq=(C.c_int * 6)(*[int(ps.get_int(k) != 0) for k in WORM_EQ_KEYS]))
 
 
 class OracleWalker:
@@ -254,6 +261,13 @@ class OracleWalker:
         a = np.zeros(p.ntau)
         if self.L.ora_get_gtau_worm(self.h, a):
             r["gtau_worm"] = a
+        for q, name in enumerate(WORM_EQ_NAMES):
+            if not p.worm_meas_eq[q]:
+                continue
+            shape = (2 * p.n2iwb + 1, 2) if q < 2 else ((p.ntau,) if q < 4 else (2 * p.n3iwf, 2 * p.n3iwb + 1, 2))
+            a = np.zeros(shape)
+            if self.L.ora_get_worm_eq(self.h, q, a):
+                r[name] = a if q in (2, 3) else a[..., 0] + 1j * a[..., 1]
         if p.fourpnt & 1:
             a = np.zeros((nd, 2, nd, 2, p.n4tau, p.n4tau, p.n4tau))
             if self.L.ora_get_g4tau(self.h, a):

@@ -304,7 +304,68 @@ def gen_wormstat(only=None):
         print("wormstat", out, "max |g4iw_worm|", np.abs(g.mean(axis=0)).max(), "max err", (np.sqrt(g.real.var(axis=0, ddof=1) + g.imag.var(axis=0, ddof=1)) / np.sqrt(nseeds)).max())
 
 
-KINDS = ("traj", "stat", "g4", "worm", "calib", "accum", "g4leg", "susz", "ssq", "steps", "wormstat")
+# worm sampling with equal-time operator pairs (round 3): sectors 6 / 7 (P2 ph / pp: two random times) and 8 / 9 (P3 ph / pp:
+# three random times); components as flavours (f1 f2 f3 f4) of c c+ c c+.  name: (sector, config, nftau, overrides, seed, component)
+def _comp4(nf, f):
+    return 1 + ((f[0] * nf + f[1]) * nf + f[2]) * nf + f[3]
+
+
+_EQ = dict(PercentageWormInsert=0.2, PercentageWormReplace=0.2, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05, NLegMax=8, Niw=4)
+WORMEQ = {
+    "P2_C1a": (6, "C1", 501, dict(_EQ, Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=50, N2iwb=3, WormEta=0.3,
+                                  WormMeasP2iwPH=1, WormMeasP2tauPH=1), 601, _comp4(2, (0, 0, 1, 1))),
+    "P2_C1b": (6, "C1", 501, dict(_EQ, Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=40, N2iwb=2, WormEta=0.3,
+                                  WormMeasP2iwPH=1, WormMeasP2tauPH=1), 602, _comp4(2, (0, 1, 1, 0))),
+    "P2_C3a": (6, "C3", 501, dict(_EQ, Nwarmups=3000, Nmeas=500, NCorr=20, TaudiffMax=6.0, Ntau=50, N2iwb=3, WormEta=0.05,
+                                  WormMeasP2iwPH=1, WormMeasP2tauPH=1), 603, _comp4(4, (0, 0, 3, 3))),
+    "P2pp_C1a": (7, "C1", 501, dict(_EQ, Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=50, N2iwb=3, WormEta=0.3,
+                                    WormMeasP2iwPP=1, WormMeasP2tauPP=1), 611, _comp4(2, (0, 0, 1, 1))),
+    "P2pp_C3a": (7, "C3", 501, dict(_EQ, Nwarmups=3000, Nmeas=500, NCorr=20, TaudiffMax=6.0, Ntau=50, N2iwb=2, WormEta=0.05,
+                                    WormMeasP2iwPP=1, WormMeasP2tauPP=1), 612, _comp4(4, (0, 0, 3, 3))),
+    "P3_C1a": (8, "C1", 501, dict(_EQ, Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=50, N3iwf=3, N3iwb=2, WormEta=0.05,
+                                  WormMeasP3iwPH=1), 621, _comp4(2, (0, 0, 1, 1))),
+    "P3_C3a": (8, "C3", 501, dict(_EQ, Nwarmups=3000, Nmeas=500, NCorr=20, TaudiffMax=6.0, Ntau=50, N3iwf=2, N3iwb=2, WormEta=0.005,
+                                  WormMeasP3iwPH=1), 622, _comp4(4, (1, 1, 2, 2))),
+    "P3pp_C1a": (9, "C1", 501, dict(_EQ, Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=50, N3iwf=3, N3iwb=2, WormEta=0.05,
+                                    WormMeasP3iwPP=1), 631, _comp4(2, (0, 0, 1, 1))),
+    "P3pp_C3a": (9, "C3", 501, dict(_EQ, Nwarmups=3000, Nmeas=500, NCorr=20, TaudiffMax=6.0, Ntau=50, N3iwf=2, N3iwb=1, WormEta=0.005,
+                                    WormMeasP3iwPP=1), 632, _comp4(4, (0, 3, 3, 0))),
+    # matrix local-trace path (2-orbital Kanamori): a spin-flip component and a density component
+    "P2_C4Sa": (6, "C4S", 501, dict(_EQ, Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=50, N2iwb=3, WormEta=0.05,
+                                    WormMeasP2iwPH=1, WormMeasP2tauPH=1), 641, _comp4(4, (0, 1, 3, 2))),
+    "P3_C4Sa": (8, "C4S", 501, dict(_EQ, Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=50, N3iwf=2, N3iwb=2, WormEta=0.005,
+                                    WormMeasP3iwPH=1), 642, _comp4(4, (0, 0, 2, 2))),
+    "P2pp_C4Sa": (7, "C4S", 501, dict(_EQ, Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=50, N2iwb=2, WormEta=0.05,
+                                      WormMeasP2iwPP=1, WormMeasP2tauPP=1), 643, _comp4(4, (0, 0, 1, 1))),
+    "P3pp_C4Sa": (9, "C4S", 501, dict(_EQ, Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=50, N3iwf=2, N3iwb=1, WormEta=0.005,
+                                      WormMeasP3iwPP=1), 644, _comp4(4, (0, 1, 3, 2))),
+}
+WORMEQ_KEYS = ("p2iw_worm", "p2iwpp_worm", "p2tau_worm", "p2taupp_worm", "p3iw_worm", "p3iwpp_worm", "mean_sign", "accwormadd", "accwormrem",
+               "accwormrep", "cntsampling", "accadd", "accrem", "occ", "histo")
+
+
+def gen_wormeq(only=None):
+    for name, (sector, cfg, nftau, over, seed, comp) in WORMEQ.items():
+        if only and name not in only:
+            continue
+        p, ps = pstring_for(cfg, nftau, over)
+        s = refdrive.RefSolver(p, ps, seed)
+        s.set_taudiffmax(over["TaudiffMax"])
+        s.warmup(over["Nwarmups"])
+        steps = s.count_steps(sector, comp, 3000)
+        s.worm_warmup(0, sector, comp)
+        s.measure(sector, comp)
+        r = s.results(WORMEQ_KEYS)
+        c_end = s.get_config()
+        s.close()
+        np.savez_compressed(os.path.join(OUT, "wormeq_%s.npz" % name), config=cfg, nftau=nftau, seed=seed, sector=sector, component=comp,
+                            overrides=repr(over), count_steps=np.array(steps), **{"end_" + k: v for k, v in c_end.items()},
+                            **{"res_" + k: v for k, v in r.items()})
+        print("wormeq", name, "steps(worm, Z) of the eta search", steps, "cntsampling", r["cntsampling"][[0, sector - 1]],
+              "acc add/rem/rep", r["accwormadd"][sector - 1], r["accwormrem"][sector - 1], r["accwormrep"][sector - 1], "nops", len(c_end["taus"]))
+
+
+KINDS = ("traj", "stat", "g4", "worm", "calib", "accum", "g4leg", "susz", "ssq", "steps", "wormstat", "wormeq")
 
 ACCUM = {   # AccumGtau = 2 (autocorrelation accumulator: gtau_blocks) and 0 (G(tau), G(l) not measured), one seeded chain
     # name: (config, nftau, overrides, seed)
@@ -467,3 +528,5 @@ if __name__ == "__main__":
         gen_steps(only)
     if "wormstat" in which:
         gen_wormstat(only)
+    if "wormeq" in which:
+        gen_wormeq(only)

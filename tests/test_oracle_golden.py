@@ -312,6 +312,43 @@ def test_oracle_g_worm_sampling_retraces_reference(name):
     w.close()
 
 
+WORMEQ = ["P2_C1a", "P2_C1b", "P2_C3a", "P2pp_C1a", "P2pp_C3a", "P3_C1a", "P3_C3a", "P3pp_C1a", "P3pp_C3a",
+          "P2_C4Sa", "P3_C4Sa", "P2pp_C4Sa", "P3pp_C4Sa"]
+
+
+@pytest.mark.parametrize("name", WORMEQ)
+def test_oracle_equal_time_worm_sampling_retraces_reference(name):
+    """Worm sampling with equal-time operator pairs, sectors 6 - 9 (P2 / P2pp: two random times, P3 / P3pp: three; worm
+    insertion with set_OperTime's pair offsets and check_EqualTime, replacement that moves the partner along): eta-search step
+    counts, sector step counts, acceptance ratios, final configuration, p2iw / p2tau / p3iw estimators agree with the reference
+    run, on the scalar (C1, C3) and the matrix trace path (C4S)."""
+    g = util.load_golden("wormeq_%s.npz" % name)
+    over = g["overrides"]; comp = int(g["component"]); sec = int(g["sector"])
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    w = pyoracle.OracleWalker(p, pset, ("std", int(g["seed"])))
+    w.set_taudiffmax(over["TaudiffMax"])
+    w.warmup(over["Nwarmups"])
+    assert w.count_steps(sec, comp, 3000) == tuple(int(x) for x in g["count_steps"])
+    w.measure_sector(sec, comp)
+    r = w.results(); wc = w.worm_counters(); c = w.get_config()
+    assert r["counters"][11] == g["res_cntsampling"][0] and wc["cnt_sampling_w"] == g["res_cntsampling"][sec - 1]
+    assert len(c["taus"]) == len(g["end_taus"])
+    if len(c["taus"]):
+        assert np.abs(c["taus"] - g["end_taus"]).max() < 1e-12
+        assert np.array_equal(c["hashybs"], g["end_hashybs"]) and np.array_equal(c["cas"], g["end_cas"])
+    for key, num, den in (("accwormadd", "acc_wadd", "try_wadd"), ("accwormrep", "acc_wrep", "try_wrep"), ("accwormrem", "acc_wrem", "try_wrem")):
+        assert wc[num] / max(wc[den], 1.0) == pytest.approx(float(g["res_" + key][sec - 2]), rel=1e-12, abs=1e-300), key
+    checked = 0
+    for k in pyoracle.WORM_EQ_NAMES:
+        if "res_" + k in g and g["res_" + k].size > 1:
+            assert k in r, k
+            assert r[k].shape == g["res_" + k].shape and rel(r[k], g["res_" + k]) < 1e-10, k
+            checked += 1
+    assert checked >= 1
+    assert rel(r["occ"], g["res_occ"]) < 1e-10
+    w.close()
+
+
 @pytest.mark.parametrize("name", ["C1", "C3", "C1off"])
 def test_oracle_gtau_accumulator_modes_retrace_reference(name):
     """AccumGtau = 2 (autocorracc, Accumulators.F90:206-362): G(tau) from the level-0 Welford mean and the log-binned

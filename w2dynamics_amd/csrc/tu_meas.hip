@@ -66,7 +66,7 @@ void launch_meas_g2iw(const DevConst &C, hipStream_t st, int n2, int nwb, double
 void launch_meas_g4iw(const DevConst &C, hipStream_t st, int nwf, int nwb, int zph, int nb4, const double2 *G2, double2 *acc4, double2 *acc4pp, double2 *acc2)
 {
     const int n2 = 2 * (nwf + nwb), nw = 2 * nwf, nreg = (nw + 63) / 64;
-    const dim3 grid(nreg * nreg, C.nflav * C.nflav * (2 * nwb + 1), nb4);
+    const dim3 grid(nreg * nreg, C.nflav * C.nflav * (2 * nwb + 1), (nb4 + 7) / 8 * 8);       // z: accumulator bins in groups of eight (one per XCD)
     if (acc4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_g4iw<false>), grid, dim3(256), 0, st, C, nwf, nwb, zph, nb4, G2, acc4);
     if (acc4pp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_g4iw<true>), grid, dim3(256), 0, st, C, nwf, nwb, zph, nb4, G2, acc4pp);
     if (acc2) {
