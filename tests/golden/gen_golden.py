@@ -316,7 +316,7 @@ WORMEQ = {
                                   WormMeasP2iwPH=1, WormMeasP2tauPH=1), 601, _comp4(2, (0, 0, 1, 1))),
     "P2_C1b": (6, "C1", 501, dict(_EQ, Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=40, N2iwb=2, WormEta=0.3,
                                   WormMeasP2iwPH=1, WormMeasP2tauPH=1), 602, _comp4(2, (0, 1, 1, 0))),
-    "P2_C3a": (6, "C3", 501, dict(_EQ, Nwarmups=3000, Nmeas=500, NCorr=20, TaudiffMax=6.0, Ntau=50, N2iwb=3, WormEta=0.05,
+    "P2_C3a": (6, "C3", 501, dict(_EQ, Nwarmups=3000, Nmeas=500, NCorr=20, TaudiffMax=6.0, Ntau=50, N2iwb=3, WormEta=0.0002,
                                   WormMeasP2iwPH=1, WormMeasP2tauPH=1), 603, _comp4(4, (0, 0, 3, 3))),
     "P2pp_C1a": (7, "C1", 501, dict(_EQ, Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=50, N2iwb=3, WormEta=0.3,
                                     WormMeasP2iwPP=1, WormMeasP2tauPP=1), 611, _comp4(2, (0, 0, 1, 1))),
@@ -324,7 +324,7 @@ WORMEQ = {
                                     WormMeasP2iwPP=1, WormMeasP2tauPP=1), 612, _comp4(4, (0, 0, 3, 3))),
     "P3_C1a": (8, "C1", 501, dict(_EQ, Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=50, N3iwf=3, N3iwb=2, WormEta=0.05,
                                   WormMeasP3iwPH=1), 621, _comp4(2, (0, 0, 1, 1))),
-    "P3_C3a": (8, "C3", 501, dict(_EQ, Nwarmups=3000, Nmeas=500, NCorr=20, TaudiffMax=6.0, Ntau=50, N3iwf=2, N3iwb=2, WormEta=0.005,
+    "P3_C3a": (8, "C3", 501, dict(_EQ, Nwarmups=3000, Nmeas=500, NCorr=20, TaudiffMax=6.0, Ntau=50, N3iwf=2, N3iwb=2, WormEta=0.00002,
                                   WormMeasP3iwPH=1), 622, _comp4(4, (1, 1, 2, 2))),
     "P3pp_C1a": (9, "C1", 501, dict(_EQ, Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=50, N3iwf=3, N3iwb=2, WormEta=0.05,
                                     WormMeasP3iwPP=1), 631, _comp4(2, (0, 0, 1, 1))),
@@ -339,6 +339,11 @@ WORMEQ = {
                                       WormMeasP2iwPP=1, WormMeasP2tauPP=1), 643, _comp4(4, (0, 0, 1, 1))),
     "P3pp_C4Sa": (9, "C4S", 501, dict(_EQ, Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=50, N3iwf=2, N3iwb=1, WormEta=0.005,
                                       WormMeasP3iwPP=1), 644, _comp4(4, (0, 1, 3, 2))),
+    # blocks of up to 9 states (3-orbital Kanamori with Nt, Szt only): the sequential trace evaluator on the GPU
+    "P2_C4Na": (6, "C4N", 501, dict(_EQ, Nwarmups=2000, Nmeas=300, NCorr=10, TaudiffMax=3.0, Ntau=50, N2iwb=2, WormEta=0.002,
+                                    WormMeasP2iwPH=1, WormMeasP2tauPH=1), 651, _comp4(6, (0, 1, 3, 2))),
+    "P3pp_C4Na": (9, "C4N", 501, dict(_EQ, Nwarmups=2000, Nmeas=300, NCorr=10, TaudiffMax=3.0, Ntau=50, N3iwf=2, N3iwb=1, WormEta=0.002,
+                                      WormMeasP3iwPP=1), 652, _comp4(6, (0, 2, 2, 0))),
 }
 WORMEQ_KEYS = ("p2iw_worm", "p2iwpp_worm", "p2tau_worm", "p2taupp_worm", "p3iw_worm", "p3iwpp_worm", "mean_sign", "accwormadd", "accwormrem",
                "accwormrep", "cntsampling", "accadd", "accrem", "occ", "histo")

@@ -797,6 +797,62 @@ def test_g_worm_sampling_chains_vs_oracle(name):
     q.dest_ctqmc(); q.close()
 
 
+WORMEQ_CASES = ["P2_C1a", "P2_C1b", "P2_C3a", "P2pp_C1a", "P2pp_C3a", "P3_C1a", "P3_C3a", "P3pp_C1a", "P3pp_C3a",
+                "P2_C4Sa", "P3_C4Sa", "P2pp_C4Sa", "P3pp_C4Sa", "P2_C4Na", "P3pp_C4Na"]
+
+
+@pytest.mark.parametrize("name", WORMEQ_CASES)
+def test_equal_time_worm_sampling_chains_vs_oracle(name):
+    """Worm sampling with equal-time pairs, sectors 6 - 9 (P2 / P2pp / P3 / P3pp), scalar (C1, C3) and matrix trace path (C4S):
+    every chain retraces the oracle chain with the same stream through count_steps, the mixed Z / worm loop (insertion with
+    the pair offsets, replacement that moves the partner along) and the p2iw / p2tau / p3iw estimators; the pooled result
+    follows from the per-chain ones.  The oracle itself retraces the reference's runs (tests/test_oracle_golden.py)."""
+    g = util.load_golden("wormeq_%s.npz" % name)
+    comp = int(g["component"]); sec = int(g["sector"]); nw = 5
+    over = g["overrides"]
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    q = make_gpu(p, ps, 29, nw, wpb=1)
+    q.set_taudiffmax(over["TaudiffMax"])
+    q.ctqmc_warmup(over["Nwarmups"])
+    sw, sz = q.count_steps(sec, comp, 3000)
+    assert sw + sz == 3000
+    chains_w = q.steps_worm_chains
+    q.ctqmc_worm_warmup(0, sec, comp)
+    q.ctqmc_measure(sec, comp)
+    wc = q.worm_counters
+    keys = [k for k in pyoracle.WORM_EQ_NAMES if "res_" + k in g and g["res_" + k].size > 1]
+    assert keys
+    pooled = {k: 0.0 for k in keys}; cw = cz = mw = 0.0; nrep = 0.0
+    for w in range(nw):
+        o = pyoracle.OracleWalker(p, pset, ("philox", 29, w))
+        o.set_taudiffmax(over["TaudiffMax"]); o.warmup(over["Nwarmups"])
+        assert o.count_steps(sec, comp, 3000)[0] == chains_w[w], w
+        o.measure_sector(sec, comp)
+        r = o.results(); oc = o.worm_counters(); c = o.get_config()
+        got = [r["counters"][11], oc["cnt_sampling_w"], oc["try_wadd"], oc["acc_wadd"], oc["try_wrem"], oc["acc_wrem"], oc["try_wrep"], oc["acc_wrep"]]
+        assert np.array_equal(wc[w], got), (w, wc[w], got)
+        nrep += oc["acc_wrep"]
+        n, osst, _ = q.get_mc_config_scalars(w)
+        assert n == len(c["taus"]) and osst == c["outer_sst"]
+        taus, orbs, spins, cas, hyb, _, _ = q.get_mc_config(n, w)
+        if n:
+            assert np.abs(taus - c["taus"]).max() < 1e-12 and np.array_equal(hyb, c["hashybs"]) and np.array_equal(cas, c["cas"])
+            assert np.array_equal(orbs, c["orbs"]) and np.array_equal(spins, c["spins"])
+        for k in keys:
+            assert rel(getattr(q, k + "_bins")[w], r[k]) < TOL, (k, w)
+            pooled[k] = pooled[k] + r[k] * (oc["cnt_meas_w"] * r["counters"][11] / max(oc["cnt_sampling_w"], 1.0))
+        cw += oc["cnt_sampling_w"]; cz += r["counters"][11]; mw += oc["cnt_meas_w"]
+        assert rel(q.histo_bins[w], r["histo"]) < TOL and rel(q.occ_bins[w], r["occ"]) < TOL
+        o.close()
+    assert mw > 0
+    if float(g["res_accwormrep"][sec - 2]) > 0.01:
+        assert nrep > 0                                 # the replacement with a moved partner is in play
+    for k in keys:
+        assert rel(getattr(q, k), pooled[k] * cw / (mw * cz)) < TOL, k
+    assert q.cntsampling[0] == cz and q.cntsampling[sec - 1] == cw
+    q.dest_ctqmc(); q.close()
+
+
 @pytest.mark.parametrize("name", WORM2_CASES)
 def test_g_worm_sampling_vs_reference_statistics(name):
     """The REFERENCE's giw_worm / gtau_worm of one short chain (worm2_*.npz, mt19937) is one draw from the distribution
@@ -1007,6 +1063,37 @@ def test_solver_worm_component_with_eta_search():
     st = r2["steps-worm-partition/00001"]
     # brentq stops at xtol = 0.001 in eta (impurity.py:744-779), a sizeable relative error for eta of a few 1e-3: looser band
     assert 0.3 < st[3] / st[0] < 3.0
+
+
+def test_solver_p2_worm_agrees_with_z_space_density_correlation():
+    """HipCtHybSolver.solve_component in sector 6 (P2, equal-time pairs c c+ = 1 - n): p2tau-worm of the component (f f g g),
+    times nflavours^4 / 16 (the 2^4 of wormNorm, CTQMC.F90:8830), is <(1 - n_f)(tau) (1 - n_g)(0)> - which the Z-space estimator
+    MeasSusz gives independently as 1 - <n_f> - <n_g> + <n_f(tau) n_g(0)>.  Two estimators, two sampling spaces, one number:
+    equal-flavour and different-flavour component within the error bars; the eta search balances the spaces."""
+    from w2dynamics_amd.solver import HipCtHybSolver
+    from w2dynamics_amd import synth
+    base = dict(BASE, Ntau=20, Nwarmups=20000, Nmeas=1000, NCorr=20, TaudiffMax=6.0, Nftau=501)
+    p = synth.config("C1", nftau=501); nfl = 2 * p.nd
+    s = HipCtHybSolver(dict(base, MeasSusz=1), seed=3, nwalkers=1024, walkers_per_bin=8)
+    s.set_problem(p)
+    r = s.solve(0)
+    chi = np.asarray(r["ntau-n0"].mean()); occ = np.asarray(r["occ"].mean())
+    for f, g in ((0, 1), (0, 0)):
+        comp = 1 + ((f * nfl + f) * nfl + g) * nfl + g
+        s2 = HipCtHybSolver(dict(base, Nwarmups2Plus=4000, N2iwb=3, PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=1.0,
+                                 WormSearchEta=1, WormMeasP2tauPH=1, WormMeasP2iwPH=1), seed=5, nwalkers=1024, walkers_per_bin=8)
+        s2.set_problem(p)
+        r2 = s2.solve_component(0, 6, comp)
+        st = r2["steps-worm-partition/%05d" % comp]
+        assert 0.5 < st[5] / st[0] < 2.0
+        pt = np.asarray(r2["p2tau-worm/%05d" % comp].mean()) * nfl ** 4 / 16.0
+        pe = np.asarray(r2["p2tau-worm/%05d" % comp].stderr()) * nfl ** 4 / 16.0
+        hh = 1.0 - occ[f // 2, f % 2, f // 2, f % 2] - occ[g // 2, g % 2, g // 2, g % 2] + chi[f // 2, f % 2, g // 2, g % 2]
+        mid = 0.5 * (hh[:-1] + hh[1:])                  # the worm estimator averages over a tau bin, the Z-space one sits on the bin edges
+        assert np.all(np.abs(pt - mid) < 5.0 * pe + 0.01 * np.abs(mid)), (f, g, np.abs(pt - mid).max(), pe.max())
+        # the static component of p2iw is the integral of the same correlator over tau
+        piw = np.asarray(r2["p2iw-worm/%05d" % comp].mean()) * nfl ** 4 / 16.0
+        assert abs(piw[3].real - pt.mean() * p.beta) < 0.02 * abs(piw[3].real) and abs(piw[3].imag) < 1e-9
 
 
 @pytest.mark.parametrize("name", ["C1", "C3", "C4"])

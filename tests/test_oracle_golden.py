@@ -313,7 +313,7 @@ def test_oracle_g_worm_sampling_retraces_reference(name):
 
 
 WORMEQ = ["P2_C1a", "P2_C1b", "P2_C3a", "P2pp_C1a", "P2pp_C3a", "P3_C1a", "P3_C3a", "P3pp_C1a", "P3pp_C3a",
-          "P2_C4Sa", "P3_C4Sa", "P2pp_C4Sa", "P3pp_C4Sa"]
+          "P2_C4Sa", "P3_C4Sa", "P2pp_C4Sa", "P3pp_C4Sa", "P2_C4Na", "P3pp_C4Na"]
 
 
 @pytest.mark.parametrize("name", WORMEQ)

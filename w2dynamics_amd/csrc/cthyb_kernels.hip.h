@@ -92,7 +92,7 @@ struct WalkerScalars {
     double det_sign;            // sign of det F in the reference's time order (Trace%Det%sign)
     double det_log;             // log|det F|
     unsigned long long cnt[C_NCOUNT];
-    // worm sampling: current sector (0/1 = Z, 2 = one-particle worm c c+, 4 = two-particle worm c c+ c c+) and the
+    // worm sampling: current sector (0/1 = Z, 2 = one-particle worm c c+, 4 = two-particle worm c c+ c c+, 6 - 9 = P2 / P2pp / P3 / P3pp) and the
     // worm operators in wormContainer order (Trace.F90:123-125): times and flavours (the first `sector` entries count)
     int sector; int wflav[4]; double wtau[4];
     // steps of an interrupted sweep launch still to do: a chain stops (ERR_KMAX set) as soon as one of its flavours has filled
@@ -1562,7 +1562,7 @@ __device__ __forceinline__ void ctx_load(Ctx &x)
     const WalkerScalars &s = C.ws[w];
     x.outer = uni(s.outer); x.npairs = uni(s.npairs); x.wpos = uni(s.wpos); x.err = uni(s.err);
     x.det_sign = uni(s.det_sign); x.det_log = uni(s.det_log);
-    { const int sec = uni(s.sector); x.sector = (sec == 4 || sec == 2) ? sec : 1; }
+    { const int sec = uni(s.sector); x.sector = (sec == 4 || sec == 2 || (sec >= 6 && sec <= 9)) ? sec : 1; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { x.wtau[i] = uni(s.wtau[i]); x.wfl[i] = uni(s.wflav[i]); }
     unsigned long long nd_ = s.ndraw;

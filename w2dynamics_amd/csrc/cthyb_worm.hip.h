@@ -1,5 +1,6 @@
-// Worm sampling in sector 4 (two-particle Green's function, NW = 4 worm operators c c+ c c+) and sector 2 (one-particle
-// Green's function, NW = 2 worm operators c c+; NOperWorm, CTQMC.F90:5282-5285) for one-state blocks (density-density problems):
+// Worm sampling in sector 4 (two-particle Green's function, NW = 4 worm operators c c+ c c+), sector 2 (one-particle
+// Green's function, NW = 2 worm operators c c+; NOperWorm, CTQMC.F90:5282-5285) and the sectors with equal-time pairs 6 / 7
+// (P2 ph / pp: two random times) and 8 / 9 (P3 ph / pp: three random times; NW = 4, the sector is DevConst::isector):
 // StepWormAdd / StepWormRem (CTQMC.F90:4992-5249), StepWormReplace with propose_/do_WormReplace (CTQMC.F90:5809-6297,
 // Trace.F90:3054-3478), the mixed Z / worm-space loop (CTQMC.F90:8428-8533) and the G4iw worm estimator with the exact
 // transform (CTQMC.F90:1618-1701, Nfft_worm.F90:94-137).  Included by cthyb_kernels.hip.h inside namespace w2dyn.
@@ -92,12 +93,49 @@ __device__ W2DYN_INLINE bool worm_delta(Ctx &x, const double (&t)[4], const int 
     return valid;
 }
 
-// get_Proposal for SectorG / SectorG4: (beta Nd)^NW eta (CTQMC.F90:5677-5684)
+// get_Proposal: SectorG / SectorG4 (beta Nd)^NW eta; P2 / P2pp beta^2 Nd^4 eta; P3 / P3pp beta^3 Nd^4 eta (CTQMC.F90:5677-5719)
 template <int NW>
 __device__ __forceinline__ double worm_prefact(const DevConst &C)
 {
+    if constexpr (NW == 4) {
+        if (C.isector >= 6) {
+            const double nd = (double)C.nd, nd4 = nd * nd * nd * nd, bb = C.beta * C.beta;
+            return (C.isector >= 8 ? bb * C.beta : bb) * nd4 * C.worm_eta;
+        }
+    }
     const double b = C.beta * (double)C.nd, b2 = b * b;
     return (NW == 4 ? b2 * b2 : b2) * C.worm_eta;
+}
+
+// set_OperTime (Trace.F90:3942-4020): independent times in sectors 2 and 4; sectors 6 / 7: tau_1 and tau_4 random, the partners
+// an offset beta 1e-14 below tau_1 and above tau_4 (P2: 2 with 1, 3 with 4; P2pp: 3 with 1, 2 with 4); sectors 8 / 9: a third
+// random time for operator 2 (P3) or 3 (P3pp), the other one an offset above tau_4.  check_EqualTime (an operator between the
+// two of a pair: needs two times within 1e-14 beta of each other) is not looked for.
+template <int NW>
+__device__ __forceinline__ void worm_draw_times(Ctx &x, double (&t)[4])
+{
+    const DevConst &C = x.C;
+    if constexpr (NW == 4) {
+        if (C.isector >= 6) {
+            const double beta = C.beta, off = beta * 1e-14;
+            t[0] = x.draw() * beta;
+            t[3] = x.draw() * beta;
+            if (C.isector <= 7) {
+                if (t[0] < off) t[0] = off;
+                if (t[3] > beta - off) t[3] = beta - off;
+                if (C.isector == 6) { t[1] = t[0] - off; t[2] = t[3] + off; } else { t[1] = t[3] + off; t[2] = t[0] - off; }
+            } else {
+                if (t[3] > beta - off) t[3] = beta - off;
+                if (C.isector == 8) { t[1] = x.draw() * beta; t[2] = t[3] + off; } else { t[1] = t[3] + off; t[2] = x.draw() * beta; }
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        t[i] = x.draw() * C.beta;
+        if (i > 0 && t[i - 1] == t[i]) t[i] += C.beta * 1e-14;
+    }
 }
 
 template <int NW>
@@ -113,11 +151,7 @@ __device__ W2DYN_INLINE void step_worm_add(Ctx &x)
     int rest = comp - 1, base = ncomp / nf;
 #pragma unroll
     for (int i = 0; i < NW; ++i) { const int bs = rest / base; rest -= bs * base; base /= nf; fl[i] = bs; }
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {                     // set_OperTime, Trace.F90:3942-3967
-        t[i] = x.draw() * C.beta;
-        if (i > 0 && t[i - 1] == t[i]) t[i] += C.beta * 1e-14;
-    }
+    worm_draw_times<NW>(x, t);
     double dlog;
     const bool valid = worm_delta<NW>(x, t, fl, dlog);
     if (worm_prefact<NW>(C) == 0.0 || !valid) { x.count(C_QNWADD); x.sector = 1; return; }
@@ -125,7 +159,7 @@ __device__ W2DYN_INLINE void step_worm_add(Ctx &x)
     if (rnd < fabs(worm_prefact<NW>(C) * exp(dlog))) {
 #pragma unroll
         for (int i = 0; i < NW; ++i) { x.wtau[i] = t[i]; x.wfl[i] = fl[i]; }
-        x.sector = NW;
+        x.sector = NW == 4 ? C.isector : NW;
         x.count(C_ACCWADD);
     } else x.sector = 1;
 }
@@ -143,13 +177,31 @@ __device__ W2DYN_INLINE void step_worm_rem(Ctx &x)
 }
 
 // a worm operator and a hybridising operator of the same flavour and type exchange their roles: one row (creator) or
-// column (annihilator) of the hybridisation matrix changes; Sherman-Morrison on the slot-ordered M, no reordering
-template <int NW>
+// column (annihilator) of the hybridisation matrix changes; Sherman-Morrison on the slot-ordered M, no reordering.
+//
+// Sectors 6 - 9: if the worm operator belongs to an equal-time pair, its partner moves along to the hybridising operator's
+// time (CTQMC.F90:6068-6127, 6183-6249): the pair then sits at (tau_h, tau_h + offset) in the order it had, the old worm operator
+// stays where it is (as a hybridising operator from now on), and the acceptance ratio gets the local-trace ratio of moving
+// ONE operator, the partner (flavour g, from t to t'), with everything else in place:
+//   one-state blocks: valid iff no other operator of flavour g lies between t and t' (the former hybridising operator at its
+//   new time included), log ratio = -dn int_(t,t') (eps_g + sum_{g'} U_gg' n_g')  with dn = -1 (+1) for a creator moved to a
+//   later (earlier) time and the reverse for an annihilator, n_g' from all other operators (level_integral<NW>);
+//   larger blocks: the partner's list entry is moved, block sequence and trace are evaluated like for a worm insertion.
+// A move that fails the quantum-number check consumes no random number (goto 99 there), a vanishing trace does.
+template <int NW, int MAT>
 __device__ W2DYN_INLINE void step_worm_replace(Ctx &x)
 {
     const DevConst &C = x.C;
     x.count(C_TRYWREP);
     const int r = x.randint(1, NW) - 1;
+    int partner = -1, pos_partner = 0;               // container index of the partner, its place in the new pair (1: at tau_h, 2: an offset above)
+    if constexpr (NW == 4) {
+        const int sec = C.isector;
+        if (sec == 6) { partner = r ^ 1; pos_partner = (r & 1) ? 2 : 1; }
+        else if (sec == 7) { partner = r ^ 2; pos_partner = r < 2 ? 1 : 2; }
+        else if (sec == 8) { if (r >= 2) { partner = r ^ 1; pos_partner = r == 2 ? 1 : 2; } }
+        else if (sec == 9) { if (r & 1) { partner = r ^ 2; pos_partner = r == 1 ? 1 : 2; } }
+    }
     double tw = 0.0; int f = 0;
 #pragma unroll
     for (int i = 0; i < NW; ++i) if (i == r) { tw = x.wtau[i]; f = x.wfl[i]; }
@@ -198,8 +250,51 @@ __device__ W2DYN_INLINE void step_worm_replace(Ctx &x)
     }
     wave_sync();
     const double detrat = creator ? 1.0 + uni(x.MQ[slot]) : 1.0 + wave_sum(part);
-    const double rnd = x.draw();
-    if (!(rnd < fabs(detrat))) return;
+    double prob = fabs(detrat);
+    double tp = 0.0, tpn = 0.0, thn = th, tl = 0.0, ts = 1.0; int fp = 0;
+    if constexpr (NW == 4) {
+        if (partner >= 0) {
+            const double off = C.beta * 1e-14;
+            tpn = th + (pos_partner == 2 ? off : 0.0); thn = th + (pos_partner == 1 ? off : 0.0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (i == partner) { tp = x.wtau[i]; fp = x.wfl[i]; }
+            const int pca = (partner & 1) ? 1 : 2;
+            if constexpr (MAT == 0) {
+                const double lo = fmin(tp, tpn), hi = fmax(tp, tpn);
+                bool ok = !worm_any_between(x, fp, lo, hi);
+                if (fp == f && thn > lo && thn < hi) ok = false;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (i != partner && x.wfl[i] == fp && x.wtau[i] > lo && x.wtau[i] < hi) ok = false;
+                if (!ok) return;
+                const double dn = ((pca == 1) == (tpn > tp)) ? -1.0 : 1.0;
+                prob = fabs(detrat * exp(-dn * level_integral<NW>(x, fp, lo, hi)));
+            } else {
+                mat_remove(x, mat_lower(x, tp));
+                wave_sync();
+                if (thn != th) { const int ih = mat_lower(x, th); if (x.lane == 0) x.ot[ih] = thn; wave_sync(); }
+                mat_insert(x, mat_lower(x, tpn), tpn, mat_code(fp, pca));
+                if (!mat_walk_into(x, x.outer, x.tsst)) ts = 0.0;
+                else {
+                    mat_trace_trial<MAT>(x, x.tsst, x.nops, -1, -1, tl, ts);
+                    prob = ts != 0.0 ? fabs(detrat * exp(tl - x.tr_log)) : 0.0;
+                    ts = ts != 0.0 ? ts : 2.0;                  // 2: the sequence is allowed, the trace vanishes (a random number is drawn)
+                }
+            }
+        }
+    }
+    bool accept = false;
+    if (ts != 0.0) { const double rnd = x.draw(); accept = rnd < prob; }
+    if (!accept) {
+        if constexpr (NW == 4 && MAT != 0) {
+            if (partner >= 0) {                                // back to the old list
+                mat_remove(x, mat_lower(x, tpn));
+                wave_sync();
+                if (thn != th) { const int ih = mat_lower(x, thn); if (x.lane == 0) x.ot[ih] = th; wave_sync(); }
+                mat_insert(x, mat_lower(x, tp), tp, mat_code(fp, (partner & 1) ? 1 : 2));
+            }
+        }
+        return;
+    }
     const int kk = k * k;
     for (int e = x.lane; e < kk; e += 64) {
         const int c = e / k, a = e - c * k;
@@ -207,7 +302,10 @@ __device__ W2DYN_INLINE void step_worm_replace(Ctx &x)
     }
     if (x.lane == 0) { if (creator) tcp[slot] = tw; else tap[slot] = tw; }
 #pragma unroll
-    for (int i = 0; i < NW; ++i) if (i == r) x.wtau[i] = th;
+    for (int i = 0; i < NW; ++i) { if (i == r) x.wtau[i] = thn; if (NW == 4 && i == partner) x.wtau[i] = tpn; }
+    if constexpr (NW == 4 && MAT != 0) {
+        if (partner >= 0) { x.tr_log = tl; x.tr_sign = ts; mat_commit_sst(x); }
+    }
     wave_sync();
     x.det_log += log(fabs(detrat));
     x.det_sign *= (detrat < 0.0 ? -1.0 : 1.0) * ((ncnt & 1) ? -1.0 : 1.0);
@@ -231,11 +329,7 @@ __device__ W2DYN_INLINE void step_worm_add_mat(Ctx &x)
     int rest = comp - 1, base = ncomp / nf;
 #pragma unroll
     for (int i = 0; i < NW; ++i) { const int bs = rest / base; rest -= bs * base; base /= nf; fl[i] = bs; }
-#pragma unroll
-    for (int i = 0; i < NW; ++i) {                     // set_OperTime, Trace.F90:3942-3967
-        t[i] = x.draw() * C.beta;
-        if (i > 0 && t[i - 1] == t[i]) t[i] += C.beta * 1e-14;
-    }
+    worm_draw_times<NW>(x, t);
     if (x.nops + NW > C.wcap) { x.err |= ERR_WCAP; x.count(C_QNWADD); x.sector = 1; return; }
 #pragma unroll
     for (int i = 0; i < NW; ++i) mat_insert(x, mat_lower(x, t[i]), t[i], mat_code(fl[i], (i & 1) ? 1 : 2));
@@ -253,7 +347,7 @@ __device__ W2DYN_INLINE void step_worm_add_mat(Ctx &x)
 #pragma unroll
         for (int i = 0; i < NW; ++i) { x.wtau[i] = t[i]; x.wfl[i] = fl[i]; }
         x.tr_log = tl; x.tr_sign = ts; mat_commit_sst(x);
-        x.sector = NW;
+        x.sector = NW == 4 ? C.isector : NW;
         x.count(C_ACCWADD);
     } else { take_out(); x.sector = 1; }
 }
@@ -320,7 +414,7 @@ __global__ __launch_bounds__(256, W2DYN_WPE_WORM) void k_sweep_worm(DevConst C, 
             const double r = x.draw();
             if (r < (1.0 - pr - pw) / 2.0) { x.skip(2); step_add<MAT, NW>(x); phase += 1; WORM_KIND(C_DBG5); }
             else if (r < 1.0 - pr - pw) { x.skip(2); step_rem<MAT, NW>(x); phase += 1; WORM_KIND(C_DBG5); }
-            else if (r < 1.0 - pw) { step_worm_replace<NW>(x); WORM_KIND(C_DBG6); }
+            else if (r < 1.0 - pw) { step_worm_replace<NW, MAT>(x); WORM_KIND(C_DBG6); }
             else { if constexpr (MAT != 0) step_worm_rem_mat<NW, MAT>(x); else step_worm_rem<NW>(x); WORM_KIND(C_DBG7); }
         }
 #ifdef W2DYN_STAMPS_WORM
@@ -443,5 +537,50 @@ __global__ __launch_bounds__(256) void k_meas_gw(DevConst C)
     }
     __syncthreads();
     if (C.acc_gtauw) { double *acc = C.acc_gtauw + (size_t)bin * C.ntau; for (int i = tid; i < C.ntau; i += 256) acc[i] += gth[i]; }
+}
+
+// Estimators of the equal-time sectors (measure_p2iw_worm, p2tau, p2iwpp, p2taupp, p3iw, p3iwpp, CTQMC.F90:1297-1507, with the
+// exact transform, Nfft_worm.F90:94-137): every chain in worm space adds cfgsign/eta times
+//   sectors 6 / 7: exp(i w_j dt), w_j = 2 pi j / beta, j = -N2iwb..N2iwb, and one count in the bin of dt (+ beta if negative, no
+//                  sign change), dt = t1 - t3 (P2) or t1 - t2 (P2pp);
+//   sectors 8 / 9: exp(i [nu_i x1 + w_j x2]), nu_i = (2 i + 1) pi / beta, i = -N3iwf..N3iwf-1, j = -N3iwb..N3iwb,
+//                  (x1, x2) = (t1 - t2, t2 - t3) (P3) or (t1 - t3, t3 - t2) (P3pp).
+// One workgroup per accumulator bin (sample bins folded onto nbe of them), the bin's chains looped, thread = element.
+__global__ __launch_bounds__(256) void k_meas_weq(DevConst C, int nbe, double *acc_iw, double *acc_tau, double *acc_p3, int n2b, int n3f, int n3b)
+{
+    const int bin = blockIdx.x, tid = threadIdx.x, sec = C.isector;
+    const double pib = M_PI / C.beta;
+    for (int cb = bin; cb < C.nbins; cb += nbe)
+    for (int w = cb * C.walkers_per_bin; w < min((cb + 1) * C.walkers_per_bin, C.nwalkers); ++w) {
+        const WalkerScalars &s = C.ws[w];
+        if (s.sector < 6) continue;                          // uniform over the workgroup
+        const double t1 = s.wtau[0], t2 = s.wtau[1], t3 = s.wtau[2];
+        const double val = C.cfgsign[w] / C.worm_eta;
+        if (sec <= 7) {
+            const double dt = sec == 6 ? t1 - t3 : t1 - t2;
+            if (acc_iw) {
+                double *a = acc_iw + (size_t)bin * (2 * n2b + 1) * 2;
+                for (int e = tid; e < 2 * n2b + 1; e += 256) {
+                    double sn, cs; sincos(pib * (double)(2 * (e - n2b)) * dt, &sn, &cs);
+                    a[2 * e] += val * cs; a[2 * e + 1] += val * sn;
+                }
+            }
+            if (acc_tau && tid == 0) {
+                double tau = dt; if (tau < 0.0) tau += C.beta;
+                int it = (int)((double)C.ntau * tau / C.beta) + 1;
+                if (it > C.ntau) it = C.ntau;
+                acc_tau[(size_t)bin * C.ntau + it - 1] += val;
+            }
+        } else if (acc_p3) {
+            const double x1 = sec == 8 ? t1 - t2 : t1 - t3, x2 = sec == 8 ? t2 - t3 : t3 - t2;
+            const int nb = 2 * n3b + 1, n = 2 * n3f * nb;
+            double *a = acc_p3 + (size_t)bin * n * 2;
+            for (int e = tid; e < n; e += 256) {
+                const int i = e / nb - n3f, j = e - (e / nb) * nb - n3b;
+                double sn, cs; sincos(pib * ((double)(2 * i + 1) * x1 + (double)(2 * j) * x2), &sn, &cs);
+                a[2 * e] += val * cs; a[2 * e + 1] += val * sn;
+            }
+        }
+    }
 }
 #endif  // W2DYN_TU_MEAS

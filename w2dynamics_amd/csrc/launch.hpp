@@ -37,6 +37,8 @@ void launch_gleg_legendre(hipStream_t st, const double *in, const double *tab, i
 void launch_meas_gtau_ac(const DevConst &C, hipStream_t st, double *dat, int nlev, long long n);
 void launch_gtau_blocks(const DevConst &C, hipStream_t st, const double *dat, int nlev, long long n, double *out);
 void launch_meas_giw(const DevConst &C, hipStream_t st);
+// estimators of the equal-time worm sectors 6 - 9 (p2iw / p2tau / p3iw); nbe accumulator bins
+void launch_meas_weq(const DevConst &C, hipStream_t st, int nbe, double *acc_iw, double *acc_tau, double *acc_p3, int n2b, int n3f, int n3b);
 void launch_meas_susz(const DevConst &C, hipStream_t st, double *acc, int nbs);
 void launch_meas_steps(const DevConst &C, hipStream_t st, double *ser, int nmeas, int m, int what);
 void launch_meas_g4leg(const DevConst &C, hipStream_t st, double *acc_tau, double *acc_leg, int nbl, int nt, int nl, int nwb);

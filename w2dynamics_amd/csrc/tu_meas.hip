@@ -75,6 +75,10 @@ void launch_meas_g4iw(const DevConst &C, hipStream_t st, int nwf, int nwb, int z
         hipLaunchKernelGGL(k_meas_g2acc, dim3((unsigned)((ng2 + 255) / 256), nb4, (per_b4 + G2ACC_CHUNK - 1) / G2ACC_CHUNK), dim3(256), 0, st, C, n2, nwb, nb4, G2, acc2);
     }
 }
+void launch_meas_weq(const DevConst &C, hipStream_t st, int nbe, double *acc_iw, double *acc_tau, double *acc_p3, int n2b, int n3f, int n3b)
+{
+    hipLaunchKernelGGL(k_meas_weq, dim3(nbe), dim3(256), 0, st, C, nbe, acc_iw, acc_tau, acc_p3, n2b, n3f, n3b);
+}
 void launch_meas_g4w(const DevConst &C, hipStream_t st, int pp, int nbw)
 {
     hipLaunchKernelGGL(k_meas_g4w, dim3(nbw), dim3(256), (size_t)(4 * C.nwf + 2 * C.nwb + 1) * sizeof(double2), st, C, pp, nbw);

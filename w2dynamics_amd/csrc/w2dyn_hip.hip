@@ -128,6 +128,9 @@ struct w2dyn_solver {
     int accum_gtau = 1, ac_lev = 0; long long ac_n = 0; double *ac_dat = nullptr, *ac_out = nullptr;
     int res_isector = 1;                             // sector of the run the result table was made from
     int worm_meas_giw = 0, worm_meas_gtau = 0;       // sector 2: WormMeasGiw, WormMeasGtau (CTQMC.F90:597-612)
+    // sectors 6 - 9 (equal-time pairs): WormMeasP2iwPH, P2iwPP, P2tauPH, P2tauPP, P3iwPH, P3iwPP; N2iwb, N3iwf, N3iwb (CTQMC.F90:654-726)
+    int worm_meas_eq[6] = {0, 0, 0, 0, 0, 0}, n2iwb = 0, n3iwf = 0, n3iwb = 0, nbe = 0;
+    double *acc_weq_iw = nullptr, *acc_weq_tau = nullptr, *acc_weq_p3 = nullptr;
     bool no_sampling = false;
     std::vector<long long> steps_worm_chains;
     // configurations of all chains kept on the host across init_solver calls (w2dyn_save_mc_configs / w2dyn_restore_mc_configs)
@@ -572,6 +575,13 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if (!get_int(s, "WormMeasG4iw", iv)) return W2DYN_EINVAL; s->worm_meas_g4iw = iv != 0;
     if (!get_int(s, "WormMeasGiw", iv)) return W2DYN_EINVAL; s->worm_meas_giw = iv != 0;
     if (!get_int(s, "WormMeasGtau", iv)) return W2DYN_EINVAL; s->worm_meas_gtau = iv != 0;
+    {
+        static const char *keys[6] = {"WormMeasP2iwPH", "WormMeasP2iwPP", "WormMeasP2tauPH", "WormMeasP2tauPP", "WormMeasP3iwPH", "WormMeasP3iwPP"};
+        for (int q = 0; q < 6; ++q) { if (!get_int(s, keys[q], iv)) return W2DYN_EINVAL; s->worm_meas_eq[q] = iv != 0; }
+        if (!get_int(s, "N2iwb", iv)) return W2DYN_EINVAL; s->n2iwb = (int)iv;
+        if (!get_int(s, "N3iwf", iv)) return W2DYN_EINVAL; s->n3iwf = (int)iv;
+        if (!get_int(s, "N3iwb", iv)) return W2DYN_EINVAL; s->n3iwb = (int)iv;
+    }
     if (!get_int(s, "G4ph", iv)) return W2DYN_EINVAL; s->g4ph = iv != 0;
     if (!get_int(s, "G4pp", iv)) return W2DYN_EINVAL; s->g4pp = iv != 0;
     if (!get_int(s, "WormPHConvention", iv)) return W2DYN_EINVAL; s->wormphconv = iv != 0;
@@ -838,6 +848,18 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
         if ((rc = dev_alloc(s, C.acc_gtauw, B * (size_t)s->ntau))) return rc;
         if ((size_t)s->ntau * sizeof(double) > 64 * 1024) return fail(s, W2DYN_EUNSUPPORTED, "Ntau=%d too large for the gtau_worm estimator", s->ntau);
     }
+    s->acc_weq_iw = s->acc_weq_tau = s->acc_weq_p3 = nullptr; s->nbe = 0;
+    {   // one sector is sampled per run: the ph and pp estimators of a kind share their accumulator
+        const bool iw = s->worm_meas_eq[0] || s->worm_meas_eq[1], tau = s->worm_meas_eq[2] || s->worm_meas_eq[3], p3 = s->worm_meas_eq[4] || s->worm_meas_eq[5];
+        if (iw || tau || p3) {
+            if (s->n2iwb < 0 || s->n3iwf < 1 || s->n3iwb < 0) return fail(s, W2DYN_EINVAL, "N2iwb=%d N3iwf=%d N3iwb=%d", s->n2iwb, s->n3iwf, s->n3iwb);
+            const size_t per = ((iw ? (size_t)2 * (2 * s->n2iwb + 1) : 0) + (tau ? (size_t)s->ntau : 0) + (p3 ? (size_t)4 * s->n3iwf * (2 * s->n3iwb + 1) : 0)) * sizeof(double);
+            s->nbe = (int)std::max<size_t>(1, std::min<size_t>(B, acc_budget() / per));
+            if (iw) { if ((rc = dev_alloc(s, s->acc_weq_iw, (size_t)s->nbe * 2 * (2 * s->n2iwb + 1)))) return rc; }
+            if (tau) { if ((rc = dev_alloc(s, s->acc_weq_tau, (size_t)s->nbe * s->ntau))) return rc; }
+            if (p3) { if ((rc = dev_alloc(s, s->acc_weq_p3, (size_t)s->nbe * 4 * s->n3iwf * (2 * s->n3iwb + 1)))) return rc; }
+        }
+    }
     if (s->g4ph || s->g4pp) {
         const size_t n = (size_t)4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1) * 2 * ((s->g4ph ? 1 : 0) + (s->g4pp ? 1 : 0));
         s->nbw = (int)std::max<size_t>(1, std::min<size_t>(B, acc_budget() / (n * sizeof(double))));
@@ -936,7 +958,7 @@ static int sweep_impl(w2dyn_solver *s, int64_t nsteps, int count_as_sampling)
     if ((rc = time_begin(s))) return rc;
     // instantiations: 0 = one-state blocks (closed-form trace); 2, 3, 4 = matrix path with blocks padded to that size
     // (tree product); 9 = matrix path, sequential propagation (blocks of 5..8 states)
-    if (s->cur_isector == 4 || s->cur_isector == 2) launch_sweep_worm(s->cur_isector, mat_variant(s), l, s->C, (long long)nsteps, 0);   // counts its own steps
+    if (s->cur_isector != 1) launch_sweep_worm(s->cur_isector, mat_variant(s), l, s->C, (long long)nsteps, 0);   // counts its own steps
     else launch_sweep(mat_variant(s), false, l, s->C, (long long)nsteps, count_as_sampling, 0);
     s->last_count_sampling = count_as_sampling;
     HIPCHK(hipGetLastError());
@@ -1060,6 +1082,9 @@ int w2dyn_measure_begin(w2dyn_solver *s)
     if (s->acc_g4leg) HIPCHK(hipMemsetAsync(s->acc_g4leg, 0, sizeof(double) * s->nbl * nf * nf * s->n4leg * s->n4leg * (2 * s->n4iwb + 1) * 2, s->stream));
     if (C.acc_giww) HIPCHK(hipMemsetAsync(C.acc_giww, 0, sizeof(double) * B * C.niw2 * 2, s->stream));
     if (C.acc_gtauw) HIPCHK(hipMemsetAsync(C.acc_gtauw, 0, sizeof(double) * B * s->ntau, s->stream));
+    if (s->acc_weq_iw) HIPCHK(hipMemsetAsync(s->acc_weq_iw, 0, sizeof(double) * (size_t)s->nbe * 2 * (2 * s->n2iwb + 1), s->stream));
+    if (s->acc_weq_tau) HIPCHK(hipMemsetAsync(s->acc_weq_tau, 0, sizeof(double) * (size_t)s->nbe * s->ntau, s->stream));
+    if (s->acc_weq_p3) HIPCHK(hipMemsetAsync(s->acc_weq_p3, 0, sizeof(double) * (size_t)s->nbe * 4 * s->n3iwf * (2 * s->n3iwb + 1), s->stream));
     if (s->acc_susz) HIPCHK(hipMemsetAsync(s->acc_susz, 0, sizeof(double) * (size_t)s->nbs * nf * nf * s->ntau, s->stream));
     if (s->ser) HIPCHK(hipMemsetAsync(s->ser, 0, sizeof(double) * (size_t)(2 * nf + 1) * (size_t)s->nmeas, s->stream));
     if (s->fourpnt & 4) {
@@ -1089,6 +1114,18 @@ static int measure_once_impl(w2dyn_solver *s, double2 *g2buf)
                 launch_meas_gw(s->C, s->stream);
                 HIPCHK(hipGetLastError());
                 if ((rc = time_end(s, "meas_gw"))) return rc;
+            }
+        } else if (s->cur_isector >= 6) {
+            // sector 6 measures p2iw / p2tau (ph), 7 the pp ones, 8 p3iw, 9 p3iwpp - each only when asked for (CTQMC.F90:8603-8616)
+            const int is = s->cur_isector;
+            double *iw = (is == 6 && s->worm_meas_eq[0]) || (is == 7 && s->worm_meas_eq[1]) ? s->acc_weq_iw : nullptr;
+            double *tau = (is == 6 && s->worm_meas_eq[2]) || (is == 7 && s->worm_meas_eq[3]) ? s->acc_weq_tau : nullptr;
+            double *p3 = (is == 8 && s->worm_meas_eq[4]) || (is == 9 && s->worm_meas_eq[5]) ? s->acc_weq_p3 : nullptr;
+            if (iw || tau || p3) {
+                if ((rc = time_begin(s))) return rc;
+                launch_meas_weq(s->C, s->stream, s->nbe, iw, tau, p3, s->n2iwb, s->n3iwf, s->n3iwb);
+                HIPCHK(hipGetLastError());
+                if ((rc = time_end(s, "meas_weq"))) return rc;
             }
         } else if (s->C.acc_g4w || s->C.acc_g4wpp) {
             if ((rc = time_begin(s))) return rc;
@@ -1394,7 +1431,7 @@ int w2dyn_measure_finish(w2dyn_solver *s)
         std::vector<double> aa(16, 0.0), ar(16, 0.0);
         aa[0] = s->counters[C_ACCADD] / s->counters[C_TRYADD]; ar[0] = s->counters[C_ACCREM] / s->counters[C_TRYREM];
         std::vector<double> wa(15, 0.0), wr(15, 0.0), wp(15, 0.0);      // AccWormAdd/Rem/Rep(2:NWormSectors), CTQMC.F90:8685-8691
-        if (s->cur_isector == 4 || s->cur_isector == 2) {
+        if (s->cur_isector != 1) {
             const int is = s->cur_isector;       // AccAdd(Sector) is indexed from 1, the worm arrays from sector 2
             aa[is - 1] = s->counters[C_W_ACCADD] / s->counters[C_W_TRYADD]; ar[is - 1] = s->counters[C_W_ACCREM] / s->counters[C_W_TRYREM];
             wa[is - 2] = s->counters[C_ACCWADD] / s->counters[C_TRYWADD]; wr[is - 2] = s->counters[C_ACCWREM] / s->counters[C_TRYWREM];
@@ -1544,6 +1581,40 @@ int w2dyn_measure_finish(w2dyn_solver *s)
         if (C.acc_gtauw) reduceg(C.acc_gtauw, (size_t)ntau, "gtau_worm", (double)ntau / beta);
         R["cntmeas_worm"] = {mwt};
     }
+    if (s->cur_isector >= 6 && s->nbe > 0) {
+        // wormScaling = CntSampling(worm) / (CntMeas(worm) CntSampling(Z)) * wormNorm / mean_sign, wormNorm = 16/beta (P2, P2pp) or
+        // 16/beta^2 (P3, P3pp); the tau histograms times Ntau/beta (CTQMC.F90:8830-8849, 9116-9130, 9165-9179, 9215-9224, 9229-9313);
+        // counts pooled over the chains that share an accumulator bin.  The division by (2 Nd)^4 is the caller's (impurity.py:817-839)
+        const int is = s->cur_isector, nbe = s->nbe;
+        std::vector<double> cw(nbe, 0.0), cz(nbe, 0.0), mw(nbe, 0.0);
+        double cwt = 0.0, czt = 0.0, mwt = 0.0;
+        for (int w = 0; w < W; ++w) { const int b = (w / C.walkers_per_bin) % nbe; cw[b] += (double)ws[w].cnt[C_W_SAMPLING]; cz[b] += (double)ws[w].cnt[C_SAMPLING]; }
+        for (int b = 0; b < B; ++b) mw[b % nbe] += nwm[b];
+        for (int b = 0; b < nbe; ++b) { cwt += cw[b]; czt += cz[b]; mwt += mw[b]; }
+        const double norm = is <= 7 ? 16.0 / beta : 16.0 / (beta * beta);
+        auto scal = [&](double c_w, double c_z, double m_w) { return m_w != 0.0 ? c_w / (m_w * c_z) * norm / ms : 0.0; };
+        auto reducee = [&](const double *dev, size_t n, const char *name, double extra) {
+            std::vector<double> raw((size_t)nbe * n), tot(n, 0.0);
+            (void)hipMemcpy(raw.data(), dev, raw.size() * sizeof(double), hipMemcpyDeviceToHost);
+            PackDesc d{dev, nbe, n, std::vector<double>(nbe), 0};
+            for (int b = 0; b < nbe; ++b) d.scale[b] = scal(cw[b], cz[b], mw[b]) * extra;
+            s->pack[name] = d;
+            for (int b = 0; b < nbe; ++b) {
+                const double f = scal(cw[b], cz[b], mw[b]) * extra;
+                for (size_t i = 0; i < n; ++i) { tot[i] += raw[(size_t)b * n + i]; raw[(size_t)b * n + i] *= f; }
+            }
+            const double f = scal(cwt, czt, mwt) * extra;
+            for (size_t i = 0; i < n; ++i) tot[i] *= f;
+            R[name] = tot; R[std::string(name) + "_bins"] = raw;
+        };
+        if (is == 6 && s->worm_meas_eq[0]) reducee(s->acc_weq_iw, (size_t)2 * (2 * s->n2iwb + 1), "p2iw_worm", 1.0);
+        if (is == 7 && s->worm_meas_eq[1]) reducee(s->acc_weq_iw, (size_t)2 * (2 * s->n2iwb + 1), "p2iwpp_worm", 1.0);
+        if (is == 6 && s->worm_meas_eq[2]) reducee(s->acc_weq_tau, (size_t)ntau, "p2tau_worm", (double)ntau / beta);
+        if (is == 7 && s->worm_meas_eq[3]) reducee(s->acc_weq_tau, (size_t)ntau, "p2taupp_worm", (double)ntau / beta);
+        if (is == 8 && s->worm_meas_eq[4]) reducee(s->acc_weq_p3, (size_t)4 * s->n3iwf * (2 * s->n3iwb + 1), "p3iw_worm", 1.0);
+        if (is == 9 && s->worm_meas_eq[5]) reducee(s->acc_weq_p3, (size_t)4 * s->n3iwf * (2 * s->n3iwb + 1), "p3iwpp_worm", 1.0);
+        R["cntmeas_worm"] = {mwt};
+    }
     {   // per-chain worm counters: steps in Z, steps in worm space, worm insertions tried / accepted, removals, replacements
         std::vector<double> wc((size_t)W * 8);
         for (int w = 0; w < W; ++w) {
@@ -1566,10 +1637,11 @@ int w2dyn_measure_finish(w2dyn_solver *s)
 // sector bookkeeping shared by ctqmc_measure and count_steps: every chain starts in Z space (CTQMC.F90:6328, 8400)
 static int enter_sector(w2dyn_solver *s, int isector, int icomponent)
 {
-    if (isector != 1 && isector != 2 && isector != 4) return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d is not supported (1 = Z, 2 = one-particle, 4 = two-particle Green's function)", isector);
+    if (isector != 1 && isector != 2 && isector != 4 && !(isector >= 6 && isector <= 9))
+        return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d is not supported (1 = Z, 2 = one-particle, 4 = two-particle Green's function, 6 - 9 = P2 / P2pp / P3 / P3pp)", isector);
     if (isector != 1) {
         const int nf = s->nflav;
-        if (icomponent < 0 || icomponent > (isector == 4 ? nf * nf * nf * nf : nf * nf)) return fail(s, W2DYN_EINVAL, "component %d out of range", icomponent);
+        if (icomponent < 0 || icomponent > (isector == 2 ? nf * nf : nf * nf * nf * nf)) return fail(s, W2DYN_EINVAL, "component %d out of range", icomponent);
     }
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -1580,7 +1652,7 @@ static int enter_sector(w2dyn_solver *s, int isector, int icomponent)
     std::vector<WalkerScalars> ws(s->nwalkers);
     HIPCHK(hipMemcpy(ws.data(), s->C.ws, ws.size() * sizeof(WalkerScalars), hipMemcpyDeviceToHost));
     bool dirty = false;
-    for (auto &w : ws) if (w.sector == 4 || w.sector == 2) { w.sector = 1; dirty = true; }
+    for (auto &w : ws) if (w.sector > 1) { w.sector = 1; dirty = true; }
     if (dirty) HIPCHK(hipMemcpy(s->C.ws, ws.data(), ws.size() * sizeof(WalkerScalars), hipMemcpyHostToDevice));
     return 0;
 }
@@ -1634,14 +1706,16 @@ int w2dyn_ctqmc_worm_warmup(w2dyn_solver *s, int64_t nwarmups2, int isector, int
     if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "ctqmc_worm_warmup before init_solver");
     // the reference allocates the buffers of the batched transform here and samples nothing (CTQMC.F90:8266-8348); this
     // library transforms every measurement on the spot, so only the arguments are checked
-    if (isector != 1 && isector != 2 && isector != 4) return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d is not supported (1 = Z, 2 = one-particle, 4 = two-particle Green's function)", isector);
+    if (isector != 1 && isector != 2 && isector != 4 && !(isector >= 6 && isector <= 9))
+        return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d is not supported (1 = Z, 2 = one-particle, 4 = two-particle Green's function, 6 - 9 = P2 / P2pp / P3 / P3pp)", isector);
     return 0;
 }
 
 int w2dyn_count_steps(w2dyn_solver *s, int isector, int icomponent, int64_t nfix, int64_t *steps_worm, int64_t *steps_z)
 {
     if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "count_steps before init_solver");
-    if (isector != 4 && isector != 2) return fail(s, W2DYN_EUNSUPPORTED, "count_steps: worm sector %d is not supported (2 = one-particle, 4 = two-particle Green's function)", isector);
+    if (isector != 4 && isector != 2 && !(isector >= 6 && isector <= 9))
+        return fail(s, W2DYN_EUNSUPPORTED, "count_steps: worm sector %d is not supported (2 = one-particle, 4 = two-particle Green's function, 6 - 9 = P2 / P2pp / P3 / P3pp)", isector);
     if (nfix < 0) return fail(s, W2DYN_EINVAL, "count_steps: nfix = %lld", (long long)nfix);
     int rc;
     if ((rc = enter_sector(s, isector, icomponent))) return rc;
@@ -1719,7 +1793,7 @@ int w2dyn_get_mc_config_scalars(w2dyn_solver *s, int walker, int *n, int *outer_
     WalkerScalars ws; std::vector<int> K; std::vector<double> TC, TA;
     int rc = fetch_walker(s, walker, ws, K, TC, TA); if (rc) return rc;
     int tot = 0; for (int k : K) tot += 2 * k;
-    if (ws.sector == 4 || ws.sector == 2) tot += ws.sector;
+    if (ws.sector > 1) tot += ws.sector == 2 ? 2 : 4;
     if (n) *n = tot; if (outer_sst) *outer_sst = ws.outer; if (outer_state) *outer_state = 1;
     return 0;
 }
@@ -1733,7 +1807,7 @@ int w2dyn_get_mc_config(w2dyn_solver *s, int walker, int n, double *taus, int *o
     std::vector<Op> ops;
     const int kmax = s->C.kmax;
     for (int f = 0; f < s->nflav; ++f) for (int e = 0; e < K[f]; ++e) { ops.push_back({TC[(size_t)f * kmax + e], f, 1, -1}); ops.push_back({TA[(size_t)f * kmax + e], f, 2, -1}); }
-    if (ws.sector == 4 || ws.sector == 2) for (int i = 0; i < ws.sector; ++i) ops.push_back({ws.wtau[i], ws.wflav[i], (i & 1) ? 1 : 2, 0});     // worm operators: hashyb 0 (Trace.F90:6861-6865)
+    if (ws.sector > 1) for (int i = 0; i < (ws.sector == 2 ? 2 : 4); ++i) ops.push_back({ws.wtau[i], ws.wflav[i], (i & 1) ? 1 : 2, 0});     // worm operators: hashyb 0 (Trace.F90:6861-6865)
     if ((int)ops.size() != n) return fail(s, W2DYN_EINVAL, "get_mc_config: n=%d but the chain holds %zu operators", n, ops.size());
     std::sort(ops.begin(), ops.end(), [](const Op &a, const Op &b) { return a.t < b.t; });
     for (int i = 0; i < n; ++i) { taus[i] = ops[i].t; orbs[i] = (ops[i].f >> 1) + 1; spins[i] = (ops[i].f & 1) + 1; cas[i] = ops[i].ca; hashybs[i] = ops[i].hyb; }
@@ -1801,7 +1875,7 @@ int w2dyn_save_mc_configs(w2dyn_solver *s)
     HIPCHK(hipMemcpy(s->snap_K.data(), C.K, W * nf * sizeof(int), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(s->snap_TC.data(), C.TC, W * nf * kmax * sizeof(double), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(s->snap_TA.data(), C.TA, W * nf * kmax * sizeof(double), hipMemcpyDeviceToHost));
-    for (auto &w : s->snap_ws) if (w.sector == 2 || w.sector == 4) return fail(s, W2DYN_EINVAL, "save_mc_configs: a chain is in worm space");
+    for (auto &w : s->snap_ws) if (w.sector > 1) return fail(s, W2DYN_EINVAL, "save_mc_configs: a chain is in worm space");
     s->snap_nf = (int)nf; s->snap_kmax = (int)kmax;
     return 0;
 }
@@ -1898,7 +1972,7 @@ int w2dyn_get_result(w2dyn_solver *s, const char *name, void *out, size_t bytes,
     else if (n == "accpairtau") { src = s->accpairtau.data(); size = s->accpairtau.size() * sizeof(double); }
     else if (n == "accpairtau_chains") { src = s->accpairtau_chains.data(); size = s->accpairtau_chains.size() * sizeof(double); }
     else if (n == "steps_worm_chains") { src = s->steps_worm_chains.data(); size = s->steps_worm_chains.size() * sizeof(long long); }
-    else if (n == "cntsampling") { ltmp.assign(16, 0); if (!s->counters.empty()) { ltmp[0] = (long long)s->counters[C_SAMPLING]; ltmp[s->res_isector == 2 ? 1 : 3] = (long long)s->counters[C_W_SAMPLING]; } src = ltmp.data(); size = ltmp.size() * sizeof(long long); }
+    else if (n == "cntsampling") { ltmp.assign(16, 0); if (!s->counters.empty()) { ltmp[0] = (long long)s->counters[C_SAMPLING]; if (s->res_isector > 1) ltmp[s->res_isector - 1] = (long long)s->counters[C_W_SAMPLING]; } src = ltmp.data(); size = ltmp.size() * sizeof(long long); }
     else if (n == "counters") { src = s->counters.data(); size = s->counters.size() * sizeof(double); }
     else {
         auto it = s->res.find(n);
@@ -1967,6 +2041,8 @@ int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out)
     else if (n == "num_windows") *out = s->C.num_windows;
     else if (n == "nb4") *out = s->nb4;
     else if (n == "nbw") *out = s->nbw;
+    else if (n == "nbe") *out = s->nbe;
+    else if (n == "n3iwb") *out = s->n3iwb;
     else if (n == "nbl") *out = s->nbl;
     else if (n == "nbs") *out = s->nbs;
     else if (n == "device") *out = s->device;

@@ -359,6 +359,14 @@ class MCTQMC:
             # one-particle worm estimator of the sampled component: giw_worm(2*Niw), CTQMC.F90:598
             a = self.result(name).reshape(-1, 2); a = a[:, 0] + 1j * a[:, 1]
             return a.reshape(int(self.scalar("nbins")), -1) if name.endswith("_bins") else a
+        if name.split("_bins")[0] in ("p2iw_worm", "p2iwpp_worm", "p3iw_worm", "p3iwpp_worm"):
+            # worm estimators of the equal-time sectors 6 - 9: P2iw_worm(-N2iwb:N2iwb), P3iw_worm(-N3iwf:N3iwf-1, -N3iwb:N3iwb), CTQMC.F90:655, 690
+            a = self.result(name).reshape(-1, 2); a = a[:, 0] + 1j * a[:, 1]
+            lead = (int(self.scalar("nbe")),) if name.endswith("_bins") else ()
+            return a.reshape(lead + ((-1, 2 * int(self.scalar("n3iwb")) + 1) if name.startswith("p3") else (-1,)))
+        if name.split("_bins")[0] in ("p2tau_worm", "p2taupp_worm"):
+            a = self.result(name)
+            return a.reshape(int(self.scalar("nbe")), -1) if name.endswith("_bins") else a
         if name in ("gtau_worm", "gtau_worm_bins"):
             a = self.result(name)
             return a.reshape(int(self.scalar("nbins")), -1) if name.endswith("_bins") else a

@@ -177,7 +177,8 @@ class HipCtHybSolver:
         """Worm estimator of one component in the call order of `CtHybSolver.solve_component` (`impurity.py:656-892`):
         init_solver -> (stored configuration | warm-up) -> eta search by count_steps -> ctqmc_worm_warmup ->
         ctqmc_measure(isector, icomponent) -> result normalised by nflavours^4.  Sectors 2 (one-particle Green's
-        function: giw-worm, gtau-worm) and 4 (two-particle Green's function) are the ones the HIP library samples."""
+        function: giw-worm, gtau-worm), 4 (two-particle Green's function) and 6 - 9 (equal-time pairs: p2iw-worm, p2tau-worm,
+        p2iwpp-worm, p2taupp-worm, p3iw-worm, p3iwpp-worm) are the ones the HIP library samples."""
         import scipy.optimize as opt
         q = self.ctqmc
         self.comm.Barrier()
@@ -259,6 +260,12 @@ class HipCtHybSolver:
                 result["giw-worm/%05d" % icomponent] = DistributedSample(q.giw_worm_bins, self.comm)
             if self.qmc["WormMeasGtau"] != 0:
                 result["gtau-worm/%05d" % icomponent] = DistributedSample(q.gtau_worm_bins, self.comm)
+        if 6 <= isector <= 9:     # equal-time sectors, impurity.py:817-839: the module array divided by nflavours^4
+            for sec, key, name, flag in ((6, "p2iw-worm", "p2iw_worm", "WormMeasP2iwPH"), (6, "p2tau-worm", "p2tau_worm", "WormMeasP2tauPH"),
+                                         (7, "p2iwpp-worm", "p2iwpp_worm", "WormMeasP2iwPP"), (7, "p2taupp-worm", "p2taupp_worm", "WormMeasP2tauPP"),
+                                         (8, "p3iw-worm", "p3iw_worm", "WormMeasP3iwPH"), (9, "p3iwpp-worm", "p3iwpp_worm", "WormMeasP3iwPP")):
+                if sec == isector and self.qmc[flag] == 1:
+                    result["%s/%05d" % (key, icomponent)] = DistributedSample(getattr(q, name + "_bins") / nfl ** 4, self.comm)
         # Z-space quantities are sampled along with every component (impurity.py:966-977)
         result["occ"] = DistributedSample(q.occ_bins, self.comm)
         result["rho1"] = DistributedSample(np.array([q.rho1]), self.comm)
