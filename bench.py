@@ -69,6 +69,11 @@ WORKLOADS = {
     "C5": dict(config="C5Z", nftau=5001, chains=16384, worm=dict(component=12, nfix=2000), overrides=dict(_BASE, **_WORM),
                text="C5: 5-orbital density-density, U=2, J=0.25, beta=100, TaudiffMax=10, NCorr=100, worm sampling in sector 4 (G4iw, "
                     "component 12 = flavours 0011, N4iwf=10, N4iwb=5, PercentageWormInsert=PercentageWormReplace=0.2, eta balanced by count_steps)"),
+    # sector 2: worm sampling of one diagonal component of the one-particle Green's function at the reference's default Niw (k_meas_gw)
+    "C2S": dict(config="C2", nftau=5001, chains=16384, worm=dict(sector=2, component=1, nfix=2000),
+                overrides=dict(_BASE, NCorr=200, Niw=2000, PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=1.0, WormMeasGiw=1, WormMeasGtau=1),
+                text="C2S: C2 with worm sampling in sector 2 (giw_worm / gtau_worm of component 1 = flavours 00, Niw=2000, "
+                     "PercentageWormInsert=PercentageWormReplace=0.2, eta balanced by count_steps)"),
 }
 HEADLINE = "C2"
 SIDE_WORKLOADS = ["C1", "C3", "C4", "C5", "C2G", "C3F"]      # run ahead of the headline by the default invocation
@@ -86,7 +91,8 @@ def _cpu_chain(args):
         over["NLookup_nfft"] = 0          # the reference built without NFFT takes the exact-sum transform (CTQMC.F90:578-595)
     ps = params.make_pstring(over, beta=p.beta, Nd=p.nd, Hamiltonian=p.hamiltonian, QuantumNumbers=p.quantum_numbers)
     worm = wl.get("worm")
-    fourpnt = 8 if worm else wl.get("fourpnt", 0)
+    wsec = worm.get("sector", 4) if worm else 1
+    fourpnt = (8 if wsec == 4 else 0) if worm else wl.get("fourpnt", 0)
     try:
         import refdrive
         if not refdrive.available():
@@ -96,8 +102,8 @@ def _cpu_chain(args):
         s.warmup(nwarm)
         if worm:
             s.set_wormeta(eta)
-            s.worm_warmup(0, 4, worm["component"])
-        t0 = time.perf_counter(); s.measure(*((4, worm["component"]) if worm else (1, 1))); dt = time.perf_counter() - t0
+            s.worm_warmup(0, wsec, worm["component"])
+        t0 = time.perf_counter(); s.measure(*((wsec, worm["component"]) if worm else (1, 1))); dt = time.perf_counter() - t0
         gl = None if worm else np.array(s.results(("gleg",))["gleg"], dtype=np.float64)
         s.close()
         return nmeas * over["NCorr"], dt, "reference", gl
@@ -110,7 +116,7 @@ def _cpu_chain(args):
             w.set_wormeta(eta)
         t0 = time.perf_counter()
         if worm:
-            w.measure_sector(4, worm["component"])
+            w.measure_sector(wsec, worm["component"])
         else:
             w.measure()
         dt = time.perf_counter() - t0
@@ -197,7 +203,8 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
     ps = params.make_pstring(over, beta=prob.beta, Nd=prob.nd, Hamiltonian=prob.hamiltonian, QuantumNumbers=prob.quantum_numbers)
     q = MCTQMC(device=env.local_rank, nwalkers=walkers, first_walker=rank * walkers, walkers_per_bin=wpb)
     worm = wl.get("worm")
-    q.fourpnt = 8 if worm else wl.get("fourpnt", 0)
+    wsec = worm.get("sector", 4) if worm else 1
+    q.fourpnt = (8 if wsec == 4 else 0) if worm else wl.get("fourpnt", 0)
     q.init_rnd(43890); q.init_paras(ps)
     q.init_solver(prob.umatrix, prob.ftau, prob.muimp, prob.screening, 1)
     q.set_taudiffmax(over["TaudiffMax"])
@@ -213,9 +220,9 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
             # eta search of solve_component (impurity.py:717-742): rescale until Z and worm space get equal numbers of
             # steps, to the reference's criterion |sw - sz| / (sw + sz) <= 0.1; starting point: insertion prefactor
             # (beta Nd)^4 eta = 1 (CTQMC.F90:5680-5684).  The reference runs this loop without a bound on its length
-            q.wormeta[:] = 1.0 / (prob.beta * prob.nd) ** 4
+            q.wormeta[:] = 1.0 / (prob.beta * prob.nd) ** (2 if wsec == 2 else 4)
             for eta_tries in range(1, 101):
-                sw, sz = q.count_steps(4, worm["component"], worm["nfix"])
+                sw, sz = q.count_steps(wsec, worm["component"], worm["nfix"])
                 if sw != 0 and sz != 0 and abs(sw - sz) / float(sw + sz) <= 0.1:
                     break
                 q.wormeta[:] = q.wormeta[:] * float(max(sz, 1)) / float(max(sw, 1))
@@ -223,14 +230,14 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
         if world > 1:      # all ranks use the mean eta (impurity.py:739-740, 784)
             t = torch.tensor([eta], dtype=torch.float64, device=red_dev); dist.all_reduce(t); eta = float(t.item()) / world
             q.wormeta[:] = eta
-        q.set_sector(4, worm["component"])
+        q.set_sector(wsec, worm["component"])
     sweep_key = "sweep_worm" if worm else "sweep"
     q.set_timing(True)      # HIP-event pairs around every launch, read out after the timed region (no host wait per launch)
     q.measure_begin()
     for _ in range(warmup):
         q.sweep(ncorr); q.measure_once()
     q.sync()
-    tkeys = (sweep_key, "meas_misc", "meas_gleg", "meas_g4w", "meas_gtau_ac", "meas_giw", "meas_g2iw", "meas_g4iw")
+    tkeys = (sweep_key, "meas_misc", "meas_gleg", "meas_g4w", "meas_gw", "meas_gtau_ac", "meas_giw", "meas_g2iw", "meas_g4iw")
     for k in tkeys:
         q.kernel_time(k, reset=True)
     if world > 1:
@@ -256,7 +263,7 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
     if rehearse:           # gloo rehearsal on one GPU: host path
         sg, sh = DistributedSample(q.gleg_bins, comm), DistributedSample(q.histo_bins, comm)
     else:
-        names = ["gleg", "gtau", "histo"] + (["g4iw_worm"] if worm else []) + (["giw"] if over.get("MeasGiw") else []) + \
+        names = ["gleg", "gtau", "histo"] + ((["g4iw_worm"] if wsec == 4 else ["giw_worm"]) if worm else []) + (["giw"] if over.get("MeasGiw") else []) + \
                 (["g4iw", "g2iw"] if q.fourpnt & 4 else [])
         pack = q.reduce_pack(names, comm).allreduce()
         sg, sh = pack.sample("gleg"), pack.sample("histo")
@@ -266,7 +273,7 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
 
     kt = {k: q.kernel_time(k) for k in tkeys}
     sweep_ms, nsweep = kt[sweep_key]
-    gleg_ms, ngleg = kt["meas_g4w" if worm else "meas_gleg"]
+    gleg_ms, ngleg = kt[("meas_g4w" if wsec == 4 else "meas_gw") if worm else "meas_gleg"]
     misc_ms, _ = kt["meas_misc"]
     out = None
     if rank == 0:
@@ -293,10 +300,10 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
         flops_gleg = W * nflav * k2 * (5 * over["NLegMax"] + 6)
         if worm:       # 8 (2 N4iwf)^2 (2 N4iwb + 1) flop per worm-space measurement
             nworm_meas = float(q.result("cntmeas_worm")[0]) / max(steps + warmup, 1)
-            flops_gleg = nworm_meas * 8 * (2 * over["N4iwf"]) ** 2 * (2 * over["N4iwb"] + 1)
+            flops_gleg = nworm_meas * (8 * (2 * over["N4iwf"]) ** 2 * (2 * over["N4iwb"] + 1) if wsec == 4 else 8 * 2 * over["Niw"])
         ach_tf = flops_gleg / (gleg_ms * 1e-3) / 1e12 if gleg_ms > 0 else 0.0
         value = world * W * ncorr * steps / dt
-        kname, mname = ("k_sweep_worm", "k_meas_g4w") if worm else ("k_sweep", "k_meas_gleg")
+        kname, mname = ("k_sweep_worm", "k_meas_g4w" if wsec == 4 else "k_meas_gw") if worm else ("k_sweep", "k_meas_gleg")
         tr_sweep, tr_src = pmc_traffic(kname, W, wname)
         tr_gleg, _ = pmc_traffic(mname, W, wname)
         out = {
@@ -383,7 +390,7 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
             out["kernel_ms"].update({"k_meas_g2iw": g2_ms, "k_meas_g4iw": g4_ms})
         if worm:
             cs = q.cntsampling
-            out["worm"] = {"eta": eta, "eta_search_rounds": eta_tries, "steps_z": int(cs[0]), "steps_worm": int(cs[3]), "component": worm["component"]}
+            out["worm"] = {"eta": eta, "eta_search_rounds": eta_tries, "steps_z": int(cs[0]), "steps_worm": int(cs[wsec - 1]), "sector": wsec, "component": worm["component"]}
         if world == 1 and with_cpu:
             # the GPU box gives one GPU's job 16 of the host's cores (worker pools beyond that are killed by its process
             # guard); os.cpu_count() reports the whole machine, stated next to the cores actually used

@@ -743,7 +743,7 @@ static int check_all_ssts(const ora_walker *w, int *ssts)
     return possible;
 }
 
-/* CTQMC.F90:4433-4554 StepGlob (no user symmetry moves) */
+/* CTQMC.F90:4433-4554 StepGlob */
 static void step_glob(ora_walker *w)
 {
     int nf = w->nflav, nd = w->p.nd;
@@ -758,6 +758,11 @@ static void step_glob(ora_walker *w)
         for (int i = nd + 1; i <= 2 * nd; ++i) gu[i] = i - nd;
     } else if (r < 0.6) {                            /* gen_CAFlip, Trace.F90:1186-1198 */
         gu[0] = 1; for (int i = 1; i <= nf; ++i) gu[i] = i;
+    } else if (r < 0.8 && w->p.nsym > 0) {           /* gen_SymUpdate, Trace.F90:1170-1182: one of the listed moves or of their inverses */
+        const int isym = RINT(w, 1, 2 * w->p.nsym);
+        gu[0] = 0;
+        if (isym <= w->p.nsym) for (int j = 1; j <= nf; ++j) gu[j] = w->p.symmoves[(isym - 1) * 16 + j - 1];
+        else for (int j = 1; j <= nf; ++j) gu[w->p.symmoves[(isym - w->p.nsym - 1) * 16 + j - 1]] = j;      /* Trace.F90:475-477 */
     } else {                                         /* gen_GlobalUpdate_new + rand_perm, Trace.F90:1083-1123 */
         for (int i = 1; i <= nf; ++i) gu[i] = i;
         for (int j = 1; j <= nf; ++j) { int i = RINT(w, j, nf); int t = gu[j]; gu[j] = gu[i]; gu[i] = t; }

@@ -58,6 +58,9 @@ typedef struct ora_params {
     /* worm sampling with equal-time pairs, sectors 6 / 7 (P2 ph / pp) and 8 / 9 (P3 ph / pp) (CTQMC.F90:654-726) */
     int n2iwb, n3iwf, n3iwb;                       /* N2iwb, N3iwf, N3iwb */
     int worm_meas_eq[6];                           /* WormMeasP2iwPH, WormMeasP2iwPP, WormMeasP2tauPH, WormMeasP2tauPP, WormMeasP3iwPH, WormMeasP3iwPP */
+    /* user symmetry moves of the global move (NSymMove, SymMoveNN; Trace.F90:403-404, 471-478): nsym rows of 2Nd entries, values
+     * 1-based in the order band + Nd * spin; the inverses are made by the oracle */
+    int nsym; int symmoves[8 * 16];
 } ora_params;
 
 typedef struct ora_walker ora_walker;

@@ -25,7 +25,8 @@ class OraParams(C.Structure):
                 ("worm_meas_g4iw", C.c_int), ("g4ph", C.c_int), ("g4pp", C.c_int), ("wormphconv", C.c_int),
                 ("worm_meas_giw", C.c_int), ("worm_meas_gtau", C.c_int), ("epsblock", C.c_double), ("accum_gtau", C.c_int),
                 ("meas_susz", C.c_int), ("step_series", C.c_int),
-                ("n2iwb", C.c_int), ("n3iwf", C.c_int), ("n3iwb", C.c_int), ("worm_meas_eq", C.c_int * 6)]
+                ("n2iwb", C.c_int), ("n3iwf", C.c_int), ("n3iwb", C.c_int), ("worm_meas_eq", C.c_int * 6),
+                ("nsym", C.c_int), ("symmoves", C.c_int * 128)]
 
 WORM_EQ_KEYS = ("WormMeasP2iwPH", "WormMeasP2iwPP", "WormMeasP2tauPH", "WormMeasP2tauPP", "WormMeasP3iwPH", "WormMeasP3iwPP")
 WORM_EQ_NAMES = ("p2iw_worm", "p2iwpp_worm", "p2tau_worm", "p2taupp_worm", "p3iw_worm", "p3iwpp_worm")
@@ -111,6 +112,17 @@ def lib():
     return L
 
 
+def _symmoves(ps):
+    n = ps.get_int("NSymMove")
+    if n > 8:
+        raise ValueError("oracle: at most 8 symmetry moves")
+    tab = [0] * 128
+    for i in range(n):
+        row = ps.get_int_list("SymMove%02d" % (i + 1))
+        tab[16 * i:16 * i + len(row)] = row
+    return (C.c_int * 128)(*tab)
+
+
 def params_from_pstring(ps, nd, beta, fourpnt=0):
     """Pick the keys the oracle needs out of a parsed parameter set (w2dynamics_amd.params.ParameterSet)."""
     return OraParams(nd=nd, beta=beta, nftau=ps.get_int("Nftau"), ntau=ps.get_int("Ntau"),
@@ -131,7 +143,8 @@ def params_from_pstring(ps, nd, beta, fourpnt=0):
                      meas_susz=int(ps.get_int("MeasSusz") == 1 and ps.get_int("segment") == 0),
                      step_series=(1 if ps.get_int("Gtau_mean_step") else 0) | (2 if ps.get_int("Gtau_mid_step") else 0) | (4 if ps.get_int("sign_step") else 0),
                      n2iwb=ps.get_int("N2iwb"), n3iwf=ps.get_int("N3iwf"), n3iwb=ps.get_int("N3iwb"),
-                     worm_meas_eq=(C.c_int * 6)(*[int(ps.get_int(k) != 0) for k in WORM_EQ_KEYS]))
+                     worm_meas_eq=(C.c_int * 6)(*[int(ps.get_int(k) != 0) for k in WORM_EQ_KEYS]),
+                     nsym=ps.get_int("NSymMove"), symmoves=_symmoves(ps))
 
 
 class OracleWalker:

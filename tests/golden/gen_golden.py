@@ -57,6 +57,12 @@ TRAJ = {
                               NLookup_nfft=0), 32),
     "C3A": ("C3A", 501, dict(Nwarmups=3000, Nmeas=100, NCorr=30, TaudiffMax=6.0, Ntau=100, NLegMax=12, Niw=8, MeasGiw=1,
                              NLookup_nfft=0, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 78),
+    # user symmetry moves of the global move (NSymMove = 2: orbital exchange, and a cyclic move whose inverse differs from it);
+    # flavours in the order band + Nd * spin; scalar path (C3) and matrix path (C4S)
+    "C3sym": ("C3", 501, dict(Nwarmups=4000, Nmeas=40, NCorr=100, TaudiffMax=6.0, Ntau=50, NLegMax=10, Niw=4, MeasGiw=1, NLookup_nfft=0, PercentageGlobalMove=0.3,
+                              PercentageTauShiftMove=0.05, SymMoves=((1, 0, 3, 2), (1, 2, 3, 0))), 41),
+    "C4Ssym": ("C4S", 501, dict(Nwarmups=3000, Nmeas=40, NCorr=100, TaudiffMax=3.0, Ntau=50, NLegMax=10, Niw=4, MeasGiw=1, NLookup_nfft=0, PercentageGlobalMove=0.3,
+                                PercentageTauShiftMove=0.05, SymMoves=((1, 0, 3, 2), (1, 2, 3, 0))), 42),
     # BASELINE.json configs[4], Z-space part: 5 orbitals, density-density, beta = 100 (1024 one-state blocks, 10 flavours)
     "C5Z": ("C5Z", 501, dict(Nwarmups=4000, Nmeas=50, NCorr=100, TaudiffMax=10.0, Ntau=100, NLegMax=40, Niw=8, MeasGiw=1,
                              NLookup_nfft=0, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 31),
@@ -73,7 +79,8 @@ def pstring_for(cfgname, nftau, over):
     p = synth.config(cfgname, nftau=nftau)
     o = dict(over)
     o.setdefault("Nftau", nftau)
-    return p, params.make_pstring(o, beta=p.beta, Nd=p.nd, Hamiltonian=p.hamiltonian, QuantumNumbers=p.quantum_numbers)
+    sym = o.pop("SymMoves", ())         # user symmetry moves (NSymMove / SymMoveNN): permutations of the flavours, 0-based
+    return p, params.make_pstring(o, symmetries=sym, beta=p.beta, Nd=p.nd, Hamiltonian=p.hamiltonian, QuantumNumbers=p.quantum_numbers)
 
 
 def gen_traj(only=None):

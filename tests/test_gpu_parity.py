@@ -65,13 +65,20 @@ TRAJ = [
     # the 5-orbital Kanamori bench workload thermalised: ~130 operators per chain, i.e. more than 64 outside the window (the
     # evaluator's second group of operators), ~50 inside it (checkpoints), default move mix
     ("C5KB", 5001, dict(BASE, Nwarmups=20000, Nmeas=4, NCorr=100, TaudiffMax=10.0, NLegMax=40, Ntau=200), 4253),
+    # user symmetry moves in the global move (NSymMove = 2: an orbital exchange and a cyclic move with a different inverse); the
+    # oracle's branch is pinned on reference runs (traj_C3sym / traj_C4Ssym)
+    ("C3", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=6.0, PercentageGlobalMove=0.3, PercentageTauShiftMove=0.05,
+                     SymMoves=((1, 0, 3, 2), (1, 2, 3, 0))), 78),
+    ("C4S", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=3.0, PercentageGlobalMove=0.3, PercentageTauShiftMove=0.05,
+                      SymMoves=((1, 0, 3, 2), (1, 2, 3, 0))), 4246),
 ]
 
 
 @pytest.mark.parametrize("cfg,nftau,over,seed", TRAJ, ids=["C1-addrem", "C1-1window-allmoves", "C3-allmoves", "C2-default", "C5Z-default", "C5Z-wide-window-lds-list",
                               "C4S-kanamori-allmoves", "C3Q-coarse-blocks-allmoves", "C4-kanamori-default",
                               "C4SA-auto-blocks", "C4SX-auto-blocks-hopping", "C4SQ-all-alone", "C4A-auto-blocks-3orb",
-                              "C4N-9-state-blocks", "C5K-5orb-kanamori-10-state-blocks", "C5KB-bench-workload-thermalised"])
+                              "C4N-9-state-blocks", "C5K-5orb-kanamori-10-state-blocks", "C5KB-bench-workload-thermalised",
+                              "C3-symmetry-moves", "C4S-symmetry-moves"])
 def test_chains_retrace_oracle(cfg, nftau, over, seed):
     """Every chain: same configuration, M, sign, window and NPairs after warm-up; same estimators after sampling."""
     _retrace(cfg, nftau, over, seed)

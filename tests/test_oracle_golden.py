@@ -30,12 +30,13 @@ def rel_nan(a, b):
 # QuantumNumbers = All (automatic block partitioning, Operator.F90:303-442): Kanamori with "Nt All" (2 and 3 orbitals),
 # with an inter-orbital hopping that breaks Qzt, "All" on its own (every state alone) and a density-density problem
 AUTO_CASES = ["C4SA", "C4SX", "C4SQ", "C4A", "C3A"]
+SYM_CASES = ["C3sym", "C4Ssym"]       # user symmetry moves in the global move (NSymMove = 2)
 
 
 BIG_BLOCK_CASES = ["C4N", "C5K"]      # blocks of 9 (3-orbital Kanamori, Nt Szt) and 10 states (5-orbital Kanamori, Nt Szt Qzt)
 
 
-@pytest.mark.parametrize("name", CASES + SCALAR_5ORB + AUTO_CASES + BIG_BLOCK_CASES)
+@pytest.mark.parametrize("name", CASES + SCALAR_5ORB + AUTO_CASES + BIG_BLOCK_CASES + SYM_CASES)
 def test_oracle_retraces_reference_chain(name):
     g = util.load_golden("traj_%s.npz" % name)
     over = g["overrides"]

@@ -20,7 +20,8 @@ def load_golden(name):
 def setup(cfgname, nftau, overrides):
     p = synth.config(cfgname, nftau=nftau)
     o = dict(overrides); o.setdefault("Nftau", nftau)
-    ps = params.make_pstring(o, beta=p.beta, Nd=p.nd, Hamiltonian=p.hamiltonian, QuantumNumbers=p.quantum_numbers)
+    sym = o.pop("SymMoves", ())         # user symmetry moves of the global move: permutations of the flavours (band + Nd * spin), 0-based
+    ps = params.make_pstring(o, symmetries=sym, beta=p.beta, Nd=p.nd, Hamiltonian=p.hamiltonian, QuantumNumbers=p.quantum_numbers)
     return p, ps, params.ParameterSet(ps)
 
 

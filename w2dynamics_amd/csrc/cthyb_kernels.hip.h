@@ -141,6 +141,9 @@ struct DevConst {
     const double *opmat_pad;      // blocks of more than 4 states: the same with rows and columns padded to mat_seq_pad(nsm) (sequential evaluator)
     // worm sampling (CTQMC.F90:335-378, 434; ctqmc_measure arguments)
     int isector, icomponent, nwf, nwb, wormphconv, g4ph, g4pp;
+    // user symmetry moves of the global move (NSymMove, Trace.F90:403-404, 471-478): 2 nsym rows (the listed moves, then their
+    // inverses) of nflav entries, 1-based flavour numbers in the order band + Nd * spin
+    int nsym; const int *symmoves;
     double p_wins, p_wrep, worm_eta;
     double *acc_g4w, *acc_g4wpp;  // [nbins][2nwf][2nwf][2nwb+1] complex
     double *acc_giww, *acc_gtauw; // [nbins][niw2] complex, [nbins][ntau]: giw_worm / gtau_worm of the sampled component (sector 2)
@@ -1397,7 +1400,10 @@ __device__ W2DYN_INLINE void step_glob(Ctx &x)
     bool spinflip = false;
     if (r < 0.3) { spinflip = true; gu[0] = 0; for (int i = 1; i <= nd; ++i) gu[i] = i + nd; for (int i = nd + 1; i <= 2 * nd; ++i) gu[i] = i - nd; }
     else if (r < 0.6) { gu[0] = 1; for (int i = 1; i <= nf; ++i) gu[i] = i; }
-    else {
+    else if (r < 0.8 && C.nsym > 0) {                // gen_SymUpdate, Trace.F90:1170-1182
+        const int isym = x.randint(1, 2 * C.nsym) - 1;
+        gu[0] = 0; for (int i = 1; i <= nf; ++i) gu[i] = C.symmoves[isym * nf + i - 1];
+    } else {
         for (int i = 1; i <= nf; ++i) gu[i] = i;
         for (int j = 1; j <= nf; ++j) { int i = x.randint(j, nf); int t = gu[j]; gu[j] = gu[i]; gu[i] = t; }
         gu[0] = x.randint(0, 1);

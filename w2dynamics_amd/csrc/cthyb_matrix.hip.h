@@ -996,7 +996,10 @@ __device__ W2DYN_INLINE void step_glob_mat(Ctx &x)
     bool spinflip = false;
     if (r < 0.3) { spinflip = true; gu[0] = 0; for (int i = 1; i <= nd; ++i) gu[i] = i + nd; for (int i = nd + 1; i <= 2 * nd; ++i) gu[i] = i - nd; }
     else if (r < 0.6) { gu[0] = 1; for (int i = 1; i <= nf; ++i) gu[i] = i; }
-    else {
+    else if (r < 0.8 && C.nsym > 0) {                // gen_SymUpdate, Trace.F90:1170-1182
+        const int isym = x.randint(1, 2 * C.nsym) - 1;
+        gu[0] = 0; for (int i = 1; i <= nf; ++i) gu[i] = C.symmoves[isym * nf + i - 1];
+    } else {
         for (int i = 1; i <= nf; ++i) gu[i] = i;
         for (int j = 1; j <= nf; ++j) { int i = x.randint(j, nf); int t = gu[j]; gu[j] = gu[i]; gu[i] = t; }
         gu[0] = x.randint(0, 1);

@@ -550,7 +550,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
         {"segment", 0}, {"offdiag", 0}, {"full_offdiag", 0}, {"statesampling", 0}, {"flavourchange_moves", 0}, {"Phonon", 0},
         {"Screening", 0}, {"Uw", 0}, {"MeasGtauDetRat", 0},
         {"MeasExpResDensityMatrix", 0},
-        {"NSymMove", 0}, {"MeasDensityMatrix", 1}, {"Eigenbasis", 1}};
+        {"MeasDensityMatrix", 1}, {"Eigenbasis", 1}};
     for (auto &z : zero_int) {
         if (!get_int(s, z.key, iv)) return W2DYN_EINVAL;
         if (iv != z.allowed) return fail(s, W2DYN_EUNSUPPORTED, "%s = %lld is not supported by the HIP solver (only %lld)", z.key, iv, z.allowed);
@@ -788,6 +788,30 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if ((rc = dev_alloc(s, C.acc_nw, B))) return rc;
     C.nwf = s->n4iwf; C.nwb = s->n4iwb; C.wormphconv = s->wormphconv; C.g4ph = s->g4ph; C.g4pp = s->g4pp;
     C.p_wins = 0.0; C.p_wrep = s->p_wrep; C.worm_eta = s->worm_eta; C.isector = 1; C.icomponent = 0;
+    {   // user symmetry moves of the global move: the listed permutations and their inverses (Trace.F90:471-478)
+        if (!get_int(s, "NSymMove", iv)) return W2DYN_EINVAL;
+        const int nsym = (int)iv;
+        if (nsym < 0 || nsym > 99) return fail(s, W2DYN_EINVAL, "NSymMove = %d", nsym);
+        C.nsym = nsym; C.symmoves = nullptr;
+        if (nsym > 0) {
+            std::vector<int> tab((size_t)2 * nsym * nf, 0);
+            for (int i = 0; i < nsym; ++i) {
+                char key[16]; snprintf(key, sizeof key, "SymMove%02d", i + 1);
+                if (!get_str(s, key, sv)) return W2DYN_EINVAL;
+                std::vector<int> row; { const char *p = sv.c_str(); char *e; for (long v = strtol(p, &e, 10); e != p; p = e, v = strtol(p, &e, 10)) row.push_back((int)v); }
+                std::vector<char> seen(nf + 1, 0);
+                if ((int)row.size() != nf) return fail(s, W2DYN_EINVAL, "%s: %zu entries, %d flavours", key, row.size(), nf);
+                for (int j = 0; j < nf; ++j) {
+                    if (row[j] < 1 || row[j] > nf || seen[row[j]]) return fail(s, W2DYN_EINVAL, "%s is not a permutation of 1..%d", key, nf);
+                    seen[row[j]] = 1;
+                    tab[(size_t)i * nf + j] = row[j]; tab[(size_t)(nsym + i) * nf + row[j] - 1] = j + 1;
+                }
+            }
+            const int *dtab = nullptr;
+            if ((rc = dev_upload(s, dtab, tab))) return rc;
+            C.symmoves = dtab;
+        }
+    }
     s->nbw = 0; s->cur_isector = 1; s->no_sampling = false; s->steps_worm_chains.clear();
     s->ac_dat = s->ac_out = nullptr; s->ac_lev = 0; s->ac_n = 0;
     if (s->accum_gtau == 2) {        // autocorracc_create(ncomp, ilog2(Nmeas)), CTQMC.F90:497-500, Accumulators.F90:89-101

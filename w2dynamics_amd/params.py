@@ -54,9 +54,10 @@ def symm_to_pstring(symmetries) -> str:
     return s
 
 
-def make_pstring(qmc_overrides=None, **problem) -> str:
+def make_pstring(qmc_overrides=None, symmetries=(), **problem) -> str:
     """Assemble a full parameter string: QMC defaults + overrides, then the problem keys
-    (`impurity.py:500-513`), then the symmetry-move block."""
+    (`impurity.py:500-513`), then the symmetry-move block (`symmetries`: permutations of the 2 Nd flavours in the
+    order band + Nd * spin, 0-based, as the reference's `problem.symmetry_moves`)."""
     qmc = dict(QMC_DEFAULTS)
     if qmc_overrides:
         for k, v in qmc_overrides.items():
@@ -66,7 +67,7 @@ def make_pstring(qmc_overrides=None, **problem) -> str:
     prob = {"Hamiltonian": "Density", "beta": 10.0, "Nd": 1, "ParaMag": 0, "QuantumNumbers": "Nt Szt Azt",
             "Phonon": 0, "g_phonon": "", "omega0": "", "Screening": 0, "Uw": 0}
     prob.update(problem)
-    return config_to_pstring(qmc) + config_to_pstring(prob) + symm_to_pstring([])
+    return config_to_pstring(qmc) + config_to_pstring(prob) + symm_to_pstring(list(symmetries))
 
 
 class ParameterSet:
