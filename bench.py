@@ -166,9 +166,10 @@ def issue_profile(config):
     return None, None
 
 
-def pmc_traffic(kernel, chains, config):
+def pmc_traffic(kernel, chains, config, sum_all=False):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/*_pmc.json, made by
-    profiles/collect.sh + pmc_summary.py on the same command); None when no pass exists for this chain count."""
+    profiles/collect.sh + pmc_summary.py on the same command); None when no pass exists for this chain count.
+    sum_all: the timed step is several kernels whose names start with `kernel` (the g4iw assembly), add them up."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
         try:
@@ -177,9 +178,9 @@ def pmc_traffic(kernel, chains, config):
             continue
         if d.get("chains_per_gpu") != chains or d.get("config", "C2") != config:
             continue
-        for name, v in d.get("kernels", {}).items():
-            if name.startswith(kernel):
-                return v["traffic"], os.path.basename(f)
+        hits = [v["traffic"] for name, v in d.get("kernels", {}).items() if name.startswith(kernel)]
+        if hits:
+            return (sum(hits) if sum_all else hits[0]), os.path.basename(f)
     return None, None
 
 
@@ -375,13 +376,13 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
             n4 = nflav ** 2 * (2 * nwf) ** 2 * (2 * nwb + 1)
             by4 = W * n4 * 32.0                                              # 32 B of accumulator traffic per element and measurement
             gb4 = by4 / (g4_ms * 1e-3) / 1e9 if g4_ms > 0 else 0.0
-            tr2, _ = pmc_traffic("k_meas_g2iw", W, wname); tr4, _ = pmc_traffic("k_meas_g4iw", W, wname)
+            tr2, _ = pmc_traffic("k_meas_g2iw", W, wname); tr4, _ = pmc_traffic("k_meas_g4iw", W, wname, sum_all=True)
             out["roofline_g2iw"] = {"kernel": "k_meas_g2iw", "bound": "mfma", "achieved": tf2, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": tf2 / FP64_PEAK_TFLOPS, "traffic": tr2, "avg_launch_ms": g2_ms, "launches": ng2, "algorithmic_flops_per_launch": fl2,
                                     # what bounds it at production boxes (n2 >> k): every chain's n2 x n2 table is written once
                                     "hbm_bytes_written_per_launch": float(W) * nflav * n2 * n2 * 16.0,
                                     "hbm_write_gbs": float(W) * nflav * n2 * n2 * 16.0 / (g2_ms * 1e-3) / 1e9 if g2_ms > 0 else 0.0}
-            out["roofline_g4iw"] = {"kernel": "k_meas_g4iw", "bound": "hbm", "achieved": gb4, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            out["roofline_g4iw"] = {"kernel": "k_meas_g4iw (+ k_meas_g4iw_exch, k_meas_g2acc: one timed step)", "bound": "hbm", "achieved": gb4, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                     "frac": gb4 / HBM_PEAK_GBS, "traffic": tr4, "avg_launch_ms": g4_ms, "launches": ng4,
                                     "algorithmic_bytes_per_launch": by4, "complex_macs_per_launch": float(W) * n4,
                                     "fp64_tflops": float(W) * n4 * 8.0 / (g4_ms * 1e-3) / 1e12 if g4_ms > 0 else 0.0,

@@ -416,6 +416,26 @@ def test_two_particle_matsubara_production_box_and_folded_bins(monkeypatch):
     q.dest_ctqmc(); q.close()
 
 
+def test_two_particle_matsubara_other_convention_ragged_box():
+    """a-14 with ZPHConvention = 1 on a box that is ragged for every kernel of the assembly (N4iwf = 9: 18 fermionic frequencies =
+    one full and one partial 16 x 16 tile; N4iwb = 4: 9 bosonic frequencies = two chunks of the exchange kernel), two orbitals
+    (equal- and different-flavour pairs), chain by chain against the oracle."""
+    over = dict(BASE, Nwarmups=2000, Nmeas=3, NCorr=20, TaudiffMax=4.0, N4iwf=9, N4iwb=4, MeasG2iw=1, ZPHConvention=1,
+                PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05)
+    p, ps, pset = util.setup("C3", 501, over)
+    nw = 4
+    q = MCTQMC(nwalkers=nw, walkers_per_bin=1)
+    q.fourpnt = 4
+    q.init_rnd(17); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+    q.set_taudiffmax(4.0); q.ctqmc_warmup(2000); q.ctqmc_measure(1, 1)
+    for w in range(nw):
+        o = pyoracle.OracleWalker(p, pset, ("philox", 17, w), fourpnt=4)
+        o.set_taudiffmax(4.0); o.warmup(2000); o.measure(); r = o.results(); o.close()
+        for k in ("g4iw", "g2iw"):
+            assert getattr(q, k + "_bins")[w].shape == r[k].shape and rel(getattr(q, k + "_bins")[w], r[k]) < TOL, (k, w)
+    q.dest_ctqmc(); q.close()
+
+
 def test_worm_estimator_folded_bins(monkeypatch):
     """a-16 with folded accumulator bins (nbw < nbins) at N4iwf = 10, N4iwb = 5 (three passes of k_meas_g4w over the
     frequency box): the pooled g4iw_worm follows from the oracle chains as in the unfolded case."""

@@ -2830,23 +2830,19 @@ __global__ __launch_bounds__(256) void k_meas_g2iw(DevConst C, int n2, int nwb, 
 
 // Assembly of the two-particle Green's function from products of two g2 (CTQMC.F90:2175-2222) and accumulation of g2.
 // acc4 / acc4pp layout [nb4][f1][f2][wb][w1][w2] (complex; the host turns it into the reference's (w1, w2, wb) order),
-// acc2 [nb4][f][wa][wc]; chains of sample bin b go to b % nb4.
+// acc2 [nb4][f][wa][wc]; chains of sample bin b go to b % nb4.  Three kernels add to acc4 / acc4pp one after the other:
 //
-// The direct term of the particle-hole channel factorises for fixed (f1, f2, wb): with A_ch(w1) = g2_ch[f1](w1 + wb, w1)
-// and B_ch(w2) = g2_ch[f2](w2, w2 + wb) it is  sum_ch A_ch(w1) B_ch(w2)  - a complex matrix product over the CHAINS of the
+// k_meas_g4iw: the direct term of the particle-hole channel.  For fixed (f1, f2, wb), with A_ch(w1) = g2_ch[f1](w1 + wb, w1)
+// and B_ch(w2) = g2_ch[f2](w2, w2 + wb), it is  sum_ch A_ch(w1) B_ch(w2)  - a complex matrix product over the CHAINS of the
 // accumulator bin, (2 N4iwf) x chains times chains x (2 N4iwf).  That is a real fp64 contraction of a size the matrix
 // cores take: four v_mfma_f64_16x16x4_f64 per 16 x 16 tile and four chains (Re += Ar Br - Ai Bi, Im += Ar Bi + Ai Br),
 // instead of four FMAs and two gathered loads per element and chain.  One workgroup = (f1, f2, wb, accumulator bin), its
 // four waves cover a 64 x 64 region of (w1, w2) in 2 x 2 tiles of 16 x 16 each (16 accumulator registers of 4 doubles per
-// lane); the operands A (lane = (w1, chain)) and B (lane = (chain, w2)) come straight from the chains' g2 tables (L2).
-// The exchange term (equal flavours) and the particle-particle channel do not factorise - both of their factors depend on
-// w1 and w2 - and stay element-wise on the same register layout (C/D of the f64 MFMA: column = lane & 15, row = (lane >> 4)
-// + 4 reg).  The accumulators cross HBM once per launch.
+// lane); the operands A (lane = (w1, chain)) and B (lane = (chain, w2)) are contiguous rows of the chains' g2 tables (the
+// diagonals k_meas_g2iw stores behind the matrix).  C/D layout of the f64 MFMA: column = lane & 15, row = (lane >> 4) + 4 reg.
+// k_meas_g4iw_exch / k_meas_g4iw_pp: the terms that do not factorise (below).  The accumulators cross HBM once per kernel.
 typedef double g4_d4 __attribute__((ext_vector_type(4)));
-// PP = false: particle-hole channel into acc (MFMA direct term, element-wise exchange term for equal flavours);
-// PP = true: particle-particle channel into acc (element-wise)
-template <bool PP>
-__global__ __launch_bounds__(256, PP ? 1 : 2) void k_meas_g4iw(DevConst C, int nwf, int nwb, int zph, int nb4, const double2 *__restrict__ G2, double2 *__restrict__ acc)
+__global__ __launch_bounds__(256, 2) void k_meas_g4iw(DevConst C, int nwf, int nwb, int zph, int nb4, const double2 *__restrict__ G2, double2 *__restrict__ acc)
 {
     const int nf = C.nflav, n2 = 2 * (nwf + nwb), h = n2 / 2, nw = 2 * nwf, nb = 2 * nwb + 1;
     const size_t n4 = (size_t)nf * nf * nw * nw * nb, g2sz = g2_stride(n2, nwb);
@@ -2869,7 +2865,6 @@ __global__ __launch_bounds__(256, PP ? 1 : 2) void k_meas_g4iw(DevConst C, int n
     const int r0 = reg_i * 64 + (wv >> 1) * 32, c0 = reg_j * 64 + (wv & 1) * 32;      // first row / column index (0-based) of this wave
     if (r0 >= nw || c0 >= nw) return;
     const int li = lane & 15, lk = lane >> 4;
-    const bool same = f1 == f2;
     // operand positions inside a chain's g2 table: A of row tile t at w1 = r0 + 16 t + li, B of column tile t at w2 = c0 + 16 t + li
     unsigned offA[2], offB[2]; bool okA[2], okB[2];
 #pragma unroll
@@ -2880,21 +2875,6 @@ __global__ __launch_bounds__(256, PP ? 1 : 2) void k_meas_g4iw(DevConst C, int n
         const int c1 = zph == 0 ? w1 : w1 - wb, c2 = zph == 0 ? w2 + wb : w2;
         offA[t] = okA[t] ? (unsigned)(n2 * n2 + (wb + nwb) * n2 + (c1 + h)) : 0u; offB[t] = okB[t] ? (unsigned)(n2 * n2 + (nwb - wb) * n2 + (c2 + h)) : 0u;
     }
-    // element-wise part: the lane's element q of tile (ti, tj) is (w1, w2) = (r0 + 16 ti + lk + 4 q, c0 + 16 tj + li) - nwf.
-    // A factor g(row, col) whose ROW runs with w2 (the lane-fast index) would be a gather of 16-byte pieces from 64
-    // different cache lines per load; it is read the other way round instead - row with lk + 4 q, column with li: whole
-    // lines - into a 16 x 16 tile of LDS and picked up transposed (stage_t).
-    __shared__ double2 g4_tile[4][4][16 * 17];                     // per wave: one tile per (ti, tj) (particle-hole) or per factor (particle-particle)
-    double2 (*tl)[16 * 17] = g4_tile[wv];
-    // out[q] = g[(rbase + sr li) n2 + cbase + sc (lk + 4 q)]; rows belong to w2 indices c0 + 16 tj + .., columns to w1 indices r0 + 16 ti + ..
-    auto stage_t_load = [&](const double2 *g, double2 *tile, int ti, int tj, int rbase, int sr, int cbase, int sc) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int rl = lk + 4 * q;                                         // row of the tile this lane fills, column li
-            const bool ok = c0 + 16 * tj + rl < nw && r0 + 16 * ti + li < nw;
-            tile[rl * 17 + li] = ok ? g[(unsigned)((rbase + sr * rl) * n2 + (cbase + sc * li))] : make_double2(0.0, 0.0);
-        }
-    };
     g4_d4 re[2][2], im[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -2903,92 +2883,25 @@ __global__ __launch_bounds__(256, PP ? 1 : 2) void k_meas_g4iw(DevConst C, int n
     for (int bin = b4; bin < C.nbins; bin += nb4) {
         const int w0 = bin * C.walkers_per_bin, w1e = min(w0 + C.walkers_per_bin, C.nwalkers);
         for (int w4 = w0; w4 < w1e; w4 += 4) {
-            if constexpr (!PP) {
-                const int wl = w4 + lk;
-                const bool wok = wl < w1e;
-                const double2 *g1 = G2 + ((size_t)(wok ? wl : w0) * nf + f1) * g2sz, *g2p = G2 + ((size_t)(wok ? wl : w0) * nf + f2) * g2sz;
-                double ar[2], ai[2], br[2], bi[2];
+            const int wl = w4 + lk;
+            const bool wok = wl < w1e;
+            const double2 *g1 = G2 + ((size_t)(wok ? wl : w0) * nf + f1) * g2sz, *g2p = G2 + ((size_t)(wok ? wl : w0) * nf + f2) * g2sz;
+            double ar[2], ai[2], br[2], bi[2];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const double2 a = g1[offA[t]], b = g2p[offB[t]];
-                    ar[t] = (wok && okA[t]) ? a.x : 0.0; ai[t] = (wok && okA[t]) ? a.y : 0.0;
-                    br[t] = (wok && okB[t]) ? b.x : 0.0; bi[t] = (wok && okB[t]) ? b.y : 0.0;
-                }
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                    for (int tj = 0; tj < 2; ++tj) {
-                        re[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[ti], br[tj], re[ti][tj], 0, 0, 0);
-                        re[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai[ti], bi[tj], re[ti][tj], 0, 0, 0);
-                        im[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[ti], bi[tj], im[ti][tj], 0, 0, 0);
-                        im[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[ti], br[tj], im[ti][tj], 0, 0, 0);
-                    }
+            for (int t = 0; t < 2; ++t) {
+                const double2 a = g1[offA[t]], b = g2p[offB[t]];
+                ar[t] = (wok && okA[t]) ? a.x : 0.0; ai[t] = (wok && okA[t]) ? a.y : 0.0;
+                br[t] = (wok && okB[t]) ? b.x : 0.0; bi[t] = (wok && okB[t]) ? b.y : 0.0;
             }
-            if (PP || same) {
-                const int wend = min(w4 + 4, w1e);
-                for (int w = w4; w < wend; ++w) {
-                    const double2 *g1 = G2 + ((size_t)w * nf + f1) * g2sz, *g2p = G2 + ((size_t)w * nf + f2) * g2sz;      // uniform bases
-                    if constexpr (!PP) {
-                        // exchange term  - g1(a3, c3) g1(a4, c4):  zph = 0: (w2, w1) (w1 + wb, w2 + wb);  zph = 1: (w1, w2) (w2 - wb, w1 - wb).
-                        // All four tiles of the chain at once: sixteen line-wise loads into the LDS tiles, sixteen direct ones into
-                        // registers, ONE hand-off - a tile at a time the wave waited for two memory round trips per tile
-                        double2 dir[2][2][4];
 #pragma unroll
-                        for (int ti = 0; ti < 2; ++ti)
+            for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-                            for (int tj = 0; tj < 2; ++tj) {
-                                const int R = r0 + 16 * ti - nwf + h, Cc = c0 + 16 * tj - nwf + h;     // w1 + h = R + (lk + 4 q), w2 + h = Cc + li
-                                if (zph == 0) stage_t_load(g1, tl[2 * ti + tj], ti, tj, Cc, 1, R, 1); else stage_t_load(g1, tl[2 * ti + tj], ti, tj, Cc - wb, 1, R - wb, 1);
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    const int rl = lk + 4 * q;
-                                    const bool ok = r0 + 16 * ti + rl < nw && c0 + 16 * tj + li < nw;
-                                    dir[ti][tj][q] = g1[ok ? (unsigned)(zph == 0 ? (R + wb + rl) * n2 + (Cc + wb + li) : (R + rl) * n2 + (Cc + li)) : 0u];
-                                }
-                            }
-                        lds_sync();
-#pragma unroll
-                        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                            for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    const int rl = lk + 4 * q;
-                                    const bool ok = r0 + 16 * ti + rl < nw && c0 + 16 * tj + li < nw;
-                                    const double2 t = tl[2 * ti + tj][li * 17 + rl], d = dir[ti][tj][q];
-                                    if (ok) { re[ti][tj][q] -= t.x * d.x - t.y * d.y; im[ti][tj][q] -= t.x * d.y + t.y * d.x; }
-                                }
-                        lds_sync();
-                    } else {
-#pragma unroll
-                    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                        for (int tj = 0; tj < 2; ++tj) {
-                            const int R = r0 + 16 * ti - nwf + h, Cc = c0 + 16 * tj - nwf + h;     // w1 + h = R + (lk + 4 q), w2 + h = Cc + li
-                            {
-                                // direct: g1(wb - w2 - 1, w1) g2(w2, wb - w1 - 1); exchange (equal flavours): - g1(w2, w1) g1(wb - w2 - 1, wb - w1 - 1)
-                                const int Rm = wb - 1 + 2 * h - Cc, Cm = wb - 1 + 2 * h - R;       // (wb - w2 - 1) + h = Rm - li, (wb - w1 - 1) + h = Cm - (lk + 4 q)
-                                stage_t_load(g1, tl[0], ti, tj, Rm, -1, R, 1);
-                                stage_t_load(g2p, tl[1], ti, tj, Cc, 1, Cm, -1);
-                                if (same) { stage_t_load(g1, tl[2], ti, tj, Cc, 1, R, 1); stage_t_load(g1, tl[3], ti, tj, Rm, -1, Cm, -1); }
-                                lds_sync();
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    const int rl = lk + 4 * q;
-                                    const bool ok = r0 + 16 * ti + rl < nw && c0 + 16 * tj + li < nw;
-                                    const double2 xx = tl[0][li * 17 + rl], yy = tl[1][li * 17 + rl];
-                                    if (ok) { re[ti][tj][q] += xx.x * yy.x - xx.y * yy.y; im[ti][tj][q] += xx.x * yy.y + xx.y * yy.x; }
-                                    if (same) {
-                                        const double2 u = tl[2][li * 17 + rl], v = tl[3][li * 17 + rl];
-                                        if (ok) { re[ti][tj][q] -= u.x * v.x - u.y * v.y; im[ti][tj][q] -= u.x * v.y + u.y * v.x; }
-                                    }
-                                }
-                                lds_sync();
-                            }
-                        }
-                    }
+                for (int tj = 0; tj < 2; ++tj) {
+                    re[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[ti], br[tj], re[ti][tj], 0, 0, 0);
+                    re[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ai[ti], bi[tj], re[ti][tj], 0, 0, 0);
+                    im[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[ti], bi[tj], im[ti][tj], 0, 0, 0);
+                    im[ti][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[ti], br[tj], im[ti][tj], 0, 0, 0);
                 }
-            }
         }
     }
 #pragma unroll
@@ -3002,6 +2915,129 @@ __global__ __launch_bounds__(256, PP ? 1 : 2) void k_meas_g4iw(DevConst C, int n
                 const size_t e = ((((size_t)f1 * nf + f2) * nb + wbi) * nw + i1) * nw + i2;      // w2 fastest: the wave writes runs of 16 elements
                 double2 *d = acc + (size_t)b4 * n4 + e; double2 o = *d; o.x += re[ti][tj][q]; o.y += im[ti][tj][q]; *d = o;
             }
+}
+// Exchange term of the particle-hole channel (equal flavours):  - g(w2, w1) g(w1 + wb, w2 + wb)  (zph = 0)  or
+// - g(w1, w2) g(w2 - wb, w1 - wb)  (zph = 1).  One factor does not depend on wb, the other is the same table read wb places
+// further along the diagonal: a workgroup owns a 16 x 16 tile of (w1, w2) for G4X_WB consecutive bosonic frequencies, thread =
+// element, and per chain stages the tile of the fixed factor (16 x 16) and the window of the shifted one ((16 + G4X_WB - 1)^2)
+// in LDS once - each laid out so that the lanes of a wave (w2 fastest) read consecutive addresses, i.e. the factor whose ROW runs
+// with w2 is transposed on its way in.  The element-wise version inside k_meas_g4iw read two 64 x 64 windows per chain and
+// bosonic frequency (~40 GB of L2 traffic per launch at N4iwf = 30, N4iwb = 10, 4096 chains; this one: 9 GB) and waited for
+// them with two waves per SIMD.  Runs behind k_meas_g4iw<false> on the same stream and adds to the same accumulators.
+constexpr int G4X_WB = 7, G4X_WIN = 16 + G4X_WB - 1;
+__global__ __launch_bounds__(256) void k_meas_g4iw_exch(DevConst C, int nwf, int nwb, int zph, int nb4, const double2 *__restrict__ G2, double2 *__restrict__ acc)
+{
+    __shared__ double2 fixt[16][17], win[G4X_WIN][G4X_WIN + 1];
+    const int nf = C.nflav, n2 = 2 * (nwf + nwb), h = n2 / 2, nw = 2 * nwf, nb = 2 * nwb + 1;
+    const size_t n4 = (size_t)nf * nf * nw * nw * nb, g2sz = g2_stride(n2, nwb);
+    const int nt = (nw + 15) / 16, nch = (nb + G4X_WB - 1) / G4X_WB;
+    // same dealing of accumulator bins to XCDs as in k_meas_g4iw
+    const unsigned per_bin = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned slot = lin >> 3, inner = slot % per_bin;
+    const int b4 = (int)((lin & 7u) + 8u * (slot / per_bin));
+    if (b4 >= nb4) return;
+    const int bx = (int)(inner % gridDim.x), f = (int)(inner / gridDim.x);
+    const int ch = bx % nch, tile = bx / nch, ti = tile / nt, tj = tile - ti * nt;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int r0 = ti * 16, c0 = tj * 16;                     // first w1 / w2 index (0-based) of the tile
+    const int wbi0 = ch * G4X_WB, wb0 = wbi0 - nwb;            // first bosonic frequency of this chunk
+    const bool ok = r0 + ty < nw && c0 + tx < nw;
+    // table positions (index + h): fixed factor rows / columns and the window's first row / column
+    //   zph 0: fixed = g(w2, w1) -> fixt[w1][w2] (transposed on the way in); window(a, b) = g(R + wb0 + a, Cc + wb0 + b), read at (ty + j, tx + j)
+    //   zph 1: fixed = g(w1, w2) -> fixt[w1][w2];  window stored transposed: win[a][b] = g(Cc - wb0 - (G4X_WB - 1) + b, R - wb0 - (G4X_WB - 1) + a),
+    //          read at (ty + G4X_WB - 1 - j, tx + G4X_WB - 1 - j)
+    const int R = r0 - nwf + h, Cc = c0 - nwf + h;
+    double re[G4X_WB], im[G4X_WB];
+#pragma unroll
+    for (int j = 0; j < G4X_WB; ++j) { re[j] = 0.0; im[j] = 0.0; }
+    auto at = [&](const double2 *g, int row, int col) { return (row >= 0 && row < n2 && col >= 0 && col < n2) ? g[(unsigned)(row * n2 + col)] : make_double2(0.0, 0.0); };
+    for (int bin = b4; bin < C.nbins; bin += nb4) {
+        const int w0 = bin * C.walkers_per_bin, w1e = min(w0 + C.walkers_per_bin, C.nwalkers);
+        for (int w = w0; w < w1e; ++w) {
+            const double2 *g = G2 + ((size_t)w * nf + f) * g2sz;
+            __syncthreads();
+            if (zph == 0) {
+                fixt[tx][ty] = at(g, Cc + ty, R + tx);                         // row w2 = ty, column w1 = tx (coalesced), stored as [w1][w2]
+                for (int e = threadIdx.x; e < G4X_WIN * G4X_WIN; e += 256) { const int a = e / G4X_WIN, b = e - a * G4X_WIN; win[a][b] = at(g, R + wb0 + a, Cc + wb0 + b); }
+            } else {
+                fixt[ty][tx] = at(g, R + ty, Cc + tx);
+                for (int e = threadIdx.x; e < G4X_WIN * G4X_WIN; e += 256) { const int b = e / G4X_WIN, a = e - b * G4X_WIN; win[a][b] = at(g, Cc - wb0 - (G4X_WB - 1) + b, R - wb0 - (G4X_WB - 1) + a); }
+            }
+            __syncthreads();
+            const double2 fx = fixt[ty][tx];
+#pragma unroll
+            for (int j = 0; j < G4X_WB; ++j) {
+                const double2 v = zph == 0 ? win[ty + j][tx + j] : win[ty + G4X_WB - 1 - j][tx + G4X_WB - 1 - j];
+                re[j] -= fx.x * v.x - fx.y * v.y; im[j] -= fx.x * v.y + fx.y * v.x;
+            }
+        }
+    }
+    if (!ok) return;
+#pragma unroll
+    for (int j = 0; j < G4X_WB; ++j) {
+        const int wbi = wbi0 + j;
+        if (wbi >= nb) break;
+        const size_t e = ((((size_t)f * nf + f) * nb + wbi) * nw + (r0 + ty)) * nw + (c0 + tx);
+        double2 *d = acc + (size_t)b4 * n4 + e; double2 o = *d; o.x += re[j]; o.y += im[j]; *d = o;
+    }
+}
+// Particle-particle channel (CTQMC.F90:2200-2222, ZPHConvention = 0 only), same tiling: with K = wb - 1 (+ 2h in table positions)
+//   direct    g_f1(K - w2, w1) g_f2(w2, K - w1)         X: row falls with w2 and rises with wb, Y: column falls with w1, rises with wb
+//   exchange  - g_f1(w2, w1) g_f1(K - w2, K - w1)       (equal flavours) fixed tile times a window that moves along the anti-diagonal
+// Four LDS arrays per chain, each stored so that a wave (w2 = tx fastest) reads consecutive addresses: xs[w1][K - w2],
+// ys[K - w1][w2], fs[w1][w2], ws[K - w1][K - w2] (window coordinates 15 + j - t for bosonic frequency j of the chunk).
+__global__ __launch_bounds__(256) void k_meas_g4iw_pp(DevConst C, int nwf, int nwb, int nb4, const double2 *__restrict__ G2, double2 *__restrict__ acc)
+{
+    __shared__ double2 xs[16][G4X_WIN + 1], ys[G4X_WIN][17], fs[16][17], ws[G4X_WIN][G4X_WIN + 1];
+    const int nf = C.nflav, n2 = 2 * (nwf + nwb), h = n2 / 2, nw = 2 * nwf, nb = 2 * nwb + 1;
+    const size_t n4 = (size_t)nf * nf * nw * nw * nb, g2sz = g2_stride(n2, nwb);
+    const int nt = (nw + 15) / 16, nch = (nb + G4X_WB - 1) / G4X_WB;
+    const unsigned per_bin = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const unsigned slot = lin >> 3, inner = slot % per_bin;
+    const int b4 = (int)((lin & 7u) + 8u * (slot / per_bin));
+    if (b4 >= nb4) return;
+    const int bx = (int)(inner % gridDim.x), ff = (int)(inner / gridDim.x), f1 = ff / nf, f2 = ff - f1 * nf;
+    const int ch = bx % nch, tile = bx / nch, ti = tile / nt, tj = tile - ti * nt;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int r0 = ti * 16, c0 = tj * 16;
+    const int wbi0 = ch * G4X_WB, wb0 = wbi0 - nwb;
+    const bool ok = r0 + ty < nw && c0 + tx < nw, same = f1 == f2;
+    const int R = r0 - nwf + h, Cc = c0 - nwf + h, K0 = wb0 - 1 + 2 * h;      // table positions: w1 + h = R + ty, w2 + h = Cc + tx, (K - w) + h = K0 + j - (w + h)
+    double re[G4X_WB], im[G4X_WB];
+#pragma unroll
+    for (int j = 0; j < G4X_WB; ++j) { re[j] = 0.0; im[j] = 0.0; }
+    auto at = [&](const double2 *g, int row, int col) { return (row >= 0 && row < n2 && col >= 0 && col < n2) ? g[(unsigned)(row * n2 + col)] : make_double2(0.0, 0.0); };
+    for (int bin = b4; bin < C.nbins; bin += nb4) {
+        const int w0 = bin * C.walkers_per_bin, w1e = min(w0 + C.walkers_per_bin, C.nwalkers);
+        for (int w = w0; w < w1e; ++w) {
+            const double2 *g1 = G2 + ((size_t)w * nf + f1) * g2sz, *g2p = G2 + ((size_t)w * nf + f2) * g2sz;
+            __syncthreads();
+            for (int e = threadIdx.x; e < 16 * G4X_WIN; e += 256) {
+                { const int u = e / 16, c = e - u * 16; xs[c][u] = at(g1, K0 - Cc - 15 + u, R + c); }                    // column (w1) fastest in memory
+                { const int t = e / G4X_WIN, v = e - t * G4X_WIN; ys[v][t] = at(g2p, Cc + t, K0 - R - 15 + v); }         // column (K - w1) fastest
+            }
+            if (same) {
+                fs[tx][ty] = at(g1, Cc + ty, R + tx);
+                for (int e = threadIdx.x; e < G4X_WIN * G4X_WIN; e += 256) { const int b = e / G4X_WIN, a = e - b * G4X_WIN; ws[a][b] = at(g1, K0 - Cc - 15 + b, K0 - R - 15 + a); }
+            }
+            __syncthreads();
+            const double2 fx = same ? fs[ty][tx] : make_double2(0.0, 0.0);
+#pragma unroll
+            for (int j = 0; j < G4X_WB; ++j) {
+                const double2 xv = xs[ty][15 + j - tx], yv = ys[15 + j - ty][tx];
+                re[j] += xv.x * yv.x - xv.y * yv.y; im[j] += xv.x * yv.y + xv.y * yv.x;
+                if (same) { const double2 v = ws[15 + j - ty][15 + j - tx]; re[j] -= fx.x * v.x - fx.y * v.y; im[j] -= fx.x * v.y + fx.y * v.x; }
+            }
+        }
+    }
+    if (!ok) return;
+#pragma unroll
+    for (int j = 0; j < G4X_WB; ++j) {
+        const int wbi = wbi0 + j;
+        if (wbi >= nb) break;
+        const size_t e = ((((size_t)f1 * nf + f2) * nb + wbi) * nw + (r0 + ty)) * nw + (c0 + tx);
+        double2 *d = acc + (size_t)b4 * n4 + e; double2 o = *d; o.x += re[j]; o.y += im[j]; *d = o;
+    }
 }
 // g2 itself (MeasG2iw): thread = element, workgroup = (256 elements, accumulator bin, chunk of G2ACC_CHUNK sample bins of that
 // accumulator bin); the chunk's chains are summed in registers (reads: unit stride across the wave) and added with one

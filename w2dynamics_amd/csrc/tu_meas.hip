@@ -67,8 +67,13 @@ void launch_meas_g4iw(const DevConst &C, hipStream_t st, int nwf, int nwb, int z
 {
     const int n2 = 2 * (nwf + nwb), nw = 2 * nwf, nreg = (nw + 63) / 64;
     const dim3 grid(nreg * nreg, C.nflav * C.nflav * (2 * nwb + 1), (nb4 + 7) / 8 * 8);       // z: accumulator bins in groups of eight (one per XCD)
-    if (acc4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_g4iw<false>), grid, dim3(256), 0, st, C, nwf, nwb, zph, nb4, G2, acc4);
-    if (acc4pp) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_meas_g4iw<true>), grid, dim3(256), 0, st, C, nwf, nwb, zph, nb4, G2, acc4pp);
+    const int nt = (nw + 15) / 16, nch = (2 * nwb + 1 + G4X_WB - 1) / G4X_WB;              // 16 x 16 tiles x chunks of bosonic frequencies
+    const unsigned gz = (unsigned)((nb4 + 7) / 8 * 8);
+    if (acc4) {
+        hipLaunchKernelGGL(k_meas_g4iw, grid, dim3(256), 0, st, C, nwf, nwb, zph, nb4, G2, acc4);
+        hipLaunchKernelGGL(k_meas_g4iw_exch, dim3(nt * nt * nch, C.nflav, gz), dim3(256), 0, st, C, nwf, nwb, zph, nb4, G2, acc4);
+    }
+    if (acc4pp) hipLaunchKernelGGL(k_meas_g4iw_pp, dim3(nt * nt * nch, C.nflav * C.nflav, gz), dim3(256), 0, st, C, nwf, nwb, nb4, G2, acc4pp);
     if (acc2) {
         const size_t ng2 = (size_t)C.nflav * n2 * n2;
         const int per_b4 = (C.nbins + nb4 - 1) / nb4;                  // sample bins per accumulator bin
