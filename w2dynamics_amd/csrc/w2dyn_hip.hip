@@ -306,9 +306,16 @@ int configure_kmax(w2dyn_solver *s, int kmax)
 LaunchCfg walker_launch(const w2dyn_solver *s)
 {
     LaunchCfg l;
-    l.block = dim3(256);
-    l.grid = dim3((s->nwalkers + 3) / 4);
-    l.lds = (size_t)s->C.shared_lds + 4 * (size_t)s->C.lds_per_wave;
+    // Chains (waves) per workgroup.  A workgroup's wave slots are free again only when its slowest chain is done, and chains
+    // differ by the global moves they happen to draw (35 step-times each on C2): one chain per workgroup on the scalar trace
+    // path, where a workgroup shares nothing (measured against four: C2 +11 %, C3 +12 %, C1 +6 %, C5Z +28 %, C5 worm +24 %).
+    // The matrix trace path stages the local problem's tables once per workgroup: four chains share them (C4: 1.81e8 steps/s
+    // with 4, 1.51e8 with 2, 1.80e8 with 1; C5K: 4.2e7, 2.4e7, 2.6e7).  W2DYN_WPG = 1 | 2 | 4 overrides.
+    int wpg = s->mat ? 4 : 1;
+    if (const char *e = getenv("W2DYN_WPG")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) wpg = v; }
+    l.block = dim3(64 * wpg);
+    l.grid = dim3((s->nwalkers + wpg - 1) / wpg);
+    l.lds = (size_t)s->C.shared_lds + (size_t)wpg * (size_t)s->C.lds_per_wave;
     l.stream = s->stream;
     return l;
 }
