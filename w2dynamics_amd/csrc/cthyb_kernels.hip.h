@@ -144,6 +144,9 @@ struct DevConst {
     // user symmetry moves of the global move (NSymMove, Trace.F90:403-404, 471-478): 2 nsym rows (the listed moves, then their
     // inverses) of nflav entries, 1-based flavour numbers in the order band + Nd * spin
     int nsym; const int *symmoves;
+    // matrix trace path: the chains of a launch are handed out to the waves from this counter (zeroed before every launch), so
+    // that the four waves of a workgroup - which share the staged tables of the local problem - never wait for one another
+    int *queue;
     double p_wins, p_wrep, worm_eta;
     double *acc_g4w, *acc_g4wpp;  // [nbins][2nwf][2nwf][2nwb+1] complex
     double *acc_giww, *acc_gtauw; // [nbins][niw2] complex, [nbins][ntau]: giw_worm / gtau_worm of the sampled component (sector 2)
@@ -1505,12 +1508,12 @@ __device__ W2DYN_INLINE void step_glob(Ctx &x)
 // ---------------------------------------------------------------------------------------------------------------
 // chain state: HBM <-> LDS/registers
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void ctx_setup(Ctx &x, unsigned char *smem)
+__device__ __forceinline__ void ctx_setup(Ctx &x, unsigned char *smem, int chain = -1)
 {
     const DevConst &C = x.C;
     int wib = threadIdx.x >> 6;
     x.lane = threadIdx.x & 63;
-    x.w = uni((int)(blockIdx.x * (blockDim.x >> 6) + wib));
+    x.w = chain >= 0 ? chain : uni((int)(blockIdx.x * (blockDim.x >> 6) + wib));
     unsigned char *base = smem + C.shared_lds + (size_t)wib * C.lds_per_wave;
     x.tc_ = (double *)base; x.ta_ = x.tc_ + C.nflav * C.kmax;
     x.MQ = x.ta_ + C.nflav * C.kmax; x.RM = x.MQ + C.kmax;
@@ -1637,6 +1640,14 @@ __device__ __forceinline__ long long launch_steps(const DevConst &C, int w, int 
     if (owed > 0) { if (lane == 0) { s.todo = owed + nsteps; atomicAdd(&C.flags[1], 1); } return 0; }
     return nsteps;
 }
+// next chain of the launch for this wave (matrix trace path); beyond the last one every wave gets nwalkers or more and leaves
+__device__ __forceinline__ int next_chain(const DevConst &C)
+{
+    int w = 0;
+    if ((threadIdx.x & 63) == 0) w = atomicAdd(C.queue, 1);
+    return __builtin_amdgcn_readfirstlane(w);
+}
+
 // a chain loaded with a full flavour (set_mc_config with k = kmax) pauses before its first step
 __device__ __forceinline__ void flag_full(Ctx &x)
 {
@@ -1667,8 +1678,10 @@ __global__ __launch_bounds__(256, MAT == 0 ? (WPE3 ? 3 : W2DYN_WPE) : W2DYN_WPE_
     extern __shared__ unsigned char smem[];
     stage_shared_tables(C, smem);
     Ctx x(C);
-    ctx_setup(x, smem);
-    if (x.w >= C.nwalkers) return;
+    // scalar path: wave = chain by position in the grid (one pass of the loop); matrix path: chains from the launch's queue
+    for (bool first = true;; first = false) {
+    if constexpr (MAT == 0) { if (!first) break; ctx_setup(x, smem); } else ctx_setup(x, smem, next_chain(C));
+    if (x.w >= C.nwalkers) break;
     if constexpr (CALIB) if (!resume) {
         bool done;
         if (C.calib == 1) done = C.apt_cnt[x.w] >= C.napt;
@@ -1676,10 +1689,10 @@ __global__ __launch_bounds__(256, MAT == 0 ? (WPE3 ? 3 : W2DYN_WPE) : W2DYN_WPE_
             done = true;
             for (int f = 0; f < C.nflav; ++f) done = done && C.calib_pairs[(size_t)x.w * C.nflav + f] >= C.phase2pairnum;
         }
-        if (uni((int)done)) return;
+        if (uni((int)done)) continue;
     }
     const long long nsteps = launch_steps(C, x.w, x.lane, nsteps_launch, resume);
-    if (nsteps == 0) return;
+    if (nsteps == 0) continue;
     ctx_load(x);
     flag_full(x);
     if constexpr (MAT != 0) mat_trace_current<MAT>(x);
@@ -1754,6 +1767,7 @@ __global__ __launch_bounds__(256, MAT == 0 ? (WPE3 ? 3 : W2DYN_WPE) : W2DYN_WPE_
     }
     if (count_sampling && x.lane == 0) x.cnt[C_SAMPLING] += (unsigned long long)it;
     ctx_store(x, nsteps - it);
+    }
 }
 
 // The library is built from several translation units (csrc/tu_*.hip, launch.hpp) that all include this header; kernel

@@ -383,10 +383,11 @@ __global__ __launch_bounds__(256, W2DYN_WPE_WORM) void k_sweep_worm(DevConst C, 
     extern __shared__ unsigned char smem[];
     stage_shared_tables(C, smem);
     Ctx x(C);
-    ctx_setup(x, smem);
-    if (x.w >= C.nwalkers) return;
+    for (bool first = true;; first = false) {          // as in k_sweep: one pass (scalar path) or chains from the launch's queue (matrix path)
+    if constexpr (MAT == 0) { if (!first) break; ctx_setup(x, smem); } else ctx_setup(x, smem, next_chain(C));
+    if (x.w >= C.nwalkers) break;
     const long long nsteps = launch_steps(C, x.w, x.lane, nsteps_launch, resume);
-    if (nsteps == 0) return;
+    if (nsteps == 0) continue;
     ctx_load(x);
     flag_full(x);
     if constexpr (MAT != 0) mat_trace_current<MAT>(x);
@@ -429,6 +430,7 @@ __global__ __launch_bounds__(256, W2DYN_WPE_WORM) void k_sweep_worm(DevConst C, 
         }
     }
     ctx_store(x, nsteps - it);
+    }
 }
 
 #ifdef W2DYN_TU_MEAS

@@ -445,14 +445,24 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 }  // namespace
 
 namespace w2dyn {
-void launch_sweep(int mat, bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count, int resume)
+// matrix trace path: the sweep kernels take their chains from DevConst::queue; no more workgroups than can share the GPU twice over
+static LaunchCfg queue_launch(const LaunchCfg &l, const DevConst &C)
 {
+    LaunchCfg q = l;
+    (void)hipMemsetAsync(C.queue, 0, sizeof(int), l.stream);
+    q.grid = dim3(std::min<unsigned>(l.grid.x, 2048u));
+    return q;
+}
+void launch_sweep(int mat, bool calib, const LaunchCfg &l0, const DevConst &C, long long nsteps, int count, int resume)
+{
+    const LaunchCfg l = mat ? queue_launch(l0, C) : l0;
     if (mat == 0) launch_sweep_scalar(calib, l, C, nsteps, count, resume);
     else if (mat <= 4) launch_sweep_tree(mat, calib, l, C, nsteps, count, resume);
     else launch_sweep_seq(calib, l, C, nsteps, count, resume);
 }
-void launch_sweep_worm(int nworm, int mat, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume)
+void launch_sweep_worm(int nworm, int mat, const LaunchCfg &l0, const DevConst &C, long long nsteps, int resume)
 {
+    const LaunchCfg l = mat ? queue_launch(l0, C) : l0;
     if (mat == 0) launch_sweep_worm_scalar(nworm, l, C, nsteps, resume);
     else if (mat <= 4) launch_sweep_worm_tree(nworm, mat, l, C, nsteps, resume);
     else launch_sweep_worm_seq(nworm, l, C, nsteps, resume);
@@ -795,6 +805,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if ((rc = dev_alloc(s, C.acc_nw, B))) return rc;
     C.nwf = s->n4iwf; C.nwb = s->n4iwb; C.wormphconv = s->wormphconv; C.g4ph = s->g4ph; C.g4pp = s->g4pp;
     C.p_wins = 0.0; C.p_wrep = s->p_wrep; C.worm_eta = s->worm_eta; C.isector = 1; C.icomponent = 0;
+    { int *qp = nullptr; if ((rc = dev_alloc(s, qp, 1))) return rc; C.queue = qp; }      // chain queue of the matrix-path sweep kernels
     {   // user symmetry moves of the global move: the listed permutations and their inverses (Trace.F90:471-478)
         if (!get_int(s, "NSymMove", iv)) return W2DYN_EINVAL;
         const int nsym = (int)iv;
