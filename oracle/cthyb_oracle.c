@@ -64,6 +64,8 @@ struct ora_walker {
     double *acbuf, *acdat; int aclev; int64_t acn;
     double *g4tau, *g4leg;                    /* FourPnt & 1: G4tau (Nd,2,Nd,2,N4tau^3); FourPnt & 2: G4leg (Nd,2,Nd,2,N4tau,N4tau,2N4iwb+1) complex */
     double *giww, *gtauw;                     /* giw_worm (2Niw complex), gtau_worm (Ntau) accumulators (sector 2) */
+    double *gsw;                              /* GSigmaiw_worm (2Niw complex) accumulator (sector 3) */
+    double *umat;                             /* U matrix (2Nd)^4, flavour index 2 * orbital + spin, as handed to init_solver */
     double *weq[6]; size_t weq_n[6];          /* p2iw, p2iwpp, p2tau, p2taupp, p3iw, p3iwpp worm accumulators (sectors 6 - 9) */
     double try_add, acc_add, accqn_add, try_rem, acc_rem, accqn_rem, try_glob, acc_glob, accqn_glob;
     double try_shift, acc_shift, cnt_sampling, cnt_meas;
@@ -903,9 +905,22 @@ static void step_shift(ora_walker *w)
 static int worm_nops(const ora_walker *w) { return w->isector == 2 ? 2 : 4; }
 
 /* get_Proposal (CTQMC.F90:5677-5719): SectorG / SectorG4 (beta Nd)^n eta; P2 / P2pp beta^2 Nd^4 eta; P3 / P3pp beta^3 Nd^4 eta */
+/* the U-matrix factor of the GSigma worm: 0.5 (U(u, g2, g1, g3) - U(g2, u, g1, g3)), u = first flavour of the component, g_i = flavour
+ * of worm operator i (CTQMC.F90:5689-5694, 1138) */
+static double gsigma_ufac(const ora_walker *w)
+{
+    const int nf = w->nflav, u = ((w->icomponent - 1) / nf) % nf;
+    int g[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < w->nops; ++i) if (w->ops[i].wid) g[w->ops[i].wid] = w->ops[i].flav;
+#define UM(a, b, c, d) w->umat[(((size_t)(a) * nf + (b)) * nf + (c)) * nf + (d)]
+    return 0.5 * (UM(u, g[2], g[1], g[3]) - UM(g[2], u, g[1], g[3]));
+#undef UM
+}
+
 static double worm_prefact(const ora_walker *w)
 {
     const double b = w->p.beta, nd = (double)w->p.nd, nd4 = nd * nd * nd * nd;
+    if (w->isector == 3) return gsigma_ufac(w) * (b * b) * (nd4 * nd) * w->eta;       /* beta^(N-2) Nd^(N+1) eta, N = 4 (CTQMC.F90:5696) */
     if (w->isector == 6 || w->isector == 7) return b * b * nd4 * w->eta;
     if (w->isector == 8 || w->isector == 9) return b * b * b * nd4 * w->eta;
     return pow(b * nd, (double)worm_nops(w)) * w->eta;
@@ -922,6 +937,7 @@ static int prev_is(const ora_walker *w, int wid, int wid_prev) { const int i = w
 static int check_equal_time(const ora_walker *w, int sector)
 {
     switch (sector) {
+    case 3: return prev_is(w, 2, 3) && prev_is(w, 3, 1);
     case 6: return prev_is(w, 1, 2) && prev_is(w, 3, 4);
     case 7: return prev_is(w, 1, 3) && prev_is(w, 2, 4);
     case 8: return prev_is(w, 3, 4);
@@ -937,14 +953,32 @@ static void step_worm_add(ora_walker *w)
     const int nw = worm_nops(w);
     int comp = w->icomponent, ncomp = 1;
     for (int i = 0; i < nw; ++i) ncomp *= nf;
+    if (w->isector == 3) ncomp = nf * nf;            /* the component has two indices: U-matrix flavour and flavour of operator 4 */
     if (comp == 0) comp = RINT(w, 1, ncomp);
     w->try_wadd += 1;
     /* set_OperFlavor (Trace.F90:3804-3826): digits of comp-1 in base 2Nd, most significant first; CA = mod(i,2)+1 */
     op_t o[4]; int rest = comp - 1, base = ncomp / nf;
-    for (int i = 0; i < nw; ++i) { int bs = rest / base; rest -= bs * base; base /= nf; o[i].flav = bs; o[i].ca = ((i + 1) % 2) + 1; o[i].wid = i + 1; }
+    for (int i = 0; i < nw; ++i) {
+        o[i].ca = ((i + 1) % 2) + 1; o[i].wid = i + 1; o[i].flav = 0;
+        if (w->isector != 3) { int bs = rest / base; rest -= bs * base; base /= nf; o[i].flav = bs; }
+    }
     /* set_OperTime (Trace.F90:3942-4020) */
     const double beta = w->p.beta, eqoff = beta * 1e-14;       /* equal_time_offset, Trace.F90:398 */
-    if (w->isector >= 6 && w->isector <= 9) {
+    if (w->isector == 3) {
+        /* set_IEOperFlavor (Trace.F90:3835-3919): the three operators of the equal-time object get random flavours until the
+         * U-matrix factor of the proposal does not vanish (CTQMC.F90:5047-5054); operator 4 carries the component's second flavour */
+        const int f4 = (comp - 1) % nf, u = ((comp - 1) / nf) % nf;
+        for (;;) {
+            for (int i = 0; i < 3; ++i) { const int orb = RINT(w, 1, w->p.nd), spin = RINT(w, 1, 2); o[i].flav = 2 * (orb - 1) + (spin - 1); }
+            o[3].flav = f4;
+#define UM(a, b, c, d) w->umat[(((size_t)(a) * nf + (b)) * nf + (c)) * nf + (d)]
+            if (0.5 * (UM(u, o[1].flav, o[0].flav, o[2].flav) - UM(o[1].flav, u, o[0].flav, o[2].flav)) != 0.0) break;
+#undef UM
+        }
+        for (int i = 0; i < 4; ++i) o[i].tau = U01(w) * beta;
+        if (o[1].tau < 2.0 * eqoff) o[1].tau = 2.0 * eqoff;
+        o[2].tau = o[1].tau - eqoff; o[0].tau = o[1].tau - 2.0 * eqoff;
+    } else if (w->isector >= 6 && w->isector <= 9) {
         o[0].tau = U01(w) * beta;
         o[3].tau = U01(w) * beta;
         if (w->isector <= 7) {                                  /* two random times */
@@ -985,6 +1019,7 @@ static void step_worm_add(ora_walker *w)
 static void step_worm_rem(ora_walker *w)
 {
     w->try_wrem += 1;
+    const double prefact = worm_prefact(w);       /* get_Proposal reads the worm operators' flavours (sector 3): before they leave the list */
     op_t saved[4]; int ns = 0;
     for (int i = 0; i < w->nops; ++i) if (w->ops[i].wid) saved[ns++] = w->ops[i];
     for (int i = w->nops - 1; i >= 0; --i) if (w->ops[i].wid) list_remove(w, i);
@@ -994,7 +1029,6 @@ static void step_worm_rem(ora_walker *w)
         return;
     }
     logval trnew = full_trace(w, w->outer_sst);
-    double prefact = worm_prefact(w);
     double rnd = U01(w);
     if (rnd < fabs(1.0 / prefact * trnew.sign * w->tr.sign * exp(trnew.log - w->tr.log))) {
         w->tr = trnew;
@@ -1014,18 +1048,24 @@ static void step_worm_replace(ora_walker *w)
 {
     w->try_wrep += 1;
     int r = RINT(w, 1, worm_nops(w));
-    /* partner that moves along and the place (1 = first, 2 = second in time) of the partner / of the new worm operator */
-    int partner = 0, pos_partner = 0, pos_new = 0;
+    /* partners that move along, and the places (1 = first, 2 = second, 3 = third in time) of the partners / of the new worm operator in
+     * the equal-time object at the hybridising operator's time (qrepind / qtimeind, CTQMC.F90:6068-6127, 6164-6178) */
+    int npart = 0, partner[2] = {0, 0}, pos_partner[2] = {0, 0}, pos_new = 0;
     {
         static const int p2[4] = {2, 1, 4, 3}, p2pp[4] = {3, 4, 1, 2};
         switch (w->sector) {
-        case 6: partner = p2[r - 1]; pos_partner = (r & 1) ? 1 : 2; break;
-        case 7: partner = p2pp[r - 1]; pos_partner = (r <= 2) ? 1 : 2; break;
-        case 8: if (r > 2) { partner = p2[r - 1]; pos_partner = (r == 3) ? 1 : 2; } break;
-        case 9: if ((r & 1) == 0) { partner = p2pp[r - 1]; pos_partner = (r == 2) ? 1 : 2; } break;
+        case 3:
+            if (r == 1) { npart = 2; partner[0] = 3; pos_partner[0] = 2; partner[1] = 2; pos_partner[1] = 3; pos_new = 1; }
+            else if (r == 2) { npart = 2; partner[0] = 1; pos_partner[0] = 1; partner[1] = 3; pos_partner[1] = 2; pos_new = 3; }
+            else if (r == 3) { npart = 2; partner[0] = 1; pos_partner[0] = 1; partner[1] = 2; pos_partner[1] = 3; pos_new = 2; }
+            break;
+        case 6: npart = 1; partner[0] = p2[r - 1]; pos_partner[0] = (r & 1) ? 1 : 2; break;
+        case 7: npart = 1; partner[0] = p2pp[r - 1]; pos_partner[0] = (r <= 2) ? 1 : 2; break;
+        case 8: if (r > 2) { npart = 1; partner[0] = p2[r - 1]; pos_partner[0] = (r == 3) ? 1 : 2; } break;
+        case 9: if ((r & 1) == 0) { npart = 1; partner[0] = p2pp[r - 1]; pos_partner[0] = (r == 2) ? 1 : 2; } break;
         default: break;
         }
-        pos_new = 3 - pos_partner;
+        if (npart == 1) pos_new = 3 - pos_partner[0];
     }
     int iw = -1;
     for (int i = 0; i < w->nops; ++i) if (w->ops[i].wid == r) iw = i;
@@ -1069,17 +1109,20 @@ static void step_worm_replace(ora_walker *w)
     for (int c = 0; c < k; ++c) detrat += v[c] * x[c];
     double prob = fabs(detrat);
     logval trnew = w->tr;
-    op_t old_partner, old_hyb;
-    if (partner) {
+    op_t old_partner[2], old_hyb;
+    if (npart) {
         const double eqoff = w->p.beta * 1e-14;
-        const int ip = worm_index(w, partner);
-        old_partner = w->ops[ip]; old_hyb = w->ops[ih];
-        list_remove(w, ip > ih ? ip : ih); list_remove(w, ip > ih ? ih : ip);
+        old_hyb = w->ops[ih];
+        for (int q = 0; q < npart; ++q) old_partner[q] = w->ops[worm_index(w, partner[q])];
+        for (int q = 0; q < npart; ++q) list_remove(w, worm_index(w, partner[q]));
+        for (int i = 0; i < w->nops; ++i)
+            if (w->ops[i].wid == 0 && w->ops[i].flav == f && w->ops[i].ca == ca && w->ops[i].tau == th) { list_remove(w, i); break; }
         w->ops[worm_index(w, r)].wid = 0;                       /* stays where it is, as a hybridising operator if accepted */
-        op_t np = old_partner, nh = old_hyb;
-        np.tau = th + (pos_partner == 2 ? eqoff : 0.0);
-        nh.tau = th + (pos_new == 2 ? eqoff : 0.0); nh.wid = r;
-        if (pos_partner == 1) { list_insert(w, np); list_insert(w, nh); } else { list_insert(w, nh); list_insert(w, np); }
+        op_t nn[3]; int npos[3];
+        for (int q = 0; q < npart; ++q) { nn[q] = old_partner[q]; npos[q] = pos_partner[q]; }
+        nn[npart] = old_hyb; nn[npart].wid = r; npos[npart] = pos_new;
+        for (int pos = 1; pos <= npart + 1; ++pos)               /* in time order: tau_h, tau_h + offset, tau_h + 2 offset */
+            for (int q = 0; q <= npart; ++q) if (npos[q] == pos) { nn[q].tau = th + (double)(pos - 1) * eqoff; list_insert(w, nn[q]); }
         int ok = check_equal_time(w, w->sector) && sequence_valid(w, w->outer_sst);
         if (ok) {
             trnew = full_trace(w, w->outer_sst);
@@ -1087,15 +1130,17 @@ static void step_worm_replace(ora_walker *w)
         }
         if (!ok || !(U01(w) < prob)) {
             /* back to the old operators (6224-6234, 6281-6290); a failed check consumes no random number */
-            list_remove(w, worm_index(w, partner)); list_remove(w, worm_index(w, r));
+            for (int q = 0; q < npart; ++q) list_remove(w, worm_index(w, partner[q]));
+            list_remove(w, worm_index(w, r));
             for (int i = 0; i < w->nops; ++i)
                 if (w->ops[i].wid == 0 && w->ops[i].flav == f && w->ops[i].ca == ca && w->ops[i].tau == tw) w->ops[i].wid = r;
-            list_insert(w, old_hyb); list_insert(w, old_partner);
+            list_insert(w, old_hyb);
+            for (int q = 0; q < npart; ++q) list_insert(w, old_partner[q]);
             free(u); free(v); free(x); free(y);
             return;
         }
     }
-    if (partner || U01(w) < prob) {
+    if (npart || U01(w) < prob) {
         for (int j = 0; j < k; ++j) { double a = 0.0; for (int c = 0; c < k; ++c) a += M[c * k + j] * v[c]; y[j] = a; }
         double *Mn = (double *)malloc(sizeof(double) * (size_t)k * k);
         for (int c = 0; c < k; ++c) for (int j = 0; j < k; ++j) Mn[c * k + j] = M[c * k + j] - x[c] * y[j] / detrat;
@@ -1115,7 +1160,7 @@ static void step_worm_replace(ora_walker *w)
         free(w->M[f]); w->M[f] = Mn;
         w->det.log += log(fabs(detrat));
         w->det.sign *= (detrat < 0.0 ? -1.0 : 1.0) * ((ncnt & 1) ? -1.0 : 1.0);
-        if (!partner) { w->ops[ih].wid = r; w->ops[iw].wid = 0; }
+        if (!npart) { w->ops[ih].wid = r; w->ops[iw].wid = 0; }
         w->tr = trnew;
         w->cfgsign = -get_sign(w);
         w->acc_wrep += 1;
@@ -1191,6 +1236,7 @@ ora_walker *ora_create(const ora_params *p, const double *U, const double *ftau_
     w->p = *p; w->rng = rng;
     w->nflav = 2 * p->nd; w->nstates = 1 << (2 * p->nd);
     if (w->nflav > MAXFLAV) { free(w); return NULL; }
+    { size_t n4 = (size_t)w->nflav * w->nflav * w->nflav * w->nflav; w->umat = (double *)malloc(sizeof(double) * n4); memcpy(w->umat, U, sizeof(double) * n4); }
     w->lp = ora_locprob_build(p->nd, U, mu_full, p->qns, p->epsevec, p->epsblock);
     if (!w->lp || w->lp->nsmax > 64) { ora_locprob_free(w->lp); free(w); return NULL; }
     w->nsst = w->lp->nsst;
@@ -1245,6 +1291,7 @@ ora_walker *ora_create(const ora_params *p, const double *U, const double *ftau_
     }
     if (p->worm_meas_giw) w->giww = (double *)calloc((size_t)4 * p->niw, sizeof(double));      /* CTQMC.F90:597-599 */
     if (p->worm_meas_gtau) w->gtauw = (double *)calloc((size_t)p->ntau, sizeof(double));        /* CTQMC.F90:609-612 */
+    if (p->worm_meas_gsigma) w->gsw = (double *)calloc((size_t)4 * p->niw, sizeof(double));     /* CTQMC.F90:619-623 */
     for (int q = 0; q < 6; ++q) {                                                   /* CTQMC.F90:654-726 */
         w->weq[q] = NULL; w->weq_n[q] = 0;
         if (!p->worm_meas_eq[q]) continue;
@@ -1275,7 +1322,7 @@ void ora_destroy(ora_walker *w)
     if (!w) return;
     for (int f = 0; f < w->nflav; ++f) free(w->M[f]);
     free(w->ops); free(w->ftab); ora_locprob_free(w->lp); free(w->ptr); free(w->dmblk); free(w->dmoff); free(w->accpair); free(w->accpairtau); free(w->gleg); free(w->gtau); free(w->giw); free(w->ntau_n0); free(w->gms); free(w->gmid); free(w->sstep);
-    free(w->histo); free(w->dm); free(w->outer_histo); free(w->sign_sst); free(w->tcontrib_sst); free(w->outer_state_histo); free(w->sign_state); free(w->tcontrib_state); free(w->g2iw); free(w->g4iw); free(w->g4iwpp); free(w->g4w); free(w->g4wpp); free(w->g4tau); free(w->g4leg); free(w->giww); free(w->gtauw); for (int q = 0; q < 6; ++q) free(w->weq[q]); free(w->acbuf); free(w->acdat); free(w);
+    free(w->histo); free(w->dm); free(w->outer_histo); free(w->sign_sst); free(w->tcontrib_sst); free(w->outer_state_histo); free(w->sign_state); free(w->tcontrib_state); free(w->g2iw); free(w->g4iw); free(w->g4iwpp); free(w->g4w); free(w->g4wpp); free(w->g4tau); free(w->g4leg); free(w->giww); free(w->gtauw); free(w->gsw); free(w->umat); for (int q = 0; q < 6; ++q) free(w->weq[q]); free(w->acbuf); free(w->acdat); free(w);
 }
 
 void ora_set_taudiffmax(ora_walker *w, double x) { init_window(w, x); }
@@ -1592,6 +1639,21 @@ static void meas_eq_worm(ora_walker *w)
     }
 }
 
+/* measure_ie_sigma_worm (CTQMC.F90:1123-1164): cfgsign/eta times the sign of the proposal's U-matrix factor times exp(i w_n (t1 - t4)),
+ * n = -Niw..Niw-1 */
+static void meas_gsigma_worm(ora_walker *w)
+{
+    double t[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < w->nops; ++i) if (w->ops[i].wid) t[w->ops[i].wid] = w->ops[i].tau;
+    const double uf = gsigma_ufac(w);
+    const double val = w->cfgsign / w->eta * (uf < 0.0 ? -1.0 : 1.0), dt = t[1] - t[4], pib = M_PI / w->p.beta;
+    const int niw = w->p.niw;
+    for (int n = -niw; n < niw; ++n) {
+        const double ph = pib * (double)(2 * n + 1) * dt;
+        w->gsw[2 * (n + niw)] += val * cos(ph); w->gsw[2 * (n + niw) + 1] += val * sin(ph);
+    }
+}
+
 static void autocorr_add(ora_walker *w)
 {
     const size_t nc = (size_t)w->nflav * w->p.ntau;
@@ -1654,6 +1716,7 @@ void ora_measure_once(ora_walker *w)
     int nf = w->nflav;
     if (w->sector != 1) {                                               /* CTQMC.F90:8586-8593 */
         if (w->sector == 2) { w->cnt_meas_w += 1; meas_g_worm(w); }
+        else if (w->sector == 3) { if (w->gsw) { w->cnt_meas_w += 1; meas_gsigma_worm(w); } }              /* 8597-8599 */
         else if (w->sector == 6 || w->sector == 7) { w->cnt_meas_w += 1; meas_eq_worm(w); }              /* 8603-8610 */
         else if (w->sector == 8 || w->sector == 9) { if (w->weq[w->sector - 4]) { w->cnt_meas_w += 1; meas_eq_worm(w); } }   /* 8611-8616 */
         else if (w->g4w || w->g4wpp) { w->cnt_meas_w += 1; meas_g4iw_worm(w); }
@@ -1795,6 +1858,10 @@ void ora_measure_finish(ora_walker *w)
         double nf2 = (double)nf * (double)nf;
         if (w->giww) for (int i = 0; i < 4 * w->p.niw; ++i) w->giww[i] = -w->giww[i] * scal / nf2;
         if (w->gtauw) for (int i = 0; i < w->p.ntau; ++i) w->gtauw[i] = w->gtauw[i] * scal * ((double)w->p.ntau / beta) / nf2;
+    }
+    if (w->isector == 3 && w->gsw) {                 /* wormNorm 32 / beta, result / (-4 (2 Nd)^2) (CTQMC.F90:8826, 8987-8998) */
+        const double scal = (w->cnt_meas_w != 0) ? w->cnt_sampling_w / (w->cnt_meas_w * w->cnt_sampling) * 32.0 / beta / w->mean_sign : 0.0;
+        for (int i = 0; i < 4 * w->p.niw; ++i) w->gsw[i] *= scal / (-4.0 * (double)nf * (double)nf);
     }
     if (w->isector >= 6 && w->isector <= 9) {        /* wormNorm 16 / beta (P2) or 16 / beta^2 (P3), CTQMC.F90:8830-8849, 9116-9130, 9215-9224, 9229-9313 */
         const double norm = w->isector <= 7 ? 16.0 / beta : 16.0 / (beta * beta);
@@ -1985,6 +2052,12 @@ int ora_get_worm_eq(const ora_walker *w, int which, double *o)
     if (which < 0 || which > 5 || !w->weq[which]) return 0;
     memcpy(o, w->weq[which], sizeof(double) * w->weq_n[which]);
     return (int)w->weq_n[which];
+}
+int ora_get_gsigmaiw_worm(const ora_walker *w, double *o)
+{
+    if (!w->gsw) return 0;
+    memcpy(o, w->gsw, sizeof(double) * (size_t)4 * w->p.niw);
+    return 1;
 }
 int ora_get_gtau_worm(const ora_walker *w, double *o)
 {

@@ -61,6 +61,7 @@ typedef struct ora_params {
     /* user symmetry moves of the global move (NSymMove, SymMoveNN; Trace.F90:403-404, 471-478): nsym rows of 2Nd entries, values
      * 1-based in the order band + Nd * spin; the inverses are made by the oracle */
     int nsym; int symmoves[8 * 16];
+    int worm_meas_gsigma;                          /* WormMeasGSigmaiw: sector 3, improved estimator of the one-particle Green's function (CTQMC.F90:619-623) */
 } ora_params;
 
 typedef struct ora_walker ora_walker;
@@ -92,6 +93,7 @@ int ora_get_giw_worm(const ora_walker *w, double *out_reim);
  * 4 p3iw_worm, 5 p3iwpp_worm (2N3iwf, 2N3iwb+1 complex interleaved); returns the number of doubles copied, 0 if not measured */
 int ora_get_worm_eq(const ora_walker *w, int which, double *out);
 int ora_get_gtau_worm(const ora_walker *w, double *out);
+int ora_get_gsigmaiw_worm(const ora_walker *w, double *out_reim);   /* GSigmaiw_worm (2Niw) complex interleaved, sector 3 */
 /* [0]TryWormAdd [1]AccWormAdd [2]AccQNWormAdd [3]TryWormRem [4]AccWormRem [5]AccQNWormRem [6]TryWormRep [7]AccWormRep
  * [8]CntSampling(worm) [9]CntMeas(worm) [10]TryAdd(worm) [11]AccAdd(worm) [12]TryRem(worm) [13]AccRem(worm) [14]sector now */
 void ora_get_worm_counters(const ora_walker *w, double *out15);

@@ -26,7 +26,7 @@ class OraParams(C.Structure):
                 ("worm_meas_giw", C.c_int), ("worm_meas_gtau", C.c_int), ("epsblock", C.c_double), ("accum_gtau", C.c_int),
                 ("meas_susz", C.c_int), ("step_series", C.c_int),
                 ("n2iwb", C.c_int), ("n3iwf", C.c_int), ("n3iwb", C.c_int), ("worm_meas_eq", C.c_int * 6),
-                ("nsym", C.c_int), ("symmoves", C.c_int * 128)]
+                ("nsym", C.c_int), ("symmoves", C.c_int * 128), ("worm_meas_gsigma", C.c_int)]
 
 WORM_EQ_KEYS = ("WormMeasP2iwPH", "WormMeasP2iwPP", "WormMeasP2tauPH", "WormMeasP2tauPP", "WormMeasP3iwPH", "WormMeasP3iwPP")
 WORM_EQ_NAMES = ("p2iw_worm", "p2iwpp_worm", "p2tau_worm", "p2taupp_worm", "p3iw_worm", "p3iwpp_worm")
@@ -92,6 +92,7 @@ def lib():
     L.ora_get_step_series.argtypes = [vp, dp, dp, dp]; L.ora_get_step_series.restype = C.c_int
     L.ora_get_gtau_worm.argtypes = [vp, dp]; L.ora_get_gtau_worm.restype = C.c_int
     L.ora_get_worm_eq.argtypes = [vp, C.c_int, dp]; L.ora_get_worm_eq.restype = C.c_int
+    L.ora_get_gsigmaiw_worm.argtypes = [vp, dp]; L.ora_get_gsigmaiw_worm.restype = C.c_int
     L.ora_get_hashybs.argtypes = [vp, ip]
     L.ora_get_g2iw.argtypes = [vp, dp]; L.ora_get_g2iw.restype = C.c_int
     L.ora_get_g4iw.argtypes = [vp, dp, C.c_int]; L.ora_get_g4iw.restype = C.c_int
@@ -144,7 +145,7 @@ def params_from_pstring(ps, nd, beta, fourpnt=0):
                      step_series=(1 if ps.get_int("Gtau_mean_step") else 0) | (2 if ps.get_int("Gtau_mid_step") else 0) | (4 if ps.get_int("sign_step") else 0),
                      n2iwb=ps.get_int("N2iwb"), n3iwf=ps.get_int("N3iwf"), n3iwb=ps.get_int("N3iwb"),
                      worm_meas_eq=(C.c_int * 6)(*[int(ps.get_int(k) != 0) for k in WORM_EQ_KEYS]),
-                     nsym=ps.get_int("NSymMove"), symmoves=_symmoves(ps))
+                     nsym=ps.get_int("NSymMove"), symmoves=_symmoves(ps), worm_meas_gsigma=int(ps.get_int("WormMeasGSigmaiw") != 0))
 
 
 class OracleWalker:
@@ -274,6 +275,9 @@ class OracleWalker:
         a = np.zeros(p.ntau)
         if self.L.ora_get_gtau_worm(self.h, a):
             r["gtau_worm"] = a
+        a = np.zeros((2 * p.niw, 2))
+        if self.L.ora_get_gsigmaiw_worm(self.h, a):
+            r["gsigmaiw_worm"] = a[..., 0] + 1j * a[..., 1]
         for q, name in enumerate(WORM_EQ_NAMES):
             if not p.worm_meas_eq[q]:
                 continue

@@ -351,8 +351,14 @@ WORMEQ = {
                                     WormMeasP2iwPH=1, WormMeasP2tauPH=1), 651, _comp4(6, (0, 1, 3, 2))),
     "P3pp_C4Na": (9, "C4N", 501, dict(_EQ, Nwarmups=2000, Nmeas=300, NCorr=10, TaudiffMax=3.0, Ntau=50, N3iwf=2, N3iwb=1, WormEta=0.002,
                                       WormMeasP3iwPP=1), 652, _comp4(6, (0, 2, 2, 0))),
+    # sector 3 (GSigma, improved estimator of the one-particle Green's function): a three-operator equal-time object with random
+    # flavours and the U-matrix factor in the proposal, operator 4 at a free time; component = (U-matrix flavour, flavour of operator 4)
+    "GS_C1a": (3, "C1", 501, dict(_EQ, Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=50, Niw=6, WormEta=0.1, WormMeasGSigmaiw=1), 661, 1 + 0 * 2 + 0),
+    "GS_C3a": (3, "C3", 501, dict(_EQ, Nwarmups=3000, Nmeas=500, NCorr=20, TaudiffMax=6.0, Ntau=50, Niw=6, WormEta=0.0005, WormMeasGSigmaiw=1), 662, 1 + 2 * 4 + 2),
+    "GS_C4Sa": (3, "C4S", 501, dict(_EQ, Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=50, Niw=6, WormEta=0.005, WormMeasGSigmaiw=1), 663, 1 + 1 * 4 + 1),
+    "GS_C4Na": (3, "C4N", 501, dict(_EQ, Nwarmups=2000, Nmeas=300, NCorr=10, TaudiffMax=3.0, Ntau=50, Niw=6, WormEta=0.001, WormMeasGSigmaiw=1), 664, 1 + 3 * 6 + 3),
 }
-WORMEQ_KEYS = ("p2iw_worm", "p2iwpp_worm", "p2tau_worm", "p2taupp_worm", "p3iw_worm", "p3iwpp_worm", "mean_sign", "accwormadd", "accwormrem",
+WORMEQ_KEYS = ("gsigmaiw_worm", "p2iw_worm", "p2iwpp_worm", "p2tau_worm", "p2taupp_worm", "p3iw_worm", "p3iwpp_worm", "mean_sign", "accwormadd", "accwormrem",
                "accwormrep", "cntsampling", "accadd", "accrem", "occ", "histo")
 
 

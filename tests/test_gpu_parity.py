@@ -825,7 +825,8 @@ def test_g_worm_sampling_chains_vs_oracle(name):
 
 
 WORMEQ_CASES = ["P2_C1a", "P2_C1b", "P2_C3a", "P2pp_C1a", "P2pp_C3a", "P3_C1a", "P3_C3a", "P3pp_C1a", "P3pp_C3a",
-                "P2_C4Sa", "P3_C4Sa", "P2pp_C4Sa", "P3pp_C4Sa", "P2_C4Na", "P3pp_C4Na"]
+                "P2_C4Sa", "P3_C4Sa", "P2pp_C4Sa", "P3pp_C4Sa", "P2_C4Na", "P3pp_C4Na",
+                "GS_C1a", "GS_C3a", "GS_C4Sa", "GS_C4Na"]      # GS: sector 3 (GSigma): three-operator object, random flavours, U-matrix factor
 
 
 @pytest.mark.parametrize("name", WORMEQ_CASES)
@@ -847,7 +848,7 @@ def test_equal_time_worm_sampling_chains_vs_oracle(name):
     q.ctqmc_worm_warmup(0, sec, comp)
     q.ctqmc_measure(sec, comp)
     wc = q.worm_counters
-    keys = [k for k in pyoracle.WORM_EQ_NAMES if "res_" + k in g and g["res_" + k].size > 1]
+    keys = [k for k in pyoracle.WORM_EQ_NAMES + ("gsigmaiw_worm",) if "res_" + k in g and g["res_" + k].size > 1]
     assert keys
     pooled = {k: 0.0 for k in keys}; cw = cz = mw = 0.0; nrep = 0.0
     for w in range(nw):
@@ -990,11 +991,12 @@ def test_solver_worm_giw_kanamori_agrees_with_z_space_estimate():
 
 
 def test_worm_modes_refused_or_ignored():
-    """Sectors other than 1, 2 and 4 are refused; eta = 0 samples nothing (CTQMC.F90:8409-8418)."""
+    """Sectors other than 1 - 4 and 6 - 9 are refused (the improved estimators with more than four worm operators: H4 = 5, QQ = 10, ...);
+    eta = 0 samples nothing (CTQMC.F90:8409-8418)."""
     g = util.load_golden("worm_C1a.npz")
     q, p, pset, over = _worm_gpu(g, 4, 2, 3)
     with pytest.raises(W2DynError) as e:
-        q.ctqmc_measure(3, 1)
+        q.ctqmc_measure(10, 1)
     assert e.value.code == -2
     with pytest.raises(W2DynError) as e:
         q.count_steps(5, 1, 100)

@@ -314,7 +314,8 @@ def test_oracle_g_worm_sampling_retraces_reference(name):
 
 
 WORMEQ = ["P2_C1a", "P2_C1b", "P2_C3a", "P2pp_C1a", "P2pp_C3a", "P3_C1a", "P3_C3a", "P3pp_C1a", "P3pp_C3a",
-          "P2_C4Sa", "P3_C4Sa", "P2pp_C4Sa", "P3pp_C4Sa", "P2_C4Na", "P3pp_C4Na"]
+          "P2_C4Sa", "P3_C4Sa", "P2pp_C4Sa", "P3pp_C4Sa", "P2_C4Na", "P3pp_C4Na",
+          "GS_C1a", "GS_C3a", "GS_C4Sa", "GS_C4Na"]
 
 
 @pytest.mark.parametrize("name", WORMEQ)
@@ -340,7 +341,7 @@ def test_oracle_equal_time_worm_sampling_retraces_reference(name):
     for key, num, den in (("accwormadd", "acc_wadd", "try_wadd"), ("accwormrep", "acc_wrep", "try_wrep"), ("accwormrem", "acc_wrem", "try_wrem")):
         assert wc[num] / max(wc[den], 1.0) == pytest.approx(float(g["res_" + key][sec - 2]), rel=1e-12, abs=1e-300), key
     checked = 0
-    for k in pyoracle.WORM_EQ_NAMES:
+    for k in pyoracle.WORM_EQ_NAMES + ("gsigmaiw_worm",):
         if "res_" + k in g and g["res_" + k].size > 1:
             assert k in r, k
             assert r[k].shape == g["res_" + k].shape and rel(r[k], g["res_" + k]) < 1e-10, k

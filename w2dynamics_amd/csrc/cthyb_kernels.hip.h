@@ -144,6 +144,7 @@ struct DevConst {
     // user symmetry moves of the global move (NSymMove, Trace.F90:403-404, 471-478): 2 nsym rows (the listed moves, then their
     // inverses) of nflav entries, 1-based flavour numbers in the order band + Nd * spin
     int nsym; const int *symmoves;
+    const double *umat;           // U matrix (2Nd)^4 as handed to init_solver (flavour = 2 * orbital + spin): proposal factor of the GSigma worm
     // matrix trace path: the chains of a launch are handed out to the waves from this counter (zeroed before every launch), so
     // that the four waves of a workgroup - which share the staged tables of the local problem - never wait for one another
     int *queue;
@@ -1571,7 +1572,7 @@ __device__ __forceinline__ void ctx_load(Ctx &x)
     const WalkerScalars &s = C.ws[w];
     x.outer = uni(s.outer); x.npairs = uni(s.npairs); x.wpos = uni(s.wpos); x.err = uni(s.err);
     x.det_sign = uni(s.det_sign); x.det_log = uni(s.det_log);
-    { const int sec = uni(s.sector); x.sector = (sec == 4 || sec == 2 || (sec >= 6 && sec <= 9)) ? sec : 1; }
+    { const int sec = uni(s.sector); x.sector = (sec == 4 || sec == 2 || sec == 3 || (sec >= 6 && sec <= 9)) ? sec : 1; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { x.wtau[i] = uni(s.wtau[i]); x.wfl[i] = uni(s.wflav[i]); }
     unsigned long long nd_ = s.ndraw;
@@ -1594,7 +1595,7 @@ __device__ __forceinline__ void ctx_load(Ctx &x)
         if (x.sector != 1) {                         // worm operators are list entries like any other (no hybridisation lines: not in M)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                if (i < x.sector) mat_insert(x, mat_lower(x, x.wtau[i]), x.wtau[i], mat_code(x.wfl[i], (i & 1) ? 1 : 2));
+                if (i < (x.sector == 2 ? 2 : 4)) mat_insert(x, mat_lower(x, x.wtau[i]), x.wtau[i], mat_code(x.wfl[i], (i & 1) ? 1 : 2));
         }
         mat_walk_sst(x);                 // the caller evaluates the trace (mat_trace_current<MAT>)
     }
@@ -1846,7 +1847,7 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
             // hybridising operators at later times than each worm operator
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (i >= x.sector) continue;                 // two worm operators in sector 2, four in sector 4
+                if (i >= (x.sector == 2 ? 2 : 4)) continue;  // two worm operators in sector 2, four in the others
                 const int bw = flav_bit(x.wfl[i], nd); const double tw = x.wtau[i];
                 if (!MAT) par ^= ((tw < ti && bw < biti) ? 1 : 0) ^ ((ti < tw && biti < bw) ? 1 : 0);   // trace sign (scalar path only)
                 par ^= (ti > tw) ? 1 : 0;
@@ -1879,7 +1880,7 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (i >= x.sector || j >= x.sector) continue;
+                if (i >= (x.sector == 2 ? 2 : 4) || j >= (x.sector == 2 ? 2 : 4)) continue;
                 if (!MAT && x.wtau[j] < x.wtau[i] && flav_bit(x.wfl[j], nd) < flav_bit(x.wfl[i], nd)) par ^= 1;
                 if (i < j && x.wtau[i] < x.wtau[j]) par ^= 1;
             }

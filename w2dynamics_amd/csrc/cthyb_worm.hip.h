@@ -94,10 +94,22 @@ __device__ W2DYN_INLINE bool worm_delta(Ctx &x, const double (&t)[4], const int 
 }
 
 // get_Proposal: SectorG / SectorG4 (beta Nd)^NW eta; P2 / P2pp beta^2 Nd^4 eta; P3 / P3pp beta^3 Nd^4 eta (CTQMC.F90:5677-5719)
+// U-matrix factor of the GSigma worm (sector 3): 0.5 (U(u, g2, g1, g3) - U(g2, u, g1, g3)), u = first flavour of the component, g_i the
+// flavour of worm operator i (get_Proposal, CTQMC.F90:5689-5694; its sign enters the estimator, 1138)
+__device__ __forceinline__ double gsigma_ufac(const DevConst &C, const int (&fl)[4])
+{
+    const int nf = C.nflav, u = ((C.icomponent - 1) / nf) % nf;
+    return 0.5 * (C.umat[(((size_t)u * nf + fl[1]) * nf + fl[0]) * nf + fl[2]] - C.umat[(((size_t)fl[1] * nf + u) * nf + fl[0]) * nf + fl[2]]);
+}
+
 template <int NW>
-__device__ __forceinline__ double worm_prefact(const DevConst &C)
+__device__ __forceinline__ double worm_prefact(const DevConst &C, const int (&fl)[4])
 {
     if constexpr (NW == 4) {
+        if (C.isector == 3) {                          // beta^(N-2) Nd^(N+1) eta times the U-matrix factor, N = 4 (CTQMC.F90:5696)
+            const double nd = (double)C.nd, nd4 = nd * nd * nd * nd;
+            return gsigma_ufac(C, fl) * (C.beta * C.beta) * (nd4 * nd) * C.worm_eta;
+        }
         if (C.isector >= 6) {
             const double nd = (double)C.nd, nd4 = nd * nd * nd * nd, bb = C.beta * C.beta;
             return (C.isector >= 8 ? bb * C.beta : bb) * nd4 * C.worm_eta;
@@ -116,6 +128,14 @@ __device__ __forceinline__ void worm_draw_times(Ctx &x, double (&t)[4])
 {
     const DevConst &C = x.C;
     if constexpr (NW == 4) {
+        if (C.isector == 3) {                          // four draws, then the equal-time object (1, 3, 2) below tau_2 (Trace.F90:3971-3983)
+            const double beta = C.beta, off = beta * 1e-14;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t[i] = x.draw() * beta;
+            if (t[1] < 2.0 * off) t[1] = 2.0 * off;
+            t[2] = t[1] - off; t[0] = t[1] - 2.0 * off;
+            return;
+        }
         if (C.isector >= 6) {
             const double beta = C.beta, off = beta * 1e-14;
             t[0] = x.draw() * beta;
@@ -138,25 +158,47 @@ __device__ __forceinline__ void worm_draw_times(Ctx &x, double (&t)[4])
     }
 }
 
+// flavours of the worm operators: digits of the component (set_OperFlavor, Trace.F90:3804-3826); sector 3: the three operators of the
+// equal-time object get random flavours until the U-matrix factor of the proposal does not vanish, operator 4 carries the component's
+// second flavour (set_IEOperFlavor, Trace.F90:3835-3919; CTQMC.F90:5047-5054)
+template <int NW>
+__device__ __forceinline__ void worm_draw_flavours(Ctx &x, int (&fl)[4])
+{
+    const DevConst &C = x.C;
+    const int nf = C.nflav;
+    if constexpr (NW == 4) {
+        if (C.isector == 3) {
+            fl[3] = (C.icomponent - 1) % nf;
+            for (int guard = 0; guard < (1 << 20); ++guard) {      // the host has checked that some choice has a non-vanishing factor
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { const int orb = x.randint(1, C.nd), spin = x.randint(1, 2); fl[i] = 2 * (orb - 1) + (spin - 1); }
+                if (gsigma_ufac(C, fl) != 0.0) break;
+            }
+            return;
+        }
+    }
+    const int ncomp = NW == 4 ? nf * nf * nf * nf : nf * nf;
+    int comp = C.icomponent;
+    if (comp == 0) comp = x.randint(1, ncomp);
+    int rest = comp - 1, base = ncomp / nf;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { const int bs = rest / base; rest -= bs * base; base /= nf; fl[i] = bs; }
+}
+
 template <int NW>
 __device__ W2DYN_INLINE void step_worm_add(Ctx &x)
 {
     const DevConst &C = x.C;
-    const int nf = C.nflav;
-    const int ncomp = NW == 4 ? nf * nf * nf * nf : nf * nf;
-    int comp = C.icomponent;
-    if (comp == 0) comp = x.randint(1, ncomp);
     x.count(C_TRYWADD);
     double t[4] = {0.0, 0.0, 0.0, 0.0}; int fl[4] = {0, 0, 0, 0};
-    int rest = comp - 1, base = ncomp / nf;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) { const int bs = rest / base; rest -= bs * base; base /= nf; fl[i] = bs; }
+    worm_draw_flavours<NW>(x, fl);
     worm_draw_times<NW>(x, t);
     double dlog;
     const bool valid = worm_delta<NW>(x, t, fl, dlog);
-    if (worm_prefact<NW>(C) == 0.0 || !valid) { x.count(C_QNWADD); x.sector = 1; return; }
+    const double prefact = worm_prefact<NW>(C, fl);
+    if (prefact == 0.0 || !valid) { x.count(C_QNWADD); x.sector = 1; return; }
     const double rnd = x.draw();
-    if (rnd < fabs(worm_prefact<NW>(C) * exp(dlog))) {
+    if (rnd < fabs(prefact * exp(dlog))) {
 #pragma unroll
         for (int i = 0; i < NW; ++i) { x.wtau[i] = t[i]; x.wfl[i] = fl[i]; }
         x.sector = NW == 4 ? C.isector : NW;
@@ -173,7 +215,78 @@ __device__ W2DYN_INLINE void step_worm_rem(Ctx &x)
     const bool valid = worm_delta<NW>(x, x.wtau, x.wfl, dlog);
     if (!valid) { x.count(C_QNWREM); return; }
     const double rnd = x.draw();
-    if (rnd < fabs(exp(-dlog) / worm_prefact<NW>(C))) { x.sector = 1; x.count(C_ACCWREM); }
+    if (rnd < fabs(exp(-dlog) / worm_prefact<NW>(C, x.wfl))) { x.sector = 1; x.count(C_ACCWREM); }
+}
+
+// One-state blocks: log ratio of the local trace when the two worm operators p1, p2 (container indices) move from their present
+// times to tn1, tn2 while every other operator stays (replacement in the three-operator object of sector 3).  The change of the
+// occupations is that of a virtual worm V on top of the PRESENT configuration: the operators at their new times plus, at the old
+// times, operators of the opposite type that undo the old ones.  With D_g(tau) the occupation change of flavour g (at most two
+// flavours), the new sequence is allowed iff no other operator of g lies where D_g != 0 and the occupation in front of each moved
+// operator's new place is what its type needs; log ratio = - sum_g int D_g (eps_g + sum_g' U_gg' n_g') - U_gg' int D_g D_g' with
+// n from all present operators, worm operators included (level_integral<4>).
+__device__ W2DYN_INLINE bool worm_shift_delta(Ctx &x, int p1, int p2, double tn1, double tn2, double &dlog)
+{
+    const DevConst &C = x.C;
+    double vt[4]; int vf[4], vs[4]; bool vreal[4];          // time, flavour, +1 creator / -1 annihilator, real (new place) or undoing (old place)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int p = q == 0 ? p1 : p2; const double tn = q == 0 ? tn1 : tn2;
+        double told = 0.0; int fp = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i == p) { told = x.wtau[i]; fp = x.wfl[i]; }
+        const int sgn = (p & 1) ? 1 : -1;
+        vt[2 * q] = tn; vf[2 * q] = fp; vs[2 * q] = sgn; vreal[2 * q] = true;
+        vt[2 * q + 1] = told; vf[2 * q + 1] = fp; vs[2 * q + 1] = -sgn; vreal[2 * q + 1] = false;
+    }
+    int ord[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r += (vt[j] < vt[i] || (vt[j] == vt[i] && j < i)) ? 1 : 0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) if (r == m) ord[m] = i;
+    }
+    const int fa = vf[0], fb = vf[2];                        // flavours of the two operators (may coincide)
+    int da = 0, db = 0;
+    dlog = 0.0;
+    bool valid = true;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        double tm = 0.0; int fm = 0, sm = 0; bool rm = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (ord[m] == q) { tm = vt[q]; fm = vf[q]; sm = vs[q]; rm = vreal[q]; }
+        if (rm) {                                            // occupation in front of the new place: all present operators, then the change so far
+            int nc, na;
+            worm_counts(x, fm, tm, nc, na);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) if (x.wfl[i] == fm && x.wtau[i] < tm) { if (i & 1) nc += 1; else na += 1; }
+            const int occ = ((x.outer >> flav_bit(fm, C.nd)) & 1) + nc - na + (fm == fa ? da : db);
+            if (occ != (sm > 0 ? 0 : 1)) valid = false;
+        }
+        if (fm == fa) da += sm; else db += sm;
+        if (m < 3) {
+            double tn = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (ord[m + 1] == q) tn = vt[q];
+            const int dA = da, dB = (fb == fa) ? 0 : db;       // equal flavours: everything is in da
+            if (valid && dA != 0) {
+                bool blocked = worm_any_between(x, fa, tm, tn);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (i != p1 && i != p2 && x.wfl[i] == fa && x.wtau[i] > tm && x.wtau[i] < tn) blocked = true;
+                if (blocked) valid = false; else dlog -= (double)dA * level_integral<4>(x, fa, tm, tn);
+            }
+            if (valid && dB != 0) {
+                bool blocked = worm_any_between(x, fb, tm, tn);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (i != p1 && i != p2 && x.wfl[i] == fb && x.wtau[i] > tm && x.wtau[i] < tn) blocked = true;
+                if (blocked) valid = false; else dlog -= (double)dB * level_integral<4>(x, fb, tm, tn);
+            }
+            if (valid && dA != 0 && dB != 0) dlog -= C.udd[fa * C.nflav + fb] * (double)(dA * dB) * (tn - tm);
+        }
+    }
+    return valid;
 }
 
 // a worm operator and a hybridising operator of the same flavour and type exchange their roles: one row (creator) or
@@ -194,13 +307,21 @@ __device__ W2DYN_INLINE void step_worm_replace(Ctx &x)
     const DevConst &C = x.C;
     x.count(C_TRYWREP);
     const int r = x.randint(1, NW) - 1;
-    int partner = -1, pos_partner = 0;               // container index of the partner, its place in the new pair (1: at tau_h, 2: an offset above)
+    // container indices of the partners that move along (-1: none) and their places in the new equal-time object (1: at tau_h, 2: one
+    // offset above, 3: two); the former hybridising operator takes the place that is left (qrepind / qtimeind, CTQMC.F90:6068-6127, 6164-6178)
+    int partner = -1, pos_partner = 0, partner2 = -1, pos_partner2 = 0, pos_new = 0;
     if constexpr (NW == 4) {
         const int sec = C.isector;
-        if (sec == 6) { partner = r ^ 1; pos_partner = (r & 1) ? 2 : 1; }
+        if (sec == 3) {
+            if (r == 0) { partner = 2; pos_partner = 2; partner2 = 1; pos_partner2 = 3; pos_new = 1; }
+            else if (r == 1) { partner = 0; pos_partner = 1; partner2 = 2; pos_partner2 = 2; pos_new = 3; }
+            else if (r == 2) { partner = 0; pos_partner = 1; partner2 = 1; pos_partner2 = 3; pos_new = 2; }
+        }
+        else if (sec == 6) { partner = r ^ 1; pos_partner = (r & 1) ? 2 : 1; }
         else if (sec == 7) { partner = r ^ 2; pos_partner = r < 2 ? 1 : 2; }
         else if (sec == 8) { if (r >= 2) { partner = r ^ 1; pos_partner = r == 2 ? 1 : 2; } }
         else if (sec == 9) { if (r & 1) { partner = r ^ 2; pos_partner = r == 1 ? 1 : 2; } }
+        if (partner >= 0 && partner2 < 0) pos_new = 3 - pos_partner;
     }
     double tw = 0.0; int f = 0;
 #pragma unroll
@@ -251,28 +372,44 @@ __device__ W2DYN_INLINE void step_worm_replace(Ctx &x)
     wave_sync();
     const double detrat = creator ? 1.0 + uni(x.MQ[slot]) : 1.0 + wave_sum(part);
     double prob = fabs(detrat);
-    double tp = 0.0, tpn = 0.0, thn = th, tl = 0.0, ts = 1.0; int fp = 0;
+    double tp = 0.0, tpn = 0.0, tp2 = 0.0, tpn2 = 0.0, thn = th, tl = 0.0, ts = 1.0; int fp = 0, fp2 = 0;
+    bool slot_moved = false;
     if constexpr (NW == 4) {
         if (partner >= 0) {
             const double off = C.beta * 1e-14;
-            tpn = th + (pos_partner == 2 ? off : 0.0); thn = th + (pos_partner == 1 ? off : 0.0);
+            tpn = th + (double)(pos_partner - 1) * off; tpn2 = th + (double)(pos_partner2 - 1) * off; thn = th + (double)(pos_new - 1) * off;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (i == partner) { tp = x.wtau[i]; fp = x.wfl[i]; }
-            const int pca = (partner & 1) ? 1 : 2;
+            for (int i = 0; i < 4; ++i) { if (i == partner) { tp = x.wtau[i]; fp = x.wfl[i]; } if (i == partner2) { tp2 = x.wtau[i]; fp2 = x.wfl[i]; } }
+            const int pca = (partner & 1) ? 1 : 2, pca2 = (partner2 & 1) ? 1 : 2;
             if constexpr (MAT == 0) {
-                const double lo = fmin(tp, tpn), hi = fmax(tp, tpn);
-                bool ok = !worm_any_between(x, fp, lo, hi);
-                if (fp == f && thn > lo && thn < hi) ok = false;
+                if (partner2 < 0) {
+                    const double lo = fmin(tp, tpn), hi = fmax(tp, tpn);
+                    bool ok = !worm_any_between(x, fp, lo, hi);
+                    if (fp == f && thn > lo && thn < hi) ok = false;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) if (i != partner && x.wfl[i] == fp && x.wtau[i] > lo && x.wtau[i] < hi) ok = false;
-                if (!ok) return;
-                const double dn = ((pca == 1) == (tpn > tp)) ? -1.0 : 1.0;
-                prob = fabs(detrat * exp(-dn * level_integral<NW>(x, fp, lo, hi)));
+                    for (int i = 0; i < 4; ++i) if (i != partner && x.wfl[i] == fp && x.wtau[i] > lo && x.wtau[i] < hi) ok = false;
+                    if (!ok) return;
+                    const double dn = ((pca == 1) == (tpn > tp)) ? -1.0 : 1.0;
+                    prob = fabs(detrat * exp(-dn * level_integral<NW>(x, fp, lo, hi)));
+                } else {
+                    // two partners (three-operator object): with the former hybridising operator at its place in the new object
+                    double dl;
+                    if (thn != th) { wave_sync(); if (x.lane == 0) { if (creator) tcp[slot] = thn; else tap[slot] = thn; } wave_sync(); slot_moved = true; }
+                    const bool ok = worm_shift_delta(x, partner, partner2, tpn, tpn2, dl);
+                    if (!ok) { if (slot_moved) { if (x.lane == 0) { if (creator) tcp[slot] = th; else tap[slot] = th; } wave_sync(); } return; }
+                    prob = fabs(detrat * exp(dl));
+                }
             } else {
                 mat_remove(x, mat_lower(x, tp));
                 wave_sync();
+                if (partner2 >= 0) { mat_remove(x, mat_lower(x, tp2)); wave_sync(); }
                 if (thn != th) { const int ih = mat_lower(x, th); if (x.lane == 0) x.ot[ih] = thn; wave_sync(); }
-                mat_insert(x, mat_lower(x, tpn), tpn, mat_code(fp, pca));
+                // the new object in time order, so that every insertion index is found with the others in place
+#pragma unroll
+                for (int place = 1; place <= 3; ++place) {
+                    if (pos_partner == place) mat_insert(x, mat_lower(x, tpn), tpn, mat_code(fp, pca));
+                    if (partner2 >= 0 && pos_partner2 == place) mat_insert(x, mat_lower(x, tpn2), tpn2, mat_code(fp2, pca2));
+                }
                 if (!mat_walk_into(x, x.outer, x.tsst)) ts = 0.0;
                 else {
                     mat_trace_trial<MAT>(x, x.tsst, x.nops, -1, -1, tl, ts);
@@ -289,10 +426,13 @@ __device__ W2DYN_INLINE void step_worm_replace(Ctx &x)
             if (partner >= 0) {                                // back to the old list
                 mat_remove(x, mat_lower(x, tpn));
                 wave_sync();
+                if (partner2 >= 0) { mat_remove(x, mat_lower(x, tpn2)); wave_sync(); }
                 if (thn != th) { const int ih = mat_lower(x, thn); if (x.lane == 0) x.ot[ih] = th; wave_sync(); }
                 mat_insert(x, mat_lower(x, tp), tp, mat_code(fp, (partner & 1) ? 1 : 2));
+                if (partner2 >= 0) mat_insert(x, mat_lower(x, tp2), tp2, mat_code(fp2, (partner2 & 1) ? 1 : 2));
             }
         }
+        if (slot_moved) { if (x.lane == 0) { if (creator) tcp[slot] = th; else tap[slot] = th; } wave_sync(); }
         return;
     }
     const int kk = k * k;
@@ -302,7 +442,7 @@ __device__ W2DYN_INLINE void step_worm_replace(Ctx &x)
     }
     if (x.lane == 0) { if (creator) tcp[slot] = tw; else tap[slot] = tw; }
 #pragma unroll
-    for (int i = 0; i < NW; ++i) { if (i == r) x.wtau[i] = thn; if (NW == 4 && i == partner) x.wtau[i] = tpn; }
+    for (int i = 0; i < NW; ++i) { if (i == r) x.wtau[i] = thn; if (NW == 4 && i == partner) x.wtau[i] = tpn; if (NW == 4 && i == partner2) x.wtau[i] = tpn2; }
     if constexpr (NW == 4 && MAT != 0) {
         if (partner >= 0) { x.tr_log = tl; x.tr_sign = ts; mat_commit_sst(x); }
     }
@@ -320,15 +460,9 @@ template <int NW, int MAT>
 __device__ W2DYN_INLINE void step_worm_add_mat(Ctx &x)
 {
     const DevConst &C = x.C;
-    const int nf = C.nflav;
-    const int ncomp = NW == 4 ? nf * nf * nf * nf : nf * nf;
-    int comp = C.icomponent;
-    if (comp == 0) comp = x.randint(1, ncomp);
     x.count(C_TRYWADD);
     double t[4] = {0.0, 0.0, 0.0, 0.0}; int fl[4] = {0, 0, 0, 0};
-    int rest = comp - 1, base = ncomp / nf;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) { const int bs = rest / base; rest -= bs * base; base /= nf; fl[i] = bs; }
+    worm_draw_flavours<NW>(x, fl);
     worm_draw_times<NW>(x, t);
     if (x.nops + NW > C.wcap) { x.err |= ERR_WCAP; x.count(C_QNWADD); x.sector = 1; return; }
 #pragma unroll
@@ -339,11 +473,12 @@ __device__ W2DYN_INLINE void step_worm_add_mat(Ctx &x)
         wave_sync();
     };
     const bool valid = mat_walk_into(x, x.outer, x.tsst);
-    if (worm_prefact<NW>(C) == 0.0 || !valid) { take_out(); x.count(C_QNWADD); x.sector = 1; return; }
+    const double prefact = worm_prefact<NW>(C, fl);
+    if (prefact == 0.0 || !valid) { take_out(); x.count(C_QNWADD); x.sector = 1; return; }
     double tl, ts;
     mat_trace_trial<MAT>(x, x.tsst, x.nops, -1, -1, tl, ts);
     const double rnd = x.draw();
-    if (ts != 0.0 && rnd < fabs(worm_prefact<NW>(C) * exp(tl - x.tr_log))) {
+    if (ts != 0.0 && rnd < fabs(prefact * exp(tl - x.tr_log))) {
 #pragma unroll
         for (int i = 0; i < NW; ++i) { x.wtau[i] = t[i]; x.wfl[i] = fl[i]; }
         x.tr_log = tl; x.tr_sign = ts; mat_commit_sst(x);
@@ -369,7 +504,7 @@ __device__ W2DYN_INLINE void step_worm_rem_mat(Ctx &x)
     double tl, ts;
     mat_trace_trial<MAT>(x, x.tsst, x.nops, -1, -1, tl, ts);
     const double rnd = x.draw();
-    if (ts != 0.0 && rnd < fabs(exp(tl - x.tr_log) / worm_prefact<NW>(C))) {
+    if (ts != 0.0 && rnd < fabs(exp(tl - x.tr_log) / worm_prefact<NW>(C, x.wfl))) {
         x.tr_log = tl; x.tr_sign = ts; mat_commit_sst(x);
         x.sector = 1; x.count(C_ACCWREM);
     } else put_back();
@@ -507,9 +642,14 @@ __global__ __launch_bounds__(256) void k_meas_gw(DevConst C)
         for (int q = 0; q < GW_PER_THREAD; ++q) { re[q] = 0.0; im[q] = 0.0; }
         for (int w = w0; w < w1; ++w) {
             const WalkerScalars &s = C.ws[w];
-            if (s.sector != 2) continue;                     // uniform over the workgroup
-            const double dt = s.wtau[0] - s.wtau[1];
-            const double val = C.cfgsign[w] / C.worm_eta;
+            if (s.sector != C.isector) continue;             // uniform over the workgroup
+            // sector 2: t1 - t2; sector 3 (GSigmaiw_worm, measure_ie_sigma_worm, CTQMC.F90:1123-1164): t1 - t4, times the sign of the U-matrix factor
+            double dt = s.wtau[0] - s.wtau[1], val = C.cfgsign[w] / C.worm_eta;
+            if (C.isector == 3) {
+                const int fl[4] = {s.wflav[0], s.wflav[1], s.wflav[2], s.wflav[3]};
+                dt = s.wtau[0] - s.wtau[3];
+                if (gsigma_ufac(C, fl) < 0.0) val = -val;
+            }
             if (C.acc_giww) {
                 double sn, cs, sr, cr;
                 sincos(pib * (double)(2 * (e0 + tid - niw) + 1) * dt, &sn, &cs);

@@ -130,6 +130,8 @@ struct w2dyn_solver {
     int worm_meas_giw = 0, worm_meas_gtau = 0;       // sector 2: WormMeasGiw, WormMeasGtau (CTQMC.F90:597-612)
     // sectors 6 - 9 (equal-time pairs): WormMeasP2iwPH, P2iwPP, P2tauPH, P2tauPP, P3iwPH, P3iwPP; N2iwb, N3iwf, N3iwb (CTQMC.F90:654-726)
     int worm_meas_eq[6] = {0, 0, 0, 0, 0, 0}, n2iwb = 0, n3iwf = 0, n3iwb = 0, nbe = 0;
+    std::vector<double> umat_h;                      // U matrix as handed to init_solver
+    int worm_meas_gsigma = 0;                        // sector 3: WormMeasGSigmaiw (CTQMC.F90:619-623); shares the giw_worm accumulator
     double *acc_weq_iw = nullptr, *acc_weq_tau = nullptr, *acc_weq_p3 = nullptr;
     bool no_sampling = false;
     std::vector<long long> steps_worm_chains;
@@ -592,6 +594,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if (!get_int(s, "WormMeasG4iw", iv)) return W2DYN_EINVAL; s->worm_meas_g4iw = iv != 0;
     if (!get_int(s, "WormMeasGiw", iv)) return W2DYN_EINVAL; s->worm_meas_giw = iv != 0;
     if (!get_int(s, "WormMeasGtau", iv)) return W2DYN_EINVAL; s->worm_meas_gtau = iv != 0;
+    if (!get_int(s, "WormMeasGSigmaiw", iv)) return W2DYN_EINVAL; s->worm_meas_gsigma = iv != 0;
     {
         static const char *keys[6] = {"WormMeasP2iwPH", "WormMeasP2iwPP", "WormMeasP2tauPH", "WormMeasP2tauPP", "WormMeasP3iwPH", "WormMeasP3iwPP"};
         for (int q = 0; q < 6; ++q) { if (!get_int(s, keys[q], iv)) return W2DYN_EINVAL; s->worm_meas_eq[q] = iv != 0; }
@@ -805,7 +808,11 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if ((rc = dev_alloc(s, C.acc_nw, B))) return rc;
     C.nwf = s->n4iwf; C.nwb = s->n4iwb; C.wormphconv = s->wormphconv; C.g4ph = s->g4ph; C.g4pp = s->g4pp;
     C.p_wins = 0.0; C.p_wrep = s->p_wrep; C.worm_eta = s->worm_eta; C.isector = 1; C.icomponent = 0;
-    { int *qp = nullptr; if ((rc = dev_alloc(s, qp, 1))) return rc; C.queue = qp; }      // chain queue of the matrix-path sweep kernels
+    { int *qp = nullptr; if ((rc = dev_alloc(s, qp, 1))) return rc; C.queue = qp; }
+    {   // the full U matrix: proposal factor of the GSigma worm (sector 3)
+        s->umat_h.assign(U, U + (size_t)nf * nf * nf * nf);
+        const double *du = nullptr; if ((rc = dev_upload(s, du, s->umat_h))) return rc; C.umat = du;
+    }      // chain queue of the matrix-path sweep kernels
     {   // user symmetry moves of the global move: the listed permutations and their inverses (Trace.F90:471-478)
         if (!get_int(s, "NSymMove", iv)) return W2DYN_EINVAL;
         const int nsym = (int)iv;
@@ -885,7 +892,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
         if (pl) { if ((rc = dev_alloc(s, s->acc_g4leg, (size_t)s->nbl * pl))) return rc; }
     }
     C.acc_giww = C.acc_gtauw = nullptr;
-    if (s->worm_meas_giw) { if ((rc = dev_alloc(s, C.acc_giww, B * (size_t)C.niw2 * 2))) return rc; }
+    if (s->worm_meas_giw || s->worm_meas_gsigma) { if ((rc = dev_alloc(s, C.acc_giww, B * (size_t)C.niw2 * 2))) return rc; }
     if (s->worm_meas_gtau) {
         if ((rc = dev_alloc(s, C.acc_gtauw, B * (size_t)s->ntau))) return rc;
         if ((size_t)s->ntau * sizeof(double) > 64 * 1024) return fail(s, W2DYN_EUNSUPPORTED, "Ntau=%d too large for the gtau_worm estimator", s->ntau);
@@ -1150,8 +1157,8 @@ static int measure_once_impl(w2dyn_solver *s, double2 *g2buf)
     HIPCHK(hipGetLastError());
     if ((rc = time_end(s, "meas_misc"))) return rc;
     if (s->cur_isector != 1) {      // component sampling: no Z-space Green's function estimators (CTQMC.F90:8554), worm estimator instead
-        if (s->cur_isector == 2) {
-            if (s->C.acc_giww || s->C.acc_gtauw) {
+        if (s->cur_isector == 2 || s->cur_isector == 3) {
+            if ((s->cur_isector == 2 && (s->C.acc_giww || s->C.acc_gtauw)) || (s->cur_isector == 3 && s->worm_meas_gsigma)) {
                 if ((rc = time_begin(s))) return rc;
                 launch_meas_gw(s->C, s->stream);
                 HIPCHK(hipGetLastError());
@@ -1623,6 +1630,24 @@ int w2dyn_measure_finish(w2dyn_solver *s)
         if (C.acc_gtauw) reduceg(C.acc_gtauw, (size_t)ntau, "gtau_worm", (double)ntau / beta);
         R["cntmeas_worm"] = {mwt};
     }
+    if (s->cur_isector == 3 && s->worm_meas_gsigma) {
+        // GSigmaiw_worm = sum * wormScaling(GSigma) / (-4 (2 Nd)^2), wormNorm = 32 / beta (CTQMC.F90:8826, 8843-8849, 8987-8998); counts pooled per bin
+        std::vector<double> cw(B, 0.0), cz(B, 0.0);
+        double cwt = 0.0, czt = 0.0, mwt = 0.0;
+        for (int w = 0; w < W; ++w) { const int b = w / C.walkers_per_bin; cw[b] += (double)ws[w].cnt[C_W_SAMPLING]; cz[b] += (double)ws[w].cnt[C_SAMPLING]; }
+        for (int b = 0; b < B; ++b) { cwt += cw[b]; czt += cz[b]; mwt += nwm[b]; }
+        auto scal = [&](double c_w, double c_z, double m_w) { return m_w != 0.0 ? c_w / (m_w * c_z) * 32.0 / beta / ms / (-4.0 * (double)nf * nf) : 0.0; };
+        const size_t n = (size_t)C.niw2 * 2;
+        std::vector<double> raw((size_t)B * n), tot(n, 0.0);
+        (void)hipMemcpy(raw.data(), C.acc_giww, raw.size() * sizeof(double), hipMemcpyDeviceToHost);
+        PackDesc d{C.acc_giww, B, n, std::vector<double>(B), 0};
+        for (int b = 0; b < B; ++b) d.scale[b] = scal(cw[b], cz[b], nwm[b]);
+        s->pack["gsigmaiw_worm"] = d;
+        for (int b = 0; b < B; ++b) { const double f = scal(cw[b], cz[b], nwm[b]); for (size_t i = 0; i < n; ++i) { tot[i] += raw[(size_t)b * n + i]; raw[(size_t)b * n + i] *= f; } }
+        const double f = scal(cwt, czt, mwt);
+        for (size_t i = 0; i < n; ++i) tot[i] *= f;
+        R["gsigmaiw_worm"] = tot; R["gsigmaiw_worm_bins"] = raw; R["cntmeas_worm"] = {mwt};
+    }
     if (s->cur_isector >= 6 && s->nbe > 0) {
         // wormScaling = CntSampling(worm) / (CntMeas(worm) CntSampling(Z)) * wormNorm / mean_sign, wormNorm = 16/beta (P2, P2pp) or
         // 16/beta^2 (P3, P3pp); the tau histograms times Ntau/beta (CTQMC.F90:8830-8849, 9116-9130, 9165-9179, 9215-9224, 9229-9313);
@@ -1679,11 +1704,21 @@ int w2dyn_measure_finish(w2dyn_solver *s)
 // sector bookkeeping shared by ctqmc_measure and count_steps: every chain starts in Z space (CTQMC.F90:6328, 8400)
 static int enter_sector(w2dyn_solver *s, int isector, int icomponent)
 {
-    if (isector != 1 && isector != 2 && isector != 4 && !(isector >= 6 && isector <= 9))
-        return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d is not supported (1 = Z, 2 = one-particle, 4 = two-particle Green's function, 6 - 9 = P2 / P2pp / P3 / P3pp)", isector);
+    if (isector != 1 && isector != 2 && isector != 3 && isector != 4 && !(isector >= 6 && isector <= 9))
+        return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d is not supported (1 = Z, 2 = one-particle, 3 = GSigma, 4 = two-particle Green's function, 6 - 9 = P2 / P2pp / P3 / P3pp)", isector);
+    if (isector == 3) {
+        // the insertion draws flavours until the U-matrix factor of the proposal does not vanish (CTQMC.F90:5047-5054): the reference
+        // loops for ever when no choice has one; here that is an error of the call
+        const int nf = s->nflav;
+        if (icomponent < 1 || icomponent > nf * nf) return fail(s, W2DYN_EINVAL, "sector 3 samples one component (1 .. %d), not %d", nf * nf, icomponent);
+        const int u = (icomponent - 1) / nf; bool any = false;
+        for (int a = 0; a < nf && !any; ++a) for (int b = 0; b < nf && !any; ++b) for (int c = 0; c < nf && !any; ++c)
+            any = 0.5 * (s->umat_h[(((size_t)u * nf + b) * nf + a) * nf + c] - s->umat_h[(((size_t)b * nf + u) * nf + a) * nf + c]) != 0.0;
+        if (!any) return fail(s, W2DYN_EINVAL, "sector 3, component %d: the U matrix has no element that lets the worm in", icomponent);
+    }
     if (isector != 1) {
         const int nf = s->nflav;
-        if (icomponent < 0 || icomponent > (isector == 2 ? nf * nf : nf * nf * nf * nf)) return fail(s, W2DYN_EINVAL, "component %d out of range", icomponent);
+        if (icomponent < 0 || icomponent > ((isector == 2 || isector == 3) ? nf * nf : nf * nf * nf * nf)) return fail(s, W2DYN_EINVAL, "component %d out of range", icomponent);
     }
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -1748,15 +1783,15 @@ int w2dyn_ctqmc_worm_warmup(w2dyn_solver *s, int64_t nwarmups2, int isector, int
     if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "ctqmc_worm_warmup before init_solver");
     // the reference allocates the buffers of the batched transform here and samples nothing (CTQMC.F90:8266-8348); this
     // library transforms every measurement on the spot, so only the arguments are checked
-    if (isector != 1 && isector != 2 && isector != 4 && !(isector >= 6 && isector <= 9))
-        return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d is not supported (1 = Z, 2 = one-particle, 4 = two-particle Green's function, 6 - 9 = P2 / P2pp / P3 / P3pp)", isector);
+    if (isector != 1 && isector != 2 && isector != 3 && isector != 4 && !(isector >= 6 && isector <= 9))
+        return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d is not supported (1 = Z, 2 = one-particle, 3 = GSigma, 4 = two-particle Green's function, 6 - 9 = P2 / P2pp / P3 / P3pp)", isector);
     return 0;
 }
 
 int w2dyn_count_steps(w2dyn_solver *s, int isector, int icomponent, int64_t nfix, int64_t *steps_worm, int64_t *steps_z)
 {
     if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "count_steps before init_solver");
-    if (isector != 4 && isector != 2 && !(isector >= 6 && isector <= 9))
+    if (isector != 4 && isector != 2 && isector != 3 && !(isector >= 6 && isector <= 9))
         return fail(s, W2DYN_EUNSUPPORTED, "count_steps: worm sector %d is not supported (2 = one-particle, 4 = two-particle Green's function, 6 - 9 = P2 / P2pp / P3 / P3pp)", isector);
     if (nfix < 0) return fail(s, W2DYN_EINVAL, "count_steps: nfix = %lld", (long long)nfix);
     int rc;

@@ -31,6 +31,13 @@ def load_library(path: str = LIB_PATH):
     """Load the C ABI and declare every prototype of include/w2dyn_hip.h. Raises if the library is absent."""
     if not os.path.exists(path):
         raise ImportError("HIP extension %s is not built (run `python -c 'import __graft_entry__ as g; g.build()'`)" % path)
+    # PyTorch ships a HIP runtime of its own.  When it is imported AFTER this library has brought in the system's, the process holds
+    # two runtimes and the second one finds no device ("No HIP GPUs are available" from the first torch.cuda call: reduce_pack, the
+    # RCCL group).  Imported first, its copy serves both.  Callers that never touch torch lose nothing but the import time.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     vp = C.c_void_p
     L.w2dyn_create.argtypes = [C.POINTER(vp), C.c_int]
@@ -355,8 +362,8 @@ class MCTQMC:
                 return np.ascontiguousarray(a.transpose(0, 1, 2, 4, 3))
             a = a.reshape(nd, 2, -1, self._ntau)
             return np.ascontiguousarray(a.transpose(0, 1, 3, 2))
-        if name in ("giw_worm", "giw_worm_bins"):
-            # one-particle worm estimator of the sampled component: giw_worm(2*Niw), CTQMC.F90:598
+        if name in ("giw_worm", "giw_worm_bins", "gsigmaiw_worm", "gsigmaiw_worm_bins"):
+            # one-particle worm estimators of the sampled component: giw_worm(2*Niw), CTQMC.F90:598; GSigmaiw_worm(2*Niw), sector 3, CTQMC.F90:621
             a = self.result(name).reshape(-1, 2); a = a[:, 0] + 1j * a[:, 1]
             return a.reshape(int(self.scalar("nbins")), -1) if name.endswith("_bins") else a
         if name.split("_bins")[0] in ("p2iw_worm", "p2iwpp_worm", "p3iw_worm", "p3iwpp_worm"):

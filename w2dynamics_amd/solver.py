@@ -260,6 +260,8 @@ class HipCtHybSolver:
                 result["giw-worm/%05d" % icomponent] = DistributedSample(q.giw_worm_bins, self.comm)
             if self.qmc["WormMeasGtau"] != 0:
                 result["gtau-worm/%05d" % icomponent] = DistributedSample(q.gtau_worm_bins, self.comm)
+        if isector == 3 and self.qmc["WormMeasGSigmaiw"] != 0:      # get_resultset_worm, impurity.py:1316-1317
+            result["gsigmaiw-worm/%05d" % icomponent] = DistributedSample(q.gsigmaiw_worm_bins, self.comm)
         if 6 <= isector <= 9:     # equal-time sectors, impurity.py:817-839: the module array divided by nflavours^4
             for sec, key, name, flag in ((6, "p2iw-worm", "p2iw_worm", "WormMeasP2iwPH"), (6, "p2tau-worm", "p2tau_worm", "WormMeasP2tauPH"),
                                          (7, "p2iwpp-worm", "p2iwpp_worm", "WormMeasP2iwPP"), (7, "p2taupp-worm", "p2taupp_worm", "WormMeasP2tauPP"),
