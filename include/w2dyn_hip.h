@@ -74,7 +74,9 @@ int w2dyn_ctqmc_warmup(w2dyn_solver *s, int64_t nwarmups);
 /* ctqmc_measure(isector, icomponent)               CTQMC.F90:8355
  * isector 1 = Z space; isector 2 = worm sampling of the one-particle Green's function component icomponent
  * (giw_worm / gtau_worm, CTQMC.F90:1061-1120); isector 4 = worm sampling of the two-particle Green's function
- * component icomponent (0 = all components); isector 6 / 7 / 8 / 9 = worm sampling with equal-time pairs (P2 ph / pp: two random
+ * component icomponent (0 = all components); isector 3 = GSigma worm (improved estimator: three-operator equal-time object with random
+ * flavours and the U-matrix factor in the proposal, Trace.F90:3835-3919, CTQMC.F90:5687-5696; GSigmaiw_worm, CTQMC.F90:1123-1164;
+ * icomponent = 1 + u (2Nd) + g4, not 0); isector 6 / 7 / 8 / 9 = worm sampling with equal-time pairs (P2 ph / pp: two random
  * times, P3 ph / pp: three; set_OperTime Trace.F90:3985-4020, replacement with the partner moved along CTQMC.F90:6068-6249;
  * estimators p2iw / p2tau / p2iwpp / p2taupp / p3iw / p3iwpp, CTQMC.F90:1297-1507); both trace paths.  Other sectors are refused. */
 int w2dyn_ctqmc_measure(w2dyn_solver *s, int isector, int icomponent);
@@ -96,7 +98,7 @@ int w2dyn_dest_ctqmc(w2dyn_solver *s);
  * nsteps Monte-Carlo steps for every chain (CTQMC.F90:8428-8533), one pass of the Z-space estimators over every
  * chain (8541-8581), normalisation (8663-8817). */
 /* sector and component of the following w2dyn_sweep / w2dyn_measure_once calls (the first lines of ctqmc_measure,
- * CTQMC.F90:8380-8400): every chain goes back to Z space; isector 1, 2, 4 or 6 - 9 */
+ * CTQMC.F90:8380-8400): every chain goes back to Z space; isector 1, 2, 3, 4 or 6 - 9 */
 int w2dyn_set_sector(w2dyn_solver *s, int isector, int icomponent);
 int w2dyn_measure_begin(w2dyn_solver *s);
 int w2dyn_sweep(w2dyn_solver *s, int64_t nsteps, int count_as_sampling);
@@ -160,6 +162,7 @@ int w2dyn_get_walker_state(w2dyn_solver *s, int walker, double *out6);
  *       FourPnt & 4: "g4iw", "g4iw_pp" (Nd,2,Nd,2,2N4iwf,2N4iwf,2N4iwb+1) complex, "g2iw" (+ "_bins") |
  *       worm sampling (FourPnt & 8): "g4iw_worm", "g4iwpp_worm" (2N4iwf,2N4iwf,2N4iwb+1) complex (+ "_bins"),
  *       worm sector 2 (WormMeasGiw / WormMeasGtau): "giw_worm" (2Niw) complex, "gtau_worm" (Ntau) (+ "_bins": nbins leading),
+ *       worm sector 3 (WormMeasGSigmaiw): "gsigmaiw_worm" (2Niw) complex (+ "_bins": nbins leading),
  *       worm sectors 6 / 7 (WormMeasP2iwPH | PP, WormMeasP2tauPH | PP): "p2iw_worm" | "p2iwpp_worm" (2N2iwb+1) complex,
  *       "p2tau_worm" | "p2taupp_worm" (Ntau); sectors 8 / 9 (WormMeasP3iwPH | PP): "p3iw_worm" | "p3iwpp_worm" (2N3iwf,2N3iwb+1)
  *       complex (+ "_bins": scalar "nbe" leading),

@@ -1125,6 +1125,33 @@ def test_solver_p2_worm_agrees_with_z_space_density_correlation():
         assert abs(piw[3].real - pt.mean() * p.beta) < 0.02 * abs(piw[3].real) and abs(piw[3].imag) < 1e-9
 
 
+def test_solver_gsigma_worm_agrees_with_dyson_self_energy():
+    """HipCtHybSolver.solve_component in sector 3 (GSigma: the improved estimator, a three-operator equal-time object with the
+    U matrix in the proposal): gsigmaiw-worm of the diagonal component is Sigma(iw) G(iw) - which the Z-space run gives
+    independently through G(l) -> G(iw) and the Dyson equation (postprocessing).  Hartree term included (Sigma ~ 1 - 0.4i at the
+    first frequency for U = 2 at half filling)."""
+    from w2dynamics_amd.solver import HipCtHybSolver
+    from w2dynamics_amd import synth
+    base = dict(BASE, Ntau=100, NLegMax=30, Niw=20, Nwarmups=20000, Nmeas=1000, NCorr=20, TaudiffMax=6.0, Nftau=501,
+                PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05)
+    p = synth.config("C1", nftau=501); nfl = 2 * p.nd
+    s = HipCtHybSolver(base, seed=3, nwalkers=1024, walkers_per_bin=8)
+    s.set_problem(p)
+    r = s.postprocessing(s.solve(0))
+    g = np.asarray(r["giw"].mean())[:, 0, 0, 0, 0]; sg = np.asarray(r["siw"].mean())[:, 0, 0, 0, 0] * g
+    s2 = HipCtHybSolver(dict(base, Nwarmups2Plus=4000, PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=1.0, WormSearchEta=1,
+                             WormMeasGSigmaiw=1), seed=5, nwalkers=1024, walkers_per_bin=8)
+    s2.set_problem(p)
+    r2 = s2.solve_component(0, 3, 1)
+    st = r2["steps-worm-partition/00001"]
+    assert 0.5 < st[2] / st[0] < 2.0
+    gs = np.asarray(r2["gsigmaiw-worm/00001"].mean()); ge = np.asarray(r2["gsigmaiw-worm/00001"].stderr())
+    assert gs.shape == sg.shape
+    n = gs.shape[0] // 2
+    assert np.all(np.abs(gs[n:n + 12] - sg[n:n + 12]) < 5.0 * ge[n:n + 12] + 0.02 * np.abs(sg[n:n + 12])), np.abs(gs - sg)[n:n + 12]
+    assert np.abs(gs[n:] - np.conj(gs[:n][::-1])).max() < 1e-12
+
+
 @pytest.mark.parametrize("name", ["C1", "C3", "C4"])
 def test_susceptibility_recorded_configuration_vs_reference_golden(name):
     """f-3, MeasSusz = 1 (matrix solver, meas_ntau_n0, Trace.F90:6472-6835): <n(tau) n(0)> of a recorded configuration ==
