@@ -1150,6 +1150,17 @@ def test_solver_gsigma_worm_agrees_with_dyson_self_energy():
     n = gs.shape[0] // 2
     assert np.all(np.abs(gs[n:n + 12] - sg[n:n + 12]) < 5.0 * ge[n:n + 12] + 0.02 * np.abs(sg[n:n + 12])), np.abs(gs - sg)[n:n + 12]
     assert np.abs(gs[n:] - np.conj(gs[:n][::-1])).max() < 1e-12
+    # solve_worm with the improved estimator (impurity.py:993-997): G = G0 + G0 GSigma from the components of both spins
+    s3 = HipCtHybSolver(dict(base, Nwarmups2Plus=4000, PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=1.0, WormSearchEta=1,
+                             WormMeasGSigmaiw=1), seed=7, nwalkers=1024, walkers_per_bin=8)
+    s3.set_problem(p)
+    rw = s3.solve_worm()
+    gw = np.asarray(rw["giw"].mean()); ew = np.asarray(rw["giw"].stderr())
+    gz = np.asarray(r["giw"].mean()); ez = np.asarray(r["giw"].stderr())
+    for sp in range(2):
+        d = np.abs(gw[:, 0, sp, 0, sp] - gz[:, 0, sp, 0, sp]); e = np.sqrt(ew[:, 0, sp, 0, sp] ** 2 + ez[:, 0, sp, 0, sp] ** 2)
+        assert np.all(d < 5.0 * e + 2e-3), (sp, d.max(), e.max())
+    assert np.abs(gw[:, 0, 0, 0, 1]).max() == 0.0
 
 
 @pytest.mark.parametrize("name", ["C1", "C3", "C4"])

@@ -280,13 +280,17 @@ class HipCtHybSolver:
         q.dest_paras()
         return result
 
-    def solve_worm(self, iter_no=0, components=None):
-        """`CtHybSolver.solve_worm` (`impurity.py:906-1010`) for `WormMeasGiw`: every diagonal component of the
-        one-particle Green's function is sampled in worm sector 2 by `solve_component`, the component list is
-        assembled into G(iw) (`get_giw` with FTType `none_worm`, `impurity.py:1066-1072`), the Z-space quantities
-        sampled along with every component are averaged and the self-energy moments follow from rho1 / rho2."""
-        if not self.qmc["WormMeasGiw"]:
-            raise ValueError("solve_worm: WormMeasGiw must be set (the sectors of WormMeasGSigmaiw / WormMeasQQ are not sampled)")
+    def solve_worm(self, iter_no=0, components=None, g0inviw=None):
+        """`CtHybSolver.solve_worm` (`impurity.py:906-1010`) for `WormMeasGiw` (worm sector 2) or `WormMeasGSigmaiw` (sector 3):
+        every diagonal component is sampled by `solve_component`, the component list is assembled into a matrix in the orbitals -
+        G(iw) itself (`get_giw` with FTType `none_worm`, `impurity.py:1066-1072`), or GSigma(iw), from which G = G0 + G0 GSigma
+        follows (`get_gsigmaiw_worm`, `giw_from_gsigmaiw_worm`, `impurity.py:1104-1138`: the improved estimator, Eq. (9) of PRB 100,
+        075119) -, the Z-space quantities sampled along with every component are averaged and the self-energy moments follow from
+        rho1 / rho2.  `g0inviw` (iw, band, spin, band, spin): the Weiss field for the improved estimator, the problem's by default."""
+        meas_g, meas_gs = self.qmc["WormMeasGiw"] != 0, self.qmc["WormMeasGSigmaiw"] != 0
+        if meas_g == meas_gs:
+            raise ValueError("solve_worm: exactly one of WormMeasGiw, WormMeasGSigmaiw must be set (the sector of WormMeasQQ is not sampled)")
+        sector, name = (2, "giw-worm") if meas_g else (3, "gsigmaiw-worm")
         p = self.problem
         nd = p.nd; nfl = 2 * nd; niw = 2 * int(self.qmc["Niw"])
         if components is None:            # ci.GFComponent(bandspin=(f, f), n_ops=2).index, impurity.py:919-921
@@ -294,16 +298,24 @@ class HipCtHybSolver:
         conf, per_comp = [], []
         for comp in components:
             self.set_problem(p, self.ctqmc.fourpnt)
-            per_comp.append((comp, self.solve_component(iter_no, 2, comp, conf)))
+            per_comp.append((comp, self.solve_component(iter_no, sector, comp, conf)))
         result = {}
         for comp, r in per_comp:
             result.update({k: v for k, v in r.items() if k.endswith("/%05d" % comp)})
-        nb = min(np.asarray(r["giw-worm/%05d" % c].local).shape[0] for c, r in per_comp)
-        giw = np.zeros((nb, niw, nd, 2, nd, 2), dtype=complex)
+        nb = min(np.asarray(r["%s/%05d" % (name, c)].local).shape[0] for c, r in per_comp)
+        mat = np.zeros((nb, niw, nd, 2, nd, 2), dtype=complex)
         for comp, r in per_comp:
             f1, f2 = divmod(comp - 1, nfl)
-            giw[:, :, f1 // 2, f1 % 2, f2 // 2, f2 % 2] = np.asarray(r["giw-worm/%05d" % comp].local)[:nb]
-        result["giw"] = DistributedSample(giw, self.comm)
+            mat[:, :, f1 // 2, f1 % 2, f2 // 2, f2 % 2] = np.asarray(r["%s/%05d" % (name, comp)].local)[:nb]
+        if meas_g:
+            result["giw"] = DistributedSample(mat, self.comm)
+        else:
+            if g0inviw is None:
+                g0inviw = p.g0inviw(niw)
+            g0 = np.linalg.inv(np.asarray(g0inviw).reshape(niw, nfl, nfl))                     # orbspin.invert
+            gs = mat.reshape(nb, niw, nfl, nfl)
+            result["gsigmaiw"] = DistributedSample(mat, self.comm)
+            result["giw"] = DistributedSample((g0[None] + np.einsum("wab,nwbc->nwac", g0, gs)).reshape(nb, niw, nd, 2, nd, 2), self.comm)
         for key in ("occ", "rho1", "rho2"):
             result[key] = DistributedSample(np.concatenate([np.asarray(r[key].local) for _, r in per_comp]), self.comm)
         result["smom"] = DistributedSample(np.array([_postproc.lattice_convention(_postproc.get_siw_mom(
