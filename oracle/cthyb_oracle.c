@@ -69,6 +69,8 @@ struct ora_walker {
     double *weq[6]; size_t weq_n[6];          /* p2iw, p2iwpp, p2tau, p2taupp, p3iw, p3iwpp worm accumulators (sectors 6 - 9) */
     double try_add, acc_add, accqn_add, try_rem, acc_rem, accqn_rem, try_glob, acc_glob, accqn_glob;
     double try_shift, acc_shift, cnt_sampling, cnt_meas;
+    double try_add4, acc_add4, try_rem4, acc_rem4;   /* TryAdd4, AccAdd4, TryRem4, AccRem4 (CTQMC.F90:3645, 3861, 4175, 4394) */
+    double try_add_outer, acc_add_outer, try_rem_outer, acc_rem_outer;   /* TryAddOuter ... (CTQMC.F90:3385, 3589, 3917, 4135) */
     int64_t *accpair;
     int naccpair; double accpair_max;          /* NAccPair, AccPairMax (CTQMC.F90:68-69): Ntau bins over beta outside the calibration */
     double *accpairtau; int napt, apt_index;   /* AccPairTau list of the window calibration, phase 1 (CTQMC.F90:67, 70) */
@@ -537,11 +539,46 @@ static void accpair_add(ora_walker *w, int f, double dt)
     if (w->accpairtau && w->apt_index < w->napt) w->accpairtau[w->apt_index++] = dt;     /* CTQMC.F90:3583-3588, 4123-4128 */
 }
 
-/* CTQMC.F90:3353-3612 StepAdd (change_outer = false, diagonal hybridisation) */
-static void step_add(ora_walker *w)
+/* Block in front of the first operator at or after tau (at_or_after = 1) or after tau (0) in the present sequence */
+static int sst_at(const ora_walker *w, double tau, int at_or_after)
+{
+    int s = w->outer_sst;
+    for (int i = 0; i < w->nops; ++i) {
+        if (at_or_after ? w->ops[i].tau >= tau : w->ops[i].tau > tau) break;
+        s = connect(w, s, w->ops[i].flav, w->ops[i].ca);
+    }
+    return s;
+}
+
+/* Pair moves that may change the outer block (change_outer, CTQMC.F90:3422-3449, 3935-3962; check_sst_sequence walking over
+ * beta, Trace.F90:1278-1295): the blocks between the two operators stay as they were, s_hi in front of the later one and s_lo
+ * behind the earlier one; the sequence from the later operator over beta to the earlier one is derived anew and names the
+ * new outer block.  `closed` : the two operators are part of the list (insertion) or not (removal).  Returns the new outer block, -1 if
+ * the sequence is not allowed. */
+static int outer_sequence(const ora_walker *w, double tlo, double thi, int closed, int s_lo, int s_hi)
+{
+    int s = s_hi, outer;
+    for (int i = 0; i < w->nops; ++i) {
+        if (closed ? w->ops[i].tau < thi : w->ops[i].tau <= thi) continue;
+        s = connect(w, s, w->ops[i].flav, w->ops[i].ca);
+        if (s < 0) return -1;
+    }
+    outer = s;
+    for (int i = 0; i < w->nops; ++i) {
+        if (closed ? w->ops[i].tau > tlo : w->ops[i].tau >= tlo) break;
+        s = connect(w, s, w->ops[i].flav, w->ops[i].ca);
+        if (s < 0) return -1;
+    }
+    return s == s_lo ? outer : -1;
+}
+
+/* CTQMC.F90:3353-3612 StepAdd (diagonal hybridisation) */
+static void step_add(ora_walker *w, int change_outer)
 {
     const double *ft;
     if (w->sector == 1) w->try_add += 1; else w->wtry_add += 1;
+    if (change_outer) w->try_add_outer += 1;
+    const int outer_old = w->outer_sst;
     /* pair_OperAdd, Trace.F90:3657-3698 */
     double width1 = w->wmax - w->wmin;
     double tau1 = w->wmin + width1 * U01(w);            /* i=1: CA = mod(1,2)+1 = 2 (annihilator) */
@@ -561,6 +598,8 @@ static void step_add(ora_walker *w)
 
     op_t oa = { tau1, f, 2 }, oc = { tau2, f, 1 };
     int ia, ic;
+    const double tlo = fmin(tau1, tau2), thi = fmax(tau1, tau2);
+    const int s_lo = change_outer ? sst_at(w, tlo, 1) : 0, s_hi = change_outer ? sst_at(w, thi, 1) : 0;
     if (tau1 < tau2) { ia = list_insert(w, oa); ic = list_insert(w, oc); }
     else { ic = list_insert(w, oc); ia = list_insert(w, oa); if (ic >= ia) {} }
     /* recompute indices after both insertions */
@@ -570,7 +609,11 @@ static void step_add(ora_walker *w)
         if (w->ops[i].tau == tau2 && w->ops[i].flav == f && w->ops[i].ca == 1) ic = i;
     }
 
-    if ((w->sector != 1 && !check_equal_time(w, w->sector)) || !sequence_valid(w, w->outer_sst)) {      /* CTQMC.F90:3455 */
+    int seq_ok;
+    if (change_outer) { const int o = outer_sequence(w, tlo, thi, 1, s_lo, s_hi); seq_ok = o >= 0; if (seq_ok) w->outer_sst = o; }
+    else seq_ok = sequence_valid(w, w->outer_sst);
+    if ((w->sector != 1 && !check_equal_time(w, w->sector)) || !seq_ok) {      /* CTQMC.F90:3455 */
+        w->outer_sst = outer_old;
         list_remove(w, ia > ic ? ia : ic); list_remove(w, ia > ic ? ic : ia);
         w->accqn_add += 1;
         return;
@@ -606,17 +649,21 @@ static void step_add(ora_walker *w)
         w->tr = trnew;
         w->cfgsign = -get_sign(w);
         if (w->sector == 1) w->acc_add += 1; else w->wacc_add += 1;
+        if (change_outer) w->acc_add_outer += 1;
         accpair_add(w, f, fabs(tau2 - tau1));
     } else {
+        w->outer_sst = outer_old;
         list_remove(w, ia > ic ? ia : ic); list_remove(w, ia > ic ? ic : ia);
     }
     free(Q); free(R);
 }
 
-/* CTQMC.F90:3892-4150 StepRem (change_outer = false) */
-static void step_rem(ora_walker *w)
+/* CTQMC.F90:3892-4150 StepRem */
+static void step_rem(ora_walker *w, int change_outer)
 {
     if (w->sector == 1) w->try_rem += 1; else w->wtry_rem += 1;
+    if (change_outer) w->try_rem_outer += 1;
+    const int outer_old = w->outer_sst;
     /* gen_OperRemove, Trace.F90:4851-4950 */
     int np = count_pairs(w, 0, NULL, NULL);
     if (np <= 0) { w->accqn_rem += 1; return; }
@@ -631,8 +678,13 @@ static void step_rem(ora_walker *w)
     double hybpairremfactor = (double)np / ((w->wmax - w->wmin)
         * (fmin(ta + w->taudiff_max, w->wmax) - fmax(ta - w->taudiff_max, w->wmin)));
 
+    const int s_lo = change_outer ? sst_at(w, o1.tau, 0) : 0, s_hi = change_outer ? sst_at(w, o2.tau, 1) : 0;
     list_remove(w, i2); list_remove(w, i1);
-    if (!sequence_valid(w, w->outer_sst)) {
+    int seq_ok;
+    if (change_outer) { const int o = outer_sequence(w, o1.tau, o2.tau, 0, s_lo, s_hi); seq_ok = o >= 0; if (seq_ok) w->outer_sst = o; }
+    else seq_ok = sequence_valid(w, w->outer_sst);
+    if (!seq_ok) {
+        w->outer_sst = outer_old;
         list_insert(w, o1); list_insert(w, o2);
         w->accqn_rem += 1;
         return;
@@ -655,9 +707,166 @@ static void step_rem(ora_walker *w)
         w->cfgsign = -get_sign(w);
         accpair_add(w, f, o2.tau - o1.tau);
         if (w->sector == 1) w->acc_rem += 1; else w->wacc_rem += 1;
+        if (change_outer) w->acc_rem_outer += 1;
     } else {
+        w->outer_sst = outer_old;
         list_insert(w, o1); list_insert(w, o2);
     }
+}
+
+/* Trace.F90:2006-2030 is_rempair (diagonal hybridisation) */
+static int is_rempair(const ora_walker *w, const op_t *a, const op_t *b)
+{
+    return a->flav == b->flav && a->ca != b->ca && a->wid == 0 && b->wid == 0
+        && a->tau >= w->wmin && a->tau <= w->wmax && b->tau >= w->wmin && b->tau <= w->wmax
+        && fabs(a->tau - b->tau) <= w->taudiff_max;
+}
+
+static int list_find(const ora_walker *w, const op_t *o)
+{
+    for (int i = 0; i < w->nops; ++i) if (w->ops[i].tau == o->tau && w->ops[i].flav == o->flav && w->ops[i].ca == o->ca && w->ops[i].wid == o->wid) return i;
+    return -1;
+}
+
+/* removable pairs with the operators a and b taken out of the list for the count */
+static int count_pairs_without(ora_walker *w, const op_t *a, const op_t *b)
+{
+    const op_t oa = *a, ob = *b;
+    list_remove(w, list_find(w, &oa)); list_remove(w, list_find(w, &ob));
+    const int n = count_pairs(w, 0, NULL, NULL);
+    list_insert(w, oa); list_insert(w, ob);
+    return n;
+}
+
+/* the sum over the ways a removal of two pairs can take the same four operators out (CTQMC.F90:3684-3772, 4207-4289): o[0] < o[1]
+ * and o[2] < o[3] in time are the two pairs, all four in the list; n_all with all four, n12 / n34 with only the first / second pair */
+static double rempair_factor4(ora_walker *w, const op_t *o, int n_all, int n12, int n34, double *tdf)
+{
+    const op_t *x = NULL, *y = NULL;           /* partner of o[0] and of o[1] in the other pairing */
+    if (is_rempair(w, &o[0], &o[3]) && is_rempair(w, &o[1], &o[2])) { x = &o[3]; y = &o[2]; }
+    else if (is_rempair(w, &o[0], &o[2]) && is_rempair(w, &o[1], &o[3])) { x = &o[2]; y = &o[3]; }
+    if (x) {
+        const int n23 = count_pairs_without(w, &o[0], x);      /* NPairs_only23 (only24) */
+        const int n14 = count_pairs_without(w, &o[1], y);      /* NPairs_only14 (only13) */
+        *tdf = *tdf / 4.0;
+        return (1.0 / (double)n_all) * (1.0 / (double)n12 + 1.0 / (double)n34 + 1.0 / (double)n14 + 1.0 / (double)n23);
+    }
+    *tdf = *tdf / 2.0;
+    return (1.0 / (double)n_all) * (1.0 / (double)n12 + 1.0 / (double)n34);
+}
+
+static void rebuild_minv(ora_walker *w, double **Mnew, int *knew, logval *det);
+static logval minv_logdet(const ora_walker *w);
+
+/* CTQMC.F90:3615-3889 StepAdd4: two pairs at once, the inverse matrices built anew */
+static void step_add4(ora_walker *w)
+{
+    w->try_add4 += 1;
+    op_t o[4]; double tdf = 1.0, tau_ref = 0.0;
+    for (int i = 0; i < 4; ++i) {                        /* pair_OperAdd with N = 4, Trace.F90:3657-3698 */
+        o[i].wid = 0; o[i].ca = (i % 2 == 0) ? 2 : 1;
+        if (i % 2 == 0) {
+            const double width = w->wmax - w->wmin;
+            tau_ref = w->wmin + width * U01(w); o[i].tau = tau_ref; tdf *= width;
+            const int orb = RINT(w, 1, w->p.nd), spin = RINT(w, 1, 2);
+            o[i].flav = 2 * (orb - 1) + (spin - 1);
+        } else {
+            const double tmin = fmax(tau_ref - w->taudiff_max, w->wmin);
+            const double width = fmin(tau_ref + w->taudiff_max, w->wmax) - tmin;
+            o[i].tau = tmin + width * U01(w); tdf *= width;
+            o[i].flav = o[i - 1].flav;
+        }
+    }
+    int equal = 0;
+    for (int i = 0; i < 4; ++i) {
+        for (int j = 0; j < i; ++j) if (o[i].tau == o[j].tau) equal = 1;
+        for (int j = 0; j < w->nops; ++j) if (w->ops[j].tau == o[i].tau) equal = 1;
+    }
+    if (equal) return;                                   /* CTQMC.F90:3790-3803: rejected, no counter */
+    for (int p = 0; p < 4; p += 2) if (o[p].tau > o[p + 1].tau) { op_t t = o[p]; o[p] = o[p + 1]; o[p + 1] = t; }   /* process_OperAdd sorts each pair in time */
+    list_insert(w, o[0]); list_insert(w, o[1]);
+    const int n12 = count_pairs(w, 0, NULL, NULL);
+    list_insert(w, o[2]); list_insert(w, o[3]);
+    const int n34 = count_pairs_without(w, &o[0], &o[1]);
+    const int n_all = count_pairs(w, 0, NULL, NULL);
+    const double rpf = rempair_factor4(w, o, n_all, n12, n34, &tdf);
+
+    if ((w->sector != 1 && !check_equal_time(w, w->sector)) || !sequence_valid(w, w->outer_sst)) {
+        for (int i = 0; i < 4; ++i) list_remove(w, list_find(w, &o[i]));
+        return;
+    }
+    double *Mn[MAXFLAV]; int kn[MAXFLAV]; logval detnew;
+    rebuild_minv(w, Mn, kn, &detnew);                    /* get_InvFullHybr */
+    const logval dold = minv_logdet(w);                  /* get_FullLogDet of the present inverse matrices */
+    const logval detrat = { detnew.log + dold.log, detnew.sign * dold.sign };
+    const logval trnew = full_trace(w, w->outer_sst);
+    const double rnd = U01(w);
+    const double nf2 = (double)(2 * w->p.nd) * (double)(2 * w->p.nd);
+    const double prob = fabs(tdf * nf2 * rpf * exp((trnew.log - w->tr.log) + detrat.log));
+    if (rnd < prob) {
+        for (int f = 0; f < w->nflav; ++f) { free(w->M[f]); w->M[f] = Mn[f]; w->k[f] = kn[f]; }
+        w->det = detnew; w->tr = trnew;
+        w->cfgsign = -get_sign(w);
+        w->acc_add4 += 1;
+    } else {
+        for (int f = 0; f < w->nflav; ++f) free(Mn[f]);
+        for (int i = 0; i < 4; ++i) list_remove(w, list_find(w, &o[i]));
+    }
+}
+
+/* CTQMC.F90:4153-4430 StepRem4 */
+static void step_rem4(ora_walker *w)
+{
+    w->try_rem4 += 1;
+    const int n_old = count_pairs(w, 0, NULL, NULL);
+    if (n_old <= 0) return;
+    op_t o[4]; int i1 = -1, i2 = -1;
+    count_pairs(w, RINT(w, 1, n_old), &i1, &i2);
+    o[0] = w->ops[i1]; o[1] = w->ops[i2];
+    const double W = w->wmax - w->wmin;
+    {
+        const double ta = o[0].ca == 2 ? o[0].tau : o[1].tau;
+        /* hybpairremfactor of the first pair, Trace.F90:4945-4948 */
+        const double f1 = (double)n_old / (W * (fmin(ta + w->taudiff_max, w->wmax) - fmax(ta - w->taudiff_max, w->wmin)));
+        list_remove(w, i2); list_remove(w, i1);
+        const int n34 = count_pairs(w, 0, NULL, NULL);
+        if (n34 <= 0) { list_insert(w, o[0]); list_insert(w, o[1]); return; }
+        count_pairs(w, RINT(w, 1, n34), &i1, &i2);
+        o[2] = w->ops[i1]; o[3] = w->ops[i2];
+        const double tb = o[2].ca == 2 ? o[2].tau : o[3].tau;
+        const double f2 = (double)n34 / (W * (fmin(tb + w->taudiff_max, w->wmax) - fmax(tb - w->taudiff_max, w->wmin)));
+        double tdf = (double)n_old * (double)n34 / f1 / f2;                  /* CTQMC.F90:4195-4196 */
+        list_insert(w, o[0]); list_insert(w, o[1]);
+        const int n12 = count_pairs_without(w, &o[2], &o[3]);
+        const double rpf = rempair_factor4(w, o, n_old, n12, n34, &tdf);
+        for (int i = 0; i < 4; ++i) list_remove(w, list_find(w, &o[i]));
+        if (!sequence_valid(w, w->outer_sst)) { for (int i = 0; i < 4; ++i) list_insert(w, o[i]); return; }
+        double *Mn[MAXFLAV]; int kn[MAXFLAV]; logval detnew;
+        rebuild_minv(w, Mn, kn, &detnew);
+        const logval dold = minv_logdet(w);
+        const logval detrat = { detnew.log + dold.log, detnew.sign * dold.sign };
+        const logval trnew = full_trace(w, w->outer_sst);
+        const double nf2 = (double)((2 * w->p.nd) * (2 * w->p.nd));
+        const double prob = fabs(1.0 / nf2 / tdf / rpf * exp((trnew.log - w->tr.log) + detrat.log));
+        const double rnd = U01(w);
+        if (rnd < prob) {
+            for (int f = 0; f < w->nflav; ++f) { free(w->M[f]); w->M[f] = Mn[f]; w->k[f] = kn[f]; }
+            w->det = detnew; w->tr = trnew;
+            w->cfgsign = -get_sign(w);
+            w->acc_rem4 += 1;
+        } else {
+            for (int f = 0; f < w->nflav; ++f) free(Mn[f]);
+            for (int i = 0; i < 4; ++i) list_insert(w, o[i]);
+        }
+    }
+}
+
+/* the pair move of one step: CTQMC.F90:8441-8449, 8456-8464 (two random numbers, used or not) */
+static void pair_move(ora_walker *w, int add)
+{
+    const int four = !(U01(w) >= w->p.p_4op);
+    if (!four) { const int outer = U01(w) < w->p.p_outer; if (add) step_add(w, outer); else step_rem(w, outer); }
+    else if (add) step_add4(w); else step_rem4(w);
 }
 
 /* Trace.F90:2279-2333 get_InvFullHybr: rebuild every M block as the inverse of F(tau_a_i - tau_c_j), det = prod */
@@ -1177,12 +1386,9 @@ static void one_step(ora_walker *w)
         double r = U01(w);
         double pg = w->p.p_glob, ps = w->p.p_shift, pw = (w->isector != 1) ? w->p.p_worm_ins : 0.0;
         if (r < (1.0 - ps - pg - pw) / 2.0) {
-            (void)U01(w);       /* grnd() >= Percentage4OperatorMove (= 0): always the pair move */
-            (void)U01(w);       /* grnd() <  PercentageOuterMove     (= 0): never an outer move  */
-            step_add(w);
+            pair_move(w, 1);
         } else if (r <= 1.0 - ps - pg - pw) {
-            (void)U01(w); (void)U01(w);
-            step_rem(w);
+            pair_move(w, 0);
         } else if (r <= 1.0 - ps - pg) {
             w->sector = w->isector;
             step_worm_add(w);
@@ -1195,8 +1401,8 @@ static void one_step(ora_walker *w)
         w->cnt_sampling_w += 1;
         double r = U01(w);
         double prep = w->p.p_worm_rep, pins = w->p.p_worm_ins;
-        if (r < (1.0 - prep - pins) / 2.0) { (void)U01(w); (void)U01(w); step_add(w); }
-        else if (r < 1.0 - prep - pins) { (void)U01(w); (void)U01(w); step_rem(w); }
+        if (r < (1.0 - prep - pins) / 2.0) pair_move(w, 1);
+        else if (r < 1.0 - prep - pins) pair_move(w, 0);
         else if (r < 1.0 - pins) step_worm_replace(w);
         else step_worm_rem(w);
     }
@@ -1213,6 +1419,8 @@ static void init_counters(ora_walker *w) /* CTQMC.F90:847-896 */
     w->try_add = w->acc_add = w->accqn_add = w->try_rem = w->acc_rem = w->accqn_rem = 0;
     w->try_glob = w->acc_glob = w->accqn_glob = w->try_shift = w->acc_shift = 0;
     w->cnt_sampling = w->cnt_meas = 0;
+    w->try_add4 = w->acc_add4 = w->try_rem4 = w->acc_rem4 = 0;
+    w->try_add_outer = w->acc_add_outer = w->try_rem_outer = w->acc_rem_outer = 0;
     w->wtry_add = w->wacc_add = w->wtry_rem = w->wacc_rem = 0;
     w->try_wadd = w->acc_wadd = w->accqn_wadd = w->try_wrem = w->acc_wrem = w->accqn_wrem = w->try_wrep = w->acc_wrep = 0;
     w->cnt_sampling_w = w->cnt_meas_w = 0;
@@ -1362,8 +1570,8 @@ int64_t ora_calibrate(ora_walker *w, int list, int phase1pairnum, int phase2taug
     for (;;) {
         ++i;
         double r = U01(w);
-        if (r < (1.0 - ps - pg) / 2.0) { (void)U01(w); (void)U01(w); step_add(w); }
-        else if (r <= 1.0 - ps - pg) { (void)U01(w); (void)U01(w); step_rem(w); }
+        if (r < (1.0 - ps - pg) / 2.0) pair_move(w, 1);
+        else if (r <= 1.0 - ps - pg) pair_move(w, 0);
         else if (r <= 1.0 - ps) step_glob(w);
         else step_shift(w);
         if (i % chunk == 0) {
@@ -2190,6 +2398,11 @@ void ora_get_occ(const ora_walker *w, double *occ, double *rho1, double *rho2)
         }
 }
 double ora_mean_sign(const ora_walker *w) { return w->mean_sign; }
+void ora_get_counters_more(const ora_walker *w, double *o)
+{
+    o[0] = w->try_add4; o[1] = w->acc_add4; o[2] = w->try_rem4; o[3] = w->acc_rem4;
+    o[4] = w->try_add_outer; o[5] = w->acc_add_outer; o[6] = w->try_rem_outer; o[7] = w->acc_rem_outer;
+}
 void ora_get_counters(const ora_walker *w, double *o)
 {
     o[0] = w->try_add; o[1] = w->acc_add; o[2] = w->accqn_add; o[3] = w->try_rem; o[4] = w->acc_rem; o[5] = w->accqn_rem;

@@ -26,7 +26,8 @@ class OraParams(C.Structure):
                 ("worm_meas_giw", C.c_int), ("worm_meas_gtau", C.c_int), ("epsblock", C.c_double), ("accum_gtau", C.c_int),
                 ("meas_susz", C.c_int), ("step_series", C.c_int),
                 ("n2iwb", C.c_int), ("n3iwf", C.c_int), ("n3iwb", C.c_int), ("worm_meas_eq", C.c_int * 6),
-                ("nsym", C.c_int), ("symmoves", C.c_int * 128), ("worm_meas_gsigma", C.c_int)]
+                ("nsym", C.c_int), ("symmoves", C.c_int * 128), ("worm_meas_gsigma", C.c_int),
+                ("p_4op", C.c_double), ("p_outer", C.c_double)]
 
 WORM_EQ_KEYS = ("WormMeasP2iwPH", "WormMeasP2iwPP", "WormMeasP2tauPH", "WormMeasP2tauPP", "WormMeasP3iwPH", "WormMeasP3iwPP")
 WORM_EQ_NAMES = ("p2iw_worm", "p2iwpp_worm", "p2tau_worm", "p2taupp_worm", "p3iw_worm", "p3iwpp_worm")
@@ -100,6 +101,7 @@ def lib():
     L.ora_get_g4leg.argtypes = [vp, dp]; L.ora_get_g4leg.restype = C.c_int
     L.ora_get_accpair.argtypes = [vp, lp]
     L.ora_get_counters.argtypes = [vp, dp]
+    L.ora_get_counters_more.argtypes = [vp, dp]
     L.ora_mean_sign.argtypes = [vp]; L.ora_mean_sign.restype = C.c_double
     L.ora_hybr.argtypes = [dp, C.c_int, C.c_double, C.c_double]; L.ora_hybr.restype = C.c_double
     L.ora_detrat_add.argtypes = [dp, C.c_int, dp, dp, C.c_double]; L.ora_detrat_add.restype = C.c_double
@@ -145,7 +147,8 @@ def params_from_pstring(ps, nd, beta, fourpnt=0):
                      step_series=(1 if ps.get_int("Gtau_mean_step") else 0) | (2 if ps.get_int("Gtau_mid_step") else 0) | (4 if ps.get_int("sign_step") else 0),
                      n2iwb=ps.get_int("N2iwb"), n3iwf=ps.get_int("N3iwf"), n3iwb=ps.get_int("N3iwb"),
                      worm_meas_eq=(C.c_int * 6)(*[int(ps.get_int(k) != 0) for k in WORM_EQ_KEYS]),
-                     nsym=ps.get_int("NSymMove"), symmoves=_symmoves(ps), worm_meas_gsigma=int(ps.get_int("WormMeasGSigmaiw") != 0))
+                     nsym=ps.get_int("NSymMove"), symmoves=_symmoves(ps), worm_meas_gsigma=int(ps.get_int("WormMeasGSigmaiw") != 0),
+                     p_4op=ps.get_real("Percentage4OperatorMove"), p_outer=ps.get_real("PercentageOuterMove"))
 
 
 class OracleWalker:
@@ -245,6 +248,7 @@ class OracleWalker:
         r["outerstatehisto"] = hs[2]; r["signhistostates"] = hs[3]; r["tracecontribstates"] = hs[4]
         r["accpair"] = self.accpair()
         a = np.zeros(13); self.L.ora_get_counters(self.h, a); r["counters"] = a
+        a = np.zeros(8); self.L.ora_get_counters_more(self.h, a); r["counters_more"] = a
         r["mean_sign"] = self.L.ora_mean_sign(self.h)
         occ = np.zeros((nd, 2, nd, 2)); rho1 = np.zeros((2 * nd, 2 * nd))
         rho2 = np.zeros((2 * nd,) * 4) if nd <= 5 else None

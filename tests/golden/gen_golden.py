@@ -63,12 +63,27 @@ TRAJ = {
                               PercentageTauShiftMove=0.05, SymMoves=((1, 0, 3, 2), (1, 2, 3, 0))), 41),
     "C4Ssym": ("C4S", 501, dict(Nwarmups=3000, Nmeas=40, NCorr=100, TaudiffMax=3.0, Ntau=50, NLegMax=10, Niw=4, MeasGiw=1, NLookup_nfft=0, PercentageGlobalMove=0.3,
                                 PercentageTauShiftMove=0.05, SymMoves=((1, 0, 3, 2), (1, 2, 3, 0))), 42),
+    # moves outside the default mix: two pairs at once (Percentage4OperatorMove, StepAdd4 / StepRem4) and pair moves that
+    # change the outer block (PercentageOuterMove); scalar trace path (C1, C3), matrix path (C4S, C4) and both together.  The outer
+    # cases use one window over all of beta: pairs nearly beta apart make the outer moves that are accepted
+    "C3four": ("C3", 501, dict(Nwarmups=4000, Nmeas=40, NCorr=100, TaudiffMax=6.0, Ntau=50, NLegMax=10, Niw=4, MeasGiw=1, NLookup_nfft=0, PercentageGlobalMove=0.05,
+                               PercentageTauShiftMove=0.05, Percentage4OperatorMove=0.3), 51),
+    "C4Sfour": ("C4S", 501, dict(Nwarmups=3000, Nmeas=40, NCorr=100, TaudiffMax=3.0, Ntau=50, NLegMax=10, Niw=4, MeasGiw=1, NLookup_nfft=0, PercentageGlobalMove=0.05,
+                                 PercentageTauShiftMove=0.05, Percentage4OperatorMove=0.3), 52),
+    "C1outer": ("C1", 501, dict(Nwarmups=4000, Nmeas=40, NCorr=100, TaudiffMax=10.0, Ntau=50, NLegMax=10, Niw=4, MeasGiw=1, NLookup_nfft=0, PercentageGlobalMove=0.05,
+                                PercentageTauShiftMove=0.05, PercentageOuterMove=0.3), 53),
+    "C3outer": ("C3", 501, dict(Nwarmups=4000, Nmeas=40, NCorr=100, TaudiffMax=25.0, Ntau=50, NLegMax=10, Niw=4, MeasGiw=1, NLookup_nfft=0, PercentageGlobalMove=0.05,
+                                PercentageTauShiftMove=0.05, PercentageOuterMove=0.3), 54),
+    "C4Souter": ("C4S", 501, dict(Nwarmups=3000, Nmeas=40, NCorr=100, TaudiffMax=10.0, Ntau=50, NLegMax=10, Niw=4, MeasGiw=1, NLookup_nfft=0, PercentageGlobalMove=0.05,
+                                  PercentageTauShiftMove=0.05, PercentageOuterMove=0.3), 55),
+    "C4mix": ("C4", 1001, dict(Nwarmups=5000, Nmeas=40, NCorr=100, TaudiffMax=10.0, Ntau=100, NLegMax=12, Niw=4, MeasGiw=1, NLookup_nfft=0,
+                               Percentage4OperatorMove=0.1, PercentageOuterMove=0.1), 56),
     # BASELINE.json configs[4], Z-space part: 5 orbitals, density-density, beta = 100 (1024 one-state blocks, 10 flavours)
     "C5Z": ("C5Z", 501, dict(Nwarmups=4000, Nmeas=50, NCorr=100, TaudiffMax=10.0, Ntau=100, NLegMax=40, Niw=8, MeasGiw=1,
                              NLookup_nfft=0, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 31),
 }
 
-KEYS = ("gleg", "gtau", "giw", "histo", "occ", "outersuperstatehisto", "accpair", "mean_sign", "accadd", "accrem",
+KEYS = ("gleg", "gtau", "giw", "histo", "occ", "outersuperstatehisto", "accpair", "mean_sign", "accadd", "accrem", "accadd4", "accrem4",
         "accglob", "accshift", "eigenstatesenergies", "densitymatrix", "rho1", "rho2", "statessuperstates",
         # MeasOuterHistograms (CTQMC.F90:3285-3339, normalised 8757-8764); lhisto / rhisto are never filled (8698-8699)
         "signhistosuperstates", "tracecontribsuperstates", "outerstatehisto", "signhistostates", "tracecontribstates",

@@ -33,10 +33,14 @@ AUTO_CASES = ["C4SA", "C4SX", "C4SQ", "C4A", "C3A"]
 SYM_CASES = ["C3sym", "C4Ssym"]       # user symmetry moves in the global move (NSymMove = 2)
 
 
+# moves outside the default mix: Percentage4OperatorMove (StepAdd4 / StepRem4, CTQMC.F90:3615-3889, 4153-4430) and
+# PercentageOuterMove (pair moves that change the outer block, CTQMC.F90:3422-3449, 3935-3962)
+MOVE_CASES = ["C3four", "C4Sfour", "C1outer", "C3outer", "C4Souter", "C4mix"]
+
 BIG_BLOCK_CASES = ["C4N", "C5K"]      # blocks of 9 (3-orbital Kanamori, Nt Szt) and 10 states (5-orbital Kanamori, Nt Szt Qzt)
 
 
-@pytest.mark.parametrize("name", CASES + SCALAR_5ORB + AUTO_CASES + BIG_BLOCK_CASES + SYM_CASES)
+@pytest.mark.parametrize("name", CASES + SCALAR_5ORB + AUTO_CASES + BIG_BLOCK_CASES + SYM_CASES + MOVE_CASES)
 def test_oracle_retraces_reference_chain(name):
     g = util.load_golden("traj_%s.npz" % name)
     over = g["overrides"]
@@ -66,6 +70,16 @@ def test_oracle_retraces_reference_chain(name):
     assert cnt[4] / cnt[3] == pytest.approx(float(g["res_accrem"][0]), rel=1e-12)
     if cnt[6] > 0:
         assert cnt[7] / cnt[6] == pytest.approx(float(g["res_accglob"]), rel=1e-12)
+    if "res_accadd4" in g and over.get("Percentage4OperatorMove", 0) > 0:
+        c4 = r["counters_more"]
+        assert c4[0] > 0 and c4[2] > 0 and c4[1] > 0 and c4[3] > 0
+        assert c4[1] / c4[0] == pytest.approx(float(g["res_accadd4"]), rel=1e-12)
+        assert c4[3] / c4[2] == pytest.approx(float(g["res_accrem4"]), rel=1e-12)
+    if over.get("PercentageOuterMove", 0) > 0:
+        c4 = r["counters_more"]
+        assert c4[4] > 0 and c4[6] > 0
+        if name in ("C1outer", "C4Souter"):      # one window over beta and few operators: outer moves are accepted in both directions
+            assert c4[5] > 10 and c4[7] > 10     # (C3outer, C4mix: other operators of the flavour outside the pair forbid nearly all of them)
     assert rel(r["eigenstatesenergies"], g["res_eigenstatesenergies"]) < 1e-13
     assert rel(np.diag(g["res_densitymatrix"]), r["dm_diag"]) < 1e-10
     for k in ("densitymatrix", "rho1", "rho2"):      # full density matrix (occupation basis) and its contractions
@@ -76,7 +90,9 @@ def test_oracle_retraces_reference_chain(name):
     # they are pinned wherever the two bases coincide (all cases but the 9- and 10-state blocks of C4N / C5K)
     assert rel(r["outerstatehisto"], g["res_outerstatehisto"]) < 1e-12
     assert rel_nan(r["signhistosuperstates"], g["res_signhistosuperstates"]) < 1e-12
-    if name not in BIG_BLOCK_CASES:      # there: rotations inside degenerate multiplets differ (relative differences 1e-4 .. 1, seen)
+    # C4mix: block 9 (two degenerate states, visited at 2 of 40 measurements) - its two per-state entries differ by the rotation,
+    # their sum of moduli by 1 %; every other block agrees to 1e-13
+    if name not in BIG_BLOCK_CASES + ["C4mix"]:      # there: rotations inside degenerate multiplets differ (relative differences 1e-4 .. 1, seen)
         assert rel(r["tracecontribsuperstates"], g["res_tracecontribsuperstates"]) < 1e-9
         assert rel(r["tracecontribstates"], g["res_tracecontribstates"]) < 1e-9
         assert rel_nan(r["signhistostates"], g["res_signhistostates"]) < 1e-12
