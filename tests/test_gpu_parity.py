@@ -84,6 +84,27 @@ def test_chains_retrace_oracle(cfg, nftau, over, seed):
     _retrace(cfg, nftau, over, seed)
 
 
+# moves outside the default mix: two pairs at once (Percentage4OperatorMove, StepAdd4 / StepRem4) and pair moves that change the
+# outer block (PercentageOuterMove); the oracle's branches are pinned on reference runs (traj_C3four ... traj_C4mix).  The
+# outer cases use one window over beta, where such moves are accepted often; C5KB: sequential trace (10-state blocks)
+XM_TRAJ = [
+    ("C1", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=20, TaudiffMax=2.0, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05, Percentage4OperatorMove=0.3), 61),
+    ("C3", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=6.0, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05, Percentage4OperatorMove=0.3), 62),
+    ("C4S", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=3.0, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05, Percentage4OperatorMove=0.3), 63),
+    ("C1", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=20, TaudiffMax=10.0, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05, PercentageOuterMove=0.3), 64),
+    ("C3", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=25.0, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05, PercentageOuterMove=0.3), 65),
+    ("C4S", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=10.0, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05, PercentageOuterMove=0.3), 66),
+    ("C4", 1001, dict(BASE, Nwarmups=4000, Nmeas=10, NCorr=100, TaudiffMax=10.0, NLegMax=20, Ntau=200, Percentage4OperatorMove=0.1, PercentageOuterMove=0.1), 67),
+    ("C5K", 501, dict(BASE, Nwarmups=2000, Nmeas=6, NCorr=50, TaudiffMax=3.0, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05, Percentage4OperatorMove=0.2, PercentageOuterMove=0.2), 68),
+]
+
+
+@pytest.mark.parametrize("cfg,nftau,over,seed", XM_TRAJ, ids=["C1-two-pair-moves", "C3-two-pair-moves", "C4S-two-pair-moves", "C1-outer-moves", "C3-outer-moves",
+                                                             "C4S-outer-moves", "C4-both", "C5K-both-sequential-trace"])
+def test_chains_retrace_oracle_with_two_pair_and_outer_moves(cfg, nftau, over, seed):
+    _retrace(cfg, nftau, over, seed)
+
+
 def test_full_size_run_properties():
     """BASELINE.json's bench configuration at full size (C2, 131072 chains, NCorr = 200, Ntau = 1000, NLegMax = 100,
     Nftau = 5001) through size-independent properties: a chain's trajectory depends on (seed, chain number) only - the
@@ -204,9 +225,9 @@ def _retrace(cfg, nftau, over, seed):
     hbins = {k: getattr(q, k + "_bins") for k in HIST}
     bins = {k: getattr(q, k + "_bins") for k in ("gleg", "gtau", "giw", "histo", "occ")}
     tot = {k: 0.0 for k in bins}
-    msign = 0.0; dm = 0.0; rho1 = 0.0; ssq = None
+    msign = 0.0; dm = 0.0; rho1 = 0.0; ssq = None; cm = np.zeros(8)
     for w, o in enumerate(oracles):
-        o.measure(); r = o.results()
+        o.measure(); r = o.results(); cm += r["counters_more"]
         for k in bins:
             assert rel(bins[k][w], r[k]) < TOL, (k, w)
             if k == "gleg":      # Chebyshev moments turned into Legendre coefficients once per run: every order on its own scale
@@ -224,6 +245,9 @@ def _retrace(cfg, nftau, over, seed):
             sop = r["ssquare_operator"]
         o.close()
     assert q.mean_sign == pytest.approx(msign, abs=1e-12)
+    if over.get("Percentage4OperatorMove", 0) > 0:      # AccAdd4 / AccRem4 pooled over the chains (CTQMC.F90:8677-8678)
+        assert cm[0] > 0 and cm[2] > 0 and cm[1] + cm[3] > 0
+        assert q.accadd4 == pytest.approx(cm[1] / cm[0], rel=1e-12) and q.accrem4 == pytest.approx(cm[3] / cm[2], rel=1e-12)
     if msign == -1.0:
         for k in bins:      # the module-level arrays are the means over chains
             assert rel(getattr(q, k), tot[k]) < TOL, k
@@ -606,8 +630,7 @@ def test_capacity_overflow_inside_measurement_run_is_reported():
 
 def test_unsupported_modes_are_refused():
     p, _, _ = util.setup("C1", 501, {})
-    for over in (dict(segment=1), dict(offdiag=1), dict(statesampling=1), dict(Percentage4OperatorMove=0.1),
-                 dict(PercentageOuterMove=0.1), dict(EnableOuterTruncation="YES")):
+    for over in (dict(segment=1), dict(offdiag=1), dict(statesampling=1), dict(flavourchange_moves=1), dict(EnableOuterTruncation="YES")):
         _, ps, _ = util.setup("C1", 501, over)
         q = MCTQMC(nwalkers=4)
         q.init_rnd(1); q.init_paras(ps)
@@ -615,6 +638,16 @@ def test_unsupported_modes_are_refused():
             q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
         assert e.value.code == -2, over
         q.close()
+    # the moves outside the default mix run in Z space only: worm sampling and the window calibration with them are refused
+    _, ps, _ = util.setup("C1", 501, dict(Percentage4OperatorMove=0.1, WormMeasGiw=1, PercentageWormInsert=0.2, PercentageWormReplace=0.2))
+    q = MCTQMC(nwalkers=4); q.init_rnd(1); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+    with pytest.raises(W2DynError) as e:
+        q.ctqmc_measure(2, 1)
+    assert e.value.code == -2
+    with pytest.raises(W2DynError) as e:
+        q.ctqmc_calibrate(True, 10, 10, 10, 100)
+    assert e.value.code == -2
+    q.close()
     # blocks of more than 8 states are refused: 3-orbital Kanamori with the particle number as the only quantum number
     from w2dynamics_amd import params, synth
     p2 = synth.config("C4", 501)

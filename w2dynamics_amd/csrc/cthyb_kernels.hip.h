@@ -79,7 +79,9 @@ enum Counter { C_TRYADD, C_ACCADD, C_QNADD, C_TRYREM, C_ACCREM, C_QNREM, C_TRYGL
                // worm sampling (sectors 2 and 4): steps and pair moves inside worm space, worm insert / remove / replace
                C_W_SAMPLING, C_W_TRYADD, C_W_ACCADD, C_W_TRYREM, C_W_ACCREM,
                C_TRYWADD, C_ACCWADD, C_QNWADD, C_TRYWREM, C_ACCWREM, C_QNWREM, C_TRYWREP, C_ACCWREP,
+               C_TRYADD4, C_ACCADD4, C_TRYREM4, C_ACCREM4,       // two pairs at once (StepAdd4 / StepRem4)
                C_NCOUNT };
+static_assert(C_NCOUNT <= 64, "one lane per event counter");
 
 enum WalkerErr { ERR_NONE = 0, ERR_KMAX = 1, ERR_WCAP = 2, ERR_DETRAT = 4, ERR_SINGULAR = 8, ERR_BLOCKSEQ = 16 };
 
@@ -144,6 +146,10 @@ struct DevConst {
     // user symmetry moves of the global move (NSymMove, Trace.F90:403-404, 471-478): 2 nsym rows (the listed moves, then their
     // inverses) of nflav entries, 1-based flavour numbers in the order band + Nd * spin
     int nsym; const int *symmoves;
+    // moves outside the default mix (CTQMC.F90:332-333, 8441-8442): probability of a two-pair move in place of a pair move, of a pair
+    // move that may change the outer block; xmoves: either is set (the sweep runs the k_sweep<..., XM = true> kernels, which keep
+    // two free slots per flavour instead of one)
+    double p_4op, p_outer; int xmoves;
     const double *umat;           // U matrix (2Nd)^4 as handed to init_solver (flavour = 2 * orbital + spin): proposal factor of the GSigma worm
     // matrix trace path: the chains of a launch are handed out to the waves from this counter (zeroed before every launch), so
     // that the four waves of a workgroup - which share the staged tables of the local problem - never wait for one another
@@ -577,8 +583,8 @@ __device__ __forceinline__ void accpair_add(Ctx &x, int f, double dt)
 #ifndef ADD_UNROLL
 #define ADD_UNROLL 8
 #endif
-template <int MAT, int WORM = 0, bool CALIB = false>
-__device__ W2DYN_INLINE void step_add(Ctx &x)
+template <int MAT, int WORM = 0, bool CALIB = false, bool XM = false>
+__device__ W2DYN_INLINE void step_add(Ctx &x, bool outer = false)
 {
     const DevConst &C = x.C;
     if (WORM && x.sector != 1) x.count(C_W_TRYADD); else x.count(C_TRYADD);
@@ -602,6 +608,7 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
     bool creator_first = tau2 < tau1;
     bool valid;
     int p_lo = 0, p_hi = 0;                              // MAT: insertion indices of the two operators in the old list
+    int outer_new = x.outer;                             // XM: outer block / outer Fock state after a move that changes it
     if constexpr (MAT) {
         // general blocks: walk the block sequence over the changed span (Trace.F90:1243-1302); equal times are rejected
         bool eq = (tau1 == tau2);
@@ -617,7 +624,18 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
         // i = p_hi: in front of the new later operator) is the old one shifted by the new earlier operator's quantum
         // numbers; the sequence is allowed iff every link is a connection (tsst[j] = block in front of trial entry j)
         bool bad = false;
-        for (int base = p_lo; base <= p_hi; base += 64) {
+        if constexpr (XM) if (outer) {
+            // the blocks between the two operators stay; from the later one over beta to the earlier one the sequence is walked
+            // anew and names the new outer block (check_sst_sequence over beta, Trace.F90:1278-1295; CTQMC.F90:3422-3449)
+            int s = uni(x.osst[p_hi]);
+            s = uni(x.t_conn[s * nf2 + code_hi]);
+            for (int i = p_hi; i < x.nops && s >= 0; ++i) s = uni(x.t_conn[s * nf2 + uni(x.om[i])]);
+            outer_new = s;
+            for (int i = 0; i < p_lo && s >= 0; ++i) s = uni(x.t_conn[s * nf2 + uni(x.om[i])]);
+            if (s >= 0) s = uni(x.t_conn[s * nf2 + code_lo]);
+            bad = !(s >= 0 && s == uni(x.osst[p_lo]));
+        }
+        for (int base = p_lo; base <= p_hi && !(XM && outer); base += 64) {
             const int i = base + x.lane;
             if (i <= p_hi) {
                 const int ci = x.t_shift[x.osst[i] * nf2 + code_lo];
@@ -653,6 +671,21 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
     }
     int occ_lo = ((x.outer >> flav_bit(f, C.nd)) & 1) + c_lo - a_lo;
     valid = !blocked && occ_lo == (creator_first ? 0 : 1);
+    if constexpr (XM) if (outer) {
+        // one-state blocks: the occupation of the flavour changes everywhere BUT between the two operators, which is allowed iff
+        // no operator of the flavour lies outside them and the earlier one fits the new occupation at tau = 0
+        int outside = 0; bool eq = (tau1 == tau2);
+        for (int base = 0; base < k; base += 64) {
+            int e = base + x.lane;
+            bool v = e < k;
+            double tce = v ? tcp[e] : lo, tae = v ? tap[e] : lo;
+            outside += count_pred(v && (tce < lo || tce > hi)) + count_pred(v && (tae < lo || tae > hi));
+            eq |= __ballot(v && (tce == lo || tce == hi || tae == lo || tae == hi)) != 0ull;
+        }
+        const int n0 = (x.outer >> flav_bit(f, C.nd)) & 1;
+        valid = !eq && outside == 0 && creator_first == (n0 == 1);
+        outer_new = x.outer ^ (1 << flav_bit(f, C.nd));
+    }
     }
     DBG_STAMP(x, C_DBG4);
     if (!valid) { x.count(C_QNADD); return; }
@@ -716,11 +749,22 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
         }
         mat_insert(x, p_lo, lo, code_lo); mat_insert(x, p_hi + 1, hi, code_hi);
         x.k_first = p_lo;
-        mat_trace_trial<MAT, (MAT > 4 && WORM == 0)>(x, x.tsst, x.nops, -1, -1, tl_new, ts_new);
+        bool plain = true;
+        if constexpr (XM) if (outer) {
+            plain = false;
+            mat_walk_into(x, outer_new, x.tsst);
+            mat_trace_trial<MAT>(x, x.tsst, x.nops, -1, -1, tl_new, ts_new);
+        }
+        if (plain) mat_trace_trial<MAT, (MAT > 4 && WORM == 0)>(x, x.tsst, x.nops, -1, -1, tl_new, ts_new);
         dlogtr = tl_new - x.tr_log;
     } else {
         double I = level_integral<WORM>(x, f, lo, hi);
         dlogtr = creator_first ? -I : I;
+        if constexpr (XM) if (outer) {
+            // occupied (n0 = 0) or emptied (n0 = 1) on [0, lo) and (hi, beta]
+            const double Ic = level_integral<WORM>(x, f, 0.0, C.beta) - I;
+            dlogtr = ((x.outer >> flav_bit(f, C.nd)) & 1) ? Ic : -Ic;
+        }
     }
     double rnd = x.draw();
 
@@ -801,7 +845,7 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
     }
     if (x.lane == 0) { Mf[(size_t)k * kmax + k] = invS; tcp[k] = tau2; tap[k] = tau1; }
     x.set_order(f, k + 1);
-    if (k + 1 >= kmax) x.err |= ERR_KMAX;              // flavour full: the sweep loop stops before the next step (capacity is enlarged by the host)
+    if (k + 1 >= kmax - (XM ? 1 : 0)) x.err |= ERR_KMAX;   // flavour full (XM: one slot left): the sweep loop stops before the next step (capacity is enlarged by the host)
     wave_sync();
     ACC_STAMP(x, C_DBG1);
     x.det_sign *= (S < 0.0 ? -1.0 : 1.0) * sig;
@@ -811,6 +855,7 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
     window_list_add(x, f, k, tau2, tau1);
     ACC_STAMP(x, C_DBG3);
     if constexpr (MAT) { x.tr_log = tl_new; x.tr_sign = ts_new; mat_commit_sst(x); }
+    if constexpr (XM) if (outer) { x.outer = outer_new; x.pvalid = 0; x.kval = 0; }
     DBG_STAMP(x, C_DBG7);
     if (WORM && x.sector != 1) x.count(C_W_ACCADD); else x.count(C_ACCADD);
     accpair_add<CALIB>(x, f, hi - lo);
@@ -819,8 +864,8 @@ __device__ W2DYN_INLINE void step_add(Ctx &x)
 // ---------------------------------------------------------------------------------------------------------------
 // pair removal: CTQMC.F90:3892-4150 (StepRem), Trace.F90:4851-4950, 2937-2963, MatrixUpdate.F90:445-482
 // ---------------------------------------------------------------------------------------------------------------
-template <int MAT, int WORM = 0, bool CALIB = false>
-__device__ W2DYN_INLINE void step_rem(Ctx &x)
+template <int MAT, int WORM = 0, bool CALIB = false, bool XM = false>
+__device__ W2DYN_INLINE void step_rem(Ctx &x, bool outer = false)
 {
     const DevConst &C = x.C;
     if (WORM && x.sector != 1) x.count(C_W_TRYREM); else x.count(C_TRYREM);
@@ -918,6 +963,7 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
     // so anything between them is in the window list too)
     bool blocked;
     int i1 = 0, i2 = 0;                                // MAT: list indices of the two operators
+    int outer_new = x.outer;                           // XM: outer block / outer Fock state after a move that changes it
     if constexpr (MAT) {
         i1 = mat_lower(x, t1); i2 = mat_lower(x, t2);
         const int nf2 = 2 * C.nflav;
@@ -926,7 +972,18 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
         // may go iff every link of that sequence is a connection (all entries checked at once)
         const int inv1 = uni(x.om[i1]) ^ 1;
         bool bad = false;
-        for (int base = i1 + 1; base <= i2; base += 64) {
+        if constexpr (XM) if (outer) {
+            // the blocks between the two operators stay; the rest of the sequence, from behind the later one over beta to the
+            // earlier one, is walked anew (CTQMC.F90:3935-3962) and written to the trial sequence as it goes
+            int s = uni(x.osst[i2]);
+            for (int i = i2 + 1; i < x.nops; ++i) { if (x.lane == 0) x.tsst[i - 2] = s; if (s >= 0) s = uni(x.t_conn[s * nf2 + uni(x.om[i])]); }
+            outer_new = s;
+            if (x.lane == 0) x.tsst[x.nops - 2] = s;
+            for (int i = 0; i < i1; ++i) { if (x.lane == 0) x.tsst[i] = s; if (s >= 0) s = uni(x.t_conn[s * nf2 + uni(x.om[i])]); }
+            bad = !(s >= 0 && s == uni(x.osst[i1 + 1]));
+            for (int j = i1 + x.lane; j < i2 - 1; j += 64) x.tsst[j] = x.osst[j + 1];
+        }
+        for (int base = i1 + 1; base <= i2 && !(XM && outer); base += 64) {
             const int i = base + x.lane;
             if (i <= i2) {
                 const int ci = x.t_shift[x.osst[i] * nf2 + inv1];        // block in front of old operator i in the trial sequence
@@ -951,6 +1008,18 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
         }
         blocked = between != 0;
     }
+    if constexpr (XM && MAT == 0) if (outer) {
+        // one-state blocks: the occupation changes everywhere but between the two operators: none of the flavour may lie outside
+        int outside = 0;
+        for (int base = 0; base < k; base += 64) {
+            int e = base + x.lane;
+            bool v = e < k;
+            double tce = v ? tcp[e] : t1, tae = v ? tap[e] : t1;
+            outside += count_pred(v && (tce < t1 || tce > t2)) + count_pred(v && (tae < t1 || tae > t2));
+        }
+        blocked = outside != 0;
+        outer_new = x.outer ^ (1 << flav_bit(f, C.nd));
+    }
     if constexpr (WORM != 0 && MAT == 0) {        // one-state blocks: a worm operator of the pair's flavour between its operators blocks the removal
         if (x.sector != 1) {                      // (with larger blocks the list walk above has seen the worm operators already)
 #pragma unroll
@@ -963,6 +1032,13 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
     bool creator_first = tau_c < tau_a;
     double dlogtr, tl_new = 0.0, ts_new = 1.0;
     if constexpr (MAT) {
+        bool plain = true;
+        if constexpr (XM) if (outer) {
+            plain = false;
+            wave_sync();
+            mat_trace_trial<MAT>(x, x.tsst, x.nops - 2, i1, i2, tl_new, ts_new);
+        }
+        if (plain) {
         for (int j = x.lane; j <= x.nops - 2; j += 64) {
             if (j < i1) x.tsst[j] = x.osst[j];
             else if (j >= i2 - 1) x.tsst[j] = x.osst[j + 2];
@@ -970,11 +1046,16 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
         wave_sync();
         x.k_first = i1;
         mat_trace_trial<MAT, (MAT > 4 && WORM == 0)>(x, x.tsst, x.nops - 2, i1, i2, tl_new, ts_new);
+        }
         dlogtr = tl_new - x.tr_log;
     } else {
         // the pair's own operators sit on the boundary of (t1,t2) and belong to flavour f, which level_integral skips
         double I = level_integral<WORM>(x, f, t1, t2);
         dlogtr = creator_first ? I : -I;
+        if constexpr (XM) if (outer) {
+            const double Ic = level_integral<WORM>(x, f, 0.0, C.beta) - I;
+            dlogtr = ((x.outer >> flav_bit(f, C.nd)) & 1) ? Ic : -Ic;
+        }
     }
     double S = uni(Sv);
     double prob = fabs(hybf / (double)(2 * C.nd) * fabs(S) * exp(dlogtr));
@@ -1040,6 +1121,7 @@ __device__ W2DYN_INLINE void step_rem(Ctx &x)
     window_list_rem(x, f, e1, e2, ic, ia, last, tau_c, tau_a);
     ACC_STAMP(x, C_DBG7);
     if constexpr (MAT) { mat_remove(x, i2); mat_remove(x, i1); x.tr_log = tl_new; x.tr_sign = ts_new; mat_commit_sst(x); }
+    if constexpr (XM) if (outer) { x.outer = outer_new; x.pvalid = 0; x.kval = 0; }
     if (WORM && x.sector != 1) x.count(C_W_ACCREM); else x.count(C_ACCREM);
     accpair_add<CALIB>(x, f, t2 - t1);
 }
@@ -1650,12 +1732,13 @@ __device__ __forceinline__ int next_chain(const DevConst &C)
 }
 
 // a chain loaded with a full flavour (set_mc_config with k = kmax) pauses before its first step
-__device__ __forceinline__ void flag_full(Ctx &x)
+__device__ __forceinline__ void flag_full(Ctx &x, int spare = 0)
 {
-    if (__ballot(x.lane < x.C.nflav && x.kreg >= x.C.kmax) != 0ull) x.err |= ERR_KMAX;
+    if (__ballot(x.lane < x.C.nflav && x.kreg >= x.C.kmax - spare) != 0ull) x.err |= ERR_KMAX;
 }
 
 #include "cthyb_worm.hip.h"
+#include "cthyb_xmoves.hip.h"
 
 #ifdef W2DYN_STAMPS
 #define STAMP_KIND(c) which_ = (c)
@@ -1673,7 +1756,8 @@ __device__ __forceinline__ void flag_full(Ctx &x)
 // WPE3: the same kernel held to 168 registers (three waves per SIMD).  With the branch weights below the ~90 spilled
 // registers land mostly in the rare moves, and the step rate rises by 6-10 % for up to three orbitals (C1, C2, C3); with five
 // (C5Z: longer flavour loops everywhere) the spills cost more than the third wave brings.  The host chooses (walker_launch).
-template <int MAT, bool CALIB = false, bool WPE3 = false>
+// XM: the moves outside the default mix (two pairs at once, pair moves that change the outer block; cthyb_xmoves.hip.h)
+template <int MAT, bool CALIB = false, bool WPE3 = false, bool XM = false>
 __global__ __launch_bounds__(256, MAT == 0 ? (WPE3 ? 3 : W2DYN_WPE) : W2DYN_WPE_MAT) void k_sweep(DevConst C, long long nsteps_launch, int count_sampling, int resume)
 {
     extern __shared__ unsigned char smem[];
@@ -1695,7 +1779,7 @@ __global__ __launch_bounds__(256, MAT == 0 ? (WPE3 ? 3 : W2DYN_WPE) : W2DYN_WPE_
     const long long nsteps = launch_steps(C, x.w, x.lane, nsteps_launch, resume);
     if (nsteps == 0) continue;
     ctx_load(x);
-    flag_full(x);
+    flag_full(x, XM ? 1 : 0);
     if constexpr (MAT != 0) mat_trace_current<MAT>(x);
     const double pg = C.p_glob, ps = C.p_shift;
     // position inside the window-shift period: (TryAdd+TryRem) mod NSlide (CTQMC.F90:8255, 8531)
@@ -1732,6 +1816,24 @@ __global__ __launch_bounds__(256, MAT == 0 ? (WPE3 ? 3 : W2DYN_WPE) : W2DYN_WPE_
                 step_shift<MAT>(x);
 #endif
                 STAMP_KIND(C_CYC_SHIFT); }
+        } else if constexpr (XM) {
+            // CTQMC.F90:8441-8449, 8456-8464: a two-pair move with probability Percentage4OperatorMove, else the pair move,
+            // which may change the outer block with probability PercentageOuterMove
+            const bool add = r < (1.0 - ps - pg) / 2.0;
+            if (add || r <= 1.0 - ps - pg) {
+                if (x.draw() >= C.p_4op) {
+                    const bool outer = x.draw() < C.p_outer;
+                    if (add) step_add<MAT, 0, false, true>(x, outer); else step_rem<MAT, 0, false, true>(x, outer);
+                    phase += 1;
+                } else if (add) step_add4<MAT>(x); else step_rem4<MAT>(x);
+                STAMP_KIND(add ? C_CYC_ADD : C_CYC_REM);
+            } else if (r <= 1.0 - ps) {
+                if constexpr (MAT != 0) step_glob_mat<MAT>(x); else step_glob(x);
+                STAMP_KIND(C_CYC_GLOB);
+            } else {
+                step_shift<MAT>(x);
+                STAMP_KIND(C_CYC_SHIFT);
+            }
         } else {
             if (r < (1.0 - ps - pg) / 2.0) { x.skip(2);
 #ifndef W2DYN_NO_ADD

@@ -21,6 +21,10 @@ void launch_sweep_scalar(bool calib, const LaunchCfg &l, const DevConst &C, long
 void launch_sweep_scalar3(const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling, int resume);    // tu_scalar3.hip
 void launch_sweep_tree(int mat, bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling, int resume);
 void launch_sweep_seq(bool calib, const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling, int resume);
+// the same sweeps with the moves outside the default mix (tu_x_*.hip)
+void launch_sweep_x_scalar(const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling, int resume);
+void launch_sweep_x_tree(int mat, const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling, int resume);
+void launch_sweep_x_seq(const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling, int resume);
 void launch_sweep_worm_scalar(int nworm, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume);
 void launch_sweep_worm_tree(int nworm, int mat, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume);
 void launch_sweep_worm_seq(int nworm, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume);

@@ -107,6 +107,7 @@ struct w2dyn_solver {
     int nd = 0, nflav = 0, nstates = 0, nftau = 0, ntau = 0, nleg = 0, niw = 0, meas_giw = 0, ncorr = 0, maxhisto = 0;
     int64_t nmeas = 0;
     double beta = 0, p_glob = 0, p_shift = 0, taudiffmax_param = 0;
+    double p_4op = 0, p_outer = 0;       // Percentage4OperatorMove, PercentageOuterMove
     int has_szt = 0;
     std::vector<double> energies, udd, eps, outer_w, outer_cum, ftab;
     double egs = 0;
@@ -458,7 +459,12 @@ static LaunchCfg queue_launch(const LaunchCfg &l, const DevConst &C)
 void launch_sweep(int mat, bool calib, const LaunchCfg &l0, const DevConst &C, long long nsteps, int count, int resume)
 {
     const LaunchCfg l = mat ? queue_launch(l0, C) : l0;
-    if (mat == 0) launch_sweep_scalar(calib, l, C, nsteps, count, resume);
+    if (C.xmoves && !calib) {
+        if (mat == 0) launch_sweep_x_scalar(l, C, nsteps, count, resume);
+        else if (mat <= 4) launch_sweep_x_tree(mat, l, C, nsteps, count, resume);
+        else launch_sweep_x_seq(l, C, nsteps, count, resume);
+    }
+    else if (mat == 0) launch_sweep_scalar(calib, l, C, nsteps, count, resume);
     else if (mat <= 4) launch_sweep_tree(mat, calib, l, C, nsteps, count, resume);
     else launch_sweep_seq(calib, l, C, nsteps, count, resume);
 }
@@ -574,11 +580,11 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
         if (!get_int(s, z.key, iv)) return W2DYN_EINVAL;
         if (iv != z.allowed) return fail(s, W2DYN_EUNSUPPORTED, "%s = %lld is not supported by the HIP solver (only %lld)", z.key, iv, z.allowed);
     }
-    const char *zero_real[] = {"Percentage4OperatorMove", "PercentageOuterMove"};
-    for (auto key : zero_real) {
-        if (!get_real(s, key, rv)) return W2DYN_EINVAL;
-        if (rv != 0.0) return fail(s, W2DYN_EUNSUPPORTED, "%s = %g is not supported by the HIP solver (only 0)", key, rv);
-    }
+    // moves outside the default mix (CTQMC.F90:332-333): two pairs at once, pair moves that change the outer block
+    if (!get_real(s, "Percentage4OperatorMove", s->p_4op)) return W2DYN_EINVAL;
+    if (!get_real(s, "PercentageOuterMove", s->p_outer)) return W2DYN_EINVAL;
+    if (s->p_4op < 0.0 || s->p_4op > 1.0 || s->p_outer < 0.0 || s->p_outer > 1.0)
+        return fail(s, W2DYN_EINVAL, "Percentage4OperatorMove = %g, PercentageOuterMove = %g: probabilities", s->p_4op, s->p_outer);
     if (!get_str(s, "EnableOuterTruncation", sv)) return W2DYN_EINVAL;
     if (sv == "YES") return fail(s, W2DYN_EUNSUPPORTED, "EnableOuterTruncation = YES is not supported");
     if (s->fourpnt & ~15)
@@ -736,6 +742,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     }
     { int rc0 = configure_kmax(s, kmax); if (rc0) return rc0; }
     C.beta = s->beta; C.rbeta = 1.0 / s->beta; C.p_glob = s->p_glob; C.p_shift = s->p_shift; C.egs = s->egs;
+    C.p_4op = s->p_4op; C.p_outer = s->p_outer; C.xmoves = (s->p_4op > 0.0 || s->p_outer > 0.0) ? 1 : 0;
     C.seed = (unsigned long long)s->seed; C.first_walker = (unsigned long long)s->first_walker;
     host_init_window(s, s->taudiffmax_param, C.num_windows, C.taudiff_max);           // Trace.F90:605
     C.nslide = std::max(2 * nd, (int)std::floor((double)s->ncorr / (double)C.num_windows));   // CTQMC.F90:8069
@@ -1028,6 +1035,7 @@ int w2dyn_ctqmc_calibrate(w2dyn_solver *s, int list, int phase1pairnum, int phas
 {
     if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "ctqmc_calibrate before init_solver");
     if (phase1pairnum < 1 || phase2taugrid < 1 || phase2pairnum < 0 || nprogress < 1) return fail(s, W2DYN_EINVAL, "ctqmc_calibrate: bad arguments");
+    if (s->C.xmoves) return fail(s, W2DYN_EUNSUPPORTED, "ctqmc_calibrate with Percentage4OperatorMove or PercentageOuterMove > 0 is not supported: calibrate the window with both at 0 and hand it over with set_taudiffmax");
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->stream));
     DevConst &C = s->C; const size_t W = s->nwalkers, nf = s->nflav;
@@ -1489,6 +1497,8 @@ int w2dyn_measure_finish(w2dyn_solver *s)
         R["accwormadd"] = wa; R["accwormrem"] = wr; R["accwormrep"] = wp;
         R["accadd"] = aa; R["accrem"] = ar;
         R["accglob"] = {s->counters[C_ACCGLOB] / s->counters[C_TRYGLOB]};
+        R["accadd4"] = {s->counters[C_ACCADD4] / s->counters[C_TRYADD4]};      // CTQMC.F90:8677-8678 (0/0 when the moves are off)
+        R["accrem4"] = {s->counters[C_ACCREM4] / s->counters[C_TRYREM4]};
         R["accshift"] = {s->counters[C_ACCSHIFT] / s->counters[C_TRYSHIFT]};
     }
     if (s->acc_susz && true) {      // CTQMC.F90:8744-8746: ntau_n0 * zScaling, point Ntau = point 0
@@ -1704,6 +1714,8 @@ int w2dyn_measure_finish(w2dyn_solver *s)
 // sector bookkeeping shared by ctqmc_measure and count_steps: every chain starts in Z space (CTQMC.F90:6328, 8400)
 static int enter_sector(w2dyn_solver *s, int isector, int icomponent)
 {
+    if (isector != 1 && s->C.xmoves)
+        return fail(s, W2DYN_EUNSUPPORTED, "worm sampling with Percentage4OperatorMove or PercentageOuterMove > 0 is not supported (the worm kernels make the default pair moves only)");
     if (isector != 1 && isector != 2 && isector != 3 && isector != 4 && !(isector >= 6 && isector <= 9))
         return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d is not supported (1 = Z, 2 = one-particle, 3 = GSigma, 4 = two-particle Green's function, 6 - 9 = P2 / P2pp / P3 / P3pp)", isector);
     if (isector == 3) {
@@ -2109,7 +2121,8 @@ int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out)
     else if (n == "time_sim_steps") *out = s->time_sim_steps;
     else if (n == "accglob") *out = first("accglob");
     else if (n == "accshift") *out = first("accshift");
-    else if (n == "accadd4" || n == "accrem4" || n == "accflavc") *out = NAN;     // 0/0 in the reference when unused
+    else if (n == "accadd4" || n == "accrem4") *out = first(name);
+    else if (n == "accflavc") *out = NAN;     // 0/0 in the reference when unused
     else if (n == "nwalkers") *out = s->nwalkers;
     else if (n == "nbins") *out = s->C.nbins;
     else if (n == "kmax") *out = s->C.kmax;
