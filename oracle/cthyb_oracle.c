@@ -46,6 +46,9 @@ struct ora_walker {
     /* configuration */
     op_t *ops; int nops, cap;
     double *M[MAXFLAV]; int k[MAXFLAV];
+    /* offdiag = 1: ONE matrix over all flavours, rows = creators, columns = annihilators, each ordered by flavour, then time
+     * (MInv_full, Trace.F90:2690-2770); F(tau) with both flavour indices [annihilator flavour][creator flavour][nftau] */
+    double *Mf; int kt; double *ffull; double *gleg_full, *gtau_full;
     int outer_sst;
     logval det, tr;
     double cfgsign;
@@ -455,8 +458,10 @@ static double worm_sign(const ora_walker *w)
     return (perm & 1) ? -1.0 : 1.0;
 }
 
+static double recalc_sign(const ora_walker *w);
 static double get_sign(const ora_walker *w)
 {
+    if (w->p.offdiag) return w->tr.sign * w->det.sign * recalc_sign(w) * worm_sign(w);      /* Trace.F90:3483-3486 */
     return w->tr.sign * w->det.sign * block_sign(w) * permaltca(w) * worm_sign(w);
 }
 
@@ -509,7 +514,7 @@ static int count_pairs(const ora_walker *w, int pick, int *i1, int *i2)
         if (a->wid) continue;
         for (int j = i + 1; j < w->nops; ++j) {
             const op_t *b = &w->ops[j];
-            if (b->flav != a->flav) continue;
+            if (b->flav != a->flav && !w->p.offdiag) continue;          /* offdiag: any flavours (Trace.F90:1820-1865) */
             if (b->tau > w->wmax) break;
             if (b->tau > a->tau + w->taudiff_max) break;
             if (b->wid == 0 && b->ca != a->ca) {
@@ -861,11 +866,173 @@ static void step_rem4(ora_walker *w)
     }
 }
 
+/* ------------------------------------------------------------------------------------------------------- */
+/* off-diagonal hybridisation (offdiag = 1, fast updates): one inverse matrix over all flavours              */
+/* ------------------------------------------------------------------------------------------------------- */
+static double hybr_full(const ora_walker *w, int f1, int f2, double dtau)      /* get_HybrF_full(tau, b1, s1, b2, s2), Trace.F90:1038-1057 */
+{
+    return ora_hybr(w->ffull + ((size_t)f1 * w->nflav + f2) * w->p.nftau, w->p.nftau, w->p.beta, dtau);
+}
+
+/* row (creator) or column (annihilator) of operator idx in the full matrix: flavours in ascending order, time inside (add_ftau_offset, Trace.F90:3002-3040) */
+static int od_rank(const ora_walker *w, int idx)
+{
+    const op_t *o = &w->ops[idx]; int r = 0;
+    for (int i = 0; i < w->nops; ++i) {
+        const op_t *e = &w->ops[i];
+        if (i == idx || e->wid || e->ca != o->ca) continue;
+        if (e->flav < o->flav || (e->flav == o->flav && i < idx)) ++r;
+    }
+    return r;
+}
+
+/* get_FullHybr_offdiag + get_MatLogDetFull (Trace.F90:2690-2770): the inverse of F(tau_a - tau_c; flavour of a, flavour of c) */
+static void rebuild_full(const ora_walker *w, double **Mnew, int *ktnew, logval *det)
+{
+    int kt = 0;
+    for (int i = 0; i < w->nops; ++i) if (w->ops[i].wid == 0 && w->ops[i].ca == 1) ++kt;
+    *ktnew = kt; det->log = 0.0; det->sign = 1.0;
+    *Mnew = (double *)malloc(sizeof(double) * (size_t)(kt * kt + 1));
+    if (kt == 0) return;
+    int *ic = (int *)malloc(sizeof(int) * kt), *ia = (int *)malloc(sizeof(int) * kt); int nc = 0, na = 0;
+    for (int f = 0; f < w->nflav; ++f) for (int i = 0; i < w->nops; ++i) {
+        if (w->ops[i].wid || w->ops[i].flav != f) continue;
+        if (w->ops[i].ca == 1) ic[nc++] = i; else ia[na++] = i;
+    }
+    double *F = (double *)malloc(sizeof(double) * (size_t)kt * kt);
+    for (int a = 0; a < kt; ++a) for (int c = 0; c < kt; ++c)
+        F[a * kt + c] = hybr_full(w, w->ops[ia[a]].flav, w->ops[ic[c]].flav, w->ops[ia[a]].tau - w->ops[ic[c]].tau);
+    ora_inverse_logdet(F, kt, &det->log, &det->sign);      /* F^-1 [creator][annihilator] */
+    memcpy(*Mnew, F, sizeof(double) * (size_t)kt * kt);
+    free(F); free(ic); free(ia);
+}
+
+/* recalc_sign, Trace.F90:3500-3545: parity of the permutation that sorts the hybridising operators from time order into
+ * the order (creators first; flavour, time descending), times (-1)^(1 + 2 + ... + (n/2 - 1)) */
+static double recalc_sign(const ora_walker *w)
+{
+    int n = 0; double *key = (double *)malloc(sizeof(double) * (size_t)(w->nops + 1));
+    for (int i = 0; i < w->nops; ++i) {
+        const op_t *e = &w->ops[i];
+        if (e->wid) continue;
+        key[n++] = (double)(3 - e->ca) * 100000.0 + (double)((e->flav >> 1) + 1) * 10000.0 + (double)((e->flav & 1) + 1) * 1000.0 + e->tau;
+    }
+    long perm = 0;
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j)
+        if (key[i] > key[j]) { const double t = key[i]; key[i] = key[j]; key[j] = t; ++perm; }
+    for (int i = 1; i <= n / 2 - 1; ++i) perm += i;
+    free(key);
+    return (perm % 2) ? -1.0 : 1.0;
+}
+
+/* StepAdd with offdiag (CTQMC.F90:3353-3612): the two flavours are drawn independently (pair_OperAdd, force_diagonal = false) */
+static void step_add_od(ora_walker *w)
+{
+    w->try_add += 1;
+    const double width1 = w->wmax - w->wmin;
+    const double tau1 = w->wmin + width1 * U01(w);                 /* annihilator */
+    const int orb1 = RINT(w, 1, w->p.nd), spin1 = RINT(w, 1, 2);
+    const double tmin = fmax(tau1 - w->taudiff_max, w->wmin);
+    const double width2 = fmin(tau1 + w->taudiff_max, w->wmax) - tmin;
+    const double tau2 = tmin + width2 * U01(w);                    /* creator */
+    const int orb2 = RINT(w, 1, w->p.nd), spin2 = RINT(w, 1, 2);
+    const double taudiff_factor = width1 * width2;
+    const int fa = 2 * (orb1 - 1) + (spin1 - 1), fc = 2 * (orb2 - 1) + (spin2 - 1);
+    int equal = (tau1 == tau2);
+    for (int i = 0; i < w->nops && !equal; ++i) if (w->ops[i].tau == tau1 || w->ops[i].tau == tau2) equal = 1;
+    if (equal) { w->accqn_add += 1; return; }
+    op_t oa = { tau1, fa, 2, 0 }, oc = { tau2, fc, 1, 0 };
+    list_insert(w, oa); list_insert(w, oc);
+    const int ia = list_find(w, &oa), ic = list_find(w, &oc);
+    if (!sequence_valid(w, w->outer_sst)) {
+        list_remove(w, ia > ic ? ia : ic); list_remove(w, ia > ic ? ic : ia);
+        w->accqn_add += 1;
+        return;
+    }
+    /* get_LogDetRatPairAdd_full, Trace.F90:2835-2932 (index order of the three look-ups as written there) */
+    const int kt = w->kt;
+    double *Q = (double *)malloc(sizeof(double) * (size_t)(kt + 1)), *R = (double *)malloc(sizeof(double) * (size_t)(kt + 1));
+    const double S0 = hybr_full(w, fa, fc, tau1 - tau2);
+    int iq = 0, ir = 0;
+    for (int f = 0; f < w->nflav; ++f) {
+        for (int i = 0; i < w->nops; ++i) {
+            const op_t *e = &w->ops[i];
+            if (e->wid || e->flav != f || e->ca != 2 || i == ia) continue;
+            Q[iq++] = hybr_full(w, fc, f, e->tau - tau2);
+        }
+        for (int i = 0; i < w->nops; ++i) {
+            const op_t *e = &w->ops[i];
+            if (e->wid || e->flav != f || e->ca != 1 || i == ic) continue;
+            R[ir++] = hybr_full(w, fa, f, tau1 - e->tau);
+        }
+    }
+    const double S = ora_detrat_add(w->Mf, kt, Q, R, S0);
+    const int pc = od_rank(w, ic), pa = od_rank(w, ia);
+    const double sig = ((abs(pc - pa) % 2) == 0) ? 1.0 : -1.0;
+    const logval detrat = { log(fabs(S)), (S < 0 ? -1.0 : 1.0) * sig };
+    const logval trnew = full_trace(w, w->outer_sst);
+    const double rnd = U01(w);
+    const int npairs = count_pairs(w, 0, NULL, NULL);
+    const double nf2 = (double)((2 * w->p.nd) * (2 * w->p.nd));
+    const double prob = fabs(taudiff_factor * nf2 / (double)npairs * exp((trnew.log - w->tr.log) + detrat.log));
+    if (rnd < prob) {
+        double *Mn = (double *)malloc(sizeof(double) * (size_t)(kt + 1) * (kt + 1));
+        ora_mat_add(w->Mf, kt, Q, R, S, pc, pa, Mn);
+        free(w->Mf); w->Mf = Mn; w->kt = kt + 1;
+        w->det.log += detrat.log; w->det.sign *= detrat.sign;
+        w->tr = trnew;
+        w->cfgsign = -get_sign(w);
+        w->acc_add += 1;
+        accpair_add(w, tau1 < tau2 ? fa : fc, fabs(tau2 - tau1));          /* flavour of the earlier operator (CTQMC.F90:3579) */
+    } else {
+        list_remove(w, ia > ic ? ia : ic); list_remove(w, ia > ic ? ic : ia);
+    }
+    free(Q); free(R);
+}
+
+/* StepRem with offdiag (CTQMC.F90:3892-4150) */
+static void step_rem_od(ora_walker *w)
+{
+    w->try_rem += 1;
+    const int np = count_pairs(w, 0, NULL, NULL);
+    if (np <= 0) { w->accqn_rem += 1; return; }
+    int i1 = -1, i2 = -1;
+    count_pairs(w, RINT(w, 1, np), &i1, &i2);
+    const op_t o1 = w->ops[i1], o2 = w->ops[i2];
+    const int ic = (o1.ca == 1) ? i1 : i2, ia = (o1.ca == 2) ? i1 : i2;
+    const int pc = od_rank(w, ic), pa = od_rank(w, ia);
+    const double ta = w->ops[ia].tau; const int fcre = w->ops[ic].flav;
+    const double hybpairremfactor = (double)np / ((w->wmax - w->wmin)
+        * (fmin(ta + w->taudiff_max, w->wmax) - fmax(ta - w->taudiff_max, w->wmin)));
+    list_remove(w, i2); list_remove(w, i1);
+    if (!sequence_valid(w, w->outer_sst)) { list_insert(w, o1); list_insert(w, o2); w->accqn_rem += 1; return; }
+    const int kt = w->kt;
+    const double S = w->Mf[pc * kt + pa];
+    const double sig = ((abs(pc - pa) % 2) == 0) ? 1.0 : -1.0;
+    const logval detrat = { log(fabs(S)), (S < 0 ? -1.0 : 1.0) * sig };
+    const logval trnew = full_trace(w, w->outer_sst);
+    const double nf2 = (double)((2 * w->p.nd) * (2 * w->p.nd));
+    const double prob = fabs(hybpairremfactor / nf2 * exp((trnew.log - w->tr.log) + detrat.log));
+    const double rnd = U01(w);
+    if (rnd < prob) {
+        if (fabs(detrat.sign * exp(detrat.log)) < 1e-12) { fprintf(stderr, "DetRat too small in removal\n"); abort(); }
+        double *Mn = (double *)malloc(sizeof(double) * (size_t)((kt - 1) * (kt - 1) + 1));
+        ora_mat_rem(w->Mf, kt, pc, pa, Mn);
+        free(w->Mf); w->Mf = Mn; w->kt = kt - 1;
+        w->det.log += detrat.log; w->det.sign *= detrat.sign;
+        w->tr = trnew;
+        w->cfgsign = -get_sign(w);
+        accpair_add(w, fcre, o2.tau - o1.tau);                             /* flavour of the creator (CTQMC.F90:4114-4122) */
+        w->acc_rem += 1;
+    } else { list_insert(w, o1); list_insert(w, o2); }
+}
+
 /* the pair move of one step: CTQMC.F90:8441-8449, 8456-8464 (two random numbers, used or not) */
 static void pair_move(ora_walker *w, int add)
 {
     const int four = !(U01(w) >= w->p.p_4op);
-    if (!four) { const int outer = U01(w) < w->p.p_outer; if (add) step_add(w, outer); else step_rem(w, outer); }
+    if (!four && w->p.offdiag) { (void)U01(w); if (add) step_add_od(w); else step_rem_od(w); }
+    else if (!four) { const int outer = U01(w) < w->p.p_outer; if (add) step_add(w, outer); else step_rem(w, outer); }
     else if (add) step_add4(w); else step_rem4(w);
 }
 
@@ -1009,6 +1176,22 @@ static void step_glob(ora_walker *w)
         w->accqn_glob += 1;
         return;
     }
+    if (w->p.offdiag) {                                /* CTQMC.F90:4491-4494: DetRat = DetNew / Det */
+        double *Mfn; int ktn; logval detnew;
+        rebuild_full(w, &Mfn, &ktn, &detnew);
+        const logval trnew = full_trace(w, w->outer_sst);
+        const double rnd = U01(w);
+        if (rnd < fabs(exp((trnew.log - w->tr.log) + (detnew.log - w->det.log)) * sst_factor)) {
+            free(w->Mf); w->Mf = Mfn; w->kt = ktn; w->det = detnew; w->tr = trnew;
+            w->cfgsign = -get_sign(w);
+            w->acc_glob += 1;
+        } else {
+            free(Mfn);
+            w->outer_sst = outer_old; memcpy(w->ops, saved, sizeof(op_t) * (size_t)w->nops);
+        }
+        free(saved);
+        return;
+    }
     double *Mn[MAXFLAV]; int kn[MAXFLAV]; logval detnew;
     rebuild_minv(w, Mn, kn, &detnew);
     logval dold = minv_logdet(w);
@@ -1083,7 +1266,29 @@ static void step_shift(ora_walker *w)
     if (rnd < fabs(trnew.sign * w->tr.sign * exp(trnew.log - w->tr.log))) {
         w->tr = trnew;
         double detrat = 1.0;
-        for (int f = 0; f < nf; ++f) {
+        if (w->p.offdiag) {                            /* update_InvFullHybrShiftTau_offdiag, Trace.F90:2462-2601 */
+            int nc[MAXFLAV], na[MAXFLAV], offc[MAXFLAV + 1], offa[MAXFLAV + 1];
+            for (int f = 0; f < nf; ++f) nc[f] = na[f] = 0;
+            for (int i = 0; i < n; ++i) if (w->ops[i].ca == 1) nc[w->ops[i].flav] += 1; else na[w->ops[i].flav] += 1;
+            offc[0] = offa[0] = 0;
+            for (int f = 0; f < nf; ++f) { offc[f + 1] = offc[f] + nc[f]; offa[f + 1] = offa[f] + na[f]; }
+            const int kt = w->kt;
+            double *Mn = (double *)malloc(sizeof(double) * (size_t)(kt * kt + 1));
+            for (int fr = 0; fr < nf; ++fr) for (int fc = 0; fc < nf; ++fc) {
+                const int sR = nc[fr], sC = na[fc], wr = wrapped[fr][1], wcol = wrapped[fc][2];
+                for (int i = 0; i < sR; ++i) for (int j = 0; j < sC; ++j) {
+                    const int io = (i + wr) % sR, jo = (j + wcol) % sC;
+                    const double sg = ((i >= sR - wr) ? -1.0 : 1.0) * ((j >= sC - wcol) ? -1.0 : 1.0);
+                    Mn[(offc[fr] + i) * kt + offa[fc] + j] = sg * w->Mf[(offc[fr] + io) * kt + offa[fc] + jo];
+                }
+            }
+            free(w->Mf); w->Mf = Mn;
+            for (int f = 0; f < nf; ++f) {
+                if ((nc[f] * wrapped[f][1]) % 2) detrat = -detrat;
+                if ((na[f] * wrapped[f][2]) % 2) detrat = -detrat;
+            }
+        }
+        for (int f = 0; f < nf && !w->p.offdiag; ++f) {
             int k = w->k[f], wc = wrapped[f][1], wa = wrapped[f][2];
             if (!((wc == 0 && wa == 0) || (wc == k && wa == k))) {
                 double *Mn = (double *)malloc(sizeof(double) * (size_t)k * k);
@@ -1461,6 +1666,13 @@ ora_walker *ora_create(const ora_params *p, const double *U, const double *ftau_
         memcpy(w->ftab + (size_t)(2 * b + s) * nft,
                ftau_full + ((((size_t)b * 2 + s) * nd + b) * 2 + s) * nft, sizeof(double) * (size_t)nft);
     for (int f = 0; f < w->nflav; ++f) { w->M[f] = (double *)malloc(sizeof(double)); w->k[f] = 0; }
+    w->Mf = (double *)malloc(sizeof(double)); w->kt = 0;
+    if (p->offdiag) {      /* HybrF_full(b1,s1,b2,s2,:) as handed over (CTQMC.F90:7950-7955) */
+        const size_t nn = (size_t)w->nflav * w->nflav * nft;
+        w->ffull = (double *)malloc(sizeof(double) * nn); memcpy(w->ffull, ftau_full, sizeof(double) * nn);
+        w->gleg_full = (double *)calloc((size_t)w->nflav * w->nflav * p->nlegmax, sizeof(double));
+        w->gtau_full = (double *)calloc((size_t)w->nflav * w->nflav * p->ntau, sizeof(double));
+    }
     w->accpair = (int64_t *)calloc((size_t)w->nflav * p->ntau, sizeof(int64_t));
     w->naccpair = p->ntau; w->accpair_max = p->beta;
     w->gleg = (double *)calloc((size_t)w->nflav * p->nlegmax, sizeof(double));
@@ -1529,6 +1741,7 @@ void ora_destroy(ora_walker *w)
 {
     if (!w) return;
     for (int f = 0; f < w->nflav; ++f) free(w->M[f]);
+    free(w->Mf); free(w->ffull); free(w->gleg_full); free(w->gtau_full);
     free(w->ops); free(w->ftab); ora_locprob_free(w->lp); free(w->ptr); free(w->dmblk); free(w->dmoff); free(w->accpair); free(w->accpairtau); free(w->gleg); free(w->gtau); free(w->giw); free(w->ntau_n0); free(w->gms); free(w->gmid); free(w->sstep);
     free(w->histo); free(w->dm); free(w->outer_histo); free(w->sign_sst); free(w->tcontrib_sst); free(w->outer_state_histo); free(w->sign_state); free(w->tcontrib_state); free(w->g2iw); free(w->g4iw); free(w->g4iwpp); free(w->g4w); free(w->g4wpp); free(w->g4tau); free(w->g4leg); free(w->giww); free(w->gtauw); free(w->gsw); free(w->umat); for (int q = 0; q < 6; ++q) free(w->weq[q]); free(w->acbuf); free(w->acdat); free(w);
 }
@@ -1947,10 +2160,43 @@ void ora_measure_once(ora_walker *w)
     }
     for (int f = 0; f < nf; ++f) {                                      /* MeasExpOrder, 3264-3282 */
         int k = w->k[f], last = w->p.maxhisto;
+        if (w->p.offdiag) { k = 0; for (int i = 0; i < w->nops; ++i) if (w->ops[i].flav == f && w->ops[i].wid == 0) ++k; k /= 2; }      /* NOSOper / 2 */
         w->histo[(size_t)f * (last + 1) + (k < last ? k : last)] += 1.0;
     }
     meas_densitymatrix(w);
     if (w->isector != 1) return;                                        /* component sampling: no Z estimators (8554) */
+    if (w->p.offdiag) {                                                 /* MeasGtauRem_full, CTQMC.F90:2475-2584 */
+        const int kt = w->kt, nleg = w->p.nlegmax, ntau = w->p.ntau; const double beta = w->p.beta;
+        int pc = 0;
+        for (int f1 = 0; f1 < nf; ++f1) for (int i = 0; i < w->nops; ++i) {
+            const op_t *c = &w->ops[i];
+            if (c->wid || c->flav != f1 || c->ca != 1) continue;
+            int pa = 0;
+            for (int f2 = 0; f2 < nf; ++f2) for (int j = 0; j < w->nops; ++j) {
+                const op_t *a = &w->ops[j];
+                if (a->wid || a->flav != f2 || a->ca != 2) continue;
+                double m = w->Mf[pc * kt + pa], x; int idt;
+                if (a->tau - c->tau > 0.0) { idt = (int)((a->tau - c->tau) / beta * (double)ntau) + 1; x = 2.0 / beta * (a->tau - c->tau) - 1.0; }
+                else { idt = (int)((beta + a->tau - c->tau) / beta * (double)ntau) + 1; x = 2.0 / beta * (beta + a->tau - c->tau) - 1.0; m = -m; }
+                m = m * w->cfgsign;
+                if (idt > ntau) idt = ntau;
+                w->gtau_full[((size_t)f2 * nf + f1) * ntau + idt - 1] += m;
+                double plx = 0.0, plm1 = 0.0, plp1 = 0.0;
+                double *gl = w->gleg_full + ((size_t)f2 * nf + f1) * nleg;
+                for (int il = 0; il < nleg; ++il) {
+                    if (x == -1.0 || x == 1.0) plp1 = pow(x, il);
+                    if (il == 0) plp1 = 1.0;
+                    else if (il == 1) plp1 = x;
+                    else { const int l = il - 1; plp1 = (2.0 * (double)l + 1.0) / (double)(l + 1) * x * plx - (double)l / (double)(l + 1) * plm1; }
+                    gl[il] += m * plp1;
+                    plm1 = plx; plx = plp1;
+                }
+                ++pa;
+            }
+            ++pc;
+        }
+        return;
+    }
     for (int f = 0; f < nf; ++f) {                                      /* MeasGtauRem + measure_giw_nfft */
         int k = w->k[f];
         if (k == 0) continue;
@@ -2041,6 +2287,14 @@ void ora_measure_finish(ora_walker *w)
             *g = *g * sqrt((double)(2 * l) + 1.0) / beta;
             *g = -*g * zs;
         }
+    if (w->gleg_full) {                                                                 /* 8752-8753, 8768, 8771 */
+        for (size_t i = 0; i < (size_t)nf * nf * w->p.ntau; ++i) w->gtau_full[i] = -w->gtau_full[i] * zs * (double)w->p.ntau / (beta * beta);
+        for (size_t ff = 0; ff < (size_t)nf * nf; ++ff) for (int l = 0; l < w->p.nlegmax; ++l) {
+            double *g = &w->gleg_full[ff * w->p.nlegmax + l];
+            *g = *g * sqrt((double)(2 * l) + 1.0) / beta;
+            *g = -*g * zs;
+        }
+    }
     if (w->p.meas_giw)
         for (size_t i = 0; i < (size_t)nf * 4 * w->p.niw; ++i) w->giw[i] = w->giw[i] * zs / beta;   /* 8815-8817 */
     {   /* 8790-8800 */
@@ -2159,6 +2413,13 @@ int ora_set_config(ora_walker *w, int n, const double *taus, const int *orbs, co
     w->outer_sst = outer_sst;
     w->wpos = 0; set_window(w);
     w->tr = full_trace(w, outer_sst);
+    if (w->p.offdiag) {
+        double *Mfn; int ktn;
+        rebuild_full(w, &Mfn, &ktn, &w->det);
+        free(w->Mf); w->Mf = Mfn; w->kt = ktn;
+        w->cfgsign = -get_sign(w);
+        return w->tr.sign == 0.0 ? 1 : 0;
+    }
     double *Mn[MAXFLAV]; int kn[MAXFLAV];
     rebuild_minv(w, Mn, kn, &w->det);
     for (int f = 0; f < w->nflav; ++f) { free(w->M[f]); w->M[f] = Mn[f]; w->k[f] = kn[f]; }
@@ -2166,6 +2427,18 @@ int ora_set_config(ora_walker *w, int n, const double *taus, const int *orbs, co
     return w->tr.sign == 0.0 ? 1 : 0;
 }
 
+int ora_get_minv_full(const ora_walker *w, double *out)
+{
+    if (out) memcpy(out, w->Mf, sizeof(double) * (size_t)w->kt * w->kt);
+    return w->kt;
+}
+int ora_get_full(const ora_walker *w, double *gleg_full, double *gtau_full)
+{
+    if (!w->gleg_full) return 0;
+    memcpy(gleg_full, w->gleg_full, sizeof(double) * (size_t)w->nflav * w->nflav * w->p.nlegmax);
+    memcpy(gtau_full, w->gtau_full, sizeof(double) * (size_t)w->nflav * w->nflav * w->p.ntau);
+    return 1;
+}
 int ora_get_minv(const ora_walker *w, int orb, int spin, double *out)
 {
     int f = 2 * (orb - 1) + (spin - 1), k = w->k[f];

@@ -62,6 +62,7 @@ typedef struct ora_params {
      * 1-based in the order band + Nd * spin; the inverses are made by the oracle */
     int nsym; int symmoves[8 * 16];
     int worm_meas_gsigma;                          /* WormMeasGSigmaiw: sector 3, improved estimator of the one-particle Green's function (CTQMC.F90:619-623) */
+    int offdiag;                                   /* offdiag = 1: hybridisation function with both flavour indices, one inverse matrix over all flavours (CTQMC.F90:461-467) */
     double p_4op, p_outer;                         /* Percentage4OperatorMove, PercentageOuterMove (CTQMC.F90:332-333, 8441-8442) */
 } ora_params;
 
@@ -118,6 +119,10 @@ int ora_set_config(ora_walker *w, int n, const double *taus, const int *orbs, co
 /* M block of flavour (orb,spin) [1-based like the reference], time ordered, row=creator, col=annihilator;
  * returns k and copies k*k doubles (row major) if out != NULL */
 int ora_get_minv(const ora_walker *w, int orb, int spin, double *out);
+/* offdiag = 1: the one inverse matrix over all flavours (rows = creators, columns = annihilators, by flavour then time); returns its order */
+int ora_get_minv_full(const ora_walker *w, double *out);
+/* gleg_full (Nd,2,Nd,2,NLegMax), gtau_full (Nd,2,Nd,2,Ntau): first index pair = annihilator flavour (CTQMC.F90:2531, 2549); 0 if not measured */
+int ora_get_full(const ora_walker *w, double *gleg_full, double *gtau_full);
 void ora_get_state(const ora_walker *w, double *det_log, double *det_sign, double *tr_log, double *tr_sign,
                    double *cfgsign, int *window_position, int *npairs);
 

@@ -27,7 +27,7 @@ class OraParams(C.Structure):
                 ("meas_susz", C.c_int), ("step_series", C.c_int),
                 ("n2iwb", C.c_int), ("n3iwf", C.c_int), ("n3iwb", C.c_int), ("worm_meas_eq", C.c_int * 6),
                 ("nsym", C.c_int), ("symmoves", C.c_int * 128), ("worm_meas_gsigma", C.c_int),
-                ("p_4op", C.c_double), ("p_outer", C.c_double)]
+                ("offdiag", C.c_int), ("p_4op", C.c_double), ("p_outer", C.c_double)]
 
 WORM_EQ_KEYS = ("WormMeasP2iwPH", "WormMeasP2iwPP", "WormMeasP2tauPH", "WormMeasP2tauPP", "WormMeasP3iwPH", "WormMeasP3iwPP")
 WORM_EQ_NAMES = ("p2iw_worm", "p2iwpp_worm", "p2tau_worm", "p2taupp_worm", "p3iw_worm", "p3iwpp_worm")
@@ -102,6 +102,8 @@ def lib():
     L.ora_get_accpair.argtypes = [vp, lp]
     L.ora_get_counters.argtypes = [vp, dp]
     L.ora_get_counters_more.argtypes = [vp, dp]
+    L.ora_get_minv_full.argtypes = [vp, C.c_void_p]; L.ora_get_minv_full.restype = C.c_int
+    L.ora_get_full.argtypes = [vp, dp, dp]; L.ora_get_full.restype = C.c_int
     L.ora_mean_sign.argtypes = [vp]; L.ora_mean_sign.restype = C.c_double
     L.ora_hybr.argtypes = [dp, C.c_int, C.c_double, C.c_double]; L.ora_hybr.restype = C.c_double
     L.ora_detrat_add.argtypes = [dp, C.c_int, dp, dp, C.c_double]; L.ora_detrat_add.restype = C.c_double
@@ -148,7 +150,7 @@ def params_from_pstring(ps, nd, beta, fourpnt=0):
                      n2iwb=ps.get_int("N2iwb"), n3iwf=ps.get_int("N3iwf"), n3iwb=ps.get_int("N3iwb"),
                      worm_meas_eq=(C.c_int * 6)(*[int(ps.get_int(k) != 0) for k in WORM_EQ_KEYS]),
                      nsym=ps.get_int("NSymMove"), symmoves=_symmoves(ps), worm_meas_gsigma=int(ps.get_int("WormMeasGSigmaiw") != 0),
-                     p_4op=ps.get_real("Percentage4OperatorMove"), p_outer=ps.get_real("PercentageOuterMove"))
+                     offdiag=int(ps.get_int("offdiag") != 0), p_4op=ps.get_real("Percentage4OperatorMove"), p_outer=ps.get_real("PercentageOuterMove"))
 
 
 class OracleWalker:
@@ -227,6 +229,13 @@ class OracleWalker:
             self.L.ora_get_minv(self.h, orb, spin, out.ctypes.data)
         return out
 
+    def minv_full(self):
+        k = self.L.ora_get_minv_full(self.h, None)
+        out = np.zeros((k, k))
+        if k:
+            self.L.ora_get_minv_full(self.h, out.ctypes.data)
+        return out
+
     def state(self):
         d = [C.c_double() for _ in range(5)]; i = [C.c_int(), C.c_int()]
         self.L.ora_get_state(self.h, *[C.byref(x) for x in d], *[C.byref(x) for x in i])
@@ -249,6 +258,10 @@ class OracleWalker:
         r["accpair"] = self.accpair()
         a = np.zeros(13); self.L.ora_get_counters(self.h, a); r["counters"] = a
         a = np.zeros(8); self.L.ora_get_counters_more(self.h, a); r["counters_more"] = a
+        if p.offdiag:
+            gl = np.zeros((nd, 2, nd, 2, p.nlegmax)); gt = np.zeros((nd, 2, nd, 2, p.ntau))
+            if self.L.ora_get_full(self.h, gl, gt):
+                r["gleg_full"] = gl; r["gtau_full"] = gt
         r["mean_sign"] = self.L.ora_mean_sign(self.h)
         occ = np.zeros((nd, 2, nd, 2)); rho1 = np.zeros((2 * nd, 2 * nd))
         rho2 = np.zeros((2 * nd,) * 4) if nd <= 5 else None

@@ -78,13 +78,20 @@ TRAJ = {
                                   PercentageTauShiftMove=0.05, PercentageOuterMove=0.3), 55),
     "C4mix": ("C4", 1001, dict(Nwarmups=5000, Nmeas=40, NCorr=100, TaudiffMax=10.0, Ntau=100, NLegMax=12, Niw=4, MeasGiw=1, NLookup_nfft=0,
                                Percentage4OperatorMove=0.1, PercentageOuterMove=0.1), 56),
+    # off-diagonal hybridisation (offdiag = 1): one inverse matrix over all flavours, pairs of unequal flavours, gleg_full / gtau_full
+    "C4SO": ("C4SO", 501, dict(Nwarmups=3000, Nmeas=60, NCorr=50, TaudiffMax=3.0, Ntau=50, NLegMax=10, Niw=4, offdiag=1, PercentageGlobalMove=0.05,
+                               PercentageTauShiftMove=0.05), 71),
+    "C3O": ("C3O", 501, dict(Nwarmups=3000, Nmeas=60, NCorr=50, TaudiffMax=3.0, Ntau=50, NLegMax=10, Niw=4, offdiag=1, PercentageGlobalMove=0.05,
+                             PercentageTauShiftMove=0.05), 72),
+    "C4O": ("C4O", 501, dict(Nwarmups=3000, Nmeas=40, NCorr=50, TaudiffMax=3.0, Ntau=50, NLegMax=10, Niw=4, offdiag=1, PercentageGlobalMove=0.05,
+                             PercentageTauShiftMove=0.05), 73),
     # BASELINE.json configs[4], Z-space part: 5 orbitals, density-density, beta = 100 (1024 one-state blocks, 10 flavours)
     "C5Z": ("C5Z", 501, dict(Nwarmups=4000, Nmeas=50, NCorr=100, TaudiffMax=10.0, Ntau=100, NLegMax=40, Niw=8, MeasGiw=1,
                              NLookup_nfft=0, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 31),
 }
 
 KEYS = ("gleg", "gtau", "giw", "histo", "occ", "outersuperstatehisto", "accpair", "mean_sign", "accadd", "accrem", "accadd4", "accrem4",
-        "accglob", "accshift", "eigenstatesenergies", "densitymatrix", "rho1", "rho2", "statessuperstates",
+        "accglob", "accshift", "gleg_full", "gtau_full", "eigenstatesenergies", "densitymatrix", "rho1", "rho2", "statessuperstates",
         # MeasOuterHistograms (CTQMC.F90:3285-3339, normalised 8757-8764); lhisto / rhisto are never filled (8698-8699)
         "signhistosuperstates", "tracecontribsuperstates", "outerstatehisto", "signhistostates", "tracecontribstates",
         "lhisto", "rhisto")
@@ -124,7 +131,7 @@ def gen_traj(only=None):
         s.set_taudiffmax(over["TaudiffMax"])
         s.set_config(c_end)
         s.measure()
-        r1 = s.results(("gleg", "gtau", "giw", "mean_sign", "occ", "histo"))
+        r1 = s.results(("gleg", "gtau", "giw", "mean_sign", "occ", "histo", "gleg_full", "gtau_full"))
         s.close()
         np.savez_compressed(os.path.join(OUT, "meas_%s.npz" % name), config=cfg, nftau=nftau, seed=seed,
                             overrides=repr(over1), **{"cfg_" + k: v for k, v in c_end.items()},

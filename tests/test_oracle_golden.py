@@ -100,6 +100,38 @@ def test_oracle_retraces_reference_chain(name):
     w.close()
 
 
+@pytest.mark.parametrize("name", ["C4SO", "C3O", "C4O"])
+def test_oracle_retraces_reference_chain_offdiag(name):
+    """offdiag = 1 (off-diagonal hybridisation, fast updates): one inverse matrix over all flavours, pairs of unequal flavours,
+    the permutation sign of recalc_sign, gleg_full / gtau_full (CTQMC.F90:2475-2584; Trace.F90:2462-2601, 2690-2770, 2835-2997, 3500-3545)."""
+    g = util.load_golden("traj_%s.npz" % name)
+    over = g["overrides"]
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    assert abs(p.ftau.sum() - float(g["ftau_sum"])) < 1e-9 * abs(float(g["ftau_sum"]))
+    w = pyoracle.OracleWalker(p, pset, ("std", int(g["seed"])))
+    w.set_taudiffmax(over["TaudiffMax"])
+    w.warmup(over["Nwarmups"])
+    c = w.get_config()
+    assert len(c["taus"]) == len(g["cfg_taus"]) and c["outer_sst"] == int(g["cfg_outer_sst"])
+    assert np.array_equal(c["orbs"], g["cfg_orbs"]) and np.array_equal(c["spins"], g["cfg_spins"]) and np.array_equal(c["cas"], g["cfg_cas"])
+    assert np.abs(c["taus"] - g["cfg_taus"]).max() < 1e-12
+    w.measure()
+    r = w.results()
+    c2 = w.get_config()
+    assert len(c2["taus"]) == len(g["end_taus"]) and np.abs(c2["taus"] - g["end_taus"]).max() < 1e-12
+    for k in ("gleg_full", "gtau_full", "histo", "occ", "outersuperstatehisto"):
+        assert rel(r[k], g["res_" + k]) < 1e-10, k
+    assert np.abs(r["gleg_full"]).max() > 0.1
+    assert r["mean_sign"] == pytest.approx(float(g["res_mean_sign"]), abs=1e-14)
+    cnt = r["counters"]
+    assert cnt[1] / cnt[0] == pytest.approx(float(g["res_accadd"][0]), rel=1e-12)
+    assert cnt[4] / cnt[3] == pytest.approx(float(g["res_accrem"][0]), rel=1e-12)
+    assert cnt[7] / cnt[6] == pytest.approx(float(g["res_accglob"]), rel=1e-12)
+    assert cnt[10] / cnt[9] == pytest.approx(float(g["res_accshift"]), rel=1e-12)
+    assert np.array_equal(r["accpair"], g["res_accpair"])
+    w.close()
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_oracle_recorded_configuration_measurement(name):
     g = util.load_golden("meas_%s.npz" % name)

@@ -90,12 +90,14 @@ class Problem:
 
 def make_problem(nd: int, beta: float, u: float, j: float = 0.0, v: float | None = None, mu: float | None = None,
                  D: float = 1.0, nftau: int = 5001, spin_split: float = 0.0, kanamori: bool = False,
-                 quantum_numbers: str | None = None, hop: float = 0.0) -> Problem:
+                 quantum_numbers: str | None = None, hop: float = 0.0, fmix: float = 0.0) -> Problem:
     """Half-filled (by default) density-density problem on a Bethe bath.
 
     mu defaults to U/2 + (Nd-1)(V - J/2) (particle-hole symmetric point for this interaction).
     `spin_split` adds +-h to the two spin species so that tests can break the symmetry; `hop` adds a spin-conserving
-    hopping between neighbouring orbitals to the local one-particle Hamiltonian (off-diagonal muimp, diagonal bath)."""
+    hopping between neighbouring orbitals to the local one-particle Hamiltonian (off-diagonal muimp, diagonal bath); `fmix`
+    adds the same fraction of F(tau) between neighbouring orbitals of equal spin, slightly different in the two directions
+    (off-diagonal hybridisation, for runs with offdiag = 1)."""
     if v is None:
         v = u - 2.0 * j
     if mu is None:
@@ -111,6 +113,9 @@ def make_problem(nd: int, beta: float, u: float, j: float = 0.0, v: float | None
     for b in range(nd - 1):
         for s in (0, 1):
             muimp[b, s, b + 1, s] = muimp[b + 1, s, b, s] = -hop
+            if fmix:
+                ftau[b, s, b + 1, s, :] = fmix * f
+                ftau[b + 1, s, b, s, :] = fmix * f
     if kanamori:
         return Problem(nd, beta, kanamori_umatrix(nd, u, v, j), ftau, muimp, hamiltonian="Kanamori",
                        quantum_numbers=quantum_numbers or "Nt Szt Qzt", bath_scale=scale, bath_D=D)
@@ -149,6 +154,13 @@ def config(name: str, nftau: int = 5001) -> Problem:
         return make_problem(2, 10.0, 2.0, j=0.25, nftau=nftau, kanamori=True, quantum_numbers="Nt All")
     if name == "C4SX":     # Kanamori + inter-orbital hopping: Qzt is not conserved, the partitioning has to find the blocks
         return make_problem(2, 10.0, 2.0, j=0.25, nftau=nftau, kanamori=True, quantum_numbers="Nt All", hop=0.3)
+    # off-diagonal hybridisation (offdiag = 1): F(tau) between the two orbitals; with the hopping the blocks mix the orbitals
+    if name == "C4SO":
+        return make_problem(2, 10.0, 2.0, j=0.25, nftau=nftau, kanamori=True, quantum_numbers="Nt All", hop=0.3, fmix=0.3)
+    if name == "C3O":      # density-density: pairs of unequal flavours never fit, the off-diagonal F enters through the determinant alone
+        return make_problem(2, 10.0, 2.0, j=0.25, nftau=nftau, fmix=0.3)
+    if name == "C4O":      # three orbitals, Kanamori, hopping
+        return make_problem(3, 10.0, 2.0, j=0.25, nftau=nftau, kanamori=True, quantum_numbers="Nt All", hop=0.2, fmix=0.25)
     if name == "C4SQ":     # "All" on its own: the starting partition is one block, whose operators connect nothing
         return make_problem(2, 10.0, 2.0, j=0.25, nftau=nftau, kanamori=True, quantum_numbers="All")   # (Operator.F90:150): every state ends up alone
     if name == "C3A":      # density-density: every Fock state is its own block
