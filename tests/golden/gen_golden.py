@@ -146,6 +146,8 @@ STAT = {
     "C4": ("C4", 1001, dict(Nwarmups=50000, Nmeas=5000, NCorr=100, TaudiffMax=10.0, Ntau=100, NLegMax=30), 8),
     # BASELINE.json configs[4], Z-space part: 5 orbitals, beta = 100 (round 3)
     "C5Z": ("C5Z", 1001, dict(Nwarmups=50000, Nmeas=5000, NCorr=100, TaudiffMax=10.0, Ntau=100, NLegMax=30), 8),
+    # off-diagonal hybridisation: 2-orbital Kanamori with hopping and F(tau) between the orbitals (mean sign about -0.6)
+    "C4SO": ("C4SO", 501, dict(Nwarmups=20000, Nmeas=20000, NCorr=50, TaudiffMax=3.0, Ntau=50, NLegMax=20, offdiag=1), 8),
 }
 
 
@@ -154,7 +156,7 @@ def gen_stat(only=None):
         if only and name not in only:
             continue
         p, ps = pstring_for(cfg, nftau, over)
-        acc = {k: [] for k in ("gleg", "gtau", "occ", "histo", "accadd", "accrem")}
+        acc = {k: [] for k in (("gleg_full", "gtau_full", "mean_sign") if over.get("offdiag") else ("gleg", "gtau")) + ("occ", "histo", "accadd", "accrem")}
         for i in range(nseeds):
             s = refdrive.RefSolver(p, ps, 1000 + i)
             s.set_taudiffmax(over["TaudiffMax"])

@@ -105,6 +105,63 @@ def test_chains_retrace_oracle_with_two_pair_and_outer_moves(cfg, nftau, over, s
     _retrace(cfg, nftau, over, seed)
 
 
+# off-diagonal hybridisation (offdiag = 1): one inverse matrix over all flavours, pairs of unequal flavours, the permutation sign,
+# gleg_full / gtau_full; the oracle's branch is pinned on reference runs (traj_C4SO, traj_C3O, traj_C4O)
+OD_TRAJ = [
+    ("C4SO", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=3.0, offdiag=1, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 81),
+    ("C3O", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=3.0, offdiag=1, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 82),
+    ("C4O", 501, dict(BASE, Nwarmups=3000, Nmeas=20, NCorr=30, TaudiffMax=3.0, offdiag=1, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 83),
+    ("C4SO", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=-1.0, offdiag=1, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 84),
+]
+
+
+@pytest.mark.parametrize("cfg,nftau,over,seed", OD_TRAJ, ids=["C4SO-kanamori-hopping", "C3O-density-density", "C4O-three-orbitals", "C4SO-one-window"])
+def test_chains_retrace_oracle_offdiag(cfg, nftau, over, seed):
+    """Every chain: same configuration, full inverse matrix, determinant, sign and NPairs after warm-up; same gleg_full / gtau_full,
+    histograms, occupations and density matrix after sampling."""
+    p, ps, pset = util.setup(cfg, nftau, over)
+    nw = 6
+    q = make_gpu(p, ps, seed, nw)
+    tdm = pset.get_real("TaudiffMax")
+    q.set_taudiffmax(tdm)
+    q.ctqmc_warmup(over["Nwarmups"])
+    oracles = []
+    for w in range(nw):
+        o = pyoracle.OracleWalker(p, pset, ("philox", seed, w))
+        o.set_taudiffmax(tdm); o.warmup(over["Nwarmups"])
+        c = o.get_config(); so = o.state()
+        n, osst, _ = q.get_mc_config_scalars(w)
+        assert n == len(c["taus"]), "chain %d" % w
+        assert osst == c["outer_sst"]
+        g = q.get_mc_config(n, w)
+        if n:
+            assert np.abs(g[0] - c["taus"]).max() < 1e-11
+            assert np.array_equal(g[1], c["orbs"]) and np.array_equal(g[2], c["spins"]) and np.array_equal(g[3], c["cas"])
+        st = q.get_walker_state(w)
+        assert st["det_sign"] == so["det_sign"] and st["window_position"] == so["window_position"]
+        assert st["det_log"] == pytest.approx(so["det_log"], abs=1e-8)
+        a, b = q.get_minv(w, 0, 0), o.minv_full()
+        assert a.shape == b.shape
+        if a.size:
+            assert rel(a, b) < TOL
+        oracles.append(o)
+    q.ctqmc_measure(1, 1)
+    bins = {k: getattr(q, k + "_bins") for k in ("gleg_full", "gtau_full", "histo", "occ")}
+    msign = 0.0; nonzero = 0.0
+    for w, o in enumerate(oracles):
+        o.measure(); r = o.results()
+        for k in bins:      # these problems have a sign problem: a bin is divided by the mean sign of its context, a chain of the oracle by its own
+            f_gpu, f_ora = (1.0, 1.0) if k == "histo" else (q.mean_sign, r["mean_sign"])
+            assert rel(bins[k][w] * f_gpu, r[k] * f_ora) < TOL, (k, w)
+        nonzero = max(nonzero, np.abs(r["gleg_full"][0, 0, 1, 0]).max())
+        assert q.get_walker_state(w)["cfgsign"] == o.state()["cfgsign"]
+        msign += r["mean_sign"] / nw
+        o.close()
+    assert nonzero > 1e-3                      # the off-diagonal elements are measured
+    assert q.mean_sign == pytest.approx(msign, abs=1e-12)
+    q.dest_ctqmc(); q.close()
+
+
 def test_full_size_run_properties():
     """BASELINE.json's bench configuration at full size (C2, 131072 chains, NCorr = 200, Ntau = 1000, NLegMax = 100,
     Nftau = 5001) through size-independent properties: a chain's trajectory depends on (seed, chain number) only - the
@@ -630,7 +687,7 @@ def test_capacity_overflow_inside_measurement_run_is_reported():
 
 def test_unsupported_modes_are_refused():
     p, _, _ = util.setup("C1", 501, {})
-    for over in (dict(segment=1), dict(offdiag=1), dict(statesampling=1), dict(flavourchange_moves=1), dict(EnableOuterTruncation="YES")):
+    for over in (dict(segment=1), dict(offdiag=1, FourPnt=0, MeasSusz=1), dict(statesampling=1), dict(flavourchange_moves=1), dict(EnableOuterTruncation="YES")):
         _, ps, _ = util.setup("C1", 501, over)
         q = MCTQMC(nwalkers=4)
         q.init_rnd(1); q.init_paras(ps)
@@ -681,6 +738,37 @@ def test_full_run_statistics_vs_reference(name):
         ref, referr = g[key + "_mean"], g[key + "_err"]
         if key == "gleg":
             mean, err, ref, referr = mean[..., :10:2], err[..., :10:2], ref[..., :10:2], referr[..., :10:2]
+        sig = np.sqrt(err ** 2 + referr ** 2)
+        mask = sig > 0
+        z = (mean[mask] - ref[mask]) / sig[mask]
+        assert np.abs(z).max() < 5.0, (key, np.abs(z).max())
+        chi.append((z ** 2).mean())
+    assert np.mean(chi) < 2.0, chi
+    assert abs(q.accadd[0] - float(g["accadd_mean"][0])) < 5 * float(g["accadd_err"][0]) + 0.003
+    q.dest_ctqmc(); q.close()
+
+
+def test_offdiag_statistics_vs_reference():
+    """offdiag = 1: gleg_full (diagonal and off-diagonal flavour pairs), occupations and the mean sign of a 512-chain run agree with
+    eight seeded REFERENCE runs (tests/golden/stat_C4SO.npz) within error bars; this problem has a sign problem (mean sign -0.68)."""
+    g = util.load_golden("stat_C4SO.npz")
+    over = dict(g["overrides"])
+    nwalk = 512
+    over.update(Nmeas=int(over["Nmeas"]) * 8 // nwalk * 2)
+    p, ps, pset = util.setup(g["config"], g["nftau"], over)
+    q = make_gpu(p, ps, 2025, nwalk, wpb=16)
+    q.set_taudiffmax(over["TaudiffMax"])
+    q.ctqmc_warmup(over["Nwarmups"] // 4)
+    q.ctqmc_measure(1, 1)
+    assert abs(q.mean_sign - float(g["mean_sign_mean"])) < 5 * float(g["mean_sign_err"]) + 0.01
+    chi = []
+    for key in ("occ", "gleg_full"):
+        b = getattr(q, key + "_bins"); nb = b.shape[0]
+        mean = b.mean(axis=0); err = b.std(axis=0, ddof=1) / np.sqrt(nb)
+        ref, referr = g[key + "_mean"], g[key + "_err"]
+        if key == "gleg_full":
+            mean, err, ref, referr = mean[..., :8], err[..., :8], ref[..., :8], referr[..., :8]
+            assert np.abs(ref[0, 0, 1, 0]).max() > 0.1            # the off-diagonal Green's function is there
         sig = np.sqrt(err ** 2 + referr ** 2)
         mask = sig > 0
         z = (mean[mask] - ref[mask]) / sig[mask]

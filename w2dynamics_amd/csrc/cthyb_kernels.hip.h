@@ -150,6 +150,9 @@ struct DevConst {
     // move that may change the outer block; xmoves: either is set (the sweep runs the k_sweep<..., XM = true> kernels, which keep
     // two free slots per flavour instead of one)
     double p_4op, p_outer; int xmoves;
+    // off-diagonal hybridisation (offdiag = 1, cthyb_offdiag.hip.h): F(tau) with both flavour indices [nflav][nflav][nftau] as handed
+    // to init_solver, flavour of every creator / annihilator slot [nwalkers][kmax]
+    int offdiag; const double *ffull; int *FC, *FA;
     const double *umat;           // U matrix (2Nd)^4 as handed to init_solver (flavour = 2 * orbital + spin): proposal factor of the GSigma worm
     // matrix trace path: the chains of a launch are handed out to the waves from this counter (zeroed before every launch), so
     // that the four waves of a workgroup - which share the staged tables of the local problem - never wait for one another
@@ -1233,8 +1236,10 @@ __device__ W2DYN_INLINE void step_shift(Ctx &x)
 // so the result is the same to the last bit; what is saved is a row swap per step, the k column swaps at the end and
 // one log per pivot (taken by all lanes at once afterwards).  Larger matrices are eliminated in place in global
 // memory with explicit swaps.
+// OD: off-diagonal hybridisation - the slots carry their flavours (fcp, fap) and F comes from the two-flavour table
+template <bool OD>
 __device__ W2DYN_INLINE void build_and_invert(Ctx &x, int f, int k, const double *tcp, const double *tap, double *A,
-                                 double &logdet, double &sgn)
+                                 double &logdet, double &sgn, const int *fcp, const int *fap)
 {
     const DevConst &C = x.C;
     const int kmax = C.kmax;
@@ -1246,7 +1251,9 @@ __device__ W2DYN_INLINE void build_and_invert(Ctx &x, int f, int k, const double
     const unsigned magic = (1u << 24) / (unsigned)k + 1u;
     for (int e = x.lane; e < kk; e += 64) {
         int r = (int)(((unsigned)e * magic) >> 24), c = e - r * k;
-        double v = hybr(ft, C.nftau, C.beta, tap[r] - tcp[c]);
+        double v;
+        if constexpr (OD) v = hybr(C.ffull + ((size_t)fap[r] * C.nflav + fcp[c]) * C.nftau, C.nftau, C.beta, tap[r] - tcp[c]);
+        else v = hybr(ft, C.nftau, C.beta, tap[r] - tcp[c]);
         if (in_lds) x.gj[e] = v; else A[(size_t)r * kmax + c] = v;
     }
     wave_sync();
@@ -1739,6 +1746,7 @@ __device__ __forceinline__ void flag_full(Ctx &x, int spare = 0)
 
 #include "cthyb_worm.hip.h"
 #include "cthyb_xmoves.hip.h"
+#include "cthyb_offdiag.hip.h"
 
 #ifdef W2DYN_STAMPS
 #define STAMP_KIND(c) which_ = (c)
@@ -1920,6 +1928,7 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
     ctx_setup(x, smem);
     if (x.w >= C.nwalkers) return;
     ctx_load(x);
+    if constexpr (MAT != 0) if (C.offdiag) od_load(x);  // off-diagonal hybridisation: the list with the true flavours
     double pt_ = 0.0, lsc_ = 0.0; int sk_ = 0;          // blocks of more than 4 states: partial traces and the block at beta/2 (mat_halves)
     constexpr int NT2 = (MAT >= 2 && MAT <= 4) ? MAT * MAT : 1;
     double Kt_[NT2], At_[NT2];                          // blocks of up to 4 states: the two halves as matrices (lane 0; mat_halves_tree), sk_ = operators up to beta/2
@@ -1932,7 +1941,9 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
     // whatever the orders of the single flavours are) and scans the operators that can contribute a transposition
     int N = 0;
     for (int f = 0; f < nf; ++f) N += 2 * x.order(f);
-    for (int base = 0; base < N; base += 64) {
+    bool odiag = false;
+    if constexpr (MAT != 0) odiag = C.offdiag != 0;
+    for (int base = 0; base < N && !odiag; base += 64) {
         const int li = base + x.lane;
         const bool act = li < N;
         int fi = 0, oi = 0, ki = 0;
@@ -1989,6 +2000,7 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
     }
     par = wave_sum(par) & 1;
     if ((N / 2) & 1) par ^= 1;
+    if constexpr (MAT != 0) if (odiag) par = od_sign_parity(x);      // Trace.F90:3483-3486: trace sign, determinant sign, recalc_sign
     double sign = x.det_sign * (par ? -1.0 : 1.0);
     if constexpr (MAT) sign *= x.tr_sign;            // the trace sign comes with the matrix elements (Trace.F90:3488)
     double cfgsign = -sign;
@@ -2040,6 +2052,12 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
         atomicAdd(&C.acc_signouter[(size_t)bin * C.nouter + x.outer], cfgsign);
     }
     if (x.lane < nf) {      // lane f holds the order of flavour f
+        if constexpr (MAT != 0) if (odiag) {      // NOSOper / 2 of the flavour: creators and annihilators counted together
+            const int kt = x.order(0); const int *fc = od_fc(x), *fa = od_fa(x);
+            int c = 0;
+            for (int e = 0; e < kt; ++e) c += (fc[e] == x.lane ? 1 : 0) + (fa[e] == x.lane ? 1 : 0);
+            x.kreg = c / 2;
+        }
         int h = x.kreg < C.maxhisto ? x.kreg : C.maxhisto;
         atomicAdd(&C.acc_histo[((size_t)bin * nf + x.lane) * (C.maxhisto + 1) + h], 1.0);
     }

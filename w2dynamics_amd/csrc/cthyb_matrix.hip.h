@@ -15,7 +15,9 @@
 // the outer states in batches of 64 / NSM.
 #pragma once
 
-__device__ W2DYN_INLINE void build_and_invert(Ctx &x, int f, int k, const double *tcp, const double *tap, double *A, double &logdet, double &sgn);
+template <bool OD = false>
+__device__ W2DYN_INLINE void build_and_invert(Ctx &x, int f, int k, const double *tcp, const double *tap, double *A, double &logdet, double &sgn,
+                                              const int *fcp = nullptr, const int *fap = nullptr);
 __device__ W2DYN_INLINE double sort_parity(Ctx &x, const double *t, int k);
 
 // code of an operator: 2*flavour + (ca - 1), ca 1 = creator, 2 = annihilator

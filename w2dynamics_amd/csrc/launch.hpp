@@ -25,6 +25,10 @@ void launch_sweep_seq(bool calib, const LaunchCfg &l, const DevConst &C, long lo
 void launch_sweep_x_scalar(const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling, int resume);
 void launch_sweep_x_tree(int mat, const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling, int resume);
 void launch_sweep_x_seq(const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling, int resume);
+// off-diagonal hybridisation (tu_offdiag.hip, tu_x_seq.hip)
+void launch_sweep_od_tree(int mat, const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling, int resume);
+void launch_sweep_od_seq(const LaunchCfg &l, const DevConst &C, long long nsteps, int count_sampling, int resume);
+void launch_meas_full(const DevConst &C, hipStream_t st, double *acc_gleg_full, double *acc_gtau_full);
 void launch_sweep_worm_scalar(int nworm, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume);
 void launch_sweep_worm_tree(int nworm, int mat, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume);
 void launch_sweep_worm_seq(int nworm, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume);

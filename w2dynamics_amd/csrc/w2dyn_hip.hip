@@ -108,6 +108,8 @@ struct w2dyn_solver {
     int64_t nmeas = 0;
     double beta = 0, p_glob = 0, p_shift = 0, taudiffmax_param = 0;
     double p_4op = 0, p_outer = 0;       // Percentage4OperatorMove, PercentageOuterMove
+    bool offdiag = false;                // offdiag = 1: one hybridisation matrix over all flavours (csrc/cthyb_offdiag.hip.h)
+    double *acc_gleg_full = nullptr, *acc_gtau_full = nullptr;      // [nbins][nflav][nflav][nleg | ntau]
     int has_szt = 0;
     std::vector<double> energies, udd, eps, outer_w, outer_cum, ftab;
     double egs = 0;
@@ -341,6 +343,7 @@ int read_flags(w2dyn_solver *s, int &max_order, int &paused)
 int grow_kmax(w2dyn_solver *s, int knew)
 {
     DevConst &C = s->C; const int kold = C.kmax, nf = s->nflav; const size_t W = s->nwalkers;
+    if (s->offdiag) return fail(s, W2DYN_EOVERFLOW, "offdiag = 1: a chain reached the capacity of %d pairs; start with a larger kmax (w2dyn_set_layout)", kold);
     knew = std::min((knew + 7) & ~7, (int)KMAX_LIMIT);
     if (knew <= kold) return fail(s, W2DYN_EOVERFLOW, "a chain reached the expansion-order capacity kmax=%d, the largest this library handles", kold);
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -459,7 +462,8 @@ static LaunchCfg queue_launch(const LaunchCfg &l, const DevConst &C)
 void launch_sweep(int mat, bool calib, const LaunchCfg &l0, const DevConst &C, long long nsteps, int count, int resume)
 {
     const LaunchCfg l = mat ? queue_launch(l0, C) : l0;
-    if (C.xmoves && !calib) {
+    if (C.offdiag) { if (mat <= 4) launch_sweep_od_tree(mat, l, C, nsteps, count, resume); else launch_sweep_od_seq(l, C, nsteps, count, resume); }
+    else if (C.xmoves && !calib) {
         if (mat == 0) launch_sweep_x_scalar(l, C, nsteps, count, resume);
         else if (mat <= 4) launch_sweep_x_tree(mat, l, C, nsteps, count, resume);
         else launch_sweep_x_seq(l, C, nsteps, count, resume);
@@ -572,7 +576,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     long long iv; double rv; std::string sv;
     // ---- modes this build refuses ----
     struct { const char *key; long long allowed; } zero_int[] = {
-        {"segment", 0}, {"offdiag", 0}, {"full_offdiag", 0}, {"statesampling", 0}, {"flavourchange_moves", 0}, {"Phonon", 0},
+        {"segment", 0}, {"statesampling", 0}, {"flavourchange_moves", 0}, {"Phonon", 0},
         {"Screening", 0}, {"Uw", 0}, {"MeasGtauDetRat", 0},
         {"MeasExpResDensityMatrix", 0},
         {"MeasDensityMatrix", 1}, {"Eigenbasis", 1}};
@@ -580,6 +584,10 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
         if (!get_int(s, z.key, iv)) return W2DYN_EINVAL;
         if (iv != z.allowed) return fail(s, W2DYN_EUNSUPPORTED, "%s = %lld is not supported by the HIP solver (only %lld)", z.key, iv, z.allowed);
     }
+    // off-diagonal hybridisation (CTQMC.F90:461-479).  full_offdiag = 1 asks the reference to build the matrix anew at every pair
+    // move, for debugging: the result is that of the fast updates up to rounding, which is what runs here either way
+    if (!get_int(s, "offdiag", iv)) return W2DYN_EINVAL; s->offdiag = iv != 0;
+    if (!get_int(s, "full_offdiag", iv)) return W2DYN_EINVAL;
     // moves outside the default mix (CTQMC.F90:332-333): two pairs at once, pair moves that change the outer block
     if (!get_real(s, "Percentage4OperatorMove", s->p_4op)) return W2DYN_EINVAL;
     if (!get_real(s, "PercentageOuterMove", s->p_outer)) return W2DYN_EINVAL;
@@ -682,7 +690,14 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     const LocalProblem &lp = s->lp;
     // one-state blocks in Fock-state order: only the diagonal of H_loc survives (terms between blocks are dropped,
     // Operator.F90:521, 1083) and the closed-form trace with eps / udd below is exact, whatever U and muimp hold
-    s->mat = !lp.identity_blocks;
+    if (s->offdiag) {      // what the off-diagonal sampler does not do (the reference measures gtau_full / gleg_full only and skips G(iw), CTQMC.F90:8562-8575)
+        long long a = 0, b = 0, c = 0, d = 0, e = 0;
+        if (!get_int(s, "MeasSusz", a) || !get_int(s, "AccumGtau", b) || !get_int(s, "Gtau_mean_step", c) || !get_int(s, "Gtau_mid_step", d) || !get_int(s, "sign_step", e)) return W2DYN_EINVAL;
+        if (s->fourpnt != 0 || a != 0 || b == 2 || c != 0 || d != 0 || e != 0 || s->p_4op > 0.0 || s->p_outer > 0.0)
+            return fail(s, W2DYN_EUNSUPPORTED, "offdiag = 1 runs the pair, shift and global moves and measures gtau_full / gleg_full, sign, histograms and the density matrix: FourPnt, MeasSusz, AccumGtau = 2, the step series and Percentage4OperatorMove / PercentageOuterMove are not supported with it");
+        s->meas_giw = 0;
+    }
+    s->mat = !lp.identity_blocks || s->offdiag;      // off-diagonal hybridisation: always the matrix trace path (list of operators with their flavours)
     (void)dd;
     if (s->mat && lp.nsmax > 16) return fail(s, W2DYN_EUNSUPPORTED, "largest block of H_loc has %d states with QuantumNumbers '%s': the HIP solver handles up to 16", lp.nsmax, qns.c_str());
     s->eps.assign(nf, 0.0); s->udd.assign((size_t)nf * nf, 0.0);
@@ -715,6 +730,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     C.nd = nd; C.nflav = nf; C.nstates = s->nstates; C.nftau = nftau; C.ntau = s->ntau; C.nleg = s->nleg; C.niw2 = 2 * s->niw;
     int kmax = s->kmax_req;
     if (kmax == 0) { kmax = (int)(0.4 * s->beta) + 24; kmax = (kmax + 7) & ~7; if (kmax > KMAX_LIMIT) kmax = KMAX_LIMIT; }   // overflow is detected and reported
+    if (s->offdiag) kmax = std::min(kmax * nf, 128);      // all flavours share the slots of flavour 0 (no growth later: w2dyn_set_layout)
     C.nwalkers = s->nwalkers; C.has_szt = s->has_szt; C.maxhisto = s->maxhisto;
     C.walkers_per_bin = s->walkers_per_bin; C.nbins = (s->nwalkers + s->walkers_per_bin - 1) / s->walkers_per_bin;
     { int G = 1, sh = 6; while (G < nf) { G <<= 1; --sh; } C.lane_shift = sh; }
@@ -743,6 +759,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     { int rc0 = configure_kmax(s, kmax); if (rc0) return rc0; }
     C.beta = s->beta; C.rbeta = 1.0 / s->beta; C.p_glob = s->p_glob; C.p_shift = s->p_shift; C.egs = s->egs;
     C.p_4op = s->p_4op; C.p_outer = s->p_outer; C.xmoves = (s->p_4op > 0.0 || s->p_outer > 0.0) ? 1 : 0;
+    C.offdiag = s->offdiag ? 1 : 0;
     C.seed = (unsigned long long)s->seed; C.first_walker = (unsigned long long)s->first_walker;
     host_init_window(s, s->taudiffmax_param, C.num_windows, C.taudiff_max);           // Trace.F90:605
     C.nslide = std::max(2 * nd, (int)std::floor((double)s->ncorr / (double)C.num_windows));   // CTQMC.F90:8069
@@ -781,6 +798,15 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if ((rc = dev_alloc(s, C.MB, W * nf * kmax * kmax))) return rc;
     if ((rc = dev_alloc(s, C.cfgsign, W))) return rc;
     if ((rc = dev_alloc(s, C.flags, 4))) return rc;
+    if (s->offdiag) {      // HybrF_full as handed over (CTQMC.F90:7950-7955), the flavours of the slots, the full-matrix accumulators
+        std::vector<double> ff(ftau_full, ftau_full + (size_t)nf * nf * nftau);
+        if ((rc = dev_upload(s, C.ffull, ff))) return rc;
+        if ((rc = dev_alloc(s, C.FC, W * kmax))) return rc;
+        if ((rc = dev_alloc(s, C.FA, W * kmax))) return rc;
+        HIPCHK(hipMemsetAsync(C.FC, 0, sizeof(int) * W * kmax, s->stream)); HIPCHK(hipMemsetAsync(C.FA, 0, sizeof(int) * W * kmax, s->stream));
+        if ((rc = dev_alloc(s, s->acc_gleg_full, (size_t)C.nbins * nf * nf * s->nleg))) return rc;
+        if ((rc = dev_alloc(s, s->acc_gtau_full, (size_t)C.nbins * nf * nf * s->ntau))) return rc;
+    } else { s->acc_gleg_full = s->acc_gtau_full = nullptr; }
     const size_t B = C.nbins;
     if ((rc = dev_alloc(s, C.acc_gleg, B * nf * s->nleg))) return rc;
     {   // prefix sums, workgroup totals, ticket of k_gleg_segments (layout: tu_meas.hip)
@@ -1035,6 +1061,7 @@ int w2dyn_ctqmc_calibrate(w2dyn_solver *s, int list, int phase1pairnum, int phas
 {
     if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "ctqmc_calibrate before init_solver");
     if (phase1pairnum < 1 || phase2taugrid < 1 || phase2pairnum < 0 || nprogress < 1) return fail(s, W2DYN_EINVAL, "ctqmc_calibrate: bad arguments");
+    if (s->offdiag) return fail(s, W2DYN_EUNSUPPORTED, "ctqmc_calibrate with offdiag = 1 is not supported: pass the window with set_taudiffmax");
     if (s->C.xmoves) return fail(s, W2DYN_EUNSUPPORTED, "ctqmc_calibrate with Percentage4OperatorMove or PercentageOuterMove > 0 is not supported: calibrate the window with both at 0 and hand it over with set_taudiffmax");
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -1118,6 +1145,10 @@ int w2dyn_measure_begin(w2dyn_solver *s)
     accpair_to_default(s);
     if ((rc = w2dyn_init_counters(s))) return rc;
     const DevConst &C = s->C; const size_t B = C.nbins; const int nf = s->nflav;
+    if (s->acc_gleg_full) {
+        HIPCHK(hipMemsetAsync(s->acc_gleg_full, 0, sizeof(double) * B * nf * nf * s->nleg, s->stream));
+        HIPCHK(hipMemsetAsync(s->acc_gtau_full, 0, sizeof(double) * B * nf * nf * s->ntau, s->stream));
+    }
     HIPCHK(hipMemsetAsync(C.acc_gleg, 0, sizeof(double) * B * nf * s->nleg, s->stream));
     HIPCHK(hipMemsetAsync(C.acc_gtau, 0, sizeof(double) * B * nf * s->ntau, s->stream));
     HIPCHK(hipMemsetAsync(C.acc_giw, 0, sizeof(double) * B * nf * C.niw2 * 2, s->stream));
@@ -1191,6 +1222,14 @@ static int measure_once_impl(w2dyn_solver *s, double2 *g2buf)
             HIPCHK(hipGetLastError());
             if ((rc = time_end(s, "meas_g4w"))) return rc;
         }
+        s->meas_done += 1;
+        return 0;
+    }
+    if (s->offdiag) {                  // CTQMC.F90:8562-8575: MeasGtauRem_full and nothing else of the Green's function estimators
+        if ((rc = time_begin(s))) return rc;
+        launch_meas_full(s->C, s->stream, s->acc_gleg_full, s->acc_gtau_full);
+        HIPCHK(hipGetLastError());
+        if ((rc = time_end(s, "meas_full"))) return rc;
         s->meas_done += 1;
         return 0;
     }
@@ -1705,7 +1744,12 @@ int w2dyn_measure_finish(w2dyn_solver *s)
     // lhisto / rhisto: the reference never fills DTrace%lhisto / rhisto (only zeroed, Trace.F90:596-597), so its results
     // are 0/0 = NaN and 0/(sum of acceptance ratios) = 0 (CTQMC.F90:8698-8699)
     R["lhisto"] = std::vector<double>(100, std::nan("")); R["rhisto"] = std::vector<double>(100, 0.0);
-    {   // gtau_full / gleg_full are only filled by the off-diagonal estimators (CTQMC.F90:8752, 8768): zero here
+    if (s->offdiag) {      // CTQMC.F90:8752-8753, 8768, 8771
+        std::vector<double> glf = fetch(s->acc_gleg_full, (size_t)B * nf * nf * nleg), gtf = fetch(s->acc_gtau_full, (size_t)B * nf * nf * ntau);
+        if (fetch_err != hipSuccess) return fail(s, W2DYN_EHIP, "measure_finish: copying the accumulators to the host: %s", hipGetErrorString(fetch_err));
+        reduce_bins(glf, (size_t)nf * nf * nleg, "gleg_full", [&](double v, double n, size_t i) { int l = (int)(i % nleg); double zs = -1.0 / (n * ms); return -(v * std::sqrt((double)(2 * l) + 1.0) / beta) * zs; }, s->acc_gleg_full);
+        reduce_bins(gtf, (size_t)nf * nf * ntau, "gtau_full", [&](double v, double n, size_t) { double zs = -1.0 / (n * ms); return -v * zs * (double)ntau / (beta * beta); }, s->acc_gtau_full);
+    } else {   // gtau_full / gleg_full are only filled by the off-diagonal estimators (CTQMC.F90:8752, 8768): zero here
         R["gtau_full"] = std::vector<double>((size_t)nf * nf * ntau, 0.0); R["gleg_full"] = std::vector<double>((size_t)nf * nf * nleg, 0.0);
     }
     return 0;
@@ -1714,6 +1758,8 @@ int w2dyn_measure_finish(w2dyn_solver *s)
 // sector bookkeeping shared by ctqmc_measure and count_steps: every chain starts in Z space (CTQMC.F90:6328, 8400)
 static int enter_sector(w2dyn_solver *s, int isector, int icomponent)
 {
+    if (isector != 1 && s->offdiag)
+        return fail(s, W2DYN_EUNSUPPORTED, "worm sampling with offdiag = 1 is not supported");
     if (isector != 1 && s->C.xmoves)
         return fail(s, W2DYN_EUNSUPPORTED, "worm sampling with Percentage4OperatorMove or PercentageOuterMove > 0 is not supported (the worm kernels make the default pair moves only)");
     if (isector != 1 && isector != 2 && isector != 3 && isector != 4 && !(isector >= 6 && isector <= 9))
@@ -1895,6 +1941,11 @@ int w2dyn_get_mc_config(w2dyn_solver *s, int walker, int n, double *taus, int *o
     struct Op { double t; int f, ca, hyb; };
     std::vector<Op> ops;
     const int kmax = s->C.kmax;
+    if (s->offdiag) {      // all operators sit in the slots of flavour 0, their flavours in the tag arrays
+        std::vector<int> fc(K[0]), fa(K[0]);
+        if (K[0]) { HIPCHK(hipMemcpy(fc.data(), s->C.FC + (size_t)walker * kmax, sizeof(int) * K[0], hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(fa.data(), s->C.FA + (size_t)walker * kmax, sizeof(int) * K[0], hipMemcpyDeviceToHost)); }
+        for (int e = 0; e < K[0]; ++e) { ops.push_back({TC[e], fc[e], 1, -1}); ops.push_back({TA[e], fa[e], 2, -1}); }
+    } else
     for (int f = 0; f < s->nflav; ++f) for (int e = 0; e < K[f]; ++e) { ops.push_back({TC[(size_t)f * kmax + e], f, 1, -1}); ops.push_back({TA[(size_t)f * kmax + e], f, 2, -1}); }
     if (ws.sector > 1) for (int i = 0; i < (ws.sector == 2 ? 2 : 4); ++i) ops.push_back({ws.wtau[i], ws.wflav[i], (i & 1) ? 1 : 2, 0});     // worm operators: hashyb 0 (Trace.F90:6861-6865)
     if ((int)ops.size() != n) return fail(s, W2DYN_EINVAL, "get_mc_config: n=%d but the chain holds %zu operators", n, ops.size());
@@ -1910,6 +1961,7 @@ int w2dyn_set_mc_config(w2dyn_solver *s, int walker, int n, const double *taus, 
     (void)outer_state;
     if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "no solver");
     if (walker < -1 || walker >= s->nwalkers) return fail(s, W2DYN_EINVAL, "walker %d out of range", walker);
+    if (s->offdiag) return fail(s, W2DYN_EUNSUPPORTED, "set_mc_config with offdiag = 1 is not supported");
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->stream));
     const DevConst &C = s->C; const int nf = s->nflav, kmax = C.kmax, nd = s->nd;
@@ -2006,6 +2058,23 @@ int w2dyn_get_minv(w2dyn_solver *s, int walker, int orb, int spin, int *kout, do
 {
     WalkerScalars ws; std::vector<int> K; std::vector<double> TC, TA;
     int rc = fetch_walker(s, walker, ws, K, TC, TA); if (rc) return rc;
+    if (s->offdiag) {      // orb = spin = 0: the one matrix over all flavours, rows and columns by flavour, then time (MInv_full)
+        if (orb != 0 || spin != 0) return fail(s, W2DYN_EINVAL, "get_minv with offdiag = 1: orb = spin = 0 asks for the full matrix");
+        const int kmax = s->C.kmax, k = K[0];
+        if (kout) *kout = k;
+        if (!out || k == 0) return 0;
+        if (out_doubles < (size_t)k * k) return fail(s, W2DYN_EINVAL, "get_minv: buffer too small");
+        std::vector<double> M((size_t)kmax * kmax); std::vector<int> fc(k), fa(k);
+        HIPCHK(hipMemcpy(M.data(), s->C.M + (size_t)walker * s->nflav * kmax * kmax, sizeof(double) * kmax * kmax, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(fc.data(), s->C.FC + (size_t)walker * kmax, sizeof(int) * k, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(fa.data(), s->C.FA + (size_t)walker * kmax, sizeof(int) * k, hipMemcpyDeviceToHost));
+        std::vector<int> oc(k), oa(k);
+        for (int i = 0; i < k; ++i) oc[i] = oa[i] = i;
+        std::sort(oc.begin(), oc.end(), [&](int a, int b) { return fc[a] != fc[b] ? fc[a] < fc[b] : TC[a] < TC[b]; });
+        std::sort(oa.begin(), oa.end(), [&](int a, int b) { return fa[a] != fa[b] ? fa[a] < fa[b] : TA[a] < TA[b]; });
+        for (int i = 0; i < k; ++i) for (int j = 0; j < k; ++j) out[(size_t)i * k + j] = M[(size_t)oc[i] * kmax + oa[j]];
+        return 0;
+    }
     int f = 2 * (orb - 1) + (spin - 1);
     if (f < 0 || f >= s->nflav) return fail(s, W2DYN_EINVAL, "bad flavour");
     const int kmax = s->C.kmax, k = K[f];

@@ -391,8 +391,10 @@ class MCTQMC:
             a = self.result(name)
             lead = (int(self.scalar("nbs")),) if name.endswith("_bins") else ()
             return a.reshape(lead + (nd, 2, nd, 2, -1))
-        if name in ("gtau_full", "gleg_full"):
+        if name in ("gtau_full", "gleg_full"):     # (annihilator flavour, creator flavour, ...): filled with offdiag = 1 (CTQMC.F90:2531, 2549)
             return self.result(name).reshape(nd, 2, nd, 2, -1)
+        if name in ("gtau_full_bins", "gleg_full_bins"):
+            return self.result(name).reshape(int(self.scalar("nbins")), nd, 2, nd, 2, -1)
         if name == "occ":
             return self.result("occ").reshape(nd, 2, nd, 2)
         if name == "rho1":
