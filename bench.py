@@ -61,6 +61,13 @@ WORKLOADS = {
                 text="C5 (Z-space part): 5-orbital density-density, U=2, J=0.25, beta=100, TaudiffMax=10, NCorr=100"),
     "C5K": dict(config="C5KB", nftau=5001, chains=16384, overrides=dict(_BASE),
                 text="C5K: 5-orbital Kanamori (d shell, QNs Nt Szt Qzt: 352 blocks of up to 10 states, matrix local trace), U=2, J=0.25, beta=50, TaudiffMax=10, NCorr=100"),
+    # C4 with the moves outside the default mix (k_sweep<3, ..., XM>: two pairs at once, pair moves that change the outer block)
+    "C4X": dict(config="C4", nftau=5001, chains=16384, overrides=dict(_BASE, Percentage4OperatorMove=0.05, PercentageOuterMove=0.05),
+                text="C4X: C4 with Percentage4OperatorMove=0.05 and PercentageOuterMove=0.05"),
+    # off-diagonal hybridisation (offdiag = 1, k_sweep_od / k_meas_full): 3-orbital Kanamori with inter-orbital hopping and F(tau) between the orbitals
+    "C4O": dict(config="C4OB", nftau=5001, chains=8192, overrides=dict(_BASE, offdiag=1),
+                text="C4O: 3-orbital Kanamori with inter-orbital hopping 0.2 and hybridisation 0.25 F(tau) between neighbouring orbitals (QNs Nt All), "
+                     "offdiag=1, beta=50, TaudiffMax=10, NCorr=100"),
     # worm sampling on the matrix trace path: 3-orbital Kanamori, component 8 = flavours 0011
     "C4W": dict(config="C4", nftau=5001, chains=8192, worm=dict(component=8, nfix=2000), overrides=dict(_BASE, **_WORM),
                 text="C4W: 3-orbital Kanamori (matrix local trace), beta=50, worm sampling in sector 4 (G4iw, component 8 = flavours 0011, "
@@ -127,7 +134,7 @@ def _cpu_chain(args):
 
 # measurements per CPU chain: about 10-20 s of CPU work for the headline, a few seconds for the side workloads (the
 # reference's G(iw) / g4iw estimators cost milliseconds to seconds per measurement: far fewer of them)
-_CPU_NMEAS = {"C2": 6000, "C2A": 6000, "C2G": 200, "C3F": 30, "C1": 3000, "C3": 2000, "C4": 1000, "C5Z": 1000, "C5K": 300, "C4W": 1000, "C5": 1000}
+_CPU_NMEAS = {"C4X": 1000, "C4O": 300, "C2": 6000, "C2A": 6000, "C2G": 200, "C3F": 30, "C1": 3000, "C3": 2000, "C4": 1000, "C5Z": 1000, "C5K": 300, "C4W": 1000, "C5": 1000}
 
 
 def cpu_baseline(cores, wname, nwarm=50000, eta=1.0):
@@ -238,7 +245,7 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
     for _ in range(warmup):
         q.sweep(ncorr); q.measure_once()
     q.sync()
-    tkeys = (sweep_key, "meas_misc", "meas_gleg", "meas_g4w", "meas_gw", "meas_gtau_ac", "meas_giw", "meas_g2iw", "meas_g4iw")
+    tkeys = (sweep_key, "meas_misc", "meas_gleg", "meas_full", "meas_g4w", "meas_gw", "meas_gtau_ac", "meas_giw", "meas_g2iw", "meas_g4iw")
     for k in tkeys:
         q.kernel_time(k, reset=True)
     if world > 1:
@@ -264,17 +271,18 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
     if rehearse:           # gloo rehearsal on one GPU: host path
         sg, sh = DistributedSample(q.gleg_bins, comm), DistributedSample(q.histo_bins, comm)
     else:
-        names = ["gleg", "gtau", "histo"] + ((["g4iw_worm"] if wsec == 4 else ["giw_worm"]) if worm else []) + (["giw"] if over.get("MeasGiw") else []) + \
+        names = (["gleg_full", "gtau_full", "gleg", "histo"] if over.get("offdiag") else ["gleg", "gtau", "histo"]) + ((["g4iw_worm"] if wsec == 4 else ["giw_worm"]) if worm else []) + (["giw"] if over.get("MeasGiw") else []) + \
                 (["g4iw", "g2iw"] if q.fourpnt & 4 else [])
         pack = q.reduce_pack(names, comm).allreduce()
-        sg, sh = pack.sample("gleg"), pack.sample("histo")
+        sg, sh = pack.sample("gleg_full" if over.get("offdiag") else "gleg"), pack.sample("histo")
     gl, hi, gl_err, nb = sg.mean(), sh.mean(), sg.stderr(), float(sg.ntotal)
     t_reduce = time.perf_counter() - t1
     oc = DistributedSample(q.occ_bins, comm).mean()
 
     kt = {k: q.kernel_time(k) for k in tkeys}
     sweep_ms, nsweep = kt[sweep_key]
-    gleg_ms, ngleg = kt[("meas_g4w" if wsec == 4 else "meas_gw") if worm else "meas_gleg"]
+    offd = bool(over.get("offdiag"))
+    gleg_ms, ngleg = kt[("meas_g4w" if wsec == 4 else "meas_gw") if worm else ("meas_full" if offd else "meas_gleg")]
     misc_ms, _ = kt["meas_misc"]
     out = None
     if rank == 0:
@@ -288,6 +296,8 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
         ks = np.arange(hi.shape[-1])
         k1 = float((hi * ks).sum(-1).mean()); k2 = float((hi * ks ** 2).sum(-1).mean())
         nflav = 2 * prob.nd
+        if offd:       # one matrix over all flavours: its order is the sum of the flavours' orders (the square of the mean stands in for the mean square)
+            k1 = nflav * k1; k2 = k1 * k1
         nlaunch_steps = W * ncorr * (steps + warmup)     # counters cover warm-up rounds too
         scale = (W * ncorr) / nlaunch_steps               # per-launch share
         # algorithmic bytes of one sweep launch: det-ratio proposals that pass the quantum-number
@@ -298,13 +308,13 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
         rem = c["tryrem"] * 8
         bytes_sweep = (prop + acc + rem) * scale
         ach_gbs = bytes_sweep / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
-        flops_gleg = W * nflav * k2 * (5 * over["NLegMax"] + 6)
+        flops_gleg = W * (1 if offd else nflav) * k2 * (5 * over["NLegMax"] + 6)
         if worm:       # 8 (2 N4iwf)^2 (2 N4iwb + 1) flop per worm-space measurement
             nworm_meas = float(q.result("cntmeas_worm")[0]) / max(steps + warmup, 1)
             flops_gleg = nworm_meas * (8 * (2 * over["N4iwf"]) ** 2 * (2 * over["N4iwb"] + 1) if wsec == 4 else 8 * 2 * over["Niw"])
         ach_tf = flops_gleg / (gleg_ms * 1e-3) / 1e12 if gleg_ms > 0 else 0.0
         value = world * W * ncorr * steps / dt
-        kname, mname = ("k_sweep_worm", "k_meas_g4w" if wsec == 4 else "k_meas_gw") if worm else ("k_sweep", "k_meas_gleg")
+        kname, mname = ("k_sweep_worm", "k_meas_g4w" if wsec == 4 else "k_meas_gw") if worm else (("k_sweep_od", "k_meas_full") if offd else ("k_sweep", "k_meas_gleg"))
         tr_sweep, tr_src = pmc_traffic(kname, W, wname)
         tr_gleg, _ = pmc_traffic(mname, W, wname)
         out = {
@@ -314,7 +324,7 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
             "config": {"workload": wl["text"], "chains_per_gpu": W,
                        "walkers_per_bin": wpb, "parallelism": "chains sharded over %d GPU(s), no data-path collective" % world},
             "measurements_per_s": world * W * steps / dt,
-            "mean_order_per_flavour": k1, "accept_ins": c["accadd"] / max(c["tryadd"], 1), "occ_double": float(oc[0, 0, 0, 1]),
+            "mean_order_per_flavour": k1 / nflav if offd else k1, "accept_ins": c["accadd"] / max(c["tryadd"], 1), "occ_double": float(oc[0, 0, 0, 1]),
             "allreduce_ms": t_reduce * 1e3,
             # the warm-up rounds are measured into the same accumulators: the error below belongs to steps+warmup rounds
             "gleg_err": {"max_stderr_l_lt_20": float(gl_err[..., :20].max()), "bins": int(nb),

@@ -181,11 +181,30 @@ __device__ W2DYN_INLINE void step_add_od(Ctx &x)
     if (kt >= kmax) { x.err |= ERR_KMAX; x.count(C_QNADD); return; }
     const double lo = fmin(tau1, tau2), hi = fmax(tau1, tau2);
     const int code_c = mat_code(fc, 1), code_a = mat_code(fa, 2);
-    const int p_lo = mat_lower(x, lo);
-    mat_insert(x, p_lo, lo, tau2 < tau1 ? code_c : code_a);
-    const int p_hi = mat_lower(x, hi);
-    mat_insert(x, p_hi, hi, tau2 < tau1 ? code_a : code_c);
-    if (!mat_walk_into(x, x.outer, x.tsst)) { mat_remove(x, p_hi); mat_remove(x, p_lo); x.count(C_QNADD); return; }
+    const int code_lo = tau2 < tau1 ? code_c : code_a, code_hi = tau2 < tau1 ? code_a : code_c;
+    // trial block sequence: the span between the two new operators is walked (check_sst_sequence, Trace.F90:1243-1302: from the
+    // block in front of the earlier one through the old operators between them to the block behind the later one); the blocks
+    // outside the span stay
+    const int q_lo = mat_lower(x, lo), q_hi = mat_lower(x, hi);      // insertion indices in the old list
+    {
+        const int nf2 = 2 * C.nflav;
+        wave_sync();
+        int sb = uni(x.osst[q_lo]);
+        sb = uni(x.t_conn[sb * nf2 + code_lo]);
+        if (x.lane == 0) x.tsst[q_lo + 1] = sb;
+        for (int i = q_lo; i < q_hi && sb >= 0; ++i) {
+            sb = uni(x.t_conn[sb * nf2 + uni(x.om[i])]);
+            if (x.lane == 0) x.tsst[i + 2] = sb;
+        }
+        if (sb >= 0) sb = uni(x.t_conn[sb * nf2 + code_hi]);
+        if (sb < 0 || sb != uni(x.osst[q_hi])) { x.count(C_QNADD); return; }
+        for (int j = x.lane; j <= x.nops + 2; j += 64) {
+            if (j <= q_lo) x.tsst[j] = x.osst[j];
+            else if (j >= q_hi + 2) x.tsst[j] = x.osst[j - 2];
+        }
+    }
+    const int p_lo = q_lo, p_hi = q_hi + 1;
+    mat_insert(x, p_lo, lo, code_lo); mat_insert(x, p_hi, hi, code_hi);
 
     // S = F(tau_a - tau_c) - R^T M Q; the flavour indices of the three look-ups as the reference writes them
     double *Mf = x.mat(0);
@@ -261,9 +280,23 @@ __device__ W2DYN_INLINE void step_rem_od(Ctx &x)
         if (ma) ia = base + __ffsll((long long)ma) - 1;
     }
     if (ic < 0 || ia < 0) { x.err |= ERR_BLOCKSEQ; return; }
+    {   // the span between the two operators is walked from the block in front of the earlier one through the operators between
+        // them; it must arrive at the block behind the later one (check_sst_sequence); the blocks outside the span stay
+        const int nf2 = 2 * C.nflav;
+        wave_sync();
+        int sb = uni(x.osst[i1]);
+        for (int i = i1 + 1; i < i2 && sb >= 0; ++i) {
+            if (x.lane == 0) x.tsst[i - 1] = sb;
+            sb = uni(x.t_conn[sb * nf2 + uni(x.om[i])]);
+        }
+        if (sb < 0 || sb != uni(x.osst[i2 + 1])) { x.count(C_QNREM); return; }
+        for (int j = x.lane; j <= x.nops - 2; j += 64) {
+            if (j < i1) x.tsst[j] = x.osst[j];
+            else if (j >= i2 - 1) x.tsst[j] = x.osst[j + 2];
+        }
+    }
     mat_remove(x, i2); mat_remove(x, i1);
     wave_sync();
-    if (!mat_walk_into(x, x.outer, x.tsst)) { mat_insert(x, i1, t1, c1); mat_insert(x, i2, t2, c2); x.count(C_QNREM); return; }
     double *Mf = x.mat(0);
     const double S = uni(Mf[(size_t)ic * kmax + ia]);
     double tl_new, ts_new;
@@ -504,33 +537,46 @@ __global__ __launch_bounds__(256, W2DYN_WPE_MAT) void k_sweep_od(DevConst C, lon
 #ifdef W2DYN_TU_OFFDIAG
 // MeasGtauRem_full (CTQMC.F90:2475-2584): every element of the full matrix into gtau_full / gleg_full[flavour of the
 // annihilator][flavour of the creator]; one wave per chain, lane = element, the Legendre recursion of the reference
-__global__ __launch_bounds__(256) void k_meas_full(DevConst C, double *__restrict__ acc_gleg_full, double *__restrict__ acc_gtau_full)
+__global__ __launch_bounds__(256) void k_meas_full(DevConst C, double *__restrict__ acc_gleg_full, double *__restrict__ acc_gtau_full, int lds_leg)
 {
+    extern __shared__ double sleg[];           // lds_leg: [nflav^2][nleg] sums of the workgroup's four chains (they share a bin: walkers_per_bin is a multiple of 4)
     const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (w >= C.nwalkers) return;
-    const int kt = C.K[(size_t)w * C.nflav], kmax = C.kmax, nf = C.nflav, nleg = C.nleg, ntau = C.ntau;
-    const double *tc = C.TC + (size_t)w * nf * kmax, *ta = C.TA + (size_t)w * nf * kmax, *M = C.M + (size_t)w * nf * kmax * kmax;
-    const int *fc = C.FC + (size_t)w * kmax, *fa = C.FA + (size_t)w * kmax;
-    const double cfgsign = C.cfgsign[w], beta = C.beta;
-    const int bin = w / C.walkers_per_bin;
-    double *gl = acc_gleg_full + (size_t)bin * nf * nf * nleg, *gt = acc_gtau_full + (size_t)bin * nf * nf * ntau;
-    for (int e = lane; e < kt * kt; e += 64) {
-        const int i = e / kt, j = e - i * kt;
-        double m = M[(size_t)i * kmax + j], xx; int idt;
-        const double d = ta[j] - tc[i];
-        if (d > 0.0) { idt = (int)(d / beta * (double)ntau) + 1; xx = 2.0 / beta * d - 1.0; }
-        else { idt = (int)((beta + ta[j] - tc[i]) / beta * (double)ntau) + 1; xx = 2.0 / beta * (beta + ta[j] - tc[i]) - 1.0; m = -m; }
-        m = m * cfgsign;
-        if (idt > ntau) idt = ntau;
-        const size_t ff = (size_t)fa[j] * nf + fc[i];
-        atomicAdd(&gt[ff * ntau + idt - 1], m);
-        double plx = 0.0, plm1 = 0.0, plp1 = 0.0;
-        for (int il = 0; il < nleg; ++il) {
-            if (il == 0) plp1 = 1.0;
-            else if (il == 1) plp1 = xx;
-            else { const int l = il - 1; plp1 = (2.0 * (double)l + 1.0) / (double)(l + 1) * xx * plx - (double)l / (double)(l + 1) * plm1; }
-            atomicAdd(&gl[ff * nleg + il], m * plp1);
-            plm1 = plx; plx = plp1;
+    const int nf = C.nflav, nleg = C.nleg, ntau = C.ntau, kmax = C.kmax;
+    if (lds_leg) { for (int i = threadIdx.x; i < nf * nf * nleg; i += blockDim.x) sleg[i] = 0.0; __syncthreads(); }
+    if (w < C.nwalkers) {
+        const int kt = C.K[(size_t)w * nf];
+        const double *tc = C.TC + (size_t)w * nf * kmax, *ta = C.TA + (size_t)w * nf * kmax, *M = C.M + (size_t)w * nf * kmax * kmax;
+        const int *fc = C.FC + (size_t)w * kmax, *fa = C.FA + (size_t)w * kmax;
+        const double cfgsign = C.cfgsign[w], beta = C.beta;
+        const int bin = w / C.walkers_per_bin;
+        double *gl = acc_gleg_full + (size_t)bin * nf * nf * nleg, *gt = acc_gtau_full + (size_t)bin * nf * nf * ntau;
+        for (int e = lane; e < kt * kt; e += 64) {
+            const int i = e / kt, j = e - i * kt;
+            double m = M[(size_t)i * kmax + j], xx; int idt;
+            const double d = ta[j] - tc[i];
+            if (d > 0.0) { idt = (int)(d / beta * (double)ntau) + 1; xx = 2.0 / beta * d - 1.0; }
+            else { idt = (int)((beta + ta[j] - tc[i]) / beta * (double)ntau) + 1; xx = 2.0 / beta * (beta + ta[j] - tc[i]) - 1.0; m = -m; }
+            m = m * cfgsign;
+            if (idt > ntau) idt = ntau;
+            const size_t ff = (size_t)fa[j] * nf + fc[i];
+            atomicAdd(&gt[ff * ntau + idt - 1], m);
+            double *dst = lds_leg ? sleg + ff * nleg : gl + ff * nleg;
+            double plx = 0.0, plm1 = 0.0, plp1 = 0.0;
+            for (int il = 0; il < nleg; ++il) {
+                if (il == 0) plp1 = 1.0;
+                else if (il == 1) plp1 = xx;
+                else { const int l = il - 1; plp1 = (2.0 * (double)l + 1.0) / (double)(l + 1) * xx * plx - (double)l / (double)(l + 1) * plm1; }
+                atomicAdd(&dst[il], m * plp1);
+                plm1 = plx; plx = plp1;
+            }
+        }
+    }
+    if (lds_leg) {
+        __syncthreads();
+        const int w0 = blockIdx.x * (blockDim.x >> 6);
+        if (w0 < C.nwalkers) {
+            double *gl = acc_gleg_full + (size_t)(w0 / C.walkers_per_bin) * nf * nf * nleg;
+            for (int i = threadIdx.x; i < nf * nf * nleg; i += blockDim.x) { const double v = sleg[i]; if (v != 0.0) atomicAdd(&gl[i], v); }
         }
     }
 }

@@ -10,6 +10,9 @@ void launch_sweep_od_tree(int mat, const LaunchCfg &l, const DevConst &C, long l
 }
 void launch_meas_full(const DevConst &C, hipStream_t st, double *acc_gleg_full, double *acc_gtau_full)
 {
-    hipLaunchKernelGGL(k_meas_full, dim3((C.nwalkers + 3) / 4), dim3(256), 0, st, C, acc_gleg_full, acc_gtau_full);
+    // the Legendre sums of a workgroup's four chains are formed in LDS when they share an accumulator bin and fit
+    const size_t bytes = (size_t)C.nflav * C.nflav * C.nleg * sizeof(double);
+    const int lds_leg = (C.walkers_per_bin % 4 == 0 && bytes <= 64 * 1024) ? 1 : 0;
+    hipLaunchKernelGGL(k_meas_full, dim3((C.nwalkers + 3) / 4), dim3(256), lds_leg ? bytes : 0, st, C, acc_gleg_full, acc_gtau_full, lds_leg);
 }
 }  // namespace w2dyn

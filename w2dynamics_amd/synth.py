@@ -161,6 +161,8 @@ def config(name: str, nftau: int = 5001) -> Problem:
         return make_problem(2, 10.0, 2.0, j=0.25, nftau=nftau, fmix=0.3)
     if name == "C4O":      # three orbitals, Kanamori, hopping
         return make_problem(3, 10.0, 2.0, j=0.25, nftau=nftau, kanamori=True, quantum_numbers="Nt All", hop=0.2, fmix=0.25)
+    if name == "C4OB":     # the same at the temperature of BASELINE.json's 3-orbital configuration
+        return make_problem(3, 50.0, 2.0, j=0.25, nftau=nftau, kanamori=True, quantum_numbers="Nt All", hop=0.2, fmix=0.25)
     if name == "C4SQ":     # "All" on its own: the starting partition is one block, whose operators connect nothing
         return make_problem(2, 10.0, 2.0, j=0.25, nftau=nftau, kanamori=True, quantum_numbers="All")   # (Operator.F90:150): every state ends up alone
     if name == "C3A":      # density-density: every Fock state is its own block
