@@ -55,7 +55,12 @@ int w2dyn_set_fourpnt(w2dyn_solver *s, int fourpnt);
 /* init_solver(u_matrix_in, ftau_full, muimp_full, screening_function, iter_no, nftau, nbands)
  *                                                  CTQMC.F90:7894-8085
  * u_matrix (2Nd)^4, ftau_full (Nd,2,Nd,2,Nftau), muimp_full (Nd,2,Nd,2) already negated (impurity.py:529),
- * screening_function (Nd,2,Nd,2,Nftau) (must be zero: Phonon/Screening/Uw are refused). Host pointers. */
+ * screening_function (Nd,2,Nd,2,Nftau) (must be zero: Phonon/Screening/Uw are refused). Host pointers.
+ * offdiag = 0 (parameter string) uses the flavour-diagonal elements of ftau_full only (CTQMC.F90:7950-7955); offdiag = 1 all of
+ * it: one hybridisation matrix over all flavours, pair moves with independent flavours (Trace.F90:2690-2770, 2835-2997), results
+ * gleg_full / gtau_full (MeasGtauRem_full, CTQMC.F90:2475-2584); Z-space runs only.
+ * Percentage4OperatorMove / PercentageOuterMove > 0: the two-pair moves StepAdd4 / StepRem4 (CTQMC.F90:3615-3889, 4153-4430) and the
+ * pair moves that change the outer block (CTQMC.F90:3422-3449, 3935-3962), results accadd4 / accrem4; Z-space runs only. */
 int w2dyn_init_solver(w2dyn_solver *s, const double *u_matrix, const double *ftau_full, const double *muimp_full,
                       const double *screening_function, int iter_no, int nftau, int nbands);
 /* set_taudiffmax(x)                                CTQMC.F90:8180 */
