@@ -72,6 +72,7 @@ struct ora_walker {
     double *weq[6]; size_t weq_n[6];          /* p2iw, p2iwpp, p2tau, p2taupp, p3iw, p3iwpp worm accumulators (sectors 6 - 9) */
     double try_add, acc_add, accqn_add, try_rem, acc_rem, accqn_rem, try_glob, acc_glob, accqn_glob;
     double try_shift, acc_shift, cnt_sampling, cnt_meas;
+    double try_flavc, acc_flavc;                      /* TryFlavc, AccFlavc (CTQMC.F90:4857, 4951) */
     double try_add4, acc_add4, try_rem4, acc_rem4;   /* TryAdd4, AccAdd4, TryRem4, AccRem4 (CTQMC.F90:3645, 3861, 4175, 4394) */
     double try_add_outer, acc_add_outer, try_rem_outer, acc_rem_outer;   /* TryAddOuter ... (CTQMC.F90:3385, 3589, 3917, 4135) */
     int64_t *accpair;
@@ -1027,12 +1028,40 @@ static void step_rem_od(ora_walker *w)
     } else { list_insert(w, o1); list_insert(w, o2); }
 }
 
+/* CTQMC.F90:4838-4989 StepFlavourchange_general (flavourchange_moves = 1; off-diagonal hybridisation): two operators inside the
+ * window get new random flavours (propose_flavourexchange_general, Trace.F90:2191-2274), the matrix is built anew */
+static void step_flavc(ora_walker *w)
+{
+    w->try_flavc += 1;
+    int jlo = 0, jhi = 0;
+    for (int i = 0; i < w->nops; ++i) { if (w->ops[i].tau < w->wmin) ++jlo; if (w->ops[i].tau <= w->wmax) ++jhi; }
+    const int N = jhi - jlo;
+    if (N <= 1) return;
+    const int pos1 = RINT(w, 1, N - 1), pos2 = RINT(w, 1, N - pos1);
+    const int i1 = jlo + pos1 - 1, i2 = i1 + pos2;
+    if (w->ops[i1].wid || w->ops[i2].wid) return;
+    const int f1o = w->ops[i1].flav, f2o = w->ops[i2].flav;
+    { const int orb = RINT(w, 1, w->p.nd), spin = RINT(w, 1, 2); w->ops[i1].flav = 2 * (orb - 1) + (spin - 1); }
+    { const int orb = RINT(w, 1, w->p.nd), spin = RINT(w, 1, 2); w->ops[i2].flav = 2 * (orb - 1) + (spin - 1); }
+    if (!sequence_valid(w, w->outer_sst)) { w->ops[i1].flav = f1o; w->ops[i2].flav = f2o; return; }
+    const logval trnew = full_trace(w, w->outer_sst);
+    double *Mfn; int ktn; logval detnew;
+    rebuild_full(w, &Mfn, &ktn, &detnew);
+    const double prob = fabs(exp((trnew.log - w->tr.log) + (detnew.log - w->det.log)));
+    if (U01(w) < prob) {
+        free(w->Mf); w->Mf = Mfn; w->kt = ktn; w->det = detnew; w->tr = trnew;
+        w->cfgsign = -get_sign(w);
+        w->acc_flavc += 1;
+    } else { free(Mfn); w->ops[i1].flav = f1o; w->ops[i2].flav = f2o; }
+}
+
 /* the pair move of one step: CTQMC.F90:8441-8449, 8456-8464 (two random numbers, used or not) */
 static void pair_move(ora_walker *w, int add)
 {
     const int four = !(U01(w) >= w->p.p_4op);
     if (!four && w->p.offdiag) { (void)U01(w); if (add) step_add_od(w); else step_rem_od(w); }
     else if (!four) { const int outer = U01(w) < w->p.p_outer; if (add) step_add(w, outer); else step_rem(w, outer); }
+    else if (w->p.flavc) step_flavc(w);                /* b_exch: the flavour change takes the place of the two-pair moves */
     else if (add) step_add4(w); else step_rem4(w);
 }
 
@@ -1624,7 +1653,7 @@ static void init_counters(ora_walker *w) /* CTQMC.F90:847-896 */
     w->try_add = w->acc_add = w->accqn_add = w->try_rem = w->acc_rem = w->accqn_rem = 0;
     w->try_glob = w->acc_glob = w->accqn_glob = w->try_shift = w->acc_shift = 0;
     w->cnt_sampling = w->cnt_meas = 0;
-    w->try_add4 = w->acc_add4 = w->try_rem4 = w->acc_rem4 = 0;
+    w->try_add4 = w->acc_add4 = w->try_rem4 = w->acc_rem4 = 0; w->try_flavc = w->acc_flavc = 0;
     w->try_add_outer = w->acc_add_outer = w->try_rem_outer = w->acc_rem_outer = 0;
     w->wtry_add = w->wacc_add = w->wtry_rem = w->wacc_rem = 0;
     w->try_wadd = w->acc_wadd = w->accqn_wadd = w->try_wrem = w->acc_wrem = w->accqn_wrem = w->try_wrep = w->acc_wrep = 0;
@@ -2675,6 +2704,7 @@ void ora_get_counters_more(const ora_walker *w, double *o)
 {
     o[0] = w->try_add4; o[1] = w->acc_add4; o[2] = w->try_rem4; o[3] = w->acc_rem4;
     o[4] = w->try_add_outer; o[5] = w->acc_add_outer; o[6] = w->try_rem_outer; o[7] = w->acc_rem_outer;
+    o[8] = w->try_flavc; o[9] = w->acc_flavc;
 }
 void ora_get_counters(const ora_walker *w, double *o)
 {

@@ -63,6 +63,7 @@ typedef struct ora_params {
     int nsym; int symmoves[8 * 16];
     int worm_meas_gsigma;                          /* WormMeasGSigmaiw: sector 3, improved estimator of the one-particle Green's function (CTQMC.F90:619-623) */
     int offdiag;                                   /* offdiag = 1: hybridisation function with both flavour indices, one inverse matrix over all flavours (CTQMC.F90:461-467) */
+    int flavc;                                     /* flavourchange_moves (b_exch, CTQMC.F90:481-485): StepFlavourchange_general in place of the two-pair moves */
     double p_4op, p_outer;                         /* Percentage4OperatorMove, PercentageOuterMove (CTQMC.F90:332-333, 8441-8442) */
 } ora_params;
 
@@ -158,8 +159,8 @@ double ora_mean_sign(const ora_walker *w);
 /* counters: [0]TryAdd [1]AccAdd [2]AccQNAdd [3]TryRem [4]AccRem [5]AccQNRem [6]TryGlob [7]AccGlob [8]AccQNGlob
  * [9]TryShift [10]AccShift [11]CntSampling [12]CntMeas */
 void ora_get_counters(const ora_walker *w, double *out13);
-/* [0]TryAdd4 [1]AccAdd4 [2]TryRem4 [3]AccRem4 [4]TryAddOuter [5]AccAddOuter [6]TryRemOuter [7]AccRemOuter */
-void ora_get_counters_more(const ora_walker *w, double *out8);
+/* [0]TryAdd4 [1]AccAdd4 [2]TryRem4 [3]AccRem4 [4]TryAddOuter [5]AccAddOuter [6]TryRemOuter [7]AccRemOuter [8]TryFlavc [9]AccFlavc */
+void ora_get_counters_more(const ora_walker *w, double *out10);
 
 /* ---- pure pieces, exposed for kernel-level parity tests ---- */
 double ora_hybr(const double *ftab, int nftau, double beta, double dtau);          /* Trace.F90:1014-1033 */

@@ -27,7 +27,7 @@ class OraParams(C.Structure):
                 ("meas_susz", C.c_int), ("step_series", C.c_int),
                 ("n2iwb", C.c_int), ("n3iwf", C.c_int), ("n3iwb", C.c_int), ("worm_meas_eq", C.c_int * 6),
                 ("nsym", C.c_int), ("symmoves", C.c_int * 128), ("worm_meas_gsigma", C.c_int),
-                ("offdiag", C.c_int), ("p_4op", C.c_double), ("p_outer", C.c_double)]
+                ("offdiag", C.c_int), ("flavc", C.c_int), ("p_4op", C.c_double), ("p_outer", C.c_double)]
 
 WORM_EQ_KEYS = ("WormMeasP2iwPH", "WormMeasP2iwPP", "WormMeasP2tauPH", "WormMeasP2tauPP", "WormMeasP3iwPH", "WormMeasP3iwPP")
 WORM_EQ_NAMES = ("p2iw_worm", "p2iwpp_worm", "p2tau_worm", "p2taupp_worm", "p3iw_worm", "p3iwpp_worm")
@@ -150,7 +150,7 @@ def params_from_pstring(ps, nd, beta, fourpnt=0):
                      n2iwb=ps.get_int("N2iwb"), n3iwf=ps.get_int("N3iwf"), n3iwb=ps.get_int("N3iwb"),
                      worm_meas_eq=(C.c_int * 6)(*[int(ps.get_int(k) != 0) for k in WORM_EQ_KEYS]),
                      nsym=ps.get_int("NSymMove"), symmoves=_symmoves(ps), worm_meas_gsigma=int(ps.get_int("WormMeasGSigmaiw") != 0),
-                     offdiag=int(ps.get_int("offdiag") != 0), p_4op=ps.get_real("Percentage4OperatorMove"), p_outer=ps.get_real("PercentageOuterMove"))
+                     offdiag=int(ps.get_int("offdiag") != 0), flavc=int(ps.get_int("flavourchange_moves") != 0), p_4op=ps.get_real("Percentage4OperatorMove"), p_outer=ps.get_real("PercentageOuterMove"))
 
 
 class OracleWalker:
@@ -257,7 +257,7 @@ class OracleWalker:
         r["outerstatehisto"] = hs[2]; r["signhistostates"] = hs[3]; r["tracecontribstates"] = hs[4]
         r["accpair"] = self.accpair()
         a = np.zeros(13); self.L.ora_get_counters(self.h, a); r["counters"] = a
-        a = np.zeros(8); self.L.ora_get_counters_more(self.h, a); r["counters_more"] = a
+        a = np.zeros(10); self.L.ora_get_counters_more(self.h, a); r["counters_more"] = a
         if p.offdiag:
             gl = np.zeros((nd, 2, nd, 2, p.nlegmax)); gt = np.zeros((nd, 2, nd, 2, p.ntau))
             if self.L.ora_get_full(self.h, gl, gt):

@@ -85,12 +85,17 @@ TRAJ = {
                              PercentageTauShiftMove=0.05), 72),
     "C4O": ("C4O", 501, dict(Nwarmups=3000, Nmeas=40, NCorr=50, TaudiffMax=3.0, Ntau=50, NLegMax=10, Niw=4, offdiag=1, PercentageGlobalMove=0.05,
                              PercentageTauShiftMove=0.05), 73),
+    # flavourchange_moves = 1 with offdiag = 1: StepFlavourchange_general in place of the two-pair moves
+    "C4SOf": ("C4SO", 501, dict(Nwarmups=3000, Nmeas=60, NCorr=50, TaudiffMax=3.0, Ntau=50, NLegMax=10, Niw=4, offdiag=1, flavourchange_moves=1,
+                                Percentage4OperatorMove=0.3, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 74),
+    "C4Of": ("C4O", 501, dict(Nwarmups=3000, Nmeas=40, NCorr=50, TaudiffMax=10.0, Ntau=50, NLegMax=10, Niw=4, offdiag=1, flavourchange_moves=1,
+                              Percentage4OperatorMove=0.3, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 75),
     # BASELINE.json configs[4], Z-space part: 5 orbitals, density-density, beta = 100 (1024 one-state blocks, 10 flavours)
     "C5Z": ("C5Z", 501, dict(Nwarmups=4000, Nmeas=50, NCorr=100, TaudiffMax=10.0, Ntau=100, NLegMax=40, Niw=8, MeasGiw=1,
                              NLookup_nfft=0, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 31),
 }
 
-KEYS = ("gleg", "gtau", "giw", "histo", "occ", "outersuperstatehisto", "accpair", "mean_sign", "accadd", "accrem", "accadd4", "accrem4",
+KEYS = ("gleg", "gtau", "giw", "histo", "occ", "outersuperstatehisto", "accpair", "mean_sign", "accadd", "accrem", "accadd4", "accrem4", "accflavc",
         "accglob", "accshift", "gleg_full", "gtau_full", "eigenstatesenergies", "densitymatrix", "rho1", "rho2", "statessuperstates",
         # MeasOuterHistograms (CTQMC.F90:3285-3339, normalised 8757-8764); lhisto / rhisto are never filled (8698-8699)
         "signhistosuperstates", "tracecontribsuperstates", "outerstatehisto", "signhistostates", "tracecontribstates",

@@ -112,10 +112,16 @@ OD_TRAJ = [
     ("C3O", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=3.0, offdiag=1, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 82),
     ("C4O", 501, dict(BASE, Nwarmups=3000, Nmeas=20, NCorr=30, TaudiffMax=3.0, offdiag=1, PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 83),
     ("C4SO", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=-1.0, offdiag=1, PercentageGlobalMove=0.1, PercentageTauShiftMove=0.1), 84),
+    # flavourchange_moves = 1: StepFlavourchange_general in place of the two-pair moves (oracle pinned on traj_C4SOf / traj_C4Of)
+    ("C4SO", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=3.0, offdiag=1, flavourchange_moves=1, Percentage4OperatorMove=0.3,
+                       PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 85),
+    ("C4O", 501, dict(BASE, Nwarmups=3000, Nmeas=20, NCorr=30, TaudiffMax=10.0, offdiag=1, flavourchange_moves=1, Percentage4OperatorMove=0.3,
+                      PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05), 86),
 ]
 
 
-@pytest.mark.parametrize("cfg,nftau,over,seed", OD_TRAJ, ids=["C4SO-kanamori-hopping", "C3O-density-density", "C4O-three-orbitals", "C4SO-one-window"])
+@pytest.mark.parametrize("cfg,nftau,over,seed", OD_TRAJ, ids=["C4SO-kanamori-hopping", "C3O-density-density", "C4O-three-orbitals", "C4SO-one-window",
+                                                             "C4SO-flavour-change", "C4O-flavour-change"])
 def test_chains_retrace_oracle_offdiag(cfg, nftau, over, seed):
     """Every chain: same configuration, full inverse matrix, determinant, sign and NPairs after warm-up; same gleg_full / gtau_full,
     histograms, occupations and density matrix after sampling."""
@@ -147,9 +153,9 @@ def test_chains_retrace_oracle_offdiag(cfg, nftau, over, seed):
         oracles.append(o)
     q.ctqmc_measure(1, 1)
     bins = {k: getattr(q, k + "_bins") for k in ("gleg_full", "gtau_full", "histo", "occ")}
-    msign = 0.0; nonzero = 0.0
+    msign = 0.0; nonzero = 0.0; cm = np.zeros(10)
     for w, o in enumerate(oracles):
-        o.measure(); r = o.results()
+        o.measure(); r = o.results(); cm += r["counters_more"]
         for k in bins:      # these problems have a sign problem: a bin is divided by the mean sign of its context, a chain of the oracle by its own
             f_gpu, f_ora = (1.0, 1.0) if k == "histo" else (q.mean_sign, r["mean_sign"])
             assert rel(bins[k][w] * f_gpu, r[k] * f_ora) < TOL, (k, w)
@@ -158,6 +164,8 @@ def test_chains_retrace_oracle_offdiag(cfg, nftau, over, seed):
         msign += r["mean_sign"] / nw
         o.close()
     assert nonzero > 1e-3                      # the off-diagonal elements are measured
+    if over.get("flavourchange_moves"):
+        assert cm[8] > 0 and cm[9] > 0 and q.accflavc == pytest.approx(cm[9] / cm[8], rel=1e-12)
     assert q.mean_sign == pytest.approx(msign, abs=1e-12)
     q.dest_ctqmc(); q.close()
 
@@ -282,7 +290,7 @@ def _retrace(cfg, nftau, over, seed):
     hbins = {k: getattr(q, k + "_bins") for k in HIST}
     bins = {k: getattr(q, k + "_bins") for k in ("gleg", "gtau", "giw", "histo", "occ")}
     tot = {k: 0.0 for k in bins}
-    msign = 0.0; dm = 0.0; rho1 = 0.0; ssq = None; cm = np.zeros(8)
+    msign = 0.0; dm = 0.0; rho1 = 0.0; ssq = None; cm = np.zeros(10)
     for w, o in enumerate(oracles):
         o.measure(); r = o.results(); cm += r["counters_more"]
         for k in bins:
@@ -687,7 +695,8 @@ def test_capacity_overflow_inside_measurement_run_is_reported():
 
 def test_unsupported_modes_are_refused():
     p, _, _ = util.setup("C1", 501, {})
-    for over in (dict(segment=1), dict(offdiag=1, FourPnt=0, MeasSusz=1), dict(statesampling=1), dict(flavourchange_moves=1), dict(EnableOuterTruncation="YES")):
+    for over in (dict(segment=1), dict(offdiag=1, FourPnt=0, MeasSusz=1), dict(statesampling=1), dict(flavourchange_moves=1), dict(offdiag=1, Percentage4OperatorMove=0.1),
+                 dict(EnableOuterTruncation="YES")):
         _, ps, _ = util.setup("C1", 501, over)
         q = MCTQMC(nwalkers=4)
         q.init_rnd(1); q.init_paras(ps)

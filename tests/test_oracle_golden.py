@@ -100,7 +100,7 @@ def test_oracle_retraces_reference_chain(name):
     w.close()
 
 
-@pytest.mark.parametrize("name", ["C4SO", "C3O", "C4O"])
+@pytest.mark.parametrize("name", ["C4SO", "C3O", "C4O", "C4SOf", "C4Of"])      # ...f: flavourchange_moves = 1 (StepFlavourchange_general, CTQMC.F90:4838-4989)
 def test_oracle_retraces_reference_chain_offdiag(name):
     """offdiag = 1 (off-diagonal hybridisation, fast updates): one inverse matrix over all flavours, pairs of unequal flavours,
     the permutation sign of recalc_sign, gleg_full / gtau_full (CTQMC.F90:2475-2584; Trace.F90:2462-2601, 2690-2770, 2835-2997, 3500-3545)."""
@@ -129,6 +129,9 @@ def test_oracle_retraces_reference_chain_offdiag(name):
     assert cnt[7] / cnt[6] == pytest.approx(float(g["res_accglob"]), rel=1e-12)
     assert cnt[10] / cnt[9] == pytest.approx(float(g["res_accshift"]), rel=1e-12)
     assert np.array_equal(r["accpair"], g["res_accpair"])
+    if over.get("flavourchange_moves"):
+        cm = r["counters_more"]
+        assert cm[8] > 0 and cm[9] > 0 and cm[9] / cm[8] == pytest.approx(float(g["res_accflavc"]), rel=1e-12)
     w.close()
 
 

@@ -80,6 +80,7 @@ enum Counter { C_TRYADD, C_ACCADD, C_QNADD, C_TRYREM, C_ACCREM, C_QNREM, C_TRYGL
                C_W_SAMPLING, C_W_TRYADD, C_W_ACCADD, C_W_TRYREM, C_W_ACCREM,
                C_TRYWADD, C_ACCWADD, C_QNWADD, C_TRYWREM, C_ACCWREM, C_QNWREM, C_TRYWREP, C_ACCWREP,
                C_TRYADD4, C_ACCADD4, C_TRYREM4, C_ACCREM4,       // two pairs at once (StepAdd4 / StepRem4)
+               C_TRYFLAVC, C_ACCFLAVC,                           // StepFlavourchange_general (offdiag with flavourchange_moves)
                C_NCOUNT };
 static_assert(C_NCOUNT <= 64, "one lane per event counter");
 

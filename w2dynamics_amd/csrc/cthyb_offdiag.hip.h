@@ -494,6 +494,84 @@ __device__ W2DYN_INLINE void step_glob_od(Ctx &x)
     x.count(C_ACCGLOB);
 }
 
+// StepFlavourchange_general (CTQMC.F90:4838-4989; flavourchange_moves = 1): two operators inside the window, chosen as
+// propose_flavourexchange_general does (Trace.F90:2191-2274), get new random flavours; their kinds and times stay.  Quantum
+// numbers over the span between them, trace in full, the matrix built anew, DetRat = DetNew / Det.
+template <int MAT>
+__device__ W2DYN_INLINE void step_flavc_od(Ctx &x)
+{
+    const DevConst &C = x.C;
+    const int nf = C.nflav, kmax = C.kmax;
+    x.count(C_TRYFLAVC);
+    const int jlo = mat_lower(x, x.wmin), N = mat_lower_eq(x, x.wmax) - jlo;
+    if (N <= 1) return;
+    const int pos1 = x.randint(1, N - 1), pos2 = x.randint(1, N - pos1);
+    const int i1 = jlo + pos1 - 1, i2 = i1 + pos2;
+    const int f1n = 2 * (x.randint(1, C.nd) - 1) + (x.randint(1, 2) - 1);
+    const int f2n = 2 * (x.randint(1, C.nd) - 1) + (x.randint(1, 2) - 1);
+    const int c1 = uni(x.om[i1]), c2 = uni(x.om[i2]);
+    const int c1n = 2 * f1n + (c1 & 1), c2n = 2 * f2n + (c2 & 1);
+    const double t1 = uni(x.ot[i1]), t2 = uni(x.ot[i2]);
+    const int kt = x.order(0);
+    double *tcp = x.tc(0), *tap = x.ta(0); int *fcs = od_fc(x), *fas = od_fa(x);
+    {   // block sequence: walked anew between the two operators, must arrive at the block behind the later one
+        const int nf2 = 2 * nf;
+        wave_sync();
+        int sb = uni(x.osst[i1]);
+        sb = uni(x.t_conn[sb * nf2 + c1n]);
+        for (int i = i1 + 1; i < i2 && sb >= 0; ++i) {
+            if (x.lane == 0) x.tsst[i] = sb;
+            sb = uni(x.t_conn[sb * nf2 + uni(x.om[i])]);
+        }
+        if (sb >= 0) { if (x.lane == 0) x.tsst[i2] = sb; sb = uni(x.t_conn[sb * nf2 + c2n]); }
+        if (sb < 0 || sb != uni(x.osst[i2 + 1])) return;
+        for (int j = x.lane; j <= x.nops; j += 64) if (j <= i1 || j > i2) x.tsst[j] = x.osst[j];
+    }
+    if (x.lane == 0) { x.om[i1] = c1n; x.om[i2] = c2n; }
+    wave_sync();
+    double tl, ts;
+    mat_trace_trial<MAT>(x, x.tsst, x.nops, -1, -1, tl, ts);
+    // slot arrays with the two flavours changed, into the chain's scratch
+    double *TS = C.TS + (size_t)x.w * nf * 2 * kmax;
+    double *tcn = TS, *tan = TS + kmax; int *fcn = (int *)(TS + 2 * kmax), *fan = fcn + kmax;
+    for (int e = x.lane; e < kt; e += 64) {
+        tcn[e] = tcp[e]; tan[e] = tap[e];
+        int fc = fcs[e], fa = fas[e];
+        if ((c1 & 1) == 0 && tcp[e] == t1) fc = f1n;
+        if ((c2 & 1) == 0 && tcp[e] == t2) fc = f2n;
+        if ((c1 & 1) == 1 && tap[e] == t1) fa = f1n;
+        if ((c2 & 1) == 1 && tap[e] == t2) fa = f2n;
+        fcn[e] = fc; fan[e] = fa;
+    }
+    wave_sync();
+    x.wvalid = 0;
+    double *Mb = C.MB + (size_t)x.w * nf * kmax * kmax;
+    double ld, sg;
+    const int err0 = x.err;
+    od_build_and_invert(x, kt, tcn, tan, fcn, fan, Mb, ld, sg);
+    const bool singular = (x.err & ERR_SINGULAR) != 0;
+    x.err = err0;
+    sg *= od_sort_parity(x, tcn, fcn, kt) * od_sort_parity(x, tan, fan, kt);
+    const double prob = (ts == 0.0 || singular) ? 0.0 : fabs(exp((tl - x.tr_log) + (ld - x.det_log)));
+    const double rnd = x.draw();
+    if (!(rnd < prob)) {
+        if (x.lane == 0) { x.om[i1] = c1; x.om[i2] = c2; }
+        wave_sync();
+        return;
+    }
+    {
+        double *Mg = x.mat(0);
+        for (int e = x.lane; e < kt; e += 64) { fcs[e] = fcn[e]; fas[e] = fan[e]; }
+        for (int e = x.lane; e < kt * kt; e += 64) { const int i = e / kt, j = e - i * kt; Mg[(size_t)i * kmax + j] = Mb[(size_t)i * kmax + j]; }
+    }
+    wave_sync();
+    x.det_log = ld; x.det_sign = sg;
+    x.tr_log = tl; x.tr_sign = ts;
+    mat_commit_sst(x);
+    x.pvalid = 0; x.kval = 0;
+    x.count(C_ACCFLAVC);
+}
+
 // sweep kernel with offdiag: the Z-space loop of k_sweep (CTQMC.F90:8428-8533) over the moves above
 template <int MAT>
 __global__ __launch_bounds__(256, W2DYN_WPE_MAT) void k_sweep_od(DevConst C, long long nsteps_launch, int count_sampling, int resume)
@@ -516,8 +594,15 @@ __global__ __launch_bounds__(256, W2DYN_WPE_MAT) void k_sweep_od(DevConst C, lon
         long long it = 0;
         for (; it < nsteps && !(x.err & ERR_KMAX); ++it) {
             const double r = x.draw();
-            if (r < (1.0 - ps - pg) / 2.0) { x.skip(2); step_add_od<MAT>(x); phase += 1; }
-            else if (r <= 1.0 - ps - pg) { x.skip(2); step_rem_od<MAT>(x); phase += 1; }
+            // CTQMC.F90:8441-8449, 8456-8464: with flavourchange_moves the flavour change takes the place of the two-pair moves
+            // (probability Percentage4OperatorMove; the host lets p_4op > 0 through only then)
+            if (r <= 1.0 - ps - pg) {
+                if (x.draw() >= C.p_4op) {
+                    x.skip(1);
+                    if (r < (1.0 - ps - pg) / 2.0) step_add_od<MAT>(x); else step_rem_od<MAT>(x);
+                    phase += 1;
+                } else step_flavc_od<MAT>(x);
+            }
             else if (r <= 1.0 - ps) step_glob_od<MAT>(x);
             else step_shift_od<MAT>(x);
             if (phase == (unsigned int)C.nslide) phase = 0;

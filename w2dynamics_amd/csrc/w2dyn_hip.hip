@@ -108,6 +108,7 @@ struct w2dyn_solver {
     int64_t nmeas = 0;
     double beta = 0, p_glob = 0, p_shift = 0, taudiffmax_param = 0;
     double p_4op = 0, p_outer = 0;       // Percentage4OperatorMove, PercentageOuterMove
+    bool flavc = false;                  // flavourchange_moves = 1 (with offdiag = 1)
     bool offdiag = false;                // offdiag = 1: one hybridisation matrix over all flavours (csrc/cthyb_offdiag.hip.h)
     double *acc_gleg_full = nullptr, *acc_gtau_full = nullptr;      // [nbins][nflav][nflav][nleg | ntau]
     int has_szt = 0;
@@ -576,7 +577,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     long long iv; double rv; std::string sv;
     // ---- modes this build refuses ----
     struct { const char *key; long long allowed; } zero_int[] = {
-        {"segment", 0}, {"statesampling", 0}, {"flavourchange_moves", 0}, {"Phonon", 0},
+        {"segment", 0}, {"statesampling", 0}, {"Phonon", 0},
         {"Screening", 0}, {"Uw", 0}, {"MeasGtauDetRat", 0},
         {"MeasExpResDensityMatrix", 0},
         {"MeasDensityMatrix", 1}, {"Eigenbasis", 1}};
@@ -588,6 +589,10 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     // move, for debugging: the result is that of the fast updates up to rounding, which is what runs here either way
     if (!get_int(s, "offdiag", iv)) return W2DYN_EINVAL; s->offdiag = iv != 0;
     if (!get_int(s, "full_offdiag", iv)) return W2DYN_EINVAL;
+    // flavourchange_moves (b_exch, CTQMC.F90:481-485): StepFlavourchange_general in place of the two-pair moves.  It gives two operators
+    // independent new flavours, which only a hybridisation matrix over all flavours can take: offdiag = 1 only
+    if (!get_int(s, "flavourchange_moves", iv)) return W2DYN_EINVAL; s->flavc = iv != 0;
+    if (s->flavc && !s->offdiag) return fail(s, W2DYN_EUNSUPPORTED, "flavourchange_moves = 1 needs offdiag = 1 (the move leaves a flavour with unequal numbers of creators and annihilators)");
     // moves outside the default mix (CTQMC.F90:332-333): two pairs at once, pair moves that change the outer block
     if (!get_real(s, "Percentage4OperatorMove", s->p_4op)) return W2DYN_EINVAL;
     if (!get_real(s, "PercentageOuterMove", s->p_outer)) return W2DYN_EINVAL;
@@ -693,8 +698,8 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if (s->offdiag) {      // what the off-diagonal sampler does not do (the reference measures gtau_full / gleg_full only and skips G(iw), CTQMC.F90:8562-8575)
         long long a = 0, b = 0, c = 0, d = 0, e = 0;
         if (!get_int(s, "MeasSusz", a) || !get_int(s, "AccumGtau", b) || !get_int(s, "Gtau_mean_step", c) || !get_int(s, "Gtau_mid_step", d) || !get_int(s, "sign_step", e)) return W2DYN_EINVAL;
-        if (s->fourpnt != 0 || a != 0 || b == 2 || c != 0 || d != 0 || e != 0 || s->p_4op > 0.0 || s->p_outer > 0.0)
-            return fail(s, W2DYN_EUNSUPPORTED, "offdiag = 1 runs the pair, shift and global moves and measures gtau_full / gleg_full, sign, histograms and the density matrix: FourPnt, MeasSusz, AccumGtau = 2, the step series and Percentage4OperatorMove / PercentageOuterMove are not supported with it");
+        if (s->fourpnt != 0 || a != 0 || b == 2 || c != 0 || d != 0 || e != 0 || (s->p_4op > 0.0 && !s->flavc) || s->p_outer > 0.0)
+            return fail(s, W2DYN_EUNSUPPORTED, "offdiag = 1 runs the pair, shift and global moves and measures gtau_full / gleg_full, sign, histograms and the density matrix: FourPnt, MeasSusz, AccumGtau = 2, the step series, PercentageOuterMove and Percentage4OperatorMove without flavourchange_moves = 1 are not supported with it");
         s->meas_giw = 0;
     }
     s->mat = !lp.identity_blocks || s->offdiag;      // off-diagonal hybridisation: always the matrix trace path (list of operators with their flavours)
@@ -758,7 +763,7 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     }
     { int rc0 = configure_kmax(s, kmax); if (rc0) return rc0; }
     C.beta = s->beta; C.rbeta = 1.0 / s->beta; C.p_glob = s->p_glob; C.p_shift = s->p_shift; C.egs = s->egs;
-    C.p_4op = s->p_4op; C.p_outer = s->p_outer; C.xmoves = (s->p_4op > 0.0 || s->p_outer > 0.0) ? 1 : 0;
+    C.p_4op = s->p_4op; C.p_outer = s->p_outer; C.xmoves = (!s->offdiag && (s->p_4op > 0.0 || s->p_outer > 0.0)) ? 1 : 0;
     C.offdiag = s->offdiag ? 1 : 0;
     C.seed = (unsigned long long)s->seed; C.first_walker = (unsigned long long)s->first_walker;
     host_init_window(s, s->taudiffmax_param, C.num_windows, C.taudiff_max);           // Trace.F90:605
@@ -1538,6 +1543,7 @@ int w2dyn_measure_finish(w2dyn_solver *s)
         R["accglob"] = {s->counters[C_ACCGLOB] / s->counters[C_TRYGLOB]};
         R["accadd4"] = {s->counters[C_ACCADD4] / s->counters[C_TRYADD4]};      // CTQMC.F90:8677-8678 (0/0 when the moves are off)
         R["accrem4"] = {s->counters[C_ACCREM4] / s->counters[C_TRYREM4]};
+        R["accflavc"] = {s->counters[C_ACCFLAVC] / s->counters[C_TRYFLAVC]};   // CTQMC.F90:8681
         R["accshift"] = {s->counters[C_ACCSHIFT] / s->counters[C_TRYSHIFT]};
     }
     if (s->acc_susz && true) {      // CTQMC.F90:8744-8746: ntau_n0 * zScaling, point Ntau = point 0
@@ -2190,8 +2196,7 @@ int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out)
     else if (n == "time_sim_steps") *out = s->time_sim_steps;
     else if (n == "accglob") *out = first("accglob");
     else if (n == "accshift") *out = first("accshift");
-    else if (n == "accadd4" || n == "accrem4") *out = first(name);
-    else if (n == "accflavc") *out = NAN;     // 0/0 in the reference when unused
+    else if (n == "accadd4" || n == "accrem4" || n == "accflavc") *out = first(name);
     else if (n == "nwalkers") *out = s->nwalkers;
     else if (n == "nbins") *out = s->C.nbins;
     else if (n == "kmax") *out = s->C.kmax;
