@@ -69,6 +69,7 @@ struct ora_walker {
     double *giww, *gtauw;                     /* giw_worm (2Niw complex), gtau_worm (Ntau) accumulators (sector 2) */
     double *gsw;                              /* GSigmaiw_worm (2Niw complex) accumulator (sector 3) */
     double *umat;                             /* U matrix (2Nd)^4, flavour index 2 * orbital + spin, as handed to init_solver */
+    double *wmore[11]; size_t wmore_n[11];    /* h4iw, qq, qqtau, qqqq, nqqdag, qqdd, ucaca, ucacatau, uccaa, uccaatau, quddag worm accumulators (sectors 5, 10 - 16) */
     double *weq[6]; size_t weq_n[6];          /* p2iw, p2iwpp, p2tau, p2taupp, p3iw, p3iwpp worm accumulators (sectors 6 - 9) */
     double try_add, acc_add, accqn_add, try_rem, acc_rem, accqn_rem, try_glob, acc_glob, accqn_glob;
     double try_shift, acc_shift, cnt_sampling, cnt_meas;
@@ -448,7 +449,7 @@ static void legendre_p(double x, int n, double *pl)
 
 static double worm_sign(const ora_walker *w)
 {
-    long perm = 0; double wt[5]; int nw = 0;
+    long perm = 0; double wt[13]; int nw = 0;
     for (int i = 0; i < w->nops; ++i) if (w->ops[i].wid) { wt[w->ops[i].wid] = w->ops[i].tau; ++nw; }
     if (nw == 0) return 1.0;
     for (int i = 0; i < w->nops; ++i) {
@@ -1345,31 +1346,71 @@ static void step_shift(ora_walker *w)
 /* and sector 2 (one-particle Green's function), two operators c c+ (NOperWorm, CTQMC.F90:5282-5285)             */
 /* ------------------------------------------------------------------------------------------------------- */
 
-static int worm_nops(const ora_walker *w) { return w->isector == 2 ? 2 : 4; }
-
-/* get_Proposal (CTQMC.F90:5677-5719): SectorG / SectorG4 (beta Nd)^n eta; P2 / P2pp beta^2 Nd^4 eta; P3 / P3pp beta^3 Nd^4 eta */
-/* the U-matrix factor of the GSigma worm: 0.5 (U(u, g2, g1, g3) - U(g2, u, g1, g3)), u = first flavour of the component, g_i = flavour
- * of worm operator i (CTQMC.F90:5689-5694, 1138) */
-static double gsigma_ufac(const ora_walker *w)
+/* NOperWorm, Parameters.F90:45 */
+static int worm_nops(const ora_walker *w)
 {
-    const int nf = w->nflav, u = ((w->icomponent - 1) / nf) % nf;
-    int g[5] = {0, 0, 0, 0, 0};
-    for (int i = 0; i < w->nops; ++i) if (w->ops[i].wid) g[w->ops[i].wid] = w->ops[i].flav;
+    static const int n[17] = {0, 0, 2, 4, 4, 6, 4, 4, 4, 4, 6, 12, 8, 8, 4, 4, 4};
+    return (w->isector >= 2 && w->isector <= 16) ? n[w->isector] : 4;
+}
+static int worm_is_ie(int sector) { return sector == 3 || sector == 5 || (sector >= 10 && sector <= 16); }
+
+/* get_Proposal (CTQMC.F90:5677-5796): SectorG / SectorG4 (beta Nd)^n eta; P2 / P2pp beta^2 Nd^4 eta; P3 / P3pp beta^3 Nd^4 eta;
+ * the sectors with U-matrix factors (3, 5, 10 - 16) below */
 #define UM(a, b, c, d) w->umat[(((size_t)(a) * nf + (b)) * nf + (c)) * nf + (d)]
-    return 0.5 * (UM(u, g[2], g[1], g[3]) - UM(g[2], u, g[1], g[3]));
-#undef UM
-}
-
-static double worm_prefact(const ora_walker *w)
+#define UA1(a, b, c, d) (0.5 * (UM(a, b, c, d) - UM(b, a, c, d)))                  /* u_matrix_antisymm_1, CTQMC.F90:7930 */
+#define UA2(a, b, c, d) (0.5 * (UM(a, b, c, d) - UM(a, b, d, c)))                  /* u_matrix_antisymm_2, 7932 */
+#define UAB(a, b, c, d) (0.5 * (UA1(a, b, c, d) - UA1(a, b, d, c)))                /* u_matrix_antisymm_both, 7943 */
+/* the U-matrix factor of the worm's proposal: g[i] = flavour of worm operator i (1-based), u[i] = i-th flavour index of the
+ * component (u_g; two digits in sectors 3 and 10, four otherwise; set_IEOperFlavor, Trace.F90:3835-3883).  meas != 0: the
+ * expression whose sign enters the estimator, which differs from the proposal's in sector 13 (CTQMC.F90:1919-1921 vs 5764-5766) */
+static double worm_ufac_of(const ora_walker *w, int sector, const int *g, int meas)
 {
-    const double b = w->p.beta, nd = (double)w->p.nd, nd4 = nd * nd * nd * nd;
-    if (w->isector == 3) return gsigma_ufac(w) * (b * b) * (nd4 * nd) * w->eta;       /* beta^(N-2) Nd^(N+1) eta, N = 4 (CTQMC.F90:5696) */
-    if (w->isector == 6 || w->isector == 7) return b * b * nd4 * w->eta;
-    if (w->isector == 8 || w->isector == 9) return b * b * b * nd4 * w->eta;
-    return pow(b * nd, (double)worm_nops(w)) * w->eta;
+    const int nf = w->nflav;
+    const int nred = (sector == 3 || sector == 10) ? 2 : 4;
+    int u[5] = {0, 0, 0, 0, 0}, rest = w->icomponent - 1;
+    for (int i = nred; i >= 1; --i) { u[i] = rest % nf; rest /= nf; }
+    switch (sector) {
+    case 3: case 5: return 0.5 * (UM(u[1], g[2], g[1], g[3]) - UM(g[2], u[1], g[1], g[3]));
+    case 10: return 0.5 * (UM(u[1], g[2], g[1], g[3]) - UM(g[2], u[1], g[1], g[3])) * 0.5 * (UM(g[6], g[4], u[2], g[5]) - UM(g[6], g[4], g[5], u[2]));
+    case 11: return 0.5 * (UM(u[1], g[2], g[1], g[3]) - UM(g[2], u[1], g[1], g[3])) * 0.5 * (UM(g[6], g[4], u[2], g[5]) - UM(g[6], g[4], g[5], u[2]))
+                  * 0.5 * (UM(u[3], g[8], g[7], g[9]) - UM(g[8], u[3], g[7], g[9])) * 0.5 * (UM(g[12], g[10], u[4], g[11]) - UM(g[12], g[10], g[11], u[4]));
+    case 12: return UA1(u[1], g[2], g[1], g[3]) * UA2(g[4], g[6], u[2], g[5]) * UAB(u[3], g[8], u[4], g[7]);
+    case 13: return meas ? UA1(u[1], g[2], g[1], g[3]) * UA1(u[3], g[4], g[5], g[7]) * UA2(g[6], g[8], u[2], u[4])
+                         : UA1(u[1], g[2], g[1], g[3]) * UA1(u[3], g[4], g[6], g[5]) * UA2(g[8], g[7], u[2], u[4]);
+    case 14: return UAB(u[1], g[2], u[2], g[1]) * UAB(u[3], g[4], u[4], g[3]);
+    case 15: return UA1(u[1], u[3], g[1], g[3]) * UA2(g[2], g[4], u[2], u[4]);       /* the proposal carries a minus sign on top (5791) */
+    case 16: return UA1(u[1], g[2], g[1], g[3]) * UAB(u[3], g[4], u[2], u[4]);
+    default: return 1.0;
+    }
 }
+static double worm_ufac(const ora_walker *w, int meas)
+{
+    int g[13] = {0};
+    for (int i = 0; i < w->nops; ++i) if (w->ops[i].wid) g[w->ops[i].wid] = w->ops[i].flav;
+    return worm_ufac_of(w, w->isector, g, meas);
+}
+static double gsigma_ufac(const ora_walker *w) { return worm_ufac(w, 0); }
 
-/* check_EqualTime (Trace.F90:4184-4269): the operators of an equal-time pair must be neighbours in the list, the one named
+static double worm_prefact_of(const ora_walker *w, double ufac)
+{
+    const double b = w->p.beta, nd = (double)w->p.nd, nd4 = nd * nd * nd * nd, b2 = b * b;
+    switch (w->isector) {
+    case 3: return ufac * b2 * (nd4 * nd) * w->eta;                                  /* beta^(N-2) Nd^(N+1) eta, N = 4 (CTQMC.F90:5696) */
+    case 5: return ufac * (b2 * b2) * (nd4 * nd * nd * nd) * w->eta;                 /* N = 6 */
+    case 6: case 7: return b2 * nd4 * w->eta;
+    case 8: case 9: return b2 * b * nd4 * w->eta;
+    case 10: return ufac * b2 * (nd4 * nd4) * w->eta;                                /* beta^(N-4) Nd^(N+2) eta, N = 6 (5731) */
+    case 11: return ufac * (b2 * b2) * (nd4 * nd4 * nd4) * w->eta;                   /* 5745 */
+    case 12: case 13: return ufac * w->eta * (b2 * b) * (nd4 * nd4);                 /* 5757, 5768 */
+    case 14: return ufac * w->eta * b2 * nd4;                                        /* 5778-5782 */
+    case 15: return -ufac * w->eta * b2 * nd4;                                       /* 5791-5795 */
+    case 16: return ufac * b2 * nd4 * w->eta;                                        /* 5706-5709 */
+    default: return pow(b * nd, (double)worm_nops(w)) * w->eta;
+    }
+}
+static double worm_prefact(const ora_walker *w) { return worm_prefact_of(w, worm_is_ie(w->isector) ? worm_ufac(w, 0) : 1.0); }
+
+/* check_EqualTime (Trace.F90:4184-4269): the operators of an equal-time object must be neighbours in the list, the one named
  * second right in front of the one named first.  wid = 1-based index in wormContainer */
 static int worm_index(const ora_walker *w, int wid)
 {
@@ -1380,11 +1421,18 @@ static int prev_is(const ora_walker *w, int wid, int wid_prev) { const int i = w
 static int check_equal_time(const ora_walker *w, int sector)
 {
     switch (sector) {
-    case 3: return prev_is(w, 2, 3) && prev_is(w, 3, 1);
+    case 3: case 5: case 16: return prev_is(w, 2, 3) && prev_is(w, 3, 1);
     case 6: return prev_is(w, 1, 2) && prev_is(w, 3, 4);
     case 7: return prev_is(w, 1, 3) && prev_is(w, 2, 4);
     case 8: return prev_is(w, 3, 4);
     case 9: return prev_is(w, 2, 4);
+    case 10: return prev_is(w, 2, 3) && prev_is(w, 3, 1) && prev_is(w, 6, 4) && prev_is(w, 4, 5);
+    case 11: return prev_is(w, 2, 3) && prev_is(w, 3, 1) && prev_is(w, 6, 4) && prev_is(w, 4, 5)
+                 && prev_is(w, 8, 9) && prev_is(w, 9, 7) && prev_is(w, 12, 10) && prev_is(w, 10, 11);
+    case 12: return prev_is(w, 2, 3) && prev_is(w, 3, 1) && prev_is(w, 4, 6) && prev_is(w, 6, 5) && prev_is(w, 8, 7);
+    case 13: return prev_is(w, 2, 3) && prev_is(w, 3, 1) && prev_is(w, 4, 7) && prev_is(w, 7, 5) && prev_is(w, 6, 8);
+    case 14: return prev_is(w, 2, 1) && prev_is(w, 4, 3);
+    case 15: return prev_is(w, 2, 4) && prev_is(w, 3, 1);
     default: return 1;
     }
 }
@@ -1392,46 +1440,78 @@ static int check_equal_time(const ora_walker *w, int sector)
 /* StepWormAdd, CTQMC.F90:4992-5140 */
 static void step_worm_add(ora_walker *w)
 {
-    const int nf = w->nflav;
+    const int nf = w->nflav, sec = w->isector;
     const int nw = worm_nops(w);
+    const int ie = worm_is_ie(sec);
     int comp = w->icomponent, ncomp = 1;
     for (int i = 0; i < nw; ++i) ncomp *= nf;
-    if (w->isector == 3) ncomp = nf * nf;            /* the component has two indices: U-matrix flavour and flavour of operator 4 */
-    if (comp == 0) comp = RINT(w, 1, ncomp);
+    if (!ie && comp == 0) comp = RINT(w, 1, ncomp);
     w->try_wadd += 1;
     /* set_OperFlavor (Trace.F90:3804-3826): digits of comp-1 in base 2Nd, most significant first; CA = mod(i,2)+1 */
-    op_t o[4]; int rest = comp - 1, base = ncomp / nf;
+    op_t o[12]; int rest = comp - 1, base = ncomp / nf;
     for (int i = 0; i < nw; ++i) {
         o[i].ca = ((i + 1) % 2) + 1; o[i].wid = i + 1; o[i].flav = 0;
-        if (w->isector != 3) { int bs = rest / base; rest -= bs * base; base /= nf; o[i].flav = bs; }
+        if (!ie) { int bs = rest / base; rest -= bs * base; base /= nf; o[i].flav = bs; }
     }
-    /* set_OperTime (Trace.F90:3942-4020) */
-    const double beta = w->p.beta, eqoff = beta * 1e-14;       /* equal_time_offset, Trace.F90:398 */
-    if (w->isector == 3) {
-        /* set_IEOperFlavor (Trace.F90:3835-3919): the three operators of the equal-time object get random flavours until the
-         * U-matrix factor of the proposal does not vanish (CTQMC.F90:5047-5054); operator 4 carries the component's second flavour */
-        const int f4 = (comp - 1) % nf, u = ((comp - 1) / nf) % nf;
+    if (ie) {
+        /* set_IEOperFlavor (Trace.F90:3835-3919): the operators of the equal-time objects get random flavours (orbital, then spin) until
+         * the U-matrix factor of the proposal does not vanish (CTQMC.F90:5047-5054); sectors 3 and 5: the operators after the third
+         * carry the component's flavours after the first */
+        int dig[4] = {0, 0, 0, 0}, r2 = comp - 1;
+        for (int i = 3; i >= 0; --i) { dig[i] = r2 % nf; r2 /= nf; }                /* four digits (sector 5) */
         for (;;) {
-            for (int i = 0; i < 3; ++i) { const int orb = RINT(w, 1, w->p.nd), spin = RINT(w, 1, 2); o[i].flav = 2 * (orb - 1) + (spin - 1); }
-            o[3].flav = f4;
-#define UM(a, b, c, d) w->umat[(((size_t)(a) * nf + (b)) * nf + (c)) * nf + (d)]
-            if (0.5 * (UM(u, o[1].flav, o[0].flav, o[2].flav) - UM(o[1].flav, u, o[0].flav, o[2].flav)) != 0.0) break;
-#undef UM
+            int g[13] = {0};
+            for (int i = 0; i < nw; ++i) {
+                if ((sec == 3 || sec == 5) && i >= 3) o[i].flav = sec == 3 ? (comp - 1) % nf : dig[i - 2];
+                else { const int orb = RINT(w, 1, w->p.nd), spin = RINT(w, 1, 2); o[i].flav = 2 * (orb - 1) + (spin - 1); }
+                g[i + 1] = o[i].flav;
+            }
+            if (worm_prefact_of(w, worm_ufac_of(w, sec, g, 0)) != 0.0) break;
         }
-        for (int i = 0; i < 4; ++i) o[i].tau = U01(w) * beta;
-        if (o[1].tau < 2.0 * eqoff) o[1].tau = 2.0 * eqoff;
-        o[2].tau = o[1].tau - eqoff; o[0].tau = o[1].tau - 2.0 * eqoff;
-    } else if (w->isector >= 6 && w->isector <= 9) {
+    }
+    /* set_OperTime (Trace.F90:3942-4164) */
+    const double beta = w->p.beta, eqoff = beta * 1e-14;       /* equal_time_offset, Trace.F90:398 */
+#define T(i) o[(i) - 1].tau
+    if (sec == 3 || sec == 5 || sec == 10 || sec == 11) {      /* a random time for every operator, then the equal-time objects */
+        for (int i = 0; i < nw; ++i) o[i].tau = U01(w) * beta;
+        if (T(2) < 2.0 * eqoff) T(2) = 2.0 * eqoff;
+        if (sec >= 10 && T(6) < 2.0 * eqoff) T(6) = 2.0 * eqoff;
+        if (sec == 11) { if (T(8) < 2.0 * eqoff) T(8) = 2.0 * eqoff; if (T(12) < 2.0 * eqoff) T(12) = 2.0 * eqoff; }
+        T(3) = T(2) - eqoff; T(1) = T(2) - 2.0 * eqoff;
+        if (sec >= 10) { T(4) = T(6) - eqoff; T(5) = T(6) - 2.0 * eqoff; }
+        if (sec == 11) { T(9) = T(8) - eqoff; T(7) = T(8) - 2.0 * eqoff; T(10) = T(12) - eqoff; T(11) = T(12) - 2.0 * eqoff; }
+    } else if (sec == 12 || sec == 13) {
+        const int third = sec == 12 ? 8 : 6;
+        T(2) = U01(w) * beta; T(4) = U01(w) * beta; T(third) = U01(w) * beta;
+        if (T(2) < 2.0 * eqoff) T(2) = 2.0 * eqoff;
+        if (T(4) < 2.0 * eqoff) T(4) = 2.0 * eqoff;
+        if (T(third) < eqoff) T(third) = eqoff;
+        T(3) = T(2) - eqoff; T(1) = T(2) - 2.0 * eqoff;
+        if (sec == 12) { T(6) = T(4) - eqoff; T(5) = T(4) - 2.0 * eqoff; T(7) = T(8) - eqoff; }
+        else { T(7) = T(4) - eqoff; T(5) = T(4) - 2.0 * eqoff; T(8) = T(6) - eqoff; }
+    } else if (sec == 14 || sec == 15) {
+        const int second = sec == 14 ? 4 : 3;
+        T(2) = U01(w) * beta; T(second) = U01(w) * beta;
+        if (T(2) < eqoff) T(2) = eqoff;
+        if (T(second) < eqoff) T(second) = eqoff;
+        if (sec == 14) { T(1) = T(2) - eqoff; T(3) = T(4) - eqoff; }
+        else { T(1) = T(3) - eqoff; T(4) = T(2) - eqoff; }
+    } else if (sec == 16) {
+        T(2) = U01(w) * beta; T(4) = U01(w) * beta;
+        if (T(2) < 2.0 * eqoff) T(2) = 2.0 * eqoff;
+        if (T(4) < eqoff) T(4) = eqoff;
+        T(3) = T(2) - eqoff; T(1) = T(2) - 2.0 * eqoff;
+    } else if (sec >= 6 && sec <= 9) {
         o[0].tau = U01(w) * beta;
         o[3].tau = U01(w) * beta;
-        if (w->isector <= 7) {                                  /* two random times */
+        if (sec <= 7) {                                         /* two random times */
             if (o[0].tau < eqoff) o[0].tau = eqoff;
             if (o[3].tau > beta - eqoff) o[3].tau = beta - eqoff;
-            if (w->isector == 6) { o[1].tau = o[0].tau - eqoff; o[2].tau = o[3].tau + eqoff; }
+            if (sec == 6) { o[1].tau = o[0].tau - eqoff; o[2].tau = o[3].tau + eqoff; }
             else { o[1].tau = o[3].tau + eqoff; o[2].tau = o[0].tau - eqoff; }
         } else {                                                /* three random times */
             if (o[3].tau > beta - eqoff) o[3].tau = beta - eqoff;
-            if (w->isector == 8) { o[1].tau = U01(w) * beta; o[2].tau = o[3].tau + eqoff; }
+            if (sec == 8) { o[1].tau = U01(w) * beta; o[2].tau = o[3].tau + eqoff; }
             else { o[1].tau = o[3].tau + eqoff; o[2].tau = U01(w) * beta; }
         }
     } else
@@ -1439,9 +1519,10 @@ static void step_worm_add(ora_walker *w)
         o[i].tau = U01(w) * w->p.beta;
         if (i > 0 && o[i - 1].tau == o[i].tau) o[i].tau += w->p.beta * 1e-14;
     }
+#undef T
     for (int i = 0; i < nw; ++i) list_insert(w, o[i]);
     double prefact = worm_prefact(w);
-    if (!check_equal_time(w, w->isector) || prefact == 0.0 || !sequence_valid(w, w->outer_sst)) {
+    if (!check_equal_time(w, sec) || prefact == 0.0 || !sequence_valid(w, w->outer_sst)) {
         for (int i = w->nops - 1; i >= 0; --i) if (w->ops[i].wid) list_remove(w, i);
         w->accqn_wadd += 1; w->sector = 1;
         return;
@@ -1463,7 +1544,7 @@ static void step_worm_rem(ora_walker *w)
 {
     w->try_wrem += 1;
     const double prefact = worm_prefact(w);       /* get_Proposal reads the worm operators' flavours (sector 3): before they leave the list */
-    op_t saved[4]; int ns = 0;
+    op_t saved[12]; int ns = 0;
     for (int i = 0; i < w->nops; ++i) if (w->ops[i].wid) saved[ns++] = w->ops[i];
     for (int i = w->nops - 1; i >= 0; --i) if (w->ops[i].wid) list_remove(w, i);
     if (!sequence_valid(w, w->outer_sst)) {
@@ -1490,23 +1571,60 @@ static void step_worm_rem(ora_walker *w)
 static void step_worm_replace(ora_walker *w)
 {
     w->try_wrep += 1;
-    int r = RINT(w, 1, worm_nops(w));
+    /* which worm operator becomes a hybridising one (CTQMC.F90:5834-5946) */
+    int r;
+    {
+        int g[13] = {0};
+        for (int i = 0; i < w->nops; ++i) if (w->ops[i].wid) g[w->ops[i].wid] = w->ops[i].flav;
+        switch (w->sector) {
+        case 5: case 16: r = RINT(w, 4, worm_nops(w)); break;       /* only the operators outside the equal-time object */
+        case 10:                                                   /* a three-operator object that holds a density moves the density */
+            if (g[2] == g[3]) { if (g[4] == g[5]) { r = RINT(w, 1, 2); r = (r - 1) * 5 + 1; } else r = 1; }
+            else { if (g[4] == g[5]) r = 6; else r = RINT(w, 1, 6); }
+            break;
+        case 12:
+            if (g[2] == g[3]) { if (g[6] == g[5]) { r = RINT(w, 1, 2); r = (r - 1) * 3 + 1; } else r = 1; }
+            else { if (g[6] == g[5]) r = 4; else r = RINT(w, 1, 6); }
+            break;
+        case 11: {
+            int nden = (g[2] == g[3]) + (g[4] == g[5]) + (g[8] == g[9]) + (g[10] == g[11]);
+            if (nden > 0) {
+                int pick = RINT(w, 1, nden); r = 0;
+                for (int q = 0; q < 2 && !r; ++q) {
+                    if (g[6 * q + 2] == g[6 * q + 3]) { if (pick <= 1) { r = 6 * q + 1; break; } pick -= 1; }
+                    if (g[6 * q + 4] == g[6 * q + 5]) { if (pick <= 1) { r = 6 * q + 6; break; } pick -= 1; }
+                }
+            } else r = RINT(w, 1, 12);
+            break; }
+        case 13: return;                                           /* no replacement move in this sector (5944-5946) */
+        default: r = RINT(w, 1, worm_nops(w)); break;
+        }
+    }
     /* partners that move along, and the places (1 = first, 2 = second, 3 = third in time) of the partners / of the new worm operator in
-     * the equal-time object at the hybridising operator's time (qrepind / qtimeind, CTQMC.F90:6068-6127, 6164-6178) */
+     * the equal-time object at the hybridising operator's time (qrepind / qtimeind, CTQMC.F90:5997-6178) */
     int npart = 0, partner[2] = {0, 0}, pos_partner[2] = {0, 0}, pos_new = 0;
     {
         static const int p2[4] = {2, 1, 4, 3}, p2pp[4] = {3, 4, 1, 2};
+        /* three-operator objects: rows = the operator that stays (1..6 of a QQ pair of objects), {partner, place, partner, place, place of the new one} */
+        static const int q3[6][5] = {{3, 2, 2, 3, 1}, {1, 1, 3, 2, 3}, {1, 1, 2, 3, 2}, {5, 1, 6, 3, 2}, {4, 2, 6, 3, 1}, {5, 1, 4, 2, 3}};
+        static const int q3n[6][5] = {{3, 2, 2, 3, 1}, {1, 1, 3, 2, 3}, {1, 1, 2, 3, 2}, {5, 1, 6, 2, 3}, {6, 2, 4, 3, 1}, {5, 1, 4, 3, 2}};   /* sector 12 */
+        const int (*tab)[5] = NULL; int row = 0, shift = 0;
         switch (w->sector) {
-        case 3:
-            if (r == 1) { npart = 2; partner[0] = 3; pos_partner[0] = 2; partner[1] = 2; pos_partner[1] = 3; pos_new = 1; }
-            else if (r == 2) { npart = 2; partner[0] = 1; pos_partner[0] = 1; partner[1] = 3; pos_partner[1] = 2; pos_new = 3; }
-            else if (r == 3) { npart = 2; partner[0] = 1; pos_partner[0] = 1; partner[1] = 2; pos_partner[1] = 3; pos_new = 2; }
-            break;
+        case 3: if (r <= 3) { tab = q3; row = r - 1; } break;
+        case 10: tab = q3; row = r - 1; break;
+        case 11: tab = q3; row = (r - 1) % 6; shift = 6 * ((r - 1) / 6); break;
+        case 12: tab = q3n; row = r - 1; break;
         case 6: npart = 1; partner[0] = p2[r - 1]; pos_partner[0] = (r & 1) ? 1 : 2; break;
         case 7: npart = 1; partner[0] = p2pp[r - 1]; pos_partner[0] = (r <= 2) ? 1 : 2; break;
         case 8: if (r > 2) { npart = 1; partner[0] = p2[r - 1]; pos_partner[0] = (r == 3) ? 1 : 2; } break;
         case 9: if ((r & 1) == 0) { npart = 1; partner[0] = p2pp[r - 1]; pos_partner[0] = (r == 2) ? 1 : 2; } break;
+        case 14: npart = 1; partner[0] = p2[r - 1]; pos_partner[0] = (r & 1) ? 2 : 1; break;          /* 6151-6162 */
+        case 15: npart = 1; partner[0] = p2pp[r - 1]; pos_partner[0] = (r == 1 || r == 4) ? 2 : 1; break;   /* 6133-6144 */
         default: break;
+        }
+        if (tab) {
+            npart = 2; partner[0] = tab[row][0] + shift; pos_partner[0] = tab[row][1]; partner[1] = tab[row][2] + shift; pos_partner[1] = tab[row][3];
+            pos_new = tab[row][4];
         }
         if (npart == 1) pos_new = 3 - pos_partner[0];
     }
@@ -1747,6 +1865,15 @@ ora_walker *ora_create(const ora_params *p, const double *U, const double *ftau_
         w->weq_n[q] = q < 2 ? (size_t)2 * (2 * p->n2iwb + 1) : (q < 4 ? (size_t)p->ntau : (size_t)2 * 2 * p->n3iwf * (2 * p->n3iwb + 1));
         w->weq[q] = (double *)calloc(w->weq_n[q], sizeof(double));
     }
+    for (int q = 0; q < 11; ++q) {                                                  /* CTQMC.F90:379-430, 624-652 */
+        const size_t n4 = (size_t)4 * p->n4iwf * p->n4iwf * (2 * p->n4iwb + 1) * 2;
+        const size_t sizes[11] = {n4, (size_t)4 * p->niw, (size_t)p->ntau, n4, (size_t)2 * 2 * p->n3iwf * (2 * p->n3iwb + 1), (size_t)2 * 4 * p->n3iwf * p->n3iwf,
+                                  (size_t)2 * (2 * p->n2iwb + 1), (size_t)p->ntau, (size_t)2 * (2 * p->n2iwb + 1), (size_t)p->ntau, (size_t)4 * p->niw};
+        w->wmore[q] = NULL; w->wmore_n[q] = 0;
+        if (!p->worm_meas_more[q] || ((q == 0 || q == 3) && !(p->fourpnt & 8))) continue;
+        w->wmore_n[q] = sizes[q];
+        w->wmore[q] = (double *)calloc(sizes[q], sizeof(double));
+    }
     if ((p->fourpnt & 8) && p->worm_meas_g4iw) {                                    /* CTQMC.F90:339-361 */
         size_t n = (size_t)4 * p->n4iwf * p->n4iwf * (2 * p->n4iwb + 1) * 2;
         if (p->g4ph) w->g4w = (double *)calloc(n, sizeof(double));
@@ -1772,7 +1899,7 @@ void ora_destroy(ora_walker *w)
     for (int f = 0; f < w->nflav; ++f) free(w->M[f]);
     free(w->Mf); free(w->ffull); free(w->gleg_full); free(w->gtau_full);
     free(w->ops); free(w->ftab); ora_locprob_free(w->lp); free(w->ptr); free(w->dmblk); free(w->dmoff); free(w->accpair); free(w->accpairtau); free(w->gleg); free(w->gtau); free(w->giw); free(w->ntau_n0); free(w->gms); free(w->gmid); free(w->sstep);
-    free(w->histo); free(w->dm); free(w->outer_histo); free(w->sign_sst); free(w->tcontrib_sst); free(w->outer_state_histo); free(w->sign_state); free(w->tcontrib_state); free(w->g2iw); free(w->g4iw); free(w->g4iwpp); free(w->g4w); free(w->g4wpp); free(w->g4tau); free(w->g4leg); free(w->giww); free(w->gtauw); free(w->gsw); free(w->umat); for (int q = 0; q < 6; ++q) free(w->weq[q]); free(w->acbuf); free(w->acdat); free(w);
+    free(w->histo); free(w->dm); free(w->outer_histo); free(w->sign_sst); free(w->tcontrib_sst); free(w->outer_state_histo); free(w->sign_state); free(w->tcontrib_state); free(w->g2iw); free(w->g4iw); free(w->g4iwpp); free(w->g4w); free(w->g4wpp); free(w->g4tau); free(w->g4leg); free(w->giww); free(w->gtauw); free(w->gsw); free(w->umat); for (int q = 0; q < 6; ++q) free(w->weq[q]); for (int q = 0; q < 11; ++q) free(w->wmore[q]); free(w->acbuf); free(w->acdat); free(w);
 }
 
 void ora_set_taudiffmax(ora_walker *w, double x) { init_window(w, x); }
@@ -2104,6 +2231,74 @@ static void meas_gsigma_worm(ora_walker *w)
     }
 }
 
+/* estimators of the worm sectors 5 and 10 - 16 (CTQMC.F90:1166-1294, 1708-2128) with the exact transform (Nfft_worm.F90:94-137): every
+ * measurement adds cfgsign/eta times the sign of the proposal's U-matrix factor times a phase (or one count in a tau bin) */
+static void acc_phase3(double *acc, int nwf, int nwb, double pib, double val, double x1, double x2, double x3)
+{
+    const int nw = 2 * nwf, nb = 2 * nwb + 1;
+    for (int i1 = -nwf; i1 < nwf; ++i1) for (int i2 = -nwf; i2 < nwf; ++i2) for (int i3 = -nwb; i3 <= nwb; ++i3) {
+        const double ph = pib * ((double)(2 * i1 + 1) * x1 + (double)(2 * i2 + 1) * x2 + (double)(2 * i3) * x3);
+        const size_t idx = ((((size_t)(i1 + nwf)) * nw + (i2 + nwf)) * nb + (i3 + nwb)) * 2;
+        acc[idx] += val * cos(ph); acc[idx + 1] += val * sin(ph);
+    }
+}
+static void acc_taubin(const ora_walker *w, double *acc, double tau, double val, int antiperiodic)
+{
+    if (tau < 0.0) { tau += w->p.beta; if (antiperiodic) val = -val; }
+    int itau = (int)((double)w->p.ntau * tau / w->p.beta) + 1;
+    if (itau > w->p.ntau) itau = w->p.ntau;
+    acc[itau - 1] += val;
+}
+static void meas_more_worm(ora_walker *w)
+{
+    double t[13] = {0};
+    for (int i = 0; i < w->nops; ++i) if (w->ops[i].wid) t[w->ops[i].wid] = w->ops[i].tau;
+    const double beta = w->p.beta, pib = M_PI / beta;
+    const int sec = w->sector, niw = w->p.niw, nb2 = w->p.n2iwb;
+    const double uf = worm_ufac(w, 1);
+    const double val = w->cfgsign / w->eta * (uf < 0.0 ? -1.0 : 1.0);
+    switch (sec) {
+    case 5:                                             /* measure_ie_chi_worm, 1708-1772 */
+        acc_phase3(w->wmore[0], w->p.n4iwf, w->p.n4iwb, pib, val, t[1] - t[4], t[5] - t[6], w->p.wormphconv ? t[4] - t[5] : t[1] - t[6]);
+        break;
+    case 10:                                            /* measure_qq_worm (minus sign, 1230), measure_qqtau_worm, 1215-1294 */
+        for (int n = -niw; n < niw; ++n) {
+            const double ph = pib * (double)(2 * n + 1) * (t[1] - t[4]);
+            w->wmore[1][2 * (n + niw)] -= val * cos(ph); w->wmore[1][2 * (n + niw) + 1] -= val * sin(ph);
+        }
+        if (w->wmore[2]) acc_taubin(w, w->wmore[2], t[2] - t[6], val, 1);
+        break;
+    case 11:                                            /* measure_qqqq_worm, 1774-1840 */
+        acc_phase3(w->wmore[3], w->p.n4iwf, w->p.n4iwb, pib, val, t[2] - t[6], t[8] - t[12], w->p.wormphconv ? t[6] - t[8] : t[2] - t[12]);
+        break;
+    case 12: case 13: {                                 /* measure_nqqdag_worm 1842-1902 (fermionic, bosonic), measure_qqdd_worm 1904-1964 (two fermionic) */
+        const int nf3 = w->p.n3iwf, nb3 = w->p.n3iwb, n2 = sec == 12 ? 2 * nb3 + 1 : 2 * nf3;
+        const double x1 = sec == 12 ? t[2] - t[4] : t[2] - t[6], x2 = sec == 12 ? t[4] - t[8] : t[4] - t[6];
+        double *g = w->wmore[sec == 12 ? 4 : 5];
+        for (int i = -nf3; i < nf3; ++i)
+            for (int j = 0; j < n2; ++j) {
+                const double m2 = sec == 12 ? (double)(2 * (j - nb3)) : (double)(2 * (j - nf3) + 1);
+                const double ph = pib * ((double)(2 * i + 1) * x1 + m2 * x2);
+                double *o = g + 2 * ((size_t)(i + nf3) * n2 + j);
+                o[0] += val * cos(ph); o[1] += val * sin(ph);
+            }
+        break; }
+    case 14: case 15: {                                 /* measure_ucaca_worm / ucacatau / uccaa / uccaatau, 1966-2128 */
+        const double dt = sec == 14 ? t[1] - t[3] : t[3] - t[2];
+        double *giw = w->wmore[sec == 14 ? 6 : 8], *gt = w->wmore[sec == 14 ? 7 : 9];
+        if (giw) for (int j = -nb2; j <= nb2; ++j) { const double ph = pib * (double)(2 * j) * dt; giw[2 * (j + nb2)] += val * cos(ph); giw[2 * (j + nb2) + 1] += val * sin(ph); }
+        if (gt) acc_taubin(w, gt, dt, val, 0);
+        break; }
+    case 16:                                            /* measure_quddag_worm, 1166-1211 */
+        for (int n = -niw; n < niw; ++n) {
+            const double ph = pib * (double)(2 * n + 1) * (t[1] - t[4]);
+            w->wmore[10][2 * (n + niw)] += val * cos(ph); w->wmore[10][2 * (n + niw) + 1] += val * sin(ph);
+        }
+        break;
+    default: break;
+    }
+}
+
 static void autocorr_add(ora_walker *w)
 {
     const size_t nc = (size_t)w->nflav * w->p.ntau;
@@ -2169,6 +2364,14 @@ void ora_measure_once(ora_walker *w)
         else if (w->sector == 3) { if (w->gsw) { w->cnt_meas_w += 1; meas_gsigma_worm(w); } }              /* 8597-8599 */
         else if (w->sector == 6 || w->sector == 7) { w->cnt_meas_w += 1; meas_eq_worm(w); }              /* 8603-8610 */
         else if (w->sector == 8 || w->sector == 9) { if (w->weq[w->sector - 4]) { w->cnt_meas_w += 1; meas_eq_worm(w); } }   /* 8611-8616 */
+        else if (w->sector == 5 || (w->sector >= 10 && w->sector <= 16)) {                            /* 8600-8602, 8617-8640 */
+            static const int need[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 3, 4, 5, -1, -1, -1};
+            const int q = need[w->sector];
+            if (w->sector == 5 ? w->wmore[0] != NULL : (q < 0 || w->wmore[q] != NULL)) {
+                w->cnt_meas_w += 1;
+                if (w->sector != 16 || w->wmore[10]) meas_more_worm(w);
+            }
+        }
         else if (w->g4w || w->g4wpp) { w->cnt_meas_w += 1; meas_g4iw_worm(w); }
         return;
     }
@@ -2362,6 +2565,55 @@ void ora_measure_finish(ora_walker *w)
             const double fac = (q == 2 || q == 3) ? scal * ((double)w->p.ntau / beta) : scal;
             for (size_t i = 0; i < w->weq_n[q]; ++i) w->weq[q][i] *= fac;
         }
+    }
+    if (w->isector == 5 || (w->isector >= 10 && w->isector <= 16)) {      /* wormNorm 8829-8841; u_sparsity and the other factors 9003-9211 */
+        static const double num[17] = {0, 0, 0, 0, 0, 128.0, 0, 0, 0, 0, 256.0, 65536.0, 4096.0, 8192.0, 256.0, 256.0, 256.0};
+        const int sec = w->isector;
+        const double norm = sec == 10 ? num[sec] / beta : num[sec] / (beta * beta);
+        const double scal = (w->cnt_meas_w != 0) ? w->cnt_sampling_w / (w->cnt_meas_w * w->cnt_sampling) * norm / w->mean_sign : 0.0;
+        /* u_sparsity: numbers of non-vanishing elements of slices of the antisymmetrised U matrices at the component's indices */
+        int u[5] = {0, 0, 0, 0, 0}, rest = w->icomponent - 1;
+        const int nred = sec == 10 ? 2 : 4;
+        for (int i = nred; i >= 1; --i) { u[i] = rest % nf; rest /= nf; }
+        double c1 = 0, c2 = 0, c3 = 0, c4 = 0;            /* counts */
+        for (int a = 0; a < nf; ++a) for (int b = 0; b < nf; ++b) {
+            for (int c = 0; c < nf; ++c) {
+                if (UA1(u[1], a, b, c) != 0.0) c1 += 1;                               /* u_matrix_antisymm_1(u_g(1),:,:,:) */
+                if (UA2(a, b, u[2], c) != 0.0) c2 += 1;                               /* u_matrix_antisymm_2(:,:,u_g(2),:) */
+                if (sec == 11) { if (UA1(u[3], a, b, c) != 0.0) c3 += 1; if (UA2(a, b, u[4], c) != 0.0) c4 += 1; }
+            }
+        }
+        const double nfd = (double)nf, nf2 = nfd * nfd, nf4 = nf2 * nf2;
+        double spars = 1.0;
+        if (sec == 10) spars = c1 * c2 / (nf4 * nf2);
+        else if (sec == 11) spars = c1 * c2 * c3 * c4 / (nf4 * nf4 * nf4);
+        else if (sec == 14) {
+            double a1 = 0, a2 = 0;
+            for (int a = 0; a < nf; ++a) for (int b = 0; b < nf; ++b) { if (UAB(u[1], a, u[2], b) != 0.0) a1 += 1; if (UAB(u[3], a, u[4], b) != 0.0) a2 += 1; }
+            spars = a1 * a2 / nf4;
+        } else if (sec == 15) {
+            double a1 = 0, a2 = 0;
+            for (int a = 0; a < nf; ++a) for (int b = 0; b < nf; ++b) { if (UA2(a, b, u[2], u[4]) != 0.0) a1 += 1; if (UA1(u[1], u[3], a, b) != 0.0) a2 += 1; }
+            spars = a1 * a2 / nf4;
+        } else if (sec == 12) {                               /* 9278-9282 */
+            double a3 = 0;
+            for (int a = 0; a < nf; ++a) for (int b = 0; b < nf; ++b) if (UAB(u[3], a, u[4], b) != 0.0) a3 += 1;
+            spars = c1 * c2 * a3 / (nf4 * nf4);
+        } else if (sec == 13) {                               /* 9339-9343 */
+            double a2 = 0, a3 = 0;
+            for (int a = 0; a < nf; ++a) for (int b = 0; b < nf; ++b) {
+                for (int c = 0; c < nf; ++c) if (UA2(a, u[3], b, c) != 0.0) a2 += 1;
+                if (UAB(a, b, u[2], u[4]) != 0.0) a3 += 1;
+            }
+            spars = c1 * a2 * a3 / (nf4 * nf4);
+        } else if (sec == 16) {
+            double a2 = 0;
+            for (int a = 0; a < nf; ++a) if (UAB(u[3], a, u[2], u[4]) != 0.0) a2 += 1;
+            spars = c1 * a2 / nf4;
+        }
+        const double tb = (double)w->p.ntau / beta;
+        const double fac[11] = {scal, scal * spars / nf2, scal * spars * tb / nf2, scal * spars, scal * spars, scal * spars, scal * spars, scal * tb * spars, scal * spars, scal * tb * spars, scal * spars};
+        for (int q = 0; q < 11; ++q) if (w->wmore[q]) for (size_t i = 0; i < w->wmore_n[q]; ++i) w->wmore[q][i] *= fac[q];
     }
     if ((w->isector == 4 || w->isector == 1) && (w->g4w || w->g4wpp)) {   /* wormScaling(SectorG4), CTQMC.F90:8833-8849, 8883-8915 */
         double scal = (w->cnt_meas_w != 0) ? w->cnt_sampling_w / (w->cnt_meas_w * w->cnt_sampling) * 16.0 / (beta * beta) / w->mean_sign : 0.0;
@@ -2562,6 +2814,12 @@ int ora_get_worm_eq(const ora_walker *w, int which, double *o)
     if (which < 0 || which > 5 || !w->weq[which]) return 0;
     memcpy(o, w->weq[which], sizeof(double) * w->weq_n[which]);
     return (int)w->weq_n[which];
+}
+int ora_get_worm_more(const ora_walker *w, int which, double *o)
+{
+    if (which < 0 || which > 10 || !w->wmore[which]) return 0;
+    memcpy(o, w->wmore[which], sizeof(double) * w->wmore_n[which]);
+    return (int)w->wmore_n[which];
 }
 int ora_get_gsigmaiw_worm(const ora_walker *w, double *o)
 {

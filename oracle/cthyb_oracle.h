@@ -65,6 +65,9 @@ typedef struct ora_params {
     int offdiag;                                   /* offdiag = 1: hybridisation function with both flavour indices, one inverse matrix over all flavours (CTQMC.F90:461-467) */
     int flavc;                                     /* flavourchange_moves (b_exch, CTQMC.F90:481-485): StepFlavourchange_general in place of the two-pair moves */
     double p_4op, p_outer;                         /* Percentage4OperatorMove, PercentageOuterMove (CTQMC.F90:332-333, 8441-8442) */
+    /* worm sectors 5, 10 - 16 (CTQMC.F90:379-430, 624-652): WormMeasH4iw, WormMeasQQ, WormMeasQQtau, WormMeasQQQQ, WormMeasNQQdag, WormMeasQQdd,
+     * WormMeasUcaca, WormMeasUcacatau, WormMeasUccaa, WormMeasUccaatau, WormMeasQUDdag */
+    int worm_meas_more[11];
 } ora_params;
 
 typedef struct ora_walker ora_walker;
@@ -96,6 +99,10 @@ int ora_get_giw_worm(const ora_walker *w, double *out_reim);
  * 4 p3iw_worm, 5 p3iwpp_worm (2N3iwf, 2N3iwb+1 complex interleaved); returns the number of doubles copied, 0 if not measured */
 int ora_get_worm_eq(const ora_walker *w, int which, double *out);
 int ora_get_gtau_worm(const ora_walker *w, double *out);
+/* which = 0 h4iw_worm (2N4iwf,2N4iwf,2N4iwb+1), 1 qq_worm (2Niw), 2 qqtau_worm (Ntau, real), 3 qqqq_worm (as h4iw), 4 nqqdag_worm (2N3iwf,2N3iwb+1),
+ * 5 qqdd_worm (2N3iwf,2N3iwf), 6 ucaca_worm (2N2iwb+1), 7 ucacatau_worm (Ntau, real), 8 uccaa_worm, 9 uccaatau_worm, 10 quddag_worm (2Niw);
+ * complex arrays interleaved; returns the number of doubles copied, 0 if not measured */
+int ora_get_worm_more(const ora_walker *w, int which, double *out);
 int ora_get_gsigmaiw_worm(const ora_walker *w, double *out_reim);   /* GSigmaiw_worm (2Niw) complex interleaved, sector 3 */
 /* [0]TryWormAdd [1]AccWormAdd [2]AccQNWormAdd [3]TryWormRem [4]AccWormRem [5]AccQNWormRem [6]TryWormRep [7]AccWormRep
  * [8]CntSampling(worm) [9]CntMeas(worm) [10]TryAdd(worm) [11]AccAdd(worm) [12]TryRem(worm) [13]AccRem(worm) [14]sector now */

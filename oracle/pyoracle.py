@@ -27,8 +27,13 @@ class OraParams(C.Structure):
                 ("meas_susz", C.c_int), ("step_series", C.c_int),
                 ("n2iwb", C.c_int), ("n3iwf", C.c_int), ("n3iwb", C.c_int), ("worm_meas_eq", C.c_int * 6),
                 ("nsym", C.c_int), ("symmoves", C.c_int * 128), ("worm_meas_gsigma", C.c_int),
-                ("offdiag", C.c_int), ("flavc", C.c_int), ("p_4op", C.c_double), ("p_outer", C.c_double)]
+                ("offdiag", C.c_int), ("flavc", C.c_int), ("p_4op", C.c_double), ("p_outer", C.c_double),
+                ("worm_meas_more", C.c_int * 11)]
 
+WORM_MORE_KEYS = ("WormMeasH4iw", "WormMeasQQ", "WormMeasQQtau", "WormMeasQQQQ", "WormMeasNQQdag", "WormMeasQQdd", "WormMeasUcaca", "WormMeasUcacatau",
+                  "WormMeasUccaa", "WormMeasUccaatau", "WormMeasQUDdag")
+WORM_MORE_NAMES = ("h4iw_worm", "qq_worm", "qqtau_worm", "qqqq_worm", "nqqdag_worm", "qqdd_worm", "ucaca_worm", "ucacatau_worm", "uccaa_worm", "uccaatau_worm",
+                   "quddag_worm")
 WORM_EQ_KEYS = ("WormMeasP2iwPH", "WormMeasP2iwPP", "WormMeasP2tauPH", "WormMeasP2tauPP", "WormMeasP3iwPH", "WormMeasP3iwPP")
 WORM_EQ_NAMES = ("p2iw_worm", "p2iwpp_worm", "p2tau_worm", "p2taupp_worm", "p3iw_worm", "p3iwpp_worm")
 
@@ -94,6 +99,7 @@ def lib():
     L.ora_get_gtau_worm.argtypes = [vp, dp]; L.ora_get_gtau_worm.restype = C.c_int
     L.ora_get_worm_eq.argtypes = [vp, C.c_int, dp]; L.ora_get_worm_eq.restype = C.c_int
     L.ora_get_gsigmaiw_worm.argtypes = [vp, dp]; L.ora_get_gsigmaiw_worm.restype = C.c_int
+    L.ora_get_worm_more.argtypes = [vp, C.c_int, dp]; L.ora_get_worm_more.restype = C.c_int
     L.ora_get_hashybs.argtypes = [vp, ip]
     L.ora_get_g2iw.argtypes = [vp, dp]; L.ora_get_g2iw.restype = C.c_int
     L.ora_get_g4iw.argtypes = [vp, dp, C.c_int]; L.ora_get_g4iw.restype = C.c_int
@@ -150,7 +156,8 @@ def params_from_pstring(ps, nd, beta, fourpnt=0):
                      n2iwb=ps.get_int("N2iwb"), n3iwf=ps.get_int("N3iwf"), n3iwb=ps.get_int("N3iwb"),
                      worm_meas_eq=(C.c_int * 6)(*[int(ps.get_int(k) != 0) for k in WORM_EQ_KEYS]),
                      nsym=ps.get_int("NSymMove"), symmoves=_symmoves(ps), worm_meas_gsigma=int(ps.get_int("WormMeasGSigmaiw") != 0),
-                     offdiag=int(ps.get_int("offdiag") != 0), flavc=int(ps.get_int("flavourchange_moves") != 0), p_4op=ps.get_real("Percentage4OperatorMove"), p_outer=ps.get_real("PercentageOuterMove"))
+                     offdiag=int(ps.get_int("offdiag") != 0), flavc=int(ps.get_int("flavourchange_moves") != 0), p_4op=ps.get_real("Percentage4OperatorMove"), p_outer=ps.get_real("PercentageOuterMove"),
+                     worm_meas_more=(C.c_int * 11)(*[int(ps.get_int(k) != 0) for k in WORM_MORE_KEYS]))
 
 
 class OracleWalker:
@@ -302,6 +309,15 @@ class OracleWalker:
             a = np.zeros(shape)
             if self.L.ora_get_worm_eq(self.h, q, a):
                 r[name] = a if q in (2, 3) else a[..., 0] + 1j * a[..., 1]
+        for q, name in enumerate(WORM_MORE_NAMES):
+            if not p.worm_meas_more[q]:
+                continue
+            n4 = (2 * p.n4iwf, 2 * p.n4iwf, 2 * p.n4iwb + 1, 2)
+            shape = (n4, (2 * p.niw, 2), (p.ntau,), n4, (2 * p.n3iwf, 2 * p.n3iwb + 1, 2), (2 * p.n3iwf, 2 * p.n3iwf, 2), (2 * p.n2iwb + 1, 2), (p.ntau,),
+                     (2 * p.n2iwb + 1, 2), (p.ntau,), (2 * p.niw, 2))[q]
+            a = np.zeros(shape)
+            if self.L.ora_get_worm_more(self.h, q, a):
+                r[name] = a if q in (2, 7, 9) else a[..., 0] + 1j * a[..., 1]
         if p.fourpnt & 1:
             a = np.zeros((nd, 2, nd, 2, p.n4tau, p.n4tau, p.n4tau))
             if self.L.ora_get_g4tau(self.h, a):

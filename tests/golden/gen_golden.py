@@ -387,7 +387,27 @@ WORMEQ = {
     "GS_C4Sa": (3, "C4S", 501, dict(_EQ, Nwarmups=2000, Nmeas=500, NCorr=10, TaudiffMax=3.0, Ntau=50, Niw=6, WormEta=0.005, WormMeasGSigmaiw=1), 663, 1 + 1 * 4 + 1),
     "GS_C4Na": (3, "C4N", 501, dict(_EQ, Nwarmups=2000, Nmeas=300, NCorr=10, TaudiffMax=3.0, Ntau=50, Niw=6, WormEta=0.001, WormMeasGSigmaiw=1), 664, 1 + 3 * 6 + 3),
 }
-WORMEQ_KEYS = ("gsigmaiw_worm", "p2iw_worm", "p2iwpp_worm", "p2tau_worm", "p2taupp_worm", "p3iw_worm", "p3iwpp_worm", "mean_sign", "accwormadd", "accwormrem",
+# sectors 5 and 10 - 16 (improved estimators with U-matrix factors in the proposal; six, twelve, eight or four worm operators in equal-time
+# objects of three or two): components are the flavour indices of the U matrices (and of the free operators in sector 5)
+_IE = dict(_EQ, Ntau=50, Niw=6, N2iwb=3, N3iwf=2, N3iwb=2, N4iwf=2, N4iwb=1, TaudiffMax=3.0, NCorr=10)
+_IEM = {5: dict(WormMeasH4iw=1), 10: dict(WormMeasQQ=1, WormMeasQQtau=1), 11: dict(WormMeasQQQQ=1), 12: dict(WormMeasNQQdag=1), 13: dict(WormMeasQQdd=1),
+        14: dict(WormMeasUcaca=1, WormMeasUcacatau=1), 15: dict(WormMeasUccaa=1, WormMeasUccaatau=1), 16: dict(WormMeasQUDdag=1)}
+_IE_ETA = {   # (sector, config): WormEta that balances worm and partition-function space (found with count_steps)
+    (5, "C1"): 0.0063, (10, "C1"): 0.143, (11, "C1"): 0.0199, (12, "C1"): 0.033, (13, "C1"): 4.0, (14, "C1"): 0.0868, (15, "C1"): 0.663, (16, "C1"): 0.108,
+    (5, "C3"): 8.45e-7, (10, "C3"): 2.66e-4, (12, "C3"): 3.33e-6, (13, "C3"): 0.056, (14, "C3"): 1.69e-4, (15, "C3"): 8.7e-3, (16, "C3"): 2.46e-3,
+    (5, "C4S"): 5.49e-5, (10, "C4S"): 4.98e-3, (11, "C4S"): 3.3e-4, (12, "C4S"): 1.25e-3, (13, "C4S"): 0.011, (14, "C4S"): 4.14e-3, (15, "C4S"): 0.143, (16, "C4S"): 0.0137,
+    (5, "C4N"): 6.93e-6, (10, "C4N"): 1.41e-4, (14, "C4N"): 1.15e-3, (15, "C4N"): 0.0798, (16, "C4N"): 3.34e-3,
+}
+_NFLAV = {"C1": 2, "C3": 4, "C4S": 4, "C4N": 6}
+_seed = 700
+for (_sec, _cfg), _eta in _IE_ETA.items():
+    _seed += 1
+    _nf = _NFLAV[_cfg]
+    _comp = 1 if _sec == 10 else _comp4(_nf, (0, 0, 1, 1))
+    WORMEQ["S%d_%s" % (_sec, _cfg)] = (_sec, _cfg, 501, dict(_IE, Nwarmups=2000, Nmeas=300 if _cfg == "C4N" else 1000, WormEta=_eta, **_IEM[_sec]), _seed, _comp)
+
+WORMEQ_KEYS = ("h4iw_worm", "qq_worm", "qqtau_worm", "qqqq_worm", "nqqdag_worm", "qqdd_worm", "ucaca_worm", "ucacatau_worm", "uccaa_worm", "uccaatau_worm", "quddag_worm",
+               "gsigmaiw_worm", "p2iw_worm", "p2iwpp_worm", "p2tau_worm", "p2taupp_worm", "p3iw_worm", "p3iwpp_worm", "mean_sign", "accwormadd", "accwormrem",
                "accwormrep", "cntsampling", "accadd", "accrem", "occ", "histo")
 
 
@@ -396,7 +416,7 @@ def gen_wormeq(only=None):
         if only and name not in only:
             continue
         p, ps = pstring_for(cfg, nftau, over)
-        s = refdrive.RefSolver(p, ps, seed)
+        s = refdrive.RefSolver(p, ps, seed, fourpnt=8 if sector in (5, 11) else 0)
         s.set_taudiffmax(over["TaudiffMax"])
         s.warmup(over["Nwarmups"])
         steps = s.count_steps(sector, comp, 3000)
@@ -409,7 +429,7 @@ def gen_wormeq(only=None):
                             overrides=repr(over), count_steps=np.array(steps), **{"end_" + k: v for k, v in c_end.items()},
                             **{"res_" + k: v for k, v in r.items()})
         print("wormeq", name, "steps(worm, Z) of the eta search", steps, "cntsampling", r["cntsampling"][[0, sector - 1]],
-              "acc add/rem/rep", r["accwormadd"][sector - 1], r["accwormrem"][sector - 1], r["accwormrep"][sector - 1], "nops", len(c_end["taus"]))
+              "acc add/rem/rep", r["accwormadd"][sector - 2], r["accwormrem"][sector - 2], r["accwormrep"][sector - 2], "nops", len(c_end["taus"]))
 
 
 KINDS = ("traj", "stat", "g4", "worm", "calib", "accum", "g4leg", "susz", "ssq", "steps", "wormstat", "wormeq")
