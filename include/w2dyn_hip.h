@@ -83,7 +83,13 @@ int w2dyn_ctqmc_warmup(w2dyn_solver *s, int64_t nwarmups);
  * flavours and the U-matrix factor in the proposal, Trace.F90:3835-3919, CTQMC.F90:5687-5696; GSigmaiw_worm, CTQMC.F90:1123-1164;
  * icomponent = 1 + u (2Nd) + g4, not 0); isector 6 / 7 / 8 / 9 = worm sampling with equal-time pairs (P2 ph / pp: two random
  * times, P3 ph / pp: three; set_OperTime Trace.F90:3985-4020, replacement with the partner moved along CTQMC.F90:6068-6249;
- * estimators p2iw / p2tau / p2iwpp / p2taupp / p3iw / p3iwpp, CTQMC.F90:1297-1507); both trace paths.  Other sectors are refused. */
+ * estimators p2iw / p2tau / p2iwpp / p2taupp / p3iw / p3iwpp, CTQMC.F90:1297-1507); both trace paths.
+ * isector 5 (H4, six worm operators), 10 (QQ, six), 11 (Q4, twelve), 12 (NQQdag, eight), 13 (QQdd, eight), 14 (Ucaca), 15 (Uccaa), 16 (QUDdag; four
+ * each): worms with U-matrix factors in the proposal and random flavours of the operators in the equal-time objects (set_IEOperFlavor
+ * Trace.F90:3835-3919, set_OperTime 4022-4158, get_Proposal CTQMC.F90:5698-5796, replacement 5841-5946 and 5997-6162, estimators 1166-1294 and
+ * 1708-2128, u_sparsity 9003-9343); icomponent = the component's two (sector 10) or four flavour indices, not 0.  Sectors 14 - 16 run on both
+ * trace paths; the sectors with more than four worm operators on the matrix trace path, which init_solver takes when WormMeasH4iw, WormMeasQQ,
+ * WormMeasQQtau, WormMeasQQQQ, WormMeasNQQdag or WormMeasQQdd is set (else the call is refused with W2DYN_EINVAL). */
 int w2dyn_ctqmc_measure(w2dyn_solver *s, int isector, int icomponent);
 /* module variable `wormeta` (impurity.py:719, 755, 784): the same value for every worm sector, CTQMC.F90:194, 434 */
 int w2dyn_set_wormeta(w2dyn_solver *s, double eta);
@@ -103,7 +109,7 @@ int w2dyn_dest_ctqmc(w2dyn_solver *s);
  * nsteps Monte-Carlo steps for every chain (CTQMC.F90:8428-8533), one pass of the Z-space estimators over every
  * chain (8541-8581), normalisation (8663-8817). */
 /* sector and component of the following w2dyn_sweep / w2dyn_measure_once calls (the first lines of ctqmc_measure,
- * CTQMC.F90:8380-8400): every chain goes back to Z space; isector 1, 2, 3, 4 or 6 - 9 */
+ * CTQMC.F90:8380-8400): every chain goes back to Z space; isector 1 - 16 */
 int w2dyn_set_sector(w2dyn_solver *s, int isector, int icomponent);
 int w2dyn_measure_begin(w2dyn_solver *s);
 int w2dyn_sweep(w2dyn_solver *s, int64_t nsteps, int count_as_sampling);
@@ -171,6 +177,9 @@ int w2dyn_get_walker_state(w2dyn_solver *s, int walker, double *out6);
  *       worm sectors 6 / 7 (WormMeasP2iwPH | PP, WormMeasP2tauPH | PP): "p2iw_worm" | "p2iwpp_worm" (2N2iwb+1) complex,
  *       "p2tau_worm" | "p2taupp_worm" (Ntau); sectors 8 / 9 (WormMeasP3iwPH | PP): "p3iw_worm" | "p3iwpp_worm" (2N3iwf,2N3iwb+1)
  *       complex (+ "_bins": scalar "nbe" leading),
+ *       worm sectors 5, 10 - 16: "h4iw_worm" | "qqqq_worm" (2N4iwf,2N4iwf,2N4iwb+1), "qq_worm" | "quddag_worm" (2Niw), "nqqdag_worm" (2N3iwf,2N3iwb+1),
+ *       "qqdd_worm" (2N3iwf,2N3iwf), "ucaca_worm" | "uccaa_worm" (2N2iwb+1) complex, "qqtau_worm" | "ucacatau_worm" | "uccaatau_worm" (Ntau)
+ *       (+ "_bins": scalar "nbie" leading),
  *       "accwormadd" "accwormrem" "accwormrep" (16), "steps_worm_chains" (int64), "worm_counters" per chain
  * Writes min(bytes, size) bytes; *needed (if not NULL) receives the full size. */
 int w2dyn_get_result(w2dyn_solver *s, const char *name, void *out, size_t bytes, size_t *needed);

@@ -714,6 +714,15 @@ def test_unsupported_modes_are_refused():
         q.ctqmc_calibrate(True, 10, 10, 10, 100)
     assert e.value.code == -2
     q.close()
+    # worms with more than four operators live in the operator list of the matrix trace path, which init_solver takes when their estimator is
+    # asked for; without it the call is an error of the caller.  A component whose U-matrix slices vanish would never let the worm in.
+    _, ps, _ = util.setup("C1", 501, dict(PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormMeasUcaca=1))
+    q = MCTQMC(nwalkers=4); q.init_rnd(1); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+    for sec, comp in ((5, 4), (10, 1), (14, 1), (14, 0)):      # (14, 1): U_ab(0, ., 0, .) = 0 in one orbital; (14, 0): these sectors sample one component
+        with pytest.raises(W2DynError) as e:
+            q.ctqmc_measure(sec, comp)
+        assert e.value.code == -1, (sec, comp)
+    q.close()
     # blocks of more than 8 states are refused: 3-orbital Kanamori with the particle number as the only quantum number
     from w2dynamics_amd import params, synth
     p2 = synth.config("C4", 501)
@@ -957,6 +966,9 @@ def test_g_worm_sampling_chains_vs_oracle(name):
 WORMEQ_CASES = ["P2_C1a", "P2_C1b", "P2_C3a", "P2pp_C1a", "P2pp_C3a", "P3_C1a", "P3_C3a", "P3pp_C1a", "P3pp_C3a",
                 "P2_C4Sa", "P3_C4Sa", "P2pp_C4Sa", "P3pp_C4Sa", "P2_C4Na", "P3pp_C4Na",
                 "GS_C1a", "GS_C3a", "GS_C4Sa", "GS_C4Na"]      # GS: sector 3 (GSigma): three-operator object, random flavours, U-matrix factor
+# sectors 5 and 10 - 16: worms of four, six, eight and twelve operators with U-matrix factors (those with more than four: matrix trace path, also for C1 / C3)
+WORMEQ_CASES += ["S%d_%s" % (sec, cfg) for cfg in ("C1", "C3", "C4S") for sec in (5, 10, 11, 12, 13, 14, 15, 16) if (sec, cfg) != (11, "C3")]
+WORMEQ_CASES += ["S%d_C4N" % sec for sec in (5, 10, 14, 15, 16)]
 
 
 @pytest.mark.parametrize("name", WORMEQ_CASES)
@@ -969,7 +981,10 @@ def test_equal_time_worm_sampling_chains_vs_oracle(name):
     comp = int(g["component"]); sec = int(g["sector"]); nw = 5
     over = g["overrides"]
     p, ps, pset = util.setup(g["config"], g["nftau"], over)
-    q = make_gpu(p, ps, 29, nw, wpb=1)
+    fourpnt = 8 if sec in (5, 11) else 0
+    q = MCTQMC(nwalkers=nw, walkers_per_bin=1); q.fourpnt = fourpnt
+    q.init_rnd(29); q.init_paras(ps)
+    q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
     q.set_taudiffmax(over["TaudiffMax"])
     q.ctqmc_warmup(over["Nwarmups"])
     sw, sz = q.count_steps(sec, comp, 3000)
@@ -978,11 +993,11 @@ def test_equal_time_worm_sampling_chains_vs_oracle(name):
     q.ctqmc_worm_warmup(0, sec, comp)
     q.ctqmc_measure(sec, comp)
     wc = q.worm_counters
-    keys = [k for k in pyoracle.WORM_EQ_NAMES + ("gsigmaiw_worm",) if "res_" + k in g and g["res_" + k].size > 1]
+    keys = [k for k in pyoracle.WORM_EQ_NAMES + pyoracle.WORM_MORE_NAMES + ("gsigmaiw_worm",) if "res_" + k in g and g["res_" + k].size > 1]
     assert keys
     pooled = {k: 0.0 for k in keys}; cw = cz = mw = 0.0; nrep = 0.0
     for w in range(nw):
-        o = pyoracle.OracleWalker(p, pset, ("philox", 29, w))
+        o = pyoracle.OracleWalker(p, pset, ("philox", 29, w), fourpnt=fourpnt)
         o.set_taudiffmax(over["TaudiffMax"]); o.warmup(over["Nwarmups"])
         assert o.count_steps(sec, comp, 3000)[0] == chains_w[w], w
         o.measure_sector(sec, comp)
@@ -997,16 +1012,17 @@ def test_equal_time_worm_sampling_chains_vs_oracle(name):
             assert np.abs(taus - c["taus"]).max() < 1e-12 and np.array_equal(hyb, c["hashybs"]) and np.array_equal(cas, c["cas"])
             assert np.array_equal(orbs, c["orbs"]) and np.array_equal(spins, c["spins"])
         for k in keys:
-            assert rel(getattr(q, k + "_bins")[w], r[k]) < TOL, (k, w)
-            pooled[k] = pooled[k] + r[k] * (oc["cnt_meas_w"] * r["counters"][11] / max(oc["cnt_sampling_w"], 1.0))
+            # every bin is divided by the mean sign of the whole run, the oracle chain by its own (3-orbital Kanamori: not always 1)
+            assert rel(getattr(q, k + "_bins")[w] * q.mean_sign, r[k] * r["mean_sign"]) < TOL, (k, w)
+            pooled[k] = pooled[k] + r[k] * r["mean_sign"] * (oc["cnt_meas_w"] * r["counters"][11] / max(oc["cnt_sampling_w"], 1.0))
         cw += oc["cnt_sampling_w"]; cz += r["counters"][11]; mw += oc["cnt_meas_w"]
-        assert rel(q.histo_bins[w], r["histo"]) < TOL and rel(q.occ_bins[w], r["occ"]) < TOL
+        assert rel(q.histo_bins[w], r["histo"]) < TOL and rel(q.occ_bins[w] * q.mean_sign, r["occ"] * r["mean_sign"]) < TOL
         o.close()
     assert mw > 0
     if float(g["res_accwormrep"][sec - 2]) > 0.01:
         assert nrep > 0                                 # the replacement with a moved partner is in play
     for k in keys:
-        assert rel(getattr(q, k), pooled[k] * cw / (mw * cz)) < TOL, k
+        assert rel(getattr(q, k) * q.mean_sign, pooled[k] * cw / (mw * cz)) < TOL, k
     assert q.cntsampling[0] == cz and q.cntsampling[sec - 1] == cw
     q.dest_ctqmc(); q.close()
 
@@ -1285,6 +1301,32 @@ def test_solver_gsigma_worm_agrees_with_dyson_self_energy():
                              WormMeasGSigmaiw=1), seed=7, nwalkers=1024, walkers_per_bin=8)
     s3.set_problem(p)
     rw = s3.solve_worm()
+    gw = np.asarray(rw["giw"].mean()); ew = np.asarray(rw["giw"].stderr())
+    gz = np.asarray(r["giw"].mean()); ez = np.asarray(r["giw"].stderr())
+    for sp in range(2):
+        d = np.abs(gw[:, 0, sp, 0, sp] - gz[:, 0, sp, 0, sp]); e = np.sqrt(ew[:, 0, sp, 0, sp] ** 2 + ez[:, 0, sp, 0, sp] ** 2)
+        assert np.all(d < 5.0 * e + 2e-3), (sp, d.max(), e.max())
+    assert np.abs(gw[:, 0, 0, 0, 1]).max() == 0.0
+
+
+def test_solver_qq_worm_symmetric_improved_estimator():
+    """HipCtHybSolver.solve_worm with WormMeasQQ (sector 10: two three-operator equal-time objects q, q+ with the U matrix in the
+    proposal, six worm operators on the matrix trace path): G = G0 + G0 (QQ + Sigma_0) G0, the symmetric improved estimator (Eq. (13)
+    of PRB 100, 075119; impurity.py:998-1003, 1141-1148), agrees with G(iw) of a Z-space run (G(l) -> G(iw))."""
+    from w2dynamics_amd.solver import HipCtHybSolver
+    from w2dynamics_amd import synth
+    base = dict(BASE, Ntau=100, NLegMax=30, Niw=20, Nwarmups=20000, Nmeas=1000, NCorr=20, TaudiffMax=6.0, Nftau=501,
+                PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05)
+    p = synth.config("C1", nftau=501)
+    s = HipCtHybSolver(base, seed=3, nwalkers=1024, walkers_per_bin=8)
+    s.set_problem(p)
+    r = s.postprocessing(s.solve(0))
+    s3 = HipCtHybSolver(dict(base, Nwarmups2Plus=4000, PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=1.0, WormSearchEta=1,
+                             WormMeasQQ=1), seed=11, nwalkers=1024, walkers_per_bin=8)
+    s3.set_problem(p)
+    rw = s3.solve_worm()
+    st = rw["steps-worm-partition/00001"]
+    assert 0.3 < st[9] / st[0] < 3.0
     gw = np.asarray(rw["giw"].mean()); ew = np.asarray(rw["giw"].stderr())
     gz = np.asarray(r["giw"].mean()); ez = np.asarray(r["giw"].stderr())
     for sp in range(2):

@@ -86,6 +86,18 @@ static_assert(C_NCOUNT <= 64, "one lane per event counter");
 
 enum WalkerErr { ERR_NONE = 0, ERR_KMAX = 1, ERR_WCAP = 2, ERR_DETRAT = 4, ERR_SINGULAR = 8, ERR_BLOCKSEQ = 16 };
 
+// number of worm operators a chain's record holds (NOperWorm, Parameters.F90:45: at most 12, sector 11) and the number a kernel keeps
+// in registers: 4 in every translation unit but the one of the sectors with 6, 8 and 12 worm operators
+constexpr int NW_STORE = 12;
+#ifndef W2DYN_NWMAX
+#define W2DYN_NWMAX 4
+#endif
+constexpr int NWMAX = W2DYN_NWMAX;
+__host__ __device__ __forceinline__ int worm_nops_of(int sector)
+{
+    return sector == 2 ? 2 : ((sector == 5 || sector == 10) ? 6 : (sector == 11 ? 12 : ((sector == 12 || sector == 13) ? 8 : 4)));
+}
+
 struct WalkerScalars {
     unsigned long long ndraw;   // random numbers consumed
     int outer;                  // outer superstate = Fock state at tau = 0/beta
@@ -95,9 +107,10 @@ struct WalkerScalars {
     double det_sign;            // sign of det F in the reference's time order (Trace%Det%sign)
     double det_log;             // log|det F|
     unsigned long long cnt[C_NCOUNT];
-    // worm sampling: current sector (0/1 = Z, 2 = one-particle worm c c+, 4 = two-particle worm c c+ c c+, 6 - 9 = P2 / P2pp / P3 / P3pp) and the
-    // worm operators in wormContainer order (Trace.F90:123-125): times and flavours (the first `sector` entries count)
-    int sector; int wflav[4]; double wtau[4];
+    // worm sampling: current sector (0/1 = Z, 2 = one-particle worm c c+, 4 = two-particle worm c c+ c c+, 6 - 9 = P2 / P2pp / P3 / P3pp, 3 / 5 /
+    // 10 - 16 = worms with U-matrix factors, Parameters.F90:28-45) and the worm operators in wormContainer order (Trace.F90:123-125): times
+    // and flavours (the first worm_nops_of(sector) entries count)
+    int sector; int wflav[NW_STORE]; double wtau[NW_STORE];
     // steps of an interrupted sweep launch still to do: a chain stops (ERR_KMAX set) as soon as one of its flavours has filled
     // its kmax slots; the host enlarges the arrays and lets it finish (w2dyn_hip.hip: finish_paused)
     long long todo;
@@ -308,8 +321,8 @@ struct Ctx {
     double tr_log, tr_sign;                          // current local trace
     int ms_, mi_, spb_;                              // lane = (outer state ms_ of the batch, component mi_); spb_ outer states per batch:
                                                      // all of them (nsm) for blocks of up to 8 states, 64 / nsm beyond (9..16 states)
-    // worm sampling
-    int sector; double wtau[4]; int wfl[4];
+    // worm sampling (kernels of the worms with more than four operators are built with W2DYN_NWMAX = 12, tu_worm_big.hip)
+    int sector; double wtau[NWMAX]; int wfl[NWMAX];
 
     __device__ Ctx(const DevConst &c) : C(c) {}
 
@@ -1662,9 +1675,9 @@ __device__ __forceinline__ void ctx_load(Ctx &x)
     const WalkerScalars &s = C.ws[w];
     x.outer = uni(s.outer); x.npairs = uni(s.npairs); x.wpos = uni(s.wpos); x.err = uni(s.err);
     x.det_sign = uni(s.det_sign); x.det_log = uni(s.det_log);
-    { const int sec = uni(s.sector); x.sector = (sec == 4 || sec == 2 || sec == 3 || (sec >= 6 && sec <= 9)) ? sec : 1; }
+    { const int sec = uni(s.sector); x.sector = (sec >= 2 && sec <= 16) ? sec : 1; }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { x.wtau[i] = uni(s.wtau[i]); x.wfl[i] = uni(s.wflav[i]); }
+    for (int i = 0; i < NWMAX; ++i) { x.wtau[i] = uni(s.wtau[i]); x.wfl[i] = uni(s.wflav[i]); }
     unsigned long long nd_ = s.ndraw;
     nd_ = ((unsigned long long)(unsigned)uni((int)(nd_ >> 32)) << 32) | (unsigned long long)(unsigned)uni((int)nd_);
     if (x.lane < C_NCOUNT) x.cnt[x.lane] = s.cnt[x.lane];
@@ -1683,9 +1696,11 @@ __device__ __forceinline__ void ctx_load(Ctx &x)
     if (C.mat) {      // time-ordered list, block sequence and trace of the stored configuration
         mat_build_list(x);
         if (x.sector != 1) {                         // worm operators are list entries like any other (no hybridisation lines: not in M)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (i < (x.sector == 2 ? 2 : 4)) mat_insert(x, mat_lower(x, x.wtau[i]), x.wtau[i], mat_code(x.wfl[i], (i & 1) ? 1 : 2));
+            // from the record, not from the registers: the estimator kernels keep four worm operators at most but need the whole list
+            for (int i = 0, nwo = worm_nops_of(x.sector); i < nwo; ++i) {
+                const double tw = uni(s.wtau[i]);
+                mat_insert(x, mat_lower(x, tw), tw, mat_code(uni(s.wflav[i]), (i & 1) ? 1 : 2));
+            }
         }
         mat_walk_sst(x);                 // the caller evaluates the trace (mat_trace_current<MAT>)
     }
@@ -1717,7 +1732,7 @@ __device__ __forceinline__ void ctx_store(Ctx &x, long long todo = 0)
         s.det_sign = x.det_sign; s.det_log = x.det_log;
         s.sector = x.sector;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { s.wtau[i] = x.wtau[i]; s.wflav[i] = x.wfl[i]; }
+        for (int i = 0; i < NWMAX; ++i) { s.wtau[i] = x.wtau[i]; s.wflav[i] = x.wfl[i]; }
     }
 }
 
@@ -1959,10 +1974,9 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
         if (x.sector != 1 && act) {
             // worm operators enter the trace sign like any other operator; get_WormSign (Trace.F90:3623-3651) adds the
             // hybridising operators at later times than each worm operator
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i >= (x.sector == 2 ? 2 : 4)) continue;  // two worm operators in sector 2, four in the others
-                const int bw = flav_bit(x.wfl[i], nd); const double tw = x.wtau[i];
+            const WalkerScalars &wsr = C.ws[x.w];             // all worm operators of the record (up to twelve)
+            for (int i = 0, nwo = worm_nops_of(x.sector); i < nwo; ++i) {
+                const int bw = flav_bit(wsr.wflav[i], nd); const double tw = wsr.wtau[i];
                 if (!MAT) par ^= ((tw < ti && bw < biti) ? 1 : 0) ^ ((ti < tw && biti < bw) ? 1 : 0);   // trace sign (scalar path only)
                 par ^= (ti > tw) ? 1 : 0;
             }
@@ -1990,13 +2004,12 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
     const bool worm = x.sector != 1;
     if (worm && x.lane == 0) {
         // worm operators among themselves: trace sign, and the pairs i < j (container order) with tau_i < tau_j
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (i >= (x.sector == 2 ? 2 : 4) || j >= (x.sector == 2 ? 2 : 4)) continue;
-                if (!MAT && x.wtau[j] < x.wtau[i] && flav_bit(x.wfl[j], nd) < flav_bit(x.wfl[i], nd)) par ^= 1;
-                if (i < j && x.wtau[i] < x.wtau[j]) par ^= 1;
+        const WalkerScalars &wsr = C.ws[x.w];
+        const int nwo = worm_nops_of(x.sector);
+        for (int i = 0; i < nwo; ++i)
+            for (int j = 0; j < nwo; ++j) {
+                if (!MAT && wsr.wtau[j] < wsr.wtau[i] && flav_bit(wsr.wflav[j], nd) < flav_bit(wsr.wflav[i], nd)) par ^= 1;
+                if (i < j && wsr.wtau[i] < wsr.wtau[j]) par ^= 1;
             }
     }
     par = wave_sum(par) & 1;

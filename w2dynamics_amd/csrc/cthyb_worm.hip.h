@@ -18,7 +18,7 @@
 
 // sort of the NW worm operators by time: ord[m] = container index of the m-th operator in time
 template <int NW>
-__device__ __forceinline__ void worm_order(const double (&t)[4], int (&ord)[4])
+__device__ __forceinline__ void worm_order(const double (&t)[NWMAX], int (&ord)[4])
 {
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
@@ -57,7 +57,7 @@ __device__ __forceinline__ bool worm_any_between(Ctx &x, int f, double lo, doubl
 // flavours fl[] on top of the present hybridising operators.  At most two distinct flavours can occur in a valid
 // worm (every flavour needs as many worm creators as annihilators).
 template <int NW>
-__device__ W2DYN_INLINE bool worm_delta(Ctx &x, const double (&t)[4], const int (&fl)[4], double &dlog)
+__device__ W2DYN_INLINE bool worm_delta(Ctx &x, const double (&t)[NWMAX], const int (&fl)[NWMAX], double &dlog)
 {
     const DevConst &C = x.C;
     int ord[4] = {0, 0, 0, 0};
@@ -93,60 +93,134 @@ __device__ W2DYN_INLINE bool worm_delta(Ctx &x, const double (&t)[4], const int 
     return valid;
 }
 
-// get_Proposal: SectorG / SectorG4 (beta Nd)^NW eta; P2 / P2pp beta^2 Nd^4 eta; P3 / P3pp beta^3 Nd^4 eta (CTQMC.F90:5677-5719)
-// U-matrix factor of the GSigma worm (sector 3): 0.5 (U(u, g2, g1, g3) - U(g2, u, g1, g3)), u = first flavour of the component, g_i the
-// flavour of worm operator i (get_Proposal, CTQMC.F90:5689-5694; its sign enters the estimator, 1138)
-__device__ __forceinline__ double gsigma_ufac(const DevConst &C, const int (&fl)[4])
+// get_Proposal (CTQMC.F90:5655-5798): SectorG / SectorG4 (beta Nd)^NW eta; P2 / P2pp beta^2 Nd^4 eta; P3 / P3pp beta^3 Nd^4 eta; the sectors
+// with U-matrix factors: 3 / 5 beta^(N-2) Nd^(N+1) eta, 10 beta^2 Nd^8 eta, 11 beta^4 Nd^12 eta, 12 / 13 beta^3 Nd^8 eta, 14 / 15 / 16 beta^2 Nd^4 eta,
+// each times the factor below.
+// U-matrix factor of a worm: g[i] = flavour of worm operator i + 1, u_i = i-th flavour index of the component (u_g, set_IEOperFlavor,
+// Trace.F90:3835-3883: two digits in sectors 3 and 10, four otherwise); UA1 / UA2 / UAB = the U matrix antisymmetrised in its first pair, its second
+// pair, both (CTQMC.F90:7926-7948).  meas: the expression whose sign enters the estimator, which differs from the proposal's in sector 13
+// (CTQMC.F90:1919-1921 against 5764-5766).
+__device__ __forceinline__ double ie_ufac(const DevConst &C, int sec, const int *g, bool meas)
 {
-    const int nf = C.nflav, u = ((C.icomponent - 1) / nf) % nf;
-    return 0.5 * (C.umat[(((size_t)u * nf + fl[1]) * nf + fl[0]) * nf + fl[2]] - C.umat[(((size_t)fl[1] * nf + u) * nf + fl[0]) * nf + fl[2]]);
+    const int nf = C.nflav;
+    int u1, u2, u3 = 0, u4 = 0;
+    {
+        int rest = C.icomponent - 1;
+        if (sec == 3 || sec == 10) { u2 = rest % nf; u1 = (rest / nf) % nf; }
+        else { u4 = rest % nf; rest /= nf; u3 = rest % nf; rest /= nf; u2 = rest % nf; u1 = (rest / nf) % nf; }
+    }
+    auto UM = [&](int a, int b, int c, int d) { return C.umat[(((size_t)a * nf + b) * nf + c) * nf + d]; };
+    auto UA1 = [&](int a, int b, int c, int d) { return 0.5 * (UM(a, b, c, d) - UM(b, a, c, d)); };
+    auto UA2 = [&](int a, int b, int c, int d) { return 0.5 * (UM(a, b, c, d) - UM(a, b, d, c)); };
+    auto UAB = [&](int a, int b, int c, int d) { return 0.5 * (UA1(a, b, c, d) - UA1(a, b, d, c)); };
+    auto q1 = [&](int u, int o) { return 0.5 * (UM(u, g[o + 1], g[o], g[o + 2]) - UM(g[o + 1], u, g[o], g[o + 2])); };        // operators o+1, o+2, o+3 (1-based) = c c+ c
+    auto q2 = [&](int u, int o) { return 0.5 * (UM(g[o + 2], g[o], u, g[o + 1]) - UM(g[o + 2], g[o], g[o + 1], u)); };        // operators o+1, o+2, o+3 = c+ c c+
+    switch (sec) {
+    case 3: case 5: return q1(u1, 0);
+    case 10: return q1(u1, 0) * q2(u2, 3);
+    case 11: return q1(u1, 0) * q2(u2, 3) * q1(u3, 6) * q2(u4, 9);
+    case 12: return UA1(u1, g[1], g[0], g[2]) * UA2(g[3], g[5], u2, g[4]) * UAB(u3, g[7], u4, g[6]);
+    case 13: return meas ? UA1(u1, g[1], g[0], g[2]) * UA1(u3, g[3], g[4], g[6]) * UA2(g[5], g[7], u2, u4)
+                         : UA1(u1, g[1], g[0], g[2]) * UA1(u3, g[3], g[5], g[4]) * UA2(g[7], g[6], u2, u4);
+    case 14: return UAB(u1, g[1], u2, g[0]) * UAB(u3, g[3], u4, g[2]);
+    case 15: return UA1(u1, u3, g[0], g[2]) * UA2(g[1], g[3], u2, u4);       // the proposal carries a minus sign on top (CTQMC.F90:5791)
+    case 16: return UA1(u1, g[1], g[0], g[2]) * UAB(u3, g[3], u2, u4);
+    default: return 1.0;
+    }
 }
+__device__ __forceinline__ bool worm_has_ufac(int sec) { return sec == 3 || sec == 5 || (sec >= 10 && sec <= 16); }
+// sector 3 (its sign enters the estimator, CTQMC.F90:1138)
+__device__ __forceinline__ double gsigma_ufac(const DevConst &C, const int (&fl)[4]) { return ie_ufac(C, 3, fl, false); }
 
 template <int NW>
-__device__ __forceinline__ double worm_prefact(const DevConst &C, const int (&fl)[4])
+__device__ __forceinline__ double worm_prefact(const DevConst &C, const int (&fl)[NWMAX])
 {
+    const double nd = (double)C.nd, nd4 = nd * nd * nd * nd, b2 = C.beta * C.beta;
+    const int sec = C.isector;
     if constexpr (NW == 4) {
-        if (C.isector == 3) {                          // beta^(N-2) Nd^(N+1) eta times the U-matrix factor, N = 4 (CTQMC.F90:5696)
-            const double nd = (double)C.nd, nd4 = nd * nd * nd * nd;
-            return gsigma_ufac(C, fl) * (C.beta * C.beta) * (nd4 * nd) * C.worm_eta;
-        }
-        if (C.isector >= 6) {
-            const double nd = (double)C.nd, nd4 = nd * nd * nd * nd, bb = C.beta * C.beta;
-            return (C.isector >= 8 ? bb * C.beta : bb) * nd4 * C.worm_eta;
-        }
+        if (sec == 3) return ie_ufac(C, 3, fl, false) * b2 * (nd4 * nd) * C.worm_eta;        // beta^(N-2) Nd^(N+1) eta times the U-matrix factor, N = 4 (CTQMC.F90:5696)
+        if (sec >= 6 && sec <= 9) return (sec >= 8 ? b2 * C.beta : b2) * nd4 * C.worm_eta;
+        if (sec == 14) return ie_ufac(C, 14, fl, false) * C.worm_eta * b2 * nd4;             // 5778-5782
+        if (sec == 15) return -ie_ufac(C, 15, fl, false) * C.worm_eta * b2 * nd4;            // 5791-5795
+        if (sec == 16) return ie_ufac(C, 16, fl, false) * b2 * nd4 * C.worm_eta;             // 5706-5709
     }
-    const double b = C.beta * (double)C.nd, b2 = b * b;
-    return (NW == 4 ? b2 * b2 : b2) * C.worm_eta;
+    if constexpr (NW == 6) {
+        if (sec == 5) return ie_ufac(C, 5, fl, false) * (b2 * b2) * (nd4 * nd * nd * nd) * C.worm_eta;
+        return ie_ufac(C, 10, fl, false) * b2 * (nd4 * nd4) * C.worm_eta;                    // 5731
+    }
+    if constexpr (NW == 8) return ie_ufac(C, sec, fl, false) * C.worm_eta * (b2 * C.beta) * (nd4 * nd4);    // 5757, 5768
+    if constexpr (NW == 12) return ie_ufac(C, 11, fl, false) * (b2 * b2) * (nd4 * nd4 * nd4) * C.worm_eta;  // 5745
+    const double b = C.beta * nd, bb = b * b;
+    return (NW == 4 ? bb * bb : bb) * C.worm_eta;
 }
 
 // set_OperTime (Trace.F90:3942-4020): independent times in sectors 2 and 4; sectors 6 / 7: tau_1 and tau_4 random, the partners
 // an offset beta 1e-14 below tau_1 and above tau_4 (P2: 2 with 1, 3 with 4; P2pp: 3 with 1, 2 with 4); sectors 8 / 9: a third
 // random time for operator 2 (P3) or 3 (P3pp), the other one an offset above tau_4.  check_EqualTime (an operator between the
 // two of a pair: needs two times within 1e-14 beta of each other) is not looked for.
+// Sectors with U-matrix factors (Trace.F90:3971-3983, 4022-4158): sectors 3, 5, 10, 11 draw a time for EVERY operator and then put the
+// three-operator objects (1, 3, 2), (5, 4, 6), (7, 9, 8), (11, 10, 12) an offset apart below their last operator's time; 12 and 13 draw three,
+// 14 - 16 two times.
 template <int NW>
-__device__ __forceinline__ void worm_draw_times(Ctx &x, double (&t)[4])
+__device__ __forceinline__ void worm_draw_times(Ctx &x, double (&t)[NWMAX])
 {
     const DevConst &C = x.C;
-    if constexpr (NW == 4) {
-        if (C.isector == 3) {                          // four draws, then the equal-time object (1, 3, 2) below tau_2 (Trace.F90:3971-3983)
-            const double beta = C.beta, off = beta * 1e-14;
+    const double beta = C.beta, off = beta * 1e-14;
+    const int sec = C.isector;
+    double *const tt = &t[0];            // operators beyond the fourth (only where NWMAX = 12)
+    if constexpr (NW >= 4) {
+        if (sec == 3 || sec == 5 || sec == 10 || sec == 11) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) t[i] = x.draw() * beta;
+            for (int i = 0; i < NW; ++i) t[i] = x.draw() * beta;
             if (t[1] < 2.0 * off) t[1] = 2.0 * off;
-            t[2] = t[1] - off; t[0] = t[1] - 2.0 * off;
+            tt[2] = tt[1] - off; tt[0] = tt[1] - 2.0 * off;
+            if constexpr (NW >= 6) if (sec >= 10) {
+                if (tt[5] < 2.0 * off) tt[5] = 2.0 * off;
+                tt[3] = tt[5] - off; tt[4] = tt[5] - 2.0 * off;
+            }
+            if constexpr (NW == 12) {
+                if (tt[7] < 2.0 * off) tt[7] = 2.0 * off;
+                if (tt[11] < 2.0 * off) tt[11] = 2.0 * off;
+                tt[8] = tt[7] - off; tt[6] = tt[7] - 2.0 * off; tt[9] = tt[11] - off; tt[10] = tt[11] - 2.0 * off;
+            }
             return;
         }
-        if (C.isector >= 6) {
-            const double beta = C.beta, off = beta * 1e-14;
+    }
+    if constexpr (NW == 8) {
+        tt[1] = x.draw() * beta; tt[3] = x.draw() * beta;
+        double third = x.draw() * beta;
+        if (tt[1] < 2.0 * off) tt[1] = 2.0 * off;
+        if (tt[3] < 2.0 * off) tt[3] = 2.0 * off;
+        if (third < off) third = off;
+        tt[2] = tt[1] - off; tt[0] = tt[1] - 2.0 * off;
+        if (sec == 12) { tt[7] = third; tt[5] = tt[3] - off; tt[4] = tt[3] - 2.0 * off; tt[6] = tt[7] - off; }
+        else { tt[5] = third; tt[6] = tt[3] - off; tt[4] = tt[3] - 2.0 * off; tt[7] = tt[5] - off; }
+        return;
+    }
+    if constexpr (NW == 4) {
+        if (sec >= 14) {
+            t[1] = x.draw() * beta;
+            double second = x.draw() * beta;
+            if (second < off) second = off;
+            if (sec == 16) {
+                if (t[1] < 2.0 * off) t[1] = 2.0 * off;
+                t[3] = second; t[2] = t[1] - off; t[0] = t[1] - 2.0 * off;
+            } else {
+                if (t[1] < off) t[1] = off;
+                if (sec == 14) { t[3] = second; t[0] = t[1] - off; t[2] = t[3] - off; } else { t[2] = second; t[0] = t[2] - off; t[3] = t[1] - off; }
+            }
+            return;
+        }
+        if (sec >= 6) {
             t[0] = x.draw() * beta;
             t[3] = x.draw() * beta;
-            if (C.isector <= 7) {
+            if (sec <= 7) {
                 if (t[0] < off) t[0] = off;
                 if (t[3] > beta - off) t[3] = beta - off;
-                if (C.isector == 6) { t[1] = t[0] - off; t[2] = t[3] + off; } else { t[1] = t[3] + off; t[2] = t[0] - off; }
+                if (sec == 6) { t[1] = t[0] - off; t[2] = t[3] + off; } else { t[1] = t[3] + off; t[2] = t[0] - off; }
             } else {
                 if (t[3] > beta - off) t[3] = beta - off;
-                if (C.isector == 8) { t[1] = x.draw() * beta; t[2] = t[3] + off; } else { t[1] = t[3] + off; t[2] = x.draw() * beta; }
+                if (sec == 8) { t[1] = x.draw() * beta; t[2] = t[3] + off; } else { t[1] = t[3] + off; t[2] = x.draw() * beta; }
             }
             return;
         }
@@ -162,17 +236,23 @@ __device__ __forceinline__ void worm_draw_times(Ctx &x, double (&t)[4])
 // equal-time object get random flavours until the U-matrix factor of the proposal does not vanish, operator 4 carries the component's
 // second flavour (set_IEOperFlavor, Trace.F90:3835-3919; CTQMC.F90:5047-5054)
 template <int NW>
-__device__ __forceinline__ void worm_draw_flavours(Ctx &x, int (&fl)[4])
+__device__ __forceinline__ void worm_draw_flavours(Ctx &x, int (&fl)[NWMAX])
 {
     const DevConst &C = x.C;
-    const int nf = C.nflav;
-    if constexpr (NW == 4) {
-        if (C.isector == 3) {
-            fl[3] = (C.icomponent - 1) % nf;
-            for (int guard = 0; guard < (1 << 20); ++guard) {      // the host has checked that some choice has a non-vanishing factor
+    const int nf = C.nflav, sec = C.isector;
+    if constexpr (NW >= 4) {
+        if (worm_has_ufac(sec)) {
+            // sectors 3 and 5: the operators after the third carry the component's flavours after the first; every other operator gets a random
+            // orbital and a random spin, again and again until the proposal's factor does not vanish (the host has checked that some choice has one)
+            int d2 = 0, d3 = 0, d4 = 0;
+            { int rest = C.icomponent - 1; d4 = rest % nf; rest /= nf; d3 = rest % nf; rest /= nf; d2 = rest % nf; }
+            for (int guard = 0; guard < (1 << 20); ++guard) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) { const int orb = x.randint(1, C.nd), spin = x.randint(1, 2); fl[i] = 2 * (orb - 1) + (spin - 1); }
-                if (gsigma_ufac(C, fl) != 0.0) break;
+                for (int i = 0; i < NW; ++i) {
+                    if ((sec == 3 || sec == 5) && i >= 3) fl[i] = sec == 3 ? d4 : (i == 3 ? d2 : (i == 4 ? d3 : d4));
+                    else { const int orb = x.randint(1, C.nd), spin = x.randint(1, 2); fl[i] = 2 * (orb - 1) + (spin - 1); }
+                }
+                if (worm_prefact<NW>(C, fl) != 0.0) break;
             }
             return;
         }
@@ -190,7 +270,7 @@ __device__ W2DYN_INLINE void step_worm_add(Ctx &x)
 {
     const DevConst &C = x.C;
     x.count(C_TRYWADD);
-    double t[4] = {0.0, 0.0, 0.0, 0.0}; int fl[4] = {0, 0, 0, 0};
+    double t[NWMAX] = {}; int fl[NWMAX] = {};
     worm_draw_flavours<NW>(x, fl);
     worm_draw_times<NW>(x, t);
     double dlog;
@@ -201,7 +281,7 @@ __device__ W2DYN_INLINE void step_worm_add(Ctx &x)
     if (rnd < fabs(prefact * exp(dlog))) {
 #pragma unroll
         for (int i = 0; i < NW; ++i) { x.wtau[i] = t[i]; x.wfl[i] = fl[i]; }
-        x.sector = NW == 4 ? C.isector : NW;
+        x.sector = C.isector;
         x.count(C_ACCWADD);
     } else x.sector = 1;
 }
@@ -306,21 +386,54 @@ __device__ W2DYN_INLINE void step_worm_replace(Ctx &x)
 {
     const DevConst &C = x.C;
     x.count(C_TRYWREP);
-    const int r = x.randint(1, NW) - 1;
+    // which worm operator becomes a hybridising one (CTQMC.F90:5834-5946): uniform over the container in sectors 2 - 4, 6 - 9, 14, 15; only
+    // the operators outside the equal-time object in sectors 5 and 16; sectors 10 - 12: a three-operator object that holds a density
+    // (operators 2, 3 or 4, 5 ... of equal flavour) moves the density; no replacement at all in sector 13
+    const int sec = C.isector;
+    int r;
+    if constexpr (NW == 8) { if (sec == 13) return; }
+    if (NW >= 4 && (sec == 5 || sec == 16)) r = x.randint(4, NW) - 1;
+    else if (NW == 6 && sec == 10) {
+        const bool d1 = x.wfl[1] == x.wfl[2], d2 = x.wfl[NW >= 6 ? 3 : 0] == x.wfl[NW >= 6 ? 4 : 0];
+        if (d1) r = d2 ? (x.randint(1, 2) - 1) * 5 : 0; else r = d2 ? 5 : x.randint(1, 6) - 1;
+    } else if (NW == 8 && sec == 12) {
+        const bool d1 = x.wfl[1] == x.wfl[2], d2 = x.wfl[NW >= 8 ? 5 : 0] == x.wfl[NW >= 8 ? 4 : 0];
+        if (d1) r = d2 ? (x.randint(1, 2) - 1) * 3 : 0; else r = d2 ? 3 : x.randint(1, 6) - 1;
+    } else if (NW == 12) {
+        const bool dd[4] = {x.wfl[1] == x.wfl[2], x.wfl[NW == 12 ? 3 : 0] == x.wfl[NW == 12 ? 4 : 0], x.wfl[NW == 12 ? 7 : 0] == x.wfl[NW == 12 ? 8 : 0],
+                            x.wfl[NW == 12 ? 9 : 0] == x.wfl[NW == 12 ? 10 : 0]};
+        const int nden = (int)dd[0] + (int)dd[1] + (int)dd[2] + (int)dd[3];
+        if (nden > 0) {
+            int pick = x.randint(1, nden); r = 0;
+            const int stay[4] = {0, 5, 6, 11};               // the operator that stays when object q gives its density away
+#pragma unroll
+            for (int q = 3; q >= 0; --q) { int before = 0; for (int p = 0; p < q; ++p) before += (int)dd[p]; if (dd[q] && before == pick - 1) r = stay[q]; }
+        } else r = x.randint(1, 12) - 1;
+    } else r = x.randint(1, NW) - 1;
     // container indices of the partners that move along (-1: none) and their places in the new equal-time object (1: at tau_h, 2: one
-    // offset above, 3: two); the former hybridising operator takes the place that is left (qrepind / qtimeind, CTQMC.F90:6068-6127, 6164-6178)
+    // offset above, 3: two); the former hybridising operator takes the place that is left (qrepind / qtimeind, CTQMC.F90:5997-6178)
     int partner = -1, pos_partner = 0, partner2 = -1, pos_partner2 = 0, pos_new = 0;
-    if constexpr (NW == 4) {
-        const int sec = C.isector;
-        if (sec == 3) {
-            if (r == 0) { partner = 2; pos_partner = 2; partner2 = 1; pos_partner2 = 3; pos_new = 1; }
-            else if (r == 1) { partner = 0; pos_partner = 1; partner2 = 2; pos_partner2 = 2; pos_new = 3; }
-            else if (r == 2) { partner = 0; pos_partner = 1; partner2 = 1; pos_partner2 = 3; pos_new = 2; }
+    if constexpr (NW >= 4) {
+        // three-operator objects: row = the operator that stays (six per pair of objects), {partner, place, partner, place, place of the new one}
+        bool three = false; int row = 0, shift = 0; bool nqq = false;
+        if (sec == 3) { three = r < 3; row = r; }
+        else if (sec == 10 || sec == 11) { three = true; row = r % 6; shift = 6 * (r / 6); }
+        else if (sec == 12) { three = true; row = r; nqq = r >= 3; }
+        if (three) {
+            const int q3[6][5] = {{2, 2, 1, 3, 1}, {0, 1, 2, 2, 3}, {0, 1, 1, 3, 2}, {4, 1, 5, 3, 2}, {3, 2, 5, 3, 1}, {4, 1, 3, 2, 3}};
+            const int q3n[3][5] = {{4, 1, 5, 2, 3}, {5, 2, 3, 3, 1}, {4, 1, 3, 3, 2}};                      // second object of sector 12
+#pragma unroll
+            for (int q = 0; q < 6; ++q) if (q == row) {
+                const int *e = (nqq && q >= 3) ? q3n[q - 3] : q3[q];
+                partner = e[0] + shift; pos_partner = e[1]; partner2 = e[2] + shift; pos_partner2 = e[3]; pos_new = e[4];
+            }
         }
         else if (sec == 6) { partner = r ^ 1; pos_partner = (r & 1) ? 2 : 1; }
         else if (sec == 7) { partner = r ^ 2; pos_partner = r < 2 ? 1 : 2; }
         else if (sec == 8) { if (r >= 2) { partner = r ^ 1; pos_partner = r == 2 ? 1 : 2; } }
         else if (sec == 9) { if (r & 1) { partner = r ^ 2; pos_partner = r == 1 ? 1 : 2; } }
+        else if (sec == 14) { partner = r ^ 1; pos_partner = (r & 1) ? 1 : 2; }                             // 6151-6162
+        else if (sec == 15) { partner = r ^ 2; pos_partner = (r == 0 || r == 3) ? 2 : 1; }                  // 6133-6144
         if (partner >= 0 && partner2 < 0) pos_new = 3 - pos_partner;
     }
     double tw = 0.0; int f = 0;
@@ -374,12 +487,12 @@ __device__ W2DYN_INLINE void step_worm_replace(Ctx &x)
     double prob = fabs(detrat);
     double tp = 0.0, tpn = 0.0, tp2 = 0.0, tpn2 = 0.0, thn = th, tl = 0.0, ts = 1.0; int fp = 0, fp2 = 0;
     bool slot_moved = false;
-    if constexpr (NW == 4) {
+    if constexpr (NW >= 4) {
         if (partner >= 0) {
             const double off = C.beta * 1e-14;
             tpn = th + (double)(pos_partner - 1) * off; tpn2 = th + (double)(pos_partner2 - 1) * off; thn = th + (double)(pos_new - 1) * off;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { if (i == partner) { tp = x.wtau[i]; fp = x.wfl[i]; } if (i == partner2) { tp2 = x.wtau[i]; fp2 = x.wfl[i]; } }
+            for (int i = 0; i < NW; ++i) { if (i == partner) { tp = x.wtau[i]; fp = x.wfl[i]; } if (i == partner2) { tp2 = x.wtau[i]; fp2 = x.wfl[i]; } }
             const int pca = (partner & 1) ? 1 : 2, pca2 = (partner2 & 1) ? 1 : 2;
             if constexpr (MAT == 0) {
                 if (partner2 < 0) {
@@ -422,7 +535,7 @@ __device__ W2DYN_INLINE void step_worm_replace(Ctx &x)
     bool accept = false;
     if (ts != 0.0) { const double rnd = x.draw(); accept = rnd < prob; }
     if (!accept) {
-        if constexpr (NW == 4 && MAT != 0) {
+        if constexpr (NW >= 4 && MAT != 0) {
             if (partner >= 0) {                                // back to the old list
                 mat_remove(x, mat_lower(x, tpn));
                 wave_sync();
@@ -442,8 +555,8 @@ __device__ W2DYN_INLINE void step_worm_replace(Ctx &x)
     }
     if (x.lane == 0) { if (creator) tcp[slot] = tw; else tap[slot] = tw; }
 #pragma unroll
-    for (int i = 0; i < NW; ++i) { if (i == r) x.wtau[i] = thn; if (NW == 4 && i == partner) x.wtau[i] = tpn; if (NW == 4 && i == partner2) x.wtau[i] = tpn2; }
-    if constexpr (NW == 4 && MAT != 0) {
+    for (int i = 0; i < NW; ++i) { if (i == r) x.wtau[i] = thn; if (NW >= 4 && i == partner) x.wtau[i] = tpn; if (NW >= 4 && i == partner2) x.wtau[i] = tpn2; }
+    if constexpr (NW >= 4 && MAT != 0) {
         if (partner >= 0) { x.tr_log = tl; x.tr_sign = ts; mat_commit_sst(x); }
     }
     wave_sync();
@@ -461,7 +574,7 @@ __device__ W2DYN_INLINE void step_worm_add_mat(Ctx &x)
 {
     const DevConst &C = x.C;
     x.count(C_TRYWADD);
-    double t[4] = {0.0, 0.0, 0.0, 0.0}; int fl[4] = {0, 0, 0, 0};
+    double t[NWMAX] = {}; int fl[NWMAX] = {};
     worm_draw_flavours<NW>(x, fl);
     worm_draw_times<NW>(x, t);
     if (x.nops + NW > C.wcap) { x.err |= ERR_WCAP; x.count(C_QNWADD); x.sector = 1; return; }
@@ -482,7 +595,7 @@ __device__ W2DYN_INLINE void step_worm_add_mat(Ctx &x)
 #pragma unroll
         for (int i = 0; i < NW; ++i) { x.wtau[i] = t[i]; x.wfl[i] = fl[i]; }
         x.tr_log = tl; x.tr_sign = ts; mat_commit_sst(x);
-        x.sector = NW == 4 ? C.isector : NW;
+        x.sector = C.isector;
         x.count(C_ACCWADD);
     } else { take_out(); x.sector = 1; }
 }
@@ -724,5 +837,64 @@ __global__ __launch_bounds__(256) void k_meas_weq(DevConst C, int nbe, double *a
             }
         }
     }
+}
+// Estimators of the worm sectors 5 and 10 - 16 (measure_ie_chi_worm, measure_qq_worm / qqtau, measure_qqqq_worm, measure_nqqdag_worm,
+// measure_qqdd_worm, measure_ucaca_worm / ucacatau, measure_uccaa_worm / uccaatau, measure_quddag_worm; CTQMC.F90:1166-1294, 1708-2128, with
+// the exact transform, Nfft_worm.F90:94-137): every chain in worm space adds cfgsign/eta times the sign of the proposal's U-matrix
+// factor times exp(i [m1 x1 + m2 x2 + m3 x3] pi / beta) to a complex array of up to three frequency axes (fermionic m = 2 n + 1 or bosonic
+// m = 2 n), and one count to the tau bin of a time difference:
+//   5  h4iw (F, F, B):  t1 - t4, t5 - t6, t1 - t6 (WormPHConvention: t4 - t5)       10 qq (F): -(t1 - t4);  qqtau: t2 - t6, antiperiodic
+//   11 qqqq (F, F, B):  t2 - t6, t8 - t12, t2 - t12 (t6 - t8)                        12 nqqdag (F, B): t2 - t4, t4 - t8
+//   13 qqdd (F, F):     t2 - t6, t4 - t6                                             14 ucaca (B), ucacatau: t1 - t3, periodic
+//   15 uccaa (B), uccaatau: t3 - t2, periodic                                        16 quddag (F): t1 - t4
+// One workgroup per accumulator bin (sample bins folded onto nbe of them), the bin's chains looped, thread = element.
+__global__ __launch_bounds__(256) void k_meas_wie(DevConst C, int nbe, double *acc_iw, double *acc_tau, int n1, int n2, int n3)
+{
+    const int bin = blockIdx.x, tid = threadIdx.x, sec = C.isector;
+    const double pib = M_PI / C.beta;
+    const bool f1 = sec != 14 && sec != 15, f2 = true, f3 = false;        // fermionic axes (the second axis of sector 12 is bosonic, below)
+    const bool b2 = sec == 12;
+    const int n = n1 * n2 * n3;
+    for (int cb = bin; cb < C.nbins; cb += nbe)
+    for (int w = cb * C.walkers_per_bin; w < min((cb + 1) * C.walkers_per_bin, C.nwalkers); ++w) {
+        const WalkerScalars &s = C.ws[w];
+        if (s.sector != sec) continue;                       // uniform over the workgroup
+        double t[NW_STORE]; int g[NW_STORE];
+#pragma unroll
+        for (int i = 0; i < NW_STORE; ++i) { t[i] = s.wtau[i]; g[i] = s.wflav[i]; }
+        double val = C.cfgsign[w] / C.worm_eta;
+        if (ie_ufac(C, sec, g, true) < 0.0) val = -val;
+        double x1 = 0.0, x2 = 0.0, x3 = 0.0, dtau = 0.0; bool anti = false;
+        switch (sec) {
+        case 5: x1 = t[0] - t[3]; x2 = t[4] - t[5]; x3 = C.wormphconv ? t[3] - t[4] : t[0] - t[5]; break;
+        case 10: x1 = t[0] - t[3]; dtau = t[1] - t[5]; anti = true; break;
+        case 11: x1 = t[1] - t[5]; x2 = t[7] - t[11]; x3 = C.wormphconv ? t[5] - t[7] : t[1] - t[11]; break;
+        case 12: x1 = t[1] - t[3]; x2 = t[3] - t[7]; break;
+        case 13: x1 = t[1] - t[5]; x2 = t[3] - t[5]; break;
+        case 14: x1 = t[0] - t[2]; dtau = x1; break;
+        case 15: x1 = t[2] - t[1]; dtau = x1; break;
+        default: x1 = t[0] - t[3]; break;
+        }
+        if (acc_iw) {
+            const double viw = sec == 10 ? -val : val;       // measure_qq_worm carries a minus sign (CTQMC.F90:1230)
+            double *a = acc_iw + (size_t)bin * n * 2;
+            for (int e = tid; e < n; e += 256) {
+                const int i3 = e % n3, i2 = (e / n3) % n2, i1 = e / (n3 * n2);
+                const double m1 = f1 ? (double)(2 * (i1 - n1 / 2) + 1) : (double)(2 * (i1 - (n1 - 1) / 2));
+                const double m2 = n2 == 1 ? 0.0 : (b2 ? (double)(2 * (i2 - (n2 - 1) / 2)) : (double)(2 * (i2 - n2 / 2) + 1));
+                const double m3 = n3 == 1 ? 0.0 : (double)(2 * (i3 - (n3 - 1) / 2));
+                double sn, cs; sincos(pib * (m1 * x1 + m2 * x2 + m3 * x3), &sn, &cs);
+                a[2 * e] += viw * cs; a[2 * e + 1] += viw * sn;
+            }
+        }
+        if (acc_tau && tid == 0) {
+            double tau = dtau, v = val;
+            if (tau < 0.0) { tau += C.beta; if (anti) v = -v; }
+            int it = (int)((double)C.ntau * tau / C.beta) + 1;
+            if (it > C.ntau) it = C.ntau;
+            acc_tau[(size_t)bin * C.ntau + it - 1] += v;
+        }
+    }
+    (void)f2; (void)f3;
 }
 #endif  // W2DYN_TU_MEAS

@@ -88,6 +88,10 @@ void launch_meas_g4w(const DevConst &C, hipStream_t st, int pp, int nbw)
 {
     hipLaunchKernelGGL(k_meas_g4w, dim3(nbw), dim3(256), (size_t)(4 * C.nwf + 2 * C.nwb + 1) * sizeof(double2), st, C, pp, nbw);
 }
+void launch_meas_wie(const DevConst &C, hipStream_t st, int nbe, double *acc_iw, double *acc_tau, int n1, int n2, int n3)
+{
+    hipLaunchKernelGGL(k_meas_wie, dim3(nbe), dim3(256), 0, st, C, nbe, acc_iw, acc_tau, n1, n2, n3);
+}
 void launch_meas_gw(const DevConst &C, hipStream_t st)
 {
     hipLaunchKernelGGL(k_meas_gw, dim3(C.nbins), dim3(256), (size_t)C.ntau * sizeof(double), st, C);

@@ -137,6 +137,12 @@ struct w2dyn_solver {
     std::vector<double> umat_h;                      // U matrix as handed to init_solver
     int worm_meas_gsigma = 0;                        // sector 3: WormMeasGSigmaiw (CTQMC.F90:619-623); shares the giw_worm accumulator
     double *acc_weq_iw = nullptr, *acc_weq_tau = nullptr, *acc_weq_p3 = nullptr;
+    // worm sectors 5, 10 - 16 (CTQMC.F90:379-430, 624-652): WormMeasH4iw, WormMeasQQ, WormMeasQQtau, WormMeasQQQQ, WormMeasNQQdag, WormMeasQQdd, WormMeasUcaca,
+    // WormMeasUcacatau, WormMeasUccaa, WormMeasUccaatau, WormMeasQUDdag; one sector is sampled per run, so the estimators share one complex and one tau accumulator
+    int worm_meas_more[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, nbie = 0;
+    size_t wie_n = 0;                                // doubles per bin of acc_wie_iw
+    double *acc_wie_iw = nullptr, *acc_wie_tau = nullptr;
+    double wie_sparsity = 1.0;                       // u_sparsity of the sector and component being sampled (CTQMC.F90:9013-9343)
     bool no_sampling = false;
     std::vector<long long> steps_worm_chains;
     // configurations of all chains kept on the host across init_solver calls (w2dyn_save_mc_configs / w2dyn_restore_mc_configs)
@@ -326,6 +332,26 @@ LaunchCfg walker_launch(const w2dyn_solver *s)
     return l;
 }
 
+// worm sectors 5, 10 - 16: index (into worm_meas_more) of the sector's complex array and of its tau histogram (-1: none), the array's axes, and
+// whether the sector counts its measurements only when its array was asked for (CTQMC.F90:8600-8640)
+struct WieSector { int q_iw, q_tau, n1, n2, n3; bool needs_iw; };
+static WieSector wie_sector(const w2dyn_solver *s, int is)
+{
+    const int f4 = 2 * s->n4iwf, b4 = 2 * s->n4iwb + 1, f3 = 2 * s->n3iwf, b3 = 2 * s->n3iwb + 1, b2 = 2 * s->n2iwb + 1, fg = 2 * s->niw;
+    switch (is) {
+    case 5: return {0, -1, f4, f4, b4, true};
+    case 10: return {1, 2, fg, 1, 1, true};
+    case 11: return {3, -1, f4, f4, b4, true};
+    case 12: return {4, -1, f3, b3, 1, true};
+    case 13: return {5, -1, f3, f3, 1, true};
+    case 14: return {6, 7, b2, 1, 1, false};
+    case 15: return {8, 9, b2, 1, 1, false};
+    default: return {10, -1, fg, 1, 1, false};
+    }
+}
+static bool is_wie_sector(int is) { return is == 5 || (is >= 10 && is <= 16); }
+static const char *const kWieNames[11] = {"h4iw_worm", "qq_worm", "qqtau_worm", "qqqq_worm", "nqqdag_worm", "qqdd_worm", "ucaca_worm", "ucacatau_worm", "uccaa_worm",
+                                          "uccaatau_worm", "quddag_worm"};
 int mat_variant(const w2dyn_solver *s) { return !s->mat ? 0 : (s->lp.nsmax <= 2 ? 2 : (s->lp.nsmax <= 4 ? s->lp.nsmax : 9)); }
 
 // ---- expansion-order capacity --------------------------------------------------------------------------------------
@@ -473,10 +499,12 @@ void launch_sweep(int mat, bool calib, const LaunchCfg &l0, const DevConst &C, l
     else if (mat <= 4) launch_sweep_tree(mat, calib, l, C, nsteps, count, resume);
     else launch_sweep_seq(calib, l, C, nsteps, count, resume);
 }
-void launch_sweep_worm(int nworm, int mat, const LaunchCfg &l0, const DevConst &C, long long nsteps, int resume)
+void launch_sweep_worm(int isector, int mat, const LaunchCfg &l0, const DevConst &C, long long nsteps, int resume)
 {
     const LaunchCfg l = mat ? queue_launch(l0, C) : l0;
-    if (mat == 0) launch_sweep_worm_scalar(nworm, l, C, nsteps, resume);
+    const int nworm = worm_nops_of(isector);
+    if (nworm > 4) launch_sweep_worm_big(nworm, mat, l, C, nsteps, resume);      // enter_sector has made sure of the matrix trace path
+    else if (mat == 0) launch_sweep_worm_scalar(nworm, l, C, nsteps, resume);
     else if (mat <= 4) launch_sweep_worm_tree(nworm, mat, l, C, nsteps, resume);
     else launch_sweep_worm_seq(nworm, l, C, nsteps, resume);
 }
@@ -621,6 +649,12 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
         if (!get_int(s, "N3iwf", iv)) return W2DYN_EINVAL; s->n3iwf = (int)iv;
         if (!get_int(s, "N3iwb", iv)) return W2DYN_EINVAL; s->n3iwb = (int)iv;
     }
+    {
+        static const char *keys[11] = {"WormMeasH4iw", "WormMeasQQ", "WormMeasQQtau", "WormMeasQQQQ", "WormMeasNQQdag", "WormMeasQQdd", "WormMeasUcaca", "WormMeasUcacatau",
+                                       "WormMeasUccaa", "WormMeasUccaatau", "WormMeasQUDdag"};
+        for (int q = 0; q < 11; ++q) { if (!get_int(s, keys[q], iv)) return W2DYN_EINVAL; s->worm_meas_more[q] = iv != 0; }
+        if (!(s->fourpnt & 8)) s->worm_meas_more[0] = s->worm_meas_more[3] = 0;         // CTQMC.F90:379, 390
+    }
     if (!get_int(s, "G4ph", iv)) return W2DYN_EINVAL; s->g4ph = iv != 0;
     if (!get_int(s, "G4pp", iv)) return W2DYN_EINVAL; s->g4pp = iv != 0;
     if (!get_int(s, "WormPHConvention", iv)) return W2DYN_EINVAL; s->wormphconv = iv != 0;
@@ -702,7 +736,9 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
             return fail(s, W2DYN_EUNSUPPORTED, "offdiag = 1 runs the pair, shift and global moves and measures gtau_full / gleg_full, sign, histograms and the density matrix: FourPnt, MeasSusz, AccumGtau = 2, the step series, PercentageOuterMove and Percentage4OperatorMove without flavourchange_moves = 1 are not supported with it");
         s->meas_giw = 0;
     }
-    s->mat = !lp.identity_blocks || s->offdiag;      // off-diagonal hybridisation: always the matrix trace path (list of operators with their flavours)
+    // the worms with six, eight and twelve operators (sectors 5, 10 - 13) are kept in the operator list only: matrix trace path, whatever the blocks
+    const bool big_worms = s->worm_meas_more[0] || s->worm_meas_more[1] || s->worm_meas_more[2] || s->worm_meas_more[3] || s->worm_meas_more[4] || s->worm_meas_more[5];
+    s->mat = !lp.identity_blocks || s->offdiag || big_worms;      // off-diagonal hybridisation: always the matrix trace path (list of operators with their flavours)
     (void)dd;
     if (s->mat && lp.nsmax > 16) return fail(s, W2DYN_EUNSUPPORTED, "largest block of H_loc has %d states with QuantumNumbers '%s': the HIP solver handles up to 16", lp.nsmax, qns.c_str());
     s->eps.assign(nf, 0.0); s->udd.assign((size_t)nf * nf, 0.0);
@@ -947,6 +983,24 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
             if (p3) { if ((rc = dev_alloc(s, s->acc_weq_p3, (size_t)s->nbe * 4 * s->n3iwf * (2 * s->n3iwb + 1)))) return rc; }
         }
     }
+    s->acc_wie_iw = s->acc_wie_tau = nullptr; s->nbie = 0; s->wie_n = 0;
+    {   // worm sectors 5, 10 - 16: the largest complex array asked for, and a tau histogram
+        const int *m = s->worm_meas_more;
+        const size_t n4 = (size_t)4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1) * 2;
+        const size_t sizes[11] = {n4, (size_t)4 * s->niw, 0, n4, (size_t)4 * s->n3iwf * (2 * s->n3iwb + 1), (size_t)8 * s->n3iwf * s->n3iwf, (size_t)2 * (2 * s->n2iwb + 1), 0,
+                                  (size_t)2 * (2 * s->n2iwb + 1), 0, (size_t)4 * s->niw};
+        bool any = false, tau = m[2] || m[7] || m[9];
+        for (int q = 0; q < 11; ++q) if (m[q]) { any = true; s->wie_n = std::max(s->wie_n, sizes[q]); }
+        if (any) {
+            if ((m[0] || m[3]) && (s->n4iwf < 1 || s->n4iwb < 0)) return fail(s, W2DYN_EINVAL, "N4iwf=%d N4iwb=%d", s->n4iwf, s->n4iwb);
+            if ((m[4] || m[5]) && (s->n3iwf < 1 || s->n3iwb < 0)) return fail(s, W2DYN_EINVAL, "N3iwf=%d N3iwb=%d", s->n3iwf, s->n3iwb);
+            if ((m[6] || m[8]) && s->n2iwb < 0) return fail(s, W2DYN_EINVAL, "N2iwb=%d", s->n2iwb);
+            const size_t per = (s->wie_n + (tau ? (size_t)s->ntau : 0)) * sizeof(double);
+            s->nbie = (int)std::max<size_t>(1, std::min<size_t>(B, acc_budget() / std::max<size_t>(per, 1)));
+            if (s->wie_n) { if ((rc = dev_alloc(s, s->acc_wie_iw, (size_t)s->nbie * s->wie_n))) return rc; }
+            if (tau) { if ((rc = dev_alloc(s, s->acc_wie_tau, (size_t)s->nbie * s->ntau))) return rc; }
+        }
+    }
     if (s->g4ph || s->g4pp) {
         const size_t n = (size_t)4 * s->n4iwf * s->n4iwf * (2 * s->n4iwb + 1) * 2 * ((s->g4ph ? 1 : 0) + (s->g4pp ? 1 : 0));
         s->nbw = (int)std::max<size_t>(1, std::min<size_t>(B, acc_budget() / (n * sizeof(double))));
@@ -1175,6 +1229,8 @@ int w2dyn_measure_begin(w2dyn_solver *s)
     if (s->acc_g4leg) HIPCHK(hipMemsetAsync(s->acc_g4leg, 0, sizeof(double) * s->nbl * nf * nf * s->n4leg * s->n4leg * (2 * s->n4iwb + 1) * 2, s->stream));
     if (C.acc_giww) HIPCHK(hipMemsetAsync(C.acc_giww, 0, sizeof(double) * B * C.niw2 * 2, s->stream));
     if (C.acc_gtauw) HIPCHK(hipMemsetAsync(C.acc_gtauw, 0, sizeof(double) * B * s->ntau, s->stream));
+    if (s->acc_wie_iw) HIPCHK(hipMemsetAsync(s->acc_wie_iw, 0, sizeof(double) * (size_t)s->nbie * s->wie_n, s->stream));
+    if (s->acc_wie_tau) HIPCHK(hipMemsetAsync(s->acc_wie_tau, 0, sizeof(double) * (size_t)s->nbie * s->ntau, s->stream));
     if (s->acc_weq_iw) HIPCHK(hipMemsetAsync(s->acc_weq_iw, 0, sizeof(double) * (size_t)s->nbe * 2 * (2 * s->n2iwb + 1), s->stream));
     if (s->acc_weq_tau) HIPCHK(hipMemsetAsync(s->acc_weq_tau, 0, sizeof(double) * (size_t)s->nbe * s->ntau, s->stream));
     if (s->acc_weq_p3) HIPCHK(hipMemsetAsync(s->acc_weq_p3, 0, sizeof(double) * (size_t)s->nbe * 4 * s->n3iwf * (2 * s->n3iwb + 1), s->stream));
@@ -1207,6 +1263,16 @@ static int measure_once_impl(w2dyn_solver *s, double2 *g2buf)
                 launch_meas_gw(s->C, s->stream);
                 HIPCHK(hipGetLastError());
                 if ((rc = time_end(s, "meas_gw"))) return rc;
+            }
+        } else if (is_wie_sector(s->cur_isector)) {
+            const WieSector e = wie_sector(s, s->cur_isector);
+            double *iw = s->worm_meas_more[e.q_iw] ? s->acc_wie_iw : nullptr;
+            double *tau = (e.q_tau >= 0 && s->worm_meas_more[e.q_tau] && (iw || !e.needs_iw)) ? s->acc_wie_tau : nullptr;
+            if (iw || tau) {
+                if ((rc = time_begin(s))) return rc;
+                launch_meas_wie(s->C, s->stream, s->nbie, iw, tau, e.n1, e.n2, e.n3);
+                HIPCHK(hipGetLastError());
+                if ((rc = time_end(s, "meas_wie"))) return rc;
             }
         } else if (s->cur_isector >= 6) {
             // sector 6 measures p2iw / p2tau (ph), 7 the pp ones, 8 p3iw, 9 p3iwpp - each only when asked for (CTQMC.F90:8603-8616)
@@ -1703,7 +1769,45 @@ int w2dyn_measure_finish(w2dyn_solver *s)
         for (size_t i = 0; i < n; ++i) tot[i] *= f;
         R["gsigmaiw_worm"] = tot; R["gsigmaiw_worm_bins"] = raw; R["cntmeas_worm"] = {mwt};
     }
-    if (s->cur_isector >= 6 && s->nbe > 0) {
+    if (is_wie_sector(s->cur_isector) && s->nbie > 0) {
+        // wormScaling = CntSampling(worm) / (CntMeas(worm) CntSampling(Z)) * wormNorm / mean_sign with wormNorm = 128/beta^2 (5), 256/beta (10), 65536/beta^2 (11),
+        // 4096/beta^2 (12), 8192/beta^2 (13), 256/beta^2 (14 - 16) (CTQMC.F90:8829-8849), times u_sparsity (all but sector 5; 9013-9343), times
+        // 1/(2Nd)^2 for qq / qqtau, times Ntau/beta for the tau histograms.  Sectors 5, 10 - 13 count a measurement only when their array is kept
+        // (8600-8629); counts pooled over the chains that share an accumulator bin
+        const int is = s->cur_isector, nbe = s->nbie;
+        const WieSector e = wie_sector(s, is);
+        static const double num[17] = {0, 0, 0, 0, 0, 128.0, 0, 0, 0, 0, 256.0, 65536.0, 4096.0, 8192.0, 256.0, 256.0, 256.0};
+        const bool counted = !e.needs_iw || s->worm_meas_more[e.q_iw];
+        std::vector<double> cw(nbe, 0.0), cz(nbe, 0.0), mw(nbe, 0.0);
+        double cwt = 0.0, czt = 0.0, mwt = 0.0;
+        for (int w = 0; w < W; ++w) { const int b = (w / C.walkers_per_bin) % nbe; cw[b] += (double)ws[w].cnt[C_W_SAMPLING]; cz[b] += (double)ws[w].cnt[C_SAMPLING]; }
+        if (counted) for (int b = 0; b < B; ++b) mw[b % nbe] += nwm[b];
+        for (int b = 0; b < nbe; ++b) { cwt += cw[b]; czt += cz[b]; mwt += mw[b]; }
+        const double norm = (is == 10 ? num[is] / beta : num[is] / (beta * beta)) * (is == 5 ? 1.0 : s->wie_sparsity) / (is == 10 ? (double)nf * nf : 1.0);
+        auto scal = [&](double c_w, double c_z, double m_w) { return m_w != 0.0 ? c_w / (m_w * c_z) * norm / ms : 0.0; };
+        auto reducei = [&](const double *dev, size_t n, size_t stride, const char *name, double extra) {
+            std::vector<double> all((size_t)nbe * stride), raw((size_t)nbe * n), tot(n, 0.0);
+            (void)hipMemcpy(all.data(), dev, all.size() * sizeof(double), hipMemcpyDeviceToHost);
+            for (int b = 0; b < nbe; ++b) for (size_t i = 0; i < n; ++i) raw[(size_t)b * n + i] = all[(size_t)b * stride + i];
+            if (stride == n) {              // the packed cross-rank reduction reads the device array as [bins][n]
+                PackDesc d{dev, nbe, n, std::vector<double>(nbe), 0};
+                for (int b = 0; b < nbe; ++b) d.scale[b] = scal(cw[b], cz[b], mw[b]) * extra;
+                s->pack[name] = d;
+            }
+            for (int b = 0; b < nbe; ++b) {
+                const double f = scal(cw[b], cz[b], mw[b]) * extra;
+                for (size_t i = 0; i < n; ++i) { tot[i] += raw[(size_t)b * n + i]; raw[(size_t)b * n + i] *= f; }
+            }
+            const double f = scal(cwt, czt, mwt) * extra;
+            for (size_t i = 0; i < n; ++i) tot[i] *= f;
+            R[name] = tot; R[std::string(name) + "_bins"] = raw;
+        };
+        const size_t niw_e = (size_t)e.n1 * e.n2 * e.n3 * 2;
+        if (s->worm_meas_more[e.q_iw]) reducei(s->acc_wie_iw, niw_e, niw_e, kWieNames[e.q_iw], 1.0);
+        if (e.q_tau >= 0 && s->worm_meas_more[e.q_tau] && counted) reducei(s->acc_wie_tau, (size_t)ntau, (size_t)ntau, kWieNames[e.q_tau], (double)ntau / beta);
+        R["cntmeas_worm"] = {mwt};
+    }
+    if (s->cur_isector >= 6 && s->cur_isector <= 9 && s->nbe > 0) {
         // wormScaling = CntSampling(worm) / (CntMeas(worm) CntSampling(Z)) * wormNorm / mean_sign, wormNorm = 16/beta (P2, P2pp) or
         // 16/beta^2 (P3, P3pp); the tau histograms times Ntau/beta (CTQMC.F90:8830-8849, 9116-9130, 9165-9179, 9215-9224, 9229-9313);
         // counts pooled over the chains that share an accumulator bin.  The division by (2 Nd)^4 is the caller's (impurity.py:817-839)
@@ -1768,21 +1872,59 @@ static int enter_sector(w2dyn_solver *s, int isector, int icomponent)
         return fail(s, W2DYN_EUNSUPPORTED, "worm sampling with offdiag = 1 is not supported");
     if (isector != 1 && s->C.xmoves)
         return fail(s, W2DYN_EUNSUPPORTED, "worm sampling with Percentage4OperatorMove or PercentageOuterMove > 0 is not supported (the worm kernels make the default pair moves only)");
-    if (isector != 1 && isector != 2 && isector != 3 && isector != 4 && !(isector >= 6 && isector <= 9))
-        return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d is not supported (1 = Z, 2 = one-particle, 3 = GSigma, 4 = two-particle Green's function, 6 - 9 = P2 / P2pp / P3 / P3pp)", isector);
-    if (isector == 3) {
-        // the insertion draws flavours until the U-matrix factor of the proposal does not vanish (CTQMC.F90:5047-5054): the reference
-        // loops for ever when no choice has one; here that is an error of the call
-        const int nf = s->nflav;
-        if (icomponent < 1 || icomponent > nf * nf) return fail(s, W2DYN_EINVAL, "sector 3 samples one component (1 .. %d), not %d", nf * nf, icomponent);
-        const int u = (icomponent - 1) / nf; bool any = false;
-        for (int a = 0; a < nf && !any; ++a) for (int b = 0; b < nf && !any; ++b) for (int c = 0; c < nf && !any; ++c)
-            any = 0.5 * (s->umat_h[(((size_t)u * nf + b) * nf + a) * nf + c] - s->umat_h[(((size_t)b * nf + u) * nf + a) * nf + c]) != 0.0;
-        if (!any) return fail(s, W2DYN_EINVAL, "sector 3, component %d: the U matrix has no element that lets the worm in", icomponent);
-    }
+    if (isector < 1 || isector > 16)
+        return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d does not exist (1 = Z, 2 - 16: Parameters.F90:28-43)", isector);
+    if (worm_nops_of(isector) > 4 && !s->mat)
+        return fail(s, W2DYN_EINVAL, "worm sector %d has %d worm operators and runs on the matrix trace path, which init_solver chooses when the sector's estimator "
+                    "(WormMeasH4iw, WormMeasQQ, WormMeasQQQQ, WormMeasNQQdag, WormMeasQQdd) is asked for", isector, worm_nops_of(isector));
     if (isector != 1) {
-        const int nf = s->nflav;
-        if (icomponent < 0 || icomponent > ((isector == 2 || isector == 3) ? nf * nf : nf * nf * nf * nf)) return fail(s, W2DYN_EINVAL, "component %d out of range", icomponent);
+        const int nf = s->nflav, nf4 = nf * nf * nf * nf;
+        const bool two = isector == 2 || isector == 3 || isector == 10;          // components of two flavour indices
+        const bool ufac = isector == 3 || isector == 5 || isector >= 10;
+        if (icomponent < (ufac ? 1 : 0) || icomponent > (two ? nf * nf : nf4))
+            return fail(s, W2DYN_EINVAL, "sector %d: component %d out of range (%d .. %d)", isector, icomponent, ufac ? 1 : 0, two ? nf * nf : nf4);
+        s->wie_sparsity = 1.0;
+        if (ufac) {
+            // the insertion draws flavours until the U-matrix factor of the proposal does not vanish (CTQMC.F90:5047-5054): the reference loops for
+            // ever when no choice has one; here that is an error of the call.  The factor is a product over disjoint sets of operators, so it can be
+            // non-zero iff every antisymmetrised slice it reads has a non-vanishing element; the same counts make u_sparsity (9013-9343).
+            int u[5] = {0, 0, 0, 0, 0}, rest = icomponent - 1;
+            for (int i = two ? 2 : 4; i >= 1; --i) { u[i] = rest % nf; rest /= nf; }
+            const std::vector<double> &U = s->umat_h;
+            auto UM = [&](int a, int b, int c, int d) { return U[(((size_t)a * nf + b) * nf + c) * nf + d]; };
+            auto UA1 = [&](int a, int b, int c, int d) { return 0.5 * (UM(a, b, c, d) - UM(b, a, c, d)); };
+            auto UA2 = [&](int a, int b, int c, int d) { return 0.5 * (UM(a, b, c, d) - UM(a, b, d, c)); };
+            auto UAB = [&](int a, int b, int c, int d) { return 0.5 * (UA1(a, b, c, d) - UA1(a, b, d, c)); };
+            // numbers of non-vanishing elements: fixed indices >= 0, free ones -1
+            auto nnz = [&](int kind, int a, int b, int c, int d) {
+                double cnt = 0.0;
+                for (int i = 0; i < nf4; ++i) {
+                    const int x[4] = {i / (nf * nf * nf), (i / (nf * nf)) % nf, (i / nf) % nf, i % nf}, fix[4] = {a, b, c, d};
+                    bool first = true;                                     // count every combination of the free indices once
+                    for (int q = 0; q < 4; ++q) if (fix[q] >= 0 && x[q] != 0) first = false;
+                    if (!first) continue;
+                    const int y[4] = {a >= 0 ? a : x[0], b >= 0 ? b : x[1], c >= 0 ? c : x[2], d >= 0 ? d : x[3]};
+                    const double v = kind == 1 ? UA1(y[0], y[1], y[2], y[3]) : (kind == 2 ? UA2(y[0], y[1], y[2], y[3]) : UAB(y[0], y[1], y[2], y[3]));
+                    if (v != 0.0) cnt += 1.0;
+                }
+                return cnt;
+            };
+            const double n2 = (double)nf * nf, n4 = n2 * n2;
+            double can = 1.0, sp = 1.0;          // can: product of the counts of the proposal's own slices (0: the worm never gets in)
+            switch (isector) {
+            case 3: case 5: can = nnz(1, u[1], -1, -1, -1); break;
+            case 10: can = sp = nnz(1, u[1], -1, -1, -1) * nnz(2, -1, -1, u[2], -1); sp /= n4 * n2; break;
+            case 11: can = sp = nnz(1, u[1], -1, -1, -1) * nnz(2, -1, -1, u[2], -1) * nnz(1, u[3], -1, -1, -1) * nnz(2, -1, -1, u[4], -1); sp /= n4 * n4 * n4; break;
+            case 12: can = sp = nnz(1, u[1], -1, -1, -1) * nnz(2, -1, -1, u[2], -1) * nnz(3, u[3], -1, u[4], -1); sp /= n4 * n4; break;
+            case 13: can = nnz(1, u[1], -1, -1, -1) * nnz(1, u[3], -1, -1, -1) * nnz(2, -1, -1, u[2], u[4]);
+                     sp = nnz(1, u[1], -1, -1, -1) * nnz(2, -1, u[3], -1, -1) * nnz(3, -1, -1, u[2], u[4]) / (n4 * n4); break;
+            case 14: can = sp = nnz(3, u[1], -1, u[2], -1) * nnz(3, u[3], -1, u[4], -1); sp /= n4; break;
+            case 15: can = sp = nnz(2, -1, -1, u[2], u[4]) * nnz(1, u[1], u[3], -1, -1); sp /= n4; break;
+            default: can = sp = nnz(1, u[1], -1, -1, -1) * nnz(3, u[3], -1, u[2], u[4]); sp /= n4; break;
+            }
+            if (can == 0.0) return fail(s, W2DYN_EINVAL, "sector %d, component %d: the U matrix has no element that lets the worm in", isector, icomponent);
+            s->wie_sparsity = sp;
+        }
     }
     HIPCHK(hipSetDevice(s->device));
     HIPCHK(hipStreamSynchronize(s->stream));
@@ -1847,16 +1989,14 @@ int w2dyn_ctqmc_worm_warmup(w2dyn_solver *s, int64_t nwarmups2, int isector, int
     if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "ctqmc_worm_warmup before init_solver");
     // the reference allocates the buffers of the batched transform here and samples nothing (CTQMC.F90:8266-8348); this
     // library transforms every measurement on the spot, so only the arguments are checked
-    if (isector != 1 && isector != 2 && isector != 3 && isector != 4 && !(isector >= 6 && isector <= 9))
-        return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d is not supported (1 = Z, 2 = one-particle, 3 = GSigma, 4 = two-particle Green's function, 6 - 9 = P2 / P2pp / P3 / P3pp)", isector);
+    if (isector < 1 || isector > 16) return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d does not exist (1 = Z, 2 - 16: Parameters.F90:28-43)", isector);
     return 0;
 }
 
 int w2dyn_count_steps(w2dyn_solver *s, int isector, int icomponent, int64_t nfix, int64_t *steps_worm, int64_t *steps_z)
 {
     if (!s || !s->have_solver) return fail(s, W2DYN_EINVAL, "count_steps before init_solver");
-    if (isector != 4 && isector != 2 && isector != 3 && !(isector >= 6 && isector <= 9))
-        return fail(s, W2DYN_EUNSUPPORTED, "count_steps: worm sector %d is not supported (2 = one-particle, 4 = two-particle Green's function, 6 - 9 = P2 / P2pp / P3 / P3pp)", isector);
+    if (isector < 2 || isector > 16) return fail(s, W2DYN_EUNSUPPORTED, "count_steps: worm sector %d does not exist (2 - 16: Parameters.F90:29-43)", isector);
     if (nfix < 0) return fail(s, W2DYN_EINVAL, "count_steps: nfix = %lld", (long long)nfix);
     int rc;
     if ((rc = enter_sector(s, isector, icomponent))) return rc;
@@ -1934,7 +2074,7 @@ int w2dyn_get_mc_config_scalars(w2dyn_solver *s, int walker, int *n, int *outer_
     WalkerScalars ws; std::vector<int> K; std::vector<double> TC, TA;
     int rc = fetch_walker(s, walker, ws, K, TC, TA); if (rc) return rc;
     int tot = 0; for (int k : K) tot += 2 * k;
-    if (ws.sector > 1) tot += ws.sector == 2 ? 2 : 4;
+    if (ws.sector > 1) tot += worm_nops_of(ws.sector);
     if (n) *n = tot; if (outer_sst) *outer_sst = ws.outer; if (outer_state) *outer_state = 1;
     return 0;
 }
@@ -1953,7 +2093,7 @@ int w2dyn_get_mc_config(w2dyn_solver *s, int walker, int n, double *taus, int *o
         for (int e = 0; e < K[0]; ++e) { ops.push_back({TC[e], fc[e], 1, -1}); ops.push_back({TA[e], fa[e], 2, -1}); }
     } else
     for (int f = 0; f < s->nflav; ++f) for (int e = 0; e < K[f]; ++e) { ops.push_back({TC[(size_t)f * kmax + e], f, 1, -1}); ops.push_back({TA[(size_t)f * kmax + e], f, 2, -1}); }
-    if (ws.sector > 1) for (int i = 0; i < (ws.sector == 2 ? 2 : 4); ++i) ops.push_back({ws.wtau[i], ws.wflav[i], (i & 1) ? 1 : 2, 0});     // worm operators: hashyb 0 (Trace.F90:6861-6865)
+    if (ws.sector > 1) for (int i = 0; i < worm_nops_of(ws.sector); ++i) ops.push_back({ws.wtau[i], ws.wflav[i], (i & 1) ? 1 : 2, 0});     // worm operators: hashyb 0 (Trace.F90:6861-6865)
     if ((int)ops.size() != n) return fail(s, W2DYN_EINVAL, "get_mc_config: n=%d but the chain holds %zu operators", n, ops.size());
     std::sort(ops.begin(), ops.end(), [](const Op &a, const Op &b) { return a.t < b.t; });
     for (int i = 0; i < n; ++i) { taus[i] = ops[i].t; orbs[i] = (ops[i].f >> 1) + 1; spins[i] = (ops[i].f & 1) + 1; cas[i] = ops[i].ca; hashybs[i] = ops[i].hyb; }
@@ -2206,6 +2346,7 @@ int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out)
     else if (n == "nb4") *out = s->nb4;
     else if (n == "nbw") *out = s->nbw;
     else if (n == "nbe") *out = s->nbe;
+    else if (n == "nbie") *out = s->nbie;
     else if (n == "n3iwb") *out = s->n3iwb;
     else if (n == "nbl") *out = s->nbl;
     else if (n == "nbs") *out = s->nbs;

@@ -371,6 +371,24 @@ class MCTQMC:
             a = self.result(name).reshape(-1, 2); a = a[:, 0] + 1j * a[:, 1]
             lead = (int(self.scalar("nbe")),) if name.endswith("_bins") else ()
             return a.reshape(lead + ((-1, 2 * int(self.scalar("n3iwb")) + 1) if name.startswith("p3") else (-1,)))
+        base = name.split("_bins")[0]
+        if base in ("h4iw_worm", "qqqq_worm", "qq_worm", "quddag_worm", "nqqdag_worm", "qqdd_worm", "ucaca_worm", "uccaa_worm"):
+            # worm estimators of the sectors 5, 10 - 16 (CTQMC.F90:385, 397, 402, 407, 412, 423, 625, 638): H4iw_worm / QQQQ_worm(2*N4iwf, 2*N4iwf,
+            # 2*N4iwb+1), QQ_worm / quddag_worm(2*Niw), nqqdag_worm(2*N3iwf, 2*N3iwb+1), qqdd_worm(2*N3iwf, 2*N3iwf), ucaca_worm / uccaa_worm(2*N2iwb+1)
+            a = self.result(name).reshape(-1, 2); a = a[:, 0] + 1j * a[:, 1]
+            lead = (int(self.scalar("nbie")),) if name.endswith("_bins") else ()
+            if base in ("h4iw_worm", "qqqq_worm"):
+                shape = (2 * self._n4iwf, 2 * self._n4iwf, 2 * self._n4iwb + 1)
+            elif base == "nqqdag_worm":
+                shape = (-1, 2 * int(self.scalar("n3iwb")) + 1)
+            elif base == "qqdd_worm":
+                n = int(round(np.sqrt(a.size // (lead[0] if lead else 1)))); shape = (n, n)
+            else:
+                shape = (-1,)
+            return a.reshape(lead + shape)
+        if base in ("qqtau_worm", "ucacatau_worm", "uccaatau_worm"):
+            a = self.result(name)
+            return a.reshape(int(self.scalar("nbie")), -1) if name.endswith("_bins") else a
         if name.split("_bins")[0] in ("p2tau_worm", "p2taupp_worm"):
             a = self.result(name)
             return a.reshape(int(self.scalar("nbe")), -1) if name.endswith("_bins") else a

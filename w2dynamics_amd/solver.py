@@ -268,6 +268,19 @@ class HipCtHybSolver:
                                          (8, "p3iw-worm", "p3iw_worm", "WormMeasP3iwPH"), (9, "p3iwpp-worm", "p3iwpp_worm", "WormMeasP3iwPP")):
                 if sec == isector and self.qmc[flag] == 1:
                     result["%s/%05d" % (key, icomponent)] = DistributedSample(getattr(q, name + "_bins") / nfl ** 4, self.comm)
+        # sectors with U-matrix factors: the module array divided by nflavours^4 (impurity.py:813-815, 841-871); qq / qqtau as they are (1318-1321)
+        for sec, key, name, flag in ((5, "h4iw-worm", "h4iw_worm", "WormMeasH4iw"), (11, "qqqq-worm", "qqqq_worm", "WormMeasQQQQ"),
+                                     (12, "nqqdag-worm", "nqqdag_worm", "WormMeasNQQdag"), (13, "qqdd-worm", "qqdd_worm", "WormMeasQQdd"),
+                                     (14, "ucaca-worm", "ucaca_worm", "WormMeasUcaca"), (14, "ucacatau-worm", "ucacatau_worm", "WormMeasUcacatau"),
+                                     (15, "uccaa-worm", "uccaa_worm", "WormMeasUccaa"), (15, "uccaatau-worm", "uccaatau_worm", "WormMeasUccaatau"),
+                                     (16, "quddag-worm", "quddag_worm", "WormMeasQUDdag")):
+            if sec == isector and self.qmc[flag] != 0:
+                result["%s/%05d" % (key, icomponent)] = DistributedSample(getattr(q, name + "_bins") / nfl ** 4, self.comm)
+        if isector == 10:
+            if self.qmc["WormMeasQQ"] != 0:
+                result["qqiw-worm/%05d" % icomponent] = DistributedSample(q.qq_worm_bins, self.comm)
+                if self.qmc["WormMeasQQtau"] != 0:
+                    result["qqtau-worm/%05d" % icomponent] = DistributedSample(q.qqtau_worm_bins, self.comm)
         # Z-space quantities are sampled along with every component (impurity.py:966-977)
         result["occ"] = DistributedSample(q.occ_bins, self.comm)
         result["rho1"] = DistributedSample(np.array([q.rho1]), self.comm)
@@ -281,16 +294,16 @@ class HipCtHybSolver:
         return result
 
     def solve_worm(self, iter_no=0, components=None, g0inviw=None):
-        """`CtHybSolver.solve_worm` (`impurity.py:906-1010`) for `WormMeasGiw` (worm sector 2) or `WormMeasGSigmaiw` (sector 3):
+        """`CtHybSolver.solve_worm` (`impurity.py:906-1010`) for `WormMeasGiw` (worm sector 2), `WormMeasGSigmaiw` (sector 3) or `WormMeasQQ` (sector 10):
         every diagonal component is sampled by `solve_component`, the component list is assembled into a matrix in the orbitals -
         G(iw) itself (`get_giw` with FTType `none_worm`, `impurity.py:1066-1072`), or GSigma(iw), from which G = G0 + G0 GSigma
         follows (`get_gsigmaiw_worm`, `giw_from_gsigmaiw_worm`, `impurity.py:1104-1138`: the improved estimator, Eq. (9) of PRB 100,
         075119) -, the Z-space quantities sampled along with every component are averaged and the self-energy moments follow from
         rho1 / rho2.  `g0inviw` (iw, band, spin, band, spin): the Weiss field for the improved estimator, the problem's by default."""
-        meas_g, meas_gs = self.qmc["WormMeasGiw"] != 0, self.qmc["WormMeasGSigmaiw"] != 0
-        if meas_g == meas_gs:
-            raise ValueError("solve_worm: exactly one of WormMeasGiw, WormMeasGSigmaiw must be set (the sector of WormMeasQQ is not sampled)")
-        sector, name = (2, "giw-worm") if meas_g else (3, "gsigmaiw-worm")
+        meas_g, meas_gs, meas_qq = self.qmc["WormMeasGiw"] != 0, self.qmc["WormMeasGSigmaiw"] != 0, self.qmc["WormMeasQQ"] != 0
+        if int(meas_g) + int(meas_gs) + int(meas_qq) != 1:
+            raise ValueError("solve_worm: exactly one of WormMeasGiw, WormMeasGSigmaiw, WormMeasQQ must be set")
+        sector, name = (2, "giw-worm") if meas_g else ((3, "gsigmaiw-worm") if meas_gs else (10, "qqiw-worm"))
         p = self.problem
         nd = p.nd; nfl = 2 * nd; niw = 2 * int(self.qmc["Niw"])
         if components is None:            # ci.GFComponent(bandspin=(f, f), n_ops=2).index, impurity.py:919-921
@@ -309,7 +322,7 @@ class HipCtHybSolver:
             mat[:, :, f1 // 2, f1 % 2, f2 // 2, f2 % 2] = np.asarray(r["%s/%05d" % (name, comp)].local)[:nb]
         if meas_g:
             result["giw"] = DistributedSample(mat, self.comm)
-        else:
+        elif meas_gs:
             if g0inviw is None:
                 g0inviw = p.g0inviw(niw)
             g0 = np.linalg.inv(np.asarray(g0inviw).reshape(niw, nfl, nfl))                     # orbspin.invert
@@ -318,8 +331,18 @@ class HipCtHybSolver:
             result["giw"] = DistributedSample((g0[None] + np.einsum("wab,nwbc->nwac", g0, gs)).reshape(nb, niw, nd, 2, nd, 2), self.comm)
         for key in ("occ", "rho1", "rho2"):
             result[key] = DistributedSample(np.concatenate([np.asarray(r[key].local) for _, r in per_comp]), self.comm)
-        result["smom"] = DistributedSample(np.array([_postproc.lattice_convention(_postproc.get_siw_mom(
-            np.asarray(p.umatrix).reshape((nfl,) * 4), np.asarray(result["rho1"].mean()), np.asarray(result["rho2"].mean())))]), self.comm)
+        smom = _postproc.lattice_convention(_postproc.get_siw_mom(
+            np.asarray(p.umatrix).reshape((nfl,) * 4), np.asarray(result["rho1"].mean()), np.asarray(result["rho2"].mean())))
+        result["smom"] = DistributedSample(np.array([smom]), self.comm)
+        if meas_qq:
+            # symmetric improved estimator, Eq. (13) of PRB 100, 075119: G = G0 + G0 (QQ + Sigma_0) G0 with the zeroth moment of the self-energy
+            # from rho1 (`get_qqiw_worm`, `giw_from_qqiw_worm`, impurity.py:1113-1119, 1141-1148, 1002-1003)
+            if g0inviw is None:
+                g0inviw = p.g0inviw(niw)
+            g0 = np.linalg.inv(np.asarray(g0inviw).reshape(niw, nfl, nfl))
+            inner = mat.reshape(nb, niw, nfl, nfl) + np.asarray(smom)[0].reshape(nfl, nfl)[None, None]
+            result["qqiw"] = DistributedSample(mat, self.comm)
+            result["giw"] = DistributedSample((g0[None] + np.einsum("wab,nwbc,wcd->nwad", g0, inner, g0)).reshape(nb, niw, nd, 2, nd, 2), self.comm)
         return result
 
     def calibrate_taudiff_max(self, phase1pairnum=1000, phase2taugrid=100, phase2pairnum=1000, nprogress=100000):
