@@ -81,6 +81,12 @@ WORKLOADS = {
                 overrides=dict(_BASE, NCorr=200, Niw=2000, PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=1.0, WormMeasGiw=1, WormMeasGtau=1),
                 text="C2S: C2 with worm sampling in sector 2 (giw_worm / gtau_worm of component 1 = flavours 00, Niw=2000, "
                      "PercentageWormInsert=PercentageWormReplace=0.2, eta balanced by count_steps)"),
+    # sector 10: the symmetric improved estimator (QQ: two three-operator equal-time objects with U-matrix factors, six worm operators kept in the
+    # operator list of the matrix trace path; k_sweep_worm<6, 4>, k_meas_wie) at the reference's default Niw
+    "C2Q": dict(config="C2", nftau=5001, chains=16384, worm=dict(sector=10, component=1, nfix=2000),
+                overrides=dict(_BASE, NCorr=200, Niw=2000, PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=1.0, WormMeasQQ=1, WormMeasQQtau=1),
+                text="C2Q: C2 with worm sampling in sector 10 (qq_worm / qqtau_worm of component 1, the symmetric improved estimator, Niw=2000, "
+                     "PercentageWormInsert=PercentageWormReplace=0.2, eta balanced by count_steps)"),
 }
 HEADLINE = "C2"
 SIDE_WORKLOADS = ["C1", "C3", "C4", "C5", "C2G", "C3F"]      # run ahead of the headline by the default invocation
@@ -99,7 +105,7 @@ def _cpu_chain(args):
     ps = params.make_pstring(over, beta=p.beta, Nd=p.nd, Hamiltonian=p.hamiltonian, QuantumNumbers=p.quantum_numbers)
     worm = wl.get("worm")
     wsec = worm.get("sector", 4) if worm else 1
-    fourpnt = (8 if wsec == 4 else 0) if worm else wl.get("fourpnt", 0)
+    fourpnt = (8 if wsec in (4, 5, 11) else 0) if worm else wl.get("fourpnt", 0)
     try:
         import refdrive
         if not refdrive.available():
@@ -134,7 +140,7 @@ def _cpu_chain(args):
 
 # measurements per CPU chain: about 10-20 s of CPU work for the headline, a few seconds for the side workloads (the
 # reference's G(iw) / g4iw estimators cost milliseconds to seconds per measurement: far fewer of them)
-_CPU_NMEAS = {"C4X": 1000, "C4O": 300, "C2": 6000, "C2A": 6000, "C2G": 200, "C3F": 30, "C1": 3000, "C3": 2000, "C4": 1000, "C5Z": 1000, "C5K": 300, "C4W": 1000, "C5": 1000}
+_CPU_NMEAS = {"C2Q": 3000, "C4X": 1000, "C4O": 300, "C2": 6000, "C2A": 6000, "C2G": 200, "C3F": 30, "C1": 3000, "C3": 2000, "C4": 1000, "C5Z": 1000, "C5K": 300, "C4W": 1000, "C5": 1000}
 
 
 def cpu_baseline(cores, wname, nwarm=50000, eta=1.0):
@@ -212,7 +218,7 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
     q = MCTQMC(device=env.local_rank, nwalkers=walkers, first_walker=rank * walkers, walkers_per_bin=wpb)
     worm = wl.get("worm")
     wsec = worm.get("sector", 4) if worm else 1
-    q.fourpnt = (8 if wsec == 4 else 0) if worm else wl.get("fourpnt", 0)
+    q.fourpnt = (8 if wsec in (4, 5, 11) else 0) if worm else wl.get("fourpnt", 0)
     q.init_rnd(43890); q.init_paras(ps)
     q.init_solver(prob.umatrix, prob.ftau, prob.muimp, prob.screening, 1)
     q.set_taudiffmax(over["TaudiffMax"])
@@ -228,7 +234,7 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
             # eta search of solve_component (impurity.py:717-742): rescale until Z and worm space get equal numbers of
             # steps, to the reference's criterion |sw - sz| / (sw + sz) <= 0.1; starting point: insertion prefactor
             # (beta Nd)^4 eta = 1 (CTQMC.F90:5680-5684).  The reference runs this loop without a bound on its length
-            q.wormeta[:] = 1.0 / (prob.beta * prob.nd) ** (2 if wsec == 2 else 4)
+            q.wormeta[:] = 1.0 / (prob.beta * prob.nd) ** (2 if wsec in (2, 10) else 4)
             for eta_tries in range(1, 101):
                 sw, sz = q.count_steps(wsec, worm["component"], worm["nfix"])
                 if sw != 0 and sz != 0 and abs(sw - sz) / float(sw + sz) <= 0.1:
@@ -245,7 +251,8 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
     for _ in range(warmup):
         q.sweep(ncorr); q.measure_once()
     q.sync()
-    tkeys = (sweep_key, "meas_misc", "meas_gleg", "meas_full", "meas_g4w", "meas_gw", "meas_gtau_ac", "meas_giw", "meas_g2iw", "meas_g4iw")
+    tkeys = (sweep_key, "meas_misc", "meas_gleg", "meas_full", "meas_g4w", "meas_gw", "meas_wie", "meas_gtau_ac", "meas_giw", "meas_g2iw", "meas_g4iw")
+    wkey, wres, wkern = {4: ("meas_g4w", "g4iw_worm", "k_meas_g4w"), 10: ("meas_wie", "qq_worm", "k_meas_wie")}.get(wsec, ("meas_gw", "giw_worm", "k_meas_gw"))
     for k in tkeys:
         q.kernel_time(k, reset=True)
     if world > 1:
@@ -271,7 +278,7 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
     if rehearse:           # gloo rehearsal on one GPU: host path
         sg, sh = DistributedSample(q.gleg_bins, comm), DistributedSample(q.histo_bins, comm)
     else:
-        names = (["gleg_full", "gtau_full", "gleg", "histo"] if over.get("offdiag") else ["gleg", "gtau", "histo"]) + ((["g4iw_worm"] if wsec == 4 else ["giw_worm"]) if worm else []) + (["giw"] if over.get("MeasGiw") else []) + \
+        names = (["gleg_full", "gtau_full", "gleg", "histo"] if over.get("offdiag") else ["gleg", "gtau", "histo"]) + ([wres] if worm else []) + (["giw"] if over.get("MeasGiw") else []) + \
                 (["g4iw", "g2iw"] if q.fourpnt & 4 else [])
         pack = q.reduce_pack(names, comm).allreduce()
         sg, sh = pack.sample("gleg_full" if over.get("offdiag") else "gleg"), pack.sample("histo")
@@ -282,7 +289,7 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
     kt = {k: q.kernel_time(k) for k in tkeys}
     sweep_ms, nsweep = kt[sweep_key]
     offd = bool(over.get("offdiag"))
-    gleg_ms, ngleg = kt[("meas_g4w" if wsec == 4 else "meas_gw") if worm else ("meas_full" if offd else "meas_gleg")]
+    gleg_ms, ngleg = kt[wkey if worm else ("meas_full" if offd else "meas_gleg")]
     misc_ms, _ = kt["meas_misc"]
     out = None
     if rank == 0:
@@ -314,7 +321,7 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
             flops_gleg = nworm_meas * (8 * (2 * over["N4iwf"]) ** 2 * (2 * over["N4iwb"] + 1) if wsec == 4 else 8 * 2 * over["Niw"])
         ach_tf = flops_gleg / (gleg_ms * 1e-3) / 1e12 if gleg_ms > 0 else 0.0
         value = world * W * ncorr * steps / dt
-        kname, mname = ("k_sweep_worm", "k_meas_g4w" if wsec == 4 else "k_meas_gw") if worm else (("k_sweep_od", "k_meas_full") if offd else ("k_sweep", "k_meas_gleg"))
+        kname, mname = ("k_sweep_worm", wkern) if worm else (("k_sweep_od", "k_meas_full") if offd else ("k_sweep", "k_meas_gleg"))
         tr_sweep, tr_src = pmc_traffic(kname, W, wname)
         tr_gleg, _ = pmc_traffic(mname, W, wname)
         out = {

@@ -1137,13 +1137,13 @@ def test_solver_worm_giw_kanamori_agrees_with_z_space_estimate():
 
 
 def test_worm_modes_refused_or_ignored():
-    """Sectors other than 1 - 4 and 6 - 9 are refused (the improved estimators with more than four worm operators: H4 = 5, QQ = 10, ...);
-    eta = 0 samples nothing (CTQMC.F90:8409-8418)."""
+    """A sector with more than four worm operators (H4 = 5, QQ = 10, ...) on a context that was not set up for it (its estimator not asked for:
+    closed-form trace path) is an error of the call; eta = 0 samples nothing (CTQMC.F90:8409-8418)."""
     g = util.load_golden("worm_C1a.npz")
     q, p, pset, over = _worm_gpu(g, 4, 2, 3)
     with pytest.raises(W2DynError) as e:
         q.ctqmc_measure(10, 1)
-    assert e.value.code == -2
+    assert e.value.code == -1
     with pytest.raises(W2DynError) as e:
         q.count_steps(5, 1, 100)
     assert e.value.code == -2

@@ -89,6 +89,7 @@ enum WalkerErr { ERR_NONE = 0, ERR_KMAX = 1, ERR_WCAP = 2, ERR_DETRAT = 4, ERR_S
 // number of worm operators a chain's record holds (NOperWorm, Parameters.F90:45: at most 12, sector 11) and the number a kernel keeps
 // in registers: 4 in every translation unit but the one of the sectors with 6, 8 and 12 worm operators
 constexpr int NW_STORE = 12;
+
 #ifndef W2DYN_NWMAX
 #define W2DYN_NWMAX 4
 #endif
@@ -1667,6 +1668,14 @@ __device__ __forceinline__ void stage_shared_tables(const DevConst &C, unsigned 
     __syncthreads();
 }
 
+// MATPATH = false: a kernel of the closed-form trace path, which never has the time-ordered list.  WORMOPS = false: a Z-space kernel, which
+// never looks at the worm operators of the record (and ctx_store<false> leaves them as they are).  Neither is used by the sweep kernels: measured
+// on the headline workload, both made k_sweep<0> SLOWER (25.2 against 24.2 ms per launch; the register allocation of the kernel's hot loop
+// follows what its prologue keeps alive), and so did a run-time loop over the record in the list branch below (25.6 ms), which is why the
+// operators beyond NWMAX join the list only where WORMREC asks for it.
+// WORMREC = true: worm operators beyond those the kernel keeps in registers join the list from the record (the estimator kernels, which see the
+// chains of every sector)
+template <bool MATPATH = true, bool WORMOPS = true, bool WORMREC = false>
 __device__ __forceinline__ void ctx_load(Ctx &x)
 {
     const DevConst &C = x.C;
@@ -1676,8 +1685,10 @@ __device__ __forceinline__ void ctx_load(Ctx &x)
     x.outer = uni(s.outer); x.npairs = uni(s.npairs); x.wpos = uni(s.wpos); x.err = uni(s.err);
     x.det_sign = uni(s.det_sign); x.det_log = uni(s.det_log);
     { const int sec = uni(s.sector); x.sector = (sec >= 2 && sec <= 16) ? sec : 1; }
+    if constexpr (WORMOPS) {
 #pragma unroll
-    for (int i = 0; i < NWMAX; ++i) { x.wtau[i] = uni(s.wtau[i]); x.wfl[i] = uni(s.wflav[i]); }
+        for (int i = 0; i < NWMAX; ++i) { x.wtau[i] = uni(s.wtau[i]); x.wfl[i] = uni(s.wflav[i]); }
+    }
     unsigned long long nd_ = s.ndraw;
     nd_ = ((unsigned long long)(unsigned)uni((int)(nd_ >> 32)) << 32) | (unsigned long long)(unsigned)uni((int)nd_);
     if (x.lane < C_NCOUNT) x.cnt[x.lane] = s.cnt[x.lane];
@@ -1693,19 +1704,26 @@ __device__ __forceinline__ void ctx_load(Ctx &x)
     x.window_bounds();
     x.rng_seek(nd_);
     wave_sync();
-    if (C.mat) {      // time-ordered list, block sequence and trace of the stored configuration
+    if constexpr (MATPATH) if (C.mat) {      // time-ordered list, block sequence and trace of the stored configuration
         mat_build_list(x);
         if (x.sector != 1) {                         // worm operators are list entries like any other (no hybridisation lines: not in M)
-            // from the record, not from the registers: the estimator kernels keep four worm operators at most but need the whole list
-            for (int i = 0, nwo = worm_nops_of(x.sector); i < nwo; ++i) {
-                const double tw = uni(s.wtau[i]);
-                mat_insert(x, mat_lower(x, tw), tw, mat_code(uni(s.wflav[i]), (i & 1) ? 1 : 2));
+            if constexpr (WORMOPS) {
+#pragma unroll
+                for (int i = 0; i < NWMAX; ++i)
+                    if (i < worm_nops_of(x.sector)) mat_insert(x, mat_lower(x, x.wtau[i]), x.wtau[i], mat_code(x.wfl[i], (i & 1) ? 1 : 2));
+            }
+            if constexpr (WORMREC) {
+                for (int i = WORMOPS ? NWMAX : 0, nwo = worm_nops_of(x.sector); i < nwo; ++i) {
+                    const double tw = uni(s.wtau[i]);
+                    mat_insert(x, mat_lower(x, tw), tw, mat_code(uni(s.wflav[i]), (i & 1) ? 1 : 2));
+                }
             }
         }
         mat_walk_sst(x);                 // the caller evaluates the trace (mat_trace_current<MAT>)
     }
 }
 
+template <bool WORMOPS = true>
 __device__ __forceinline__ void ctx_store(Ctx &x, long long todo = 0)
 {
     const DevConst &C = x.C;
@@ -1731,8 +1749,10 @@ __device__ __forceinline__ void ctx_store(Ctx &x, long long todo = 0)
         s.ndraw = x.rng_tell(); s.outer = x.outer; s.npairs = x.npairs; s.wpos = x.wpos; s.err = x.err; s.todo = todo;
         s.det_sign = x.det_sign; s.det_log = x.det_log;
         s.sector = x.sector;
+        if constexpr (WORMOPS) {
 #pragma unroll
-        for (int i = 0; i < NWMAX; ++i) { s.wtau[i] = x.wtau[i]; s.wflav[i] = x.wfl[i]; }
+            for (int i = 0; i < NWMAX; ++i) { s.wtau[i] = x.wtau[i]; s.wflav[i] = x.wfl[i]; }
+        }
     }
 }
 
@@ -1943,7 +1963,7 @@ __global__ __launch_bounds__(256) void k_meas_misc(DevConst C)
     Ctx x(C);
     ctx_setup(x, smem);
     if (x.w >= C.nwalkers) return;
-    ctx_load(x);
+    ctx_load<true, true, true>(x);
     if constexpr (MAT != 0) if (C.offdiag) od_load(x);  // off-diagonal hybridisation: the list with the true flavours
     double pt_ = 0.0, lsc_ = 0.0; int sk_ = 0;          // blocks of more than 4 states: partial traces and the block at beta/2 (mat_halves)
     constexpr int NT2 = (MAT >= 2 && MAT <= 4) ? MAT * MAT : 1;
