@@ -1146,7 +1146,7 @@ def test_worm_modes_refused_or_ignored():
     assert e.value.code == -1
     with pytest.raises(W2DynError) as e:
         q.count_steps(5, 1, 100)
-    assert e.value.code == -2
+    assert e.value.code == -1
     q.wormeta[:] = 0.0
     q.ctqmc_measure(4, 1)
     assert q.aborted == 0 and np.all(q.g4iw_worm == 0.0) and q.cntsampling[3] == 0

@@ -130,10 +130,10 @@ __device__ __forceinline__ double ie_ufac(const DevConst &C, int sec, const int 
 }
 __device__ __forceinline__ bool worm_has_ufac(int sec) { return sec == 3 || sec == 5 || (sec >= 10 && sec <= 16); }
 // sector 3 (its sign enters the estimator, CTQMC.F90:1138)
-__device__ __forceinline__ double gsigma_ufac(const DevConst &C, const int (&fl)[4]) { return ie_ufac(C, 3, fl, false); }
+__device__ __forceinline__ double gsigma_ufac(const DevConst &C, const int *fl) { return ie_ufac(C, 3, fl, false); }
 
 template <int NW>
-__device__ __forceinline__ double worm_prefact(const DevConst &C, const int (&fl)[NWMAX])
+__device__ __forceinline__ double worm_prefact_ie(const DevConst &C, const int (&fl)[NWMAX])
 {
     const double nd = (double)C.nd, nd4 = nd * nd * nd * nd, b2 = C.beta * C.beta;
     const int sec = C.isector;
@@ -162,7 +162,7 @@ __device__ __forceinline__ double worm_prefact(const DevConst &C, const int (&fl
 // three-operator objects (1, 3, 2), (5, 4, 6), (7, 9, 8), (11, 10, 12) an offset apart below their last operator's time; 12 and 13 draw three,
 // 14 - 16 two times.
 template <int NW>
-__device__ __forceinline__ void worm_draw_times(Ctx &x, double (&t)[NWMAX])
+__device__ __forceinline__ void worm_draw_times_ie(Ctx &x, double (&t)[NWMAX])
 {
     const DevConst &C = x.C;
     const double beta = C.beta, off = beta * 1e-14;
@@ -236,7 +236,7 @@ __device__ __forceinline__ void worm_draw_times(Ctx &x, double (&t)[NWMAX])
 // equal-time object get random flavours until the U-matrix factor of the proposal does not vanish, operator 4 carries the component's
 // second flavour (set_IEOperFlavor, Trace.F90:3835-3919; CTQMC.F90:5047-5054)
 template <int NW>
-__device__ __forceinline__ void worm_draw_flavours(Ctx &x, int (&fl)[NWMAX])
+__device__ __forceinline__ void worm_draw_flavours_ie(Ctx &x, int (&fl)[NWMAX])
 {
     const DevConst &C = x.C;
     const int nf = C.nflav, sec = C.isector;
@@ -252,7 +252,7 @@ __device__ __forceinline__ void worm_draw_flavours(Ctx &x, int (&fl)[NWMAX])
                     if ((sec == 3 || sec == 5) && i >= 3) fl[i] = sec == 3 ? d4 : (i == 3 ? d2 : (i == 4 ? d3 : d4));
                     else { const int orb = x.randint(1, C.nd), spin = x.randint(1, 2); fl[i] = 2 * (orb - 1) + (spin - 1); }
                 }
-                if (worm_prefact<NW>(C, fl) != 0.0) break;
+                if (worm_prefact_ie<NW>(C, fl) != 0.0) break;
             }
             return;
         }
@@ -265,17 +265,112 @@ __device__ __forceinline__ void worm_draw_flavours(Ctx &x, int (&fl)[NWMAX])
     for (int i = 0; i < NW; ++i) { const int bs = rest / base; rest -= bs * base; base /= nf; fl[i] = bs; }
 }
 
+// The kernels of the sectors 2, 3, 4 and 6 - 9 (IE = false) keep the code they had before the sectors with U-matrix factors beyond sector 3 came
+// (IE = true: 5, 10 - 16): the run-time branches of the new sectors cost the NW = 4 kernels 2.3 % (C5: 4.65 -> 4.75 ms per launch) when both
+// shared one body, so each set has its own instantiation.
 template <int NW>
+__device__ __forceinline__ double worm_prefact_base(const DevConst &C, const int (&fl)[NWMAX])
+{
+    if constexpr (NW == 4) {
+        if (C.isector == 3) {                          // beta^(N-2) Nd^(N+1) eta times the U-matrix factor, N = 4 (CTQMC.F90:5696)
+            const double nd = (double)C.nd, nd4 = nd * nd * nd * nd;
+            return gsigma_ufac(C, fl) * (C.beta * C.beta) * (nd4 * nd) * C.worm_eta;
+        }
+        if (C.isector >= 6) {
+            const double nd = (double)C.nd, nd4 = nd * nd * nd * nd, bb = C.beta * C.beta;
+            return (C.isector >= 8 ? bb * C.beta : bb) * nd4 * C.worm_eta;
+        }
+    }
+    const double b = C.beta * (double)C.nd, b2 = b * b;
+    return (NW == 4 ? b2 * b2 : b2) * C.worm_eta;
+}
+
+template <int NW>
+__device__ __forceinline__ void worm_draw_times_base(Ctx &x, double (&t)[NWMAX])
+{
+    const DevConst &C = x.C;
+    if constexpr (NW == 4) {
+        if (C.isector == 3) {                          // four draws, then the equal-time object (1, 3, 2) below tau_2 (Trace.F90:3971-3983)
+            const double beta = C.beta, off = beta * 1e-14;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t[i] = x.draw() * beta;
+            if (t[1] < 2.0 * off) t[1] = 2.0 * off;
+            t[2] = t[1] - off; t[0] = t[1] - 2.0 * off;
+            return;
+        }
+        if (C.isector >= 6) {
+            const double beta = C.beta, off = beta * 1e-14;
+            t[0] = x.draw() * beta;
+            t[3] = x.draw() * beta;
+            if (C.isector <= 7) {
+                if (t[0] < off) t[0] = off;
+                if (t[3] > beta - off) t[3] = beta - off;
+                if (C.isector == 6) { t[1] = t[0] - off; t[2] = t[3] + off; } else { t[1] = t[3] + off; t[2] = t[0] - off; }
+            } else {
+                if (t[3] > beta - off) t[3] = beta - off;
+                if (C.isector == 8) { t[1] = x.draw() * beta; t[2] = t[3] + off; } else { t[1] = t[3] + off; t[2] = x.draw() * beta; }
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        t[i] = x.draw() * C.beta;
+        if (i > 0 && t[i - 1] == t[i]) t[i] += C.beta * 1e-14;
+    }
+}
+
+template <int NW>
+__device__ __forceinline__ void worm_draw_flavours_base(Ctx &x, int (&fl)[NWMAX])
+{
+    const DevConst &C = x.C;
+    const int nf = C.nflav;
+    if constexpr (NW == 4) {
+        if (C.isector == 3) {
+            fl[3] = (C.icomponent - 1) % nf;
+            for (int guard = 0; guard < (1 << 20); ++guard) {      // the host has checked that some choice has a non-vanishing factor
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { const int orb = x.randint(1, C.nd), spin = x.randint(1, 2); fl[i] = 2 * (orb - 1) + (spin - 1); }
+                if (gsigma_ufac(C, fl) != 0.0) break;
+            }
+            return;
+        }
+    }
+    const int ncomp = NW == 4 ? nf * nf * nf * nf : nf * nf;
+    int comp = C.icomponent;
+    if (comp == 0) comp = x.randint(1, ncomp);
+    int rest = comp - 1, base = ncomp / nf;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { const int bs = rest / base; rest -= bs * base; base /= nf; fl[i] = bs; }
+}
+
+template <int NW, bool IE>
+__device__ __forceinline__ double worm_prefact(const DevConst &C, const int (&fl)[NWMAX])
+{
+    if constexpr (IE) return worm_prefact_ie<NW>(C, fl); else return worm_prefact_base<NW>(C, fl);
+}
+template <int NW, bool IE>
+__device__ __forceinline__ void worm_draw_times(Ctx &x, double (&t)[NWMAX])
+{
+    if constexpr (IE) worm_draw_times_ie<NW>(x, t); else worm_draw_times_base<NW>(x, t);
+}
+template <int NW, bool IE>
+__device__ __forceinline__ void worm_draw_flavours(Ctx &x, int (&fl)[NWMAX])
+{
+    if constexpr (IE) worm_draw_flavours_ie<NW>(x, fl); else worm_draw_flavours_base<NW>(x, fl);
+}
+
+template <int NW, bool IE = false>
 __device__ W2DYN_INLINE void step_worm_add(Ctx &x)
 {
     const DevConst &C = x.C;
     x.count(C_TRYWADD);
     double t[NWMAX] = {}; int fl[NWMAX] = {};
-    worm_draw_flavours<NW>(x, fl);
-    worm_draw_times<NW>(x, t);
+    worm_draw_flavours<NW, IE>(x, fl);
+    worm_draw_times<NW, IE>(x, t);
     double dlog;
     const bool valid = worm_delta<NW>(x, t, fl, dlog);
-    const double prefact = worm_prefact<NW>(C, fl);
+    const double prefact = worm_prefact<NW, IE>(C, fl);
     if (prefact == 0.0 || !valid) { x.count(C_QNWADD); x.sector = 1; return; }
     const double rnd = x.draw();
     if (rnd < fabs(prefact * exp(dlog))) {
@@ -286,7 +381,7 @@ __device__ W2DYN_INLINE void step_worm_add(Ctx &x)
     } else x.sector = 1;
 }
 
-template <int NW>
+template <int NW, bool IE = false>
 __device__ W2DYN_INLINE void step_worm_rem(Ctx &x)
 {
     const DevConst &C = x.C;
@@ -295,7 +390,7 @@ __device__ W2DYN_INLINE void step_worm_rem(Ctx &x)
     const bool valid = worm_delta<NW>(x, x.wtau, x.wfl, dlog);
     if (!valid) { x.count(C_QNWREM); return; }
     const double rnd = x.draw();
-    if (rnd < fabs(exp(-dlog) / worm_prefact<NW>(C, x.wfl))) { x.sector = 1; x.count(C_ACCWREM); }
+    if (rnd < fabs(exp(-dlog) / worm_prefact<NW, IE>(C, x.wfl))) { x.sector = 1; x.count(C_ACCWREM); }
 }
 
 // One-state blocks: log ratio of the local trace when the two worm operators p1, p2 (container indices) move from their present
@@ -381,60 +476,78 @@ __device__ W2DYN_INLINE bool worm_shift_delta(Ctx &x, int p1, int p2, double tn1
 //   later (earlier) time and the reverse for an annihilator, n_g' from all other operators (level_integral<NW>);
 //   larger blocks: the partner's list entry is moved, block sequence and trace are evaluated like for a worm insertion.
 // A move that fails the quantum-number check consumes no random number (goto 99 there), a vanishing trace does.
-template <int NW, int MAT>
+template <int NW, int MAT, bool IE = false>
 __device__ W2DYN_INLINE void step_worm_replace(Ctx &x)
 {
     const DevConst &C = x.C;
     x.count(C_TRYWREP);
-    // which worm operator becomes a hybridising one (CTQMC.F90:5834-5946): uniform over the container in sectors 2 - 4, 6 - 9, 14, 15; only
-    // the operators outside the equal-time object in sectors 5 and 16; sectors 10 - 12: a three-operator object that holds a density
-    // (operators 2, 3 or 4, 5 ... of equal flavour) moves the density; no replacement at all in sector 13
-    const int sec = C.isector;
-    int r;
-    if constexpr (NW == 8) { if (sec == 13) return; }
-    if (NW >= 4 && (sec == 5 || sec == 16)) r = x.randint(4, NW) - 1;
-    else if (NW == 6 && sec == 10) {
-        const bool d1 = x.wfl[1] == x.wfl[2], d2 = x.wfl[NW >= 6 ? 3 : 0] == x.wfl[NW >= 6 ? 4 : 0];
-        if (d1) r = d2 ? (x.randint(1, 2) - 1) * 5 : 0; else r = d2 ? 5 : x.randint(1, 6) - 1;
-    } else if (NW == 8 && sec == 12) {
-        const bool d1 = x.wfl[1] == x.wfl[2], d2 = x.wfl[NW >= 8 ? 5 : 0] == x.wfl[NW >= 8 ? 4 : 0];
-        if (d1) r = d2 ? (x.randint(1, 2) - 1) * 3 : 0; else r = d2 ? 3 : x.randint(1, 6) - 1;
-    } else if (NW == 12) {
-        const bool dd[4] = {x.wfl[1] == x.wfl[2], x.wfl[NW == 12 ? 3 : 0] == x.wfl[NW == 12 ? 4 : 0], x.wfl[NW == 12 ? 7 : 0] == x.wfl[NW == 12 ? 8 : 0],
-                            x.wfl[NW == 12 ? 9 : 0] == x.wfl[NW == 12 ? 10 : 0]};
-        const int nden = (int)dd[0] + (int)dd[1] + (int)dd[2] + (int)dd[3];
-        if (nden > 0) {
-            int pick = x.randint(1, nden); r = 0;
-            const int stay[4] = {0, 5, 6, 11};               // the operator that stays when object q gives its density away
-#pragma unroll
-            for (int q = 3; q >= 0; --q) { int before = 0; for (int p = 0; p < q; ++p) before += (int)dd[p]; if (dd[q] && before == pick - 1) r = stay[q]; }
-        } else r = x.randint(1, 12) - 1;
-    } else r = x.randint(1, NW) - 1;
-    // container indices of the partners that move along (-1: none) and their places in the new equal-time object (1: at tau_h, 2: one
-    // offset above, 3: two); the former hybridising operator takes the place that is left (qrepind / qtimeind, CTQMC.F90:5997-6178)
-    int partner = -1, pos_partner = 0, partner2 = -1, pos_partner2 = 0, pos_new = 0;
-    if constexpr (NW >= 4) {
-        // three-operator objects: row = the operator that stays (six per pair of objects), {partner, place, partner, place, place of the new one}
-        bool three = false; int row = 0, shift = 0; bool nqq = false;
-        if (sec == 3) { three = r < 3; row = r; }
-        else if (sec == 10 || sec == 11) { three = true; row = r % 6; shift = 6 * (r / 6); }
-        else if (sec == 12) { three = true; row = r; nqq = r >= 3; }
-        if (three) {
-            const int q3[6][5] = {{2, 2, 1, 3, 1}, {0, 1, 2, 2, 3}, {0, 1, 1, 3, 2}, {4, 1, 5, 3, 2}, {3, 2, 5, 3, 1}, {4, 1, 3, 2, 3}};
-            const int q3n[3][5] = {{4, 1, 5, 2, 3}, {5, 2, 3, 3, 1}, {4, 1, 3, 3, 2}};                      // second object of sector 12
-#pragma unroll
-            for (int q = 0; q < 6; ++q) if (q == row) {
-                const int *e = (nqq && q >= 3) ? q3n[q - 3] : q3[q];
-                partner = e[0] + shift; pos_partner = e[1]; partner2 = e[2] + shift; pos_partner2 = e[3]; pos_new = e[4];
+    int r = 0, partner = -1, pos_partner = 0, partner2 = -1, pos_partner2 = 0, pos_new = 0;
+    if constexpr (!IE) {
+            r = x.randint(1, NW) - 1;
+        // container indices of the partners that move along (-1: none) and their places in the new equal-time object (1: at tau_h, 2: one
+        // offset above, 3: two); the former hybridising operator takes the place that is left (qrepind / qtimeind, CTQMC.F90:6068-6127, 6164-6178)
+        if constexpr (NW == 4) {
+            const int sec = C.isector;
+            if (sec == 3) {
+                if (r == 0) { partner = 2; pos_partner = 2; partner2 = 1; pos_partner2 = 3; pos_new = 1; }
+                else if (r == 1) { partner = 0; pos_partner = 1; partner2 = 2; pos_partner2 = 2; pos_new = 3; }
+                else if (r == 2) { partner = 0; pos_partner = 1; partner2 = 1; pos_partner2 = 3; pos_new = 2; }
             }
+            else if (sec == 6) { partner = r ^ 1; pos_partner = (r & 1) ? 2 : 1; }
+            else if (sec == 7) { partner = r ^ 2; pos_partner = r < 2 ? 1 : 2; }
+            else if (sec == 8) { if (r >= 2) { partner = r ^ 1; pos_partner = r == 2 ? 1 : 2; } }
+            else if (sec == 9) { if (r & 1) { partner = r ^ 2; pos_partner = r == 1 ? 1 : 2; } }
+            if (partner >= 0 && partner2 < 0) pos_new = 3 - pos_partner;
         }
-        else if (sec == 6) { partner = r ^ 1; pos_partner = (r & 1) ? 2 : 1; }
-        else if (sec == 7) { partner = r ^ 2; pos_partner = r < 2 ? 1 : 2; }
-        else if (sec == 8) { if (r >= 2) { partner = r ^ 1; pos_partner = r == 2 ? 1 : 2; } }
-        else if (sec == 9) { if (r & 1) { partner = r ^ 2; pos_partner = r == 1 ? 1 : 2; } }
-        else if (sec == 14) { partner = r ^ 1; pos_partner = (r & 1) ? 1 : 2; }                             // 6151-6162
-        else if (sec == 15) { partner = r ^ 2; pos_partner = (r == 0 || r == 3) ? 2 : 1; }                  // 6133-6144
-        if (partner >= 0 && partner2 < 0) pos_new = 3 - pos_partner;
+    } else {
+        // which worm operator becomes a hybridising one (CTQMC.F90:5834-5946): uniform over the container in sectors 2 - 4, 6 - 9, 14, 15; only
+        // the operators outside the equal-time object in sectors 5 and 16; sectors 10 - 12: a three-operator object that holds a density
+        // (operators 2, 3 or 4, 5 ... of equal flavour) moves the density; no replacement at all in sector 13
+        const int sec = C.isector;
+        if constexpr (NW == 8) { if (sec == 13) return; }
+        if (NW >= 4 && (sec == 5 || sec == 16)) r = x.randint(4, NW) - 1;
+        else if (NW == 6 && sec == 10) {
+            const bool d1 = x.wfl[1] == x.wfl[2], d2 = x.wfl[NW >= 6 ? 3 : 0] == x.wfl[NW >= 6 ? 4 : 0];
+            if (d1) r = d2 ? (x.randint(1, 2) - 1) * 5 : 0; else r = d2 ? 5 : x.randint(1, 6) - 1;
+        } else if (NW == 8 && sec == 12) {
+            const bool d1 = x.wfl[1] == x.wfl[2], d2 = x.wfl[NW >= 8 ? 5 : 0] == x.wfl[NW >= 8 ? 4 : 0];
+            if (d1) r = d2 ? (x.randint(1, 2) - 1) * 3 : 0; else r = d2 ? 3 : x.randint(1, 6) - 1;
+        } else if (NW == 12) {
+            const bool dd[4] = {x.wfl[1] == x.wfl[2], x.wfl[NW == 12 ? 3 : 0] == x.wfl[NW == 12 ? 4 : 0], x.wfl[NW == 12 ? 7 : 0] == x.wfl[NW == 12 ? 8 : 0],
+                                x.wfl[NW == 12 ? 9 : 0] == x.wfl[NW == 12 ? 10 : 0]};
+            const int nden = (int)dd[0] + (int)dd[1] + (int)dd[2] + (int)dd[3];
+            if (nden > 0) {
+                int pick = x.randint(1, nden); r = 0;
+                const int stay[4] = {0, 5, 6, 11};               // the operator that stays when object q gives its density away
+    #pragma unroll
+                for (int q = 3; q >= 0; --q) { int before = 0; for (int p = 0; p < q; ++p) before += (int)dd[p]; if (dd[q] && before == pick - 1) r = stay[q]; }
+            } else r = x.randint(1, 12) - 1;
+        } else r = x.randint(1, NW) - 1;
+        // container indices of the partners that move along (-1: none) and their places in the new equal-time object (1: at tau_h, 2: one
+        // offset above, 3: two); the former hybridising operator takes the place that is left (qrepind / qtimeind, CTQMC.F90:5997-6178)
+        if constexpr (NW >= 4) {
+            // three-operator objects: row = the operator that stays (six per pair of objects), {partner, place, partner, place, place of the new one}
+            bool three = false; int row = 0, shift = 0; bool nqq = false;
+            if (sec == 3) { three = r < 3; row = r; }
+            else if (sec == 10 || sec == 11) { three = true; row = r % 6; shift = 6 * (r / 6); }
+            else if (sec == 12) { three = true; row = r; nqq = r >= 3; }
+            if (three) {
+                const int q3[6][5] = {{2, 2, 1, 3, 1}, {0, 1, 2, 2, 3}, {0, 1, 1, 3, 2}, {4, 1, 5, 3, 2}, {3, 2, 5, 3, 1}, {4, 1, 3, 2, 3}};
+                const int q3n[3][5] = {{4, 1, 5, 2, 3}, {5, 2, 3, 3, 1}, {4, 1, 3, 3, 2}};                      // second object of sector 12
+    #pragma unroll
+                for (int q = 0; q < 6; ++q) if (q == row) {
+                    const int *e = (nqq && q >= 3) ? q3n[q - 3] : q3[q];
+                    partner = e[0] + shift; pos_partner = e[1]; partner2 = e[2] + shift; pos_partner2 = e[3]; pos_new = e[4];
+                }
+            }
+            else if (sec == 6) { partner = r ^ 1; pos_partner = (r & 1) ? 2 : 1; }
+            else if (sec == 7) { partner = r ^ 2; pos_partner = r < 2 ? 1 : 2; }
+            else if (sec == 8) { if (r >= 2) { partner = r ^ 1; pos_partner = r == 2 ? 1 : 2; } }
+            else if (sec == 9) { if (r & 1) { partner = r ^ 2; pos_partner = r == 1 ? 1 : 2; } }
+            else if (sec == 14) { partner = r ^ 1; pos_partner = (r & 1) ? 1 : 2; }                             // 6151-6162
+            else if (sec == 15) { partner = r ^ 2; pos_partner = (r == 0 || r == 3) ? 2 : 1; }                  // 6133-6144
+            if (partner >= 0 && partner2 < 0) pos_new = 3 - pos_partner;
+        }
     }
     double tw = 0.0; int f = 0;
 #pragma unroll
@@ -569,14 +682,14 @@ __device__ W2DYN_INLINE void step_worm_replace(Ctx &x)
 // Matrix trace path: the worm operators are entries of the time-ordered operator list (they take part in the block
 // sequence and in the trace like any operator, but not in M).  Insertion: put the NW operators into the list, walk the
 // block sequence from the outer block (this IS the quantum-number check, check_sst_sequence), evaluate the trace.
-template <int NW, int MAT>
+template <int NW, int MAT, bool IE = false>
 __device__ W2DYN_INLINE void step_worm_add_mat(Ctx &x)
 {
     const DevConst &C = x.C;
     x.count(C_TRYWADD);
     double t[NWMAX] = {}; int fl[NWMAX] = {};
-    worm_draw_flavours<NW>(x, fl);
-    worm_draw_times<NW>(x, t);
+    worm_draw_flavours<NW, IE>(x, fl);
+    worm_draw_times<NW, IE>(x, t);
     if (x.nops + NW > C.wcap) { x.err |= ERR_WCAP; x.count(C_QNWADD); x.sector = 1; return; }
 #pragma unroll
     for (int i = 0; i < NW; ++i) mat_insert(x, mat_lower(x, t[i]), t[i], mat_code(fl[i], (i & 1) ? 1 : 2));
@@ -586,7 +699,7 @@ __device__ W2DYN_INLINE void step_worm_add_mat(Ctx &x)
         wave_sync();
     };
     const bool valid = mat_walk_into(x, x.outer, x.tsst);
-    const double prefact = worm_prefact<NW>(C, fl);
+    const double prefact = worm_prefact<NW, IE>(C, fl);
     if (prefact == 0.0 || !valid) { take_out(); x.count(C_QNWADD); x.sector = 1; return; }
     double tl, ts;
     mat_trace_trial<MAT>(x, x.tsst, x.nops, -1, -1, tl, ts);
@@ -600,7 +713,7 @@ __device__ W2DYN_INLINE void step_worm_add_mat(Ctx &x)
     } else { take_out(); x.sector = 1; }
 }
 
-template <int NW, int MAT>
+template <int NW, int MAT, bool IE = false>
 __device__ W2DYN_INLINE void step_worm_rem_mat(Ctx &x)
 {
     const DevConst &C = x.C;
@@ -617,7 +730,7 @@ __device__ W2DYN_INLINE void step_worm_rem_mat(Ctx &x)
     double tl, ts;
     mat_trace_trial<MAT>(x, x.tsst, x.nops, -1, -1, tl, ts);
     const double rnd = x.draw();
-    if (ts != 0.0 && rnd < fabs(exp(tl - x.tr_log) / worm_prefact<NW>(C, x.wfl))) {
+    if (ts != 0.0 && rnd < fabs(exp(tl - x.tr_log) / worm_prefact<NW, IE>(C, x.wfl))) {
         x.tr_log = tl; x.tr_sign = ts; mat_commit_sst(x);
         x.sector = 1; x.count(C_ACCWREM);
     } else put_back();
@@ -625,7 +738,7 @@ __device__ W2DYN_INLINE void step_worm_rem_mat(Ctx &x)
 
 // sweep kernel with worm sampling: Z space CTQMC.F90:8431-8488, worm space 8489-8528.  MAT = 0: scalar trace path,
 // otherwise the matrix trace path instantiation (2, 3, 4, 9 as in k_sweep)
-template <int NW, int MAT>
+template <int NW, int MAT, bool IE = false>
 __global__ __launch_bounds__(256, W2DYN_WPE_WORM) void k_sweep_worm(DevConst C, long long nsteps_launch, int resume)
 {
     extern __shared__ unsigned char smem[];
@@ -655,7 +768,7 @@ __global__ __launch_bounds__(256, W2DYN_WPE_WORM) void k_sweep_worm(DevConst C, 
             const double r = x.draw();
             if (r < (1.0 - ps - pg - pw) / 2.0) { x.skip(2); step_add<MAT, NW>(x); phase += 1; WORM_KIND(C_CYC_ADD); }
             else if (r <= 1.0 - ps - pg - pw) { x.skip(2); step_rem<MAT, NW>(x); phase += 1; WORM_KIND(C_CYC_REM); }
-            else if (r <= 1.0 - ps - pg) { if constexpr (MAT != 0) step_worm_add_mat<NW, MAT>(x); else step_worm_add<NW>(x); WORM_KIND(C_CYC_GLOB); }
+            else if (r <= 1.0 - ps - pg) { if constexpr (MAT != 0) step_worm_add_mat<NW, MAT, IE>(x); else step_worm_add<NW, IE>(x); WORM_KIND(C_CYC_GLOB); }
             else if (r <= 1.0 - ps) { if constexpr (MAT != 0) step_glob_mat<MAT>(x); else step_glob(x); WORM_KIND(C_CYC_SHIFT); }
             else { step_shift<MAT>(x); WORM_KIND(C_CYC_SHIFT); }
         } else {
@@ -663,8 +776,8 @@ __global__ __launch_bounds__(256, W2DYN_WPE_WORM) void k_sweep_worm(DevConst C, 
             const double r = x.draw();
             if (r < (1.0 - pr - pw) / 2.0) { x.skip(2); step_add<MAT, NW>(x); phase += 1; WORM_KIND(C_DBG5); }
             else if (r < 1.0 - pr - pw) { x.skip(2); step_rem<MAT, NW>(x); phase += 1; WORM_KIND(C_DBG5); }
-            else if (r < 1.0 - pw) { step_worm_replace<NW, MAT>(x); WORM_KIND(C_DBG6); }
-            else { if constexpr (MAT != 0) step_worm_rem_mat<NW, MAT>(x); else step_worm_rem<NW>(x); WORM_KIND(C_DBG7); }
+            else if (r < 1.0 - pw) { step_worm_replace<NW, MAT, IE>(x); WORM_KIND(C_DBG6); }
+            else { if constexpr (MAT != 0) step_worm_rem_mat<NW, MAT, IE>(x); else step_worm_rem<NW, IE>(x); WORM_KIND(C_DBG7); }
         }
 #ifdef W2DYN_STAMPS_WORM
         if (x.lane == 0) x.cnt[kind_] += __builtin_amdgcn_s_memtime() - t0_;

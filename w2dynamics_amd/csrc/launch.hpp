@@ -58,7 +58,7 @@ void launch_meas_g4w(const DevConst &C, hipStream_t st, int pp, int nbw);
 void launch_meas_gw(const DevConst &C, hipStream_t st);
 // estimators of the worm sectors 5, 10 - 16: a complex array of n1 x n2 x n3 frequencies and / or a tau histogram, nbe accumulator bins
 void launch_meas_wie(const DevConst &C, hipStream_t st, int nbe, double *acc_iw, double *acc_tau, int n1, int n2, int n3);
-// mixed Z / worm-space sweep of the sectors with six, eight and twelve worm operators (5, 10 - 13): matrix trace path only
+// mixed Z / worm-space sweep of the sectors 5 and 10 - 16 (those with six, eight and twelve worm operators: matrix trace path only)
 void launch_sweep_worm_big(int nworm, int mat, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume);
 // moments of B normalised bins of `per` doubles for the cross-rank reduction: out[1 + 3 per] (w2dyn_reduce_pack)
 void launch_pack_moments(hipStream_t st, const double *acc, int B, size_t per, const double *scale, int nleg, double *out);

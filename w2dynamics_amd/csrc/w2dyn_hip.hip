@@ -503,7 +503,7 @@ void launch_sweep_worm(int isector, int mat, const LaunchCfg &l0, const DevConst
 {
     const LaunchCfg l = mat ? queue_launch(l0, C) : l0;
     const int nworm = worm_nops_of(isector);
-    if (nworm > 4) launch_sweep_worm_big(nworm, mat, l, C, nsteps, resume);      // enter_sector has made sure of the matrix trace path
+    if (isector == 5 || isector >= 10) launch_sweep_worm_big(nworm, mat, l, C, nsteps, resume);      // more than four operators: enter_sector has made sure of the matrix trace path
     else if (mat == 0) launch_sweep_worm_scalar(nworm, l, C, nsteps, resume);
     else if (mat <= 4) launch_sweep_worm_tree(nworm, mat, l, C, nsteps, resume);
     else launch_sweep_worm_seq(nworm, l, C, nsteps, resume);
