@@ -718,7 +718,7 @@ def test_unsupported_modes_are_refused():
     # asked for; without it the call is an error of the caller.  A component whose U-matrix slices vanish would never let the worm in.
     _, ps, _ = util.setup("C1", 501, dict(PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormMeasUcaca=1))
     q = MCTQMC(nwalkers=4); q.init_rnd(1); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
-    for sec, comp in ((5, 4), (10, 1), (14, 1), (14, 0)):      # (14, 1): U_ab(0, ., 0, .) = 0 in one orbital; (14, 0): these sectors sample one component
+    for sec, comp in ((5, 4), (10, 1), (15, 2), (14, 0)):      # (15, 2): u1 = u3, the antisymmetrised U(u1, u3, ., .) vanishes; (14, 0): these sectors sample one component
         with pytest.raises(W2DynError) as e:
             q.ctqmc_measure(sec, comp)
         assert e.value.code == -1, (sec, comp)
