@@ -1072,7 +1072,7 @@ static void rebuild_minv(ora_walker *w, double **Mnew, int *knew, logval *det)
     det->log = 0.0; det->sign = 1.0;
     for (int f = 0; f < w->nflav; ++f) {
         int k = 0;
-        for (int i = 0; i < w->nops; ++i) if (w->ops[i].flav == f && w->ops[i].ca == 1) ++k;
+        for (int i = 0; i < w->nops; ++i) if (w->ops[i].flav == f && w->ops[i].ca == 1 && !w->ops[i].wid) ++k;     /* hybridising operators only */
         knew[f] = k;
         Mnew[f] = (double *)malloc(sizeof(double) * (size_t)(k * k + 1));
         if (k == 0) continue;
@@ -1080,7 +1080,7 @@ static void rebuild_minv(ora_walker *w, double **Mnew, int *knew, logval *det)
         double *tc = (double *)malloc(sizeof(double) * k), *ta = (double *)malloc(sizeof(double) * k);
         int nc = 0, na = 0;
         for (int i = 0; i < w->nops; ++i) {
-            if (w->ops[i].flav != f) continue;
+            if (w->ops[i].flav != f || w->ops[i].wid) continue;
             if (w->ops[i].ca == 1) tc[nc++] = w->ops[i].tau; else ta[na++] = w->ops[i].tau;
         }
         /* Fortran Mat(pos_a, pos_c) column major == row-major [c][a]: after inversion this array read as
@@ -1979,7 +1979,7 @@ static void meas_g4iw(ora_walker *w)
         double *tc = (double *)malloc(sizeof(double) * k), *ta = (double *)malloc(sizeof(double) * k);
         int nc = 0, na = 0;
         for (int i = 0; i < w->nops; ++i) {
-            if (w->ops[i].flav != f) continue;
+            if (w->ops[i].flav != f || w->ops[i].wid) continue;
             if (w->ops[i].ca == 1) tc[nc++] = w->ops[i].tau; else ta[na++] = w->ops[i].tau;
         }
         for (int ifc = 0; ifc < n2; ++ifc) for (int ifa = 0; ifa < n2; ++ifa) {
@@ -2435,7 +2435,7 @@ void ora_measure_once(ora_walker *w)
         double *tc = (double *)malloc(sizeof(double) * k), *ta = (double *)malloc(sizeof(double) * k);
         int nc = 0, na = 0;
         for (int i = 0; i < w->nops; ++i) {
-            if (w->ops[i].flav != f) continue;
+            if (w->ops[i].flav != f || w->ops[i].wid) continue;
             if (w->ops[i].ca == 1) tc[nc++] = w->ops[i].tau; else ta[na++] = w->ops[i].tau;
         }
         /* AccumGtau = 0: MeasGtauRem returns at once (CTQMC.F90:2267), neither G(l) nor G(tau); 2: per-measurement buffer */

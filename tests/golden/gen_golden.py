@@ -398,6 +398,19 @@ _IE_ETA = {   # (sector, config): WormEta that balances worm and partition-funct
     (5, "C4S"): 5.49e-5, (10, "C4S"): 4.98e-3, (11, "C4S"): 3.3e-4, (12, "C4S"): 1.25e-3, (13, "C4S"): 0.011, (14, "C4S"): 4.14e-3, (15, "C4S"): 0.143, (16, "C4S"): 0.0137,
     (5, "C4N"): 6.93e-6, (10, "C4N"): 1.41e-4, (14, "C4N"): 1.15e-3, (15, "C4N"): 0.0798, (16, "C4N"): 3.34e-3,
 }
+# worm sampling together with the moves outside the default mix (two pairs at once, pair moves that change the outer block; CTQMC.F90:8496-8516):
+# name: (sector, config, nftau, overrides, seed, component)
+_XW = dict(_EQ, Ntau=50, Niw=6, N2iwb=3, N3iwf=2, N3iwb=2, N4iwf=2, N4iwb=1, TaudiffMax=3.0, NCorr=10, Nwarmups=2000, Nmeas=600,
+           Percentage4OperatorMove=0.15, PercentageOuterMove=0.15)
+WORMEQ.update({
+    "X4_C4S": (4, "C4S", 501, dict(_XW, WormEta=0.02, WormMeasG4iw=1), 801, _comp4(4, (0, 0, 1, 1))),
+    "X2_C4S": (2, "C4S", 501, dict(_XW, WormEta=0.2, WormMeasGiw=1, WormMeasGtau=1), 802, 1),
+    "X3_C4S": (3, "C4S", 501, dict(_XW, WormEta=0.005, WormMeasGSigmaiw=1), 803, 1 + 1 * 4 + 1),
+    "X6_C4N": (6, "C4N", 501, dict(_XW, Nmeas=300, WormEta=0.002, WormMeasP2iwPH=1, WormMeasP2tauPH=1), 804, _comp4(6, (0, 1, 3, 2))),
+    "X10_C4S": (10, "C4S", 501, dict(_XW, WormEta=5e-3, WormMeasQQ=1, WormMeasQQtau=1), 805, 1),
+    "X4_C3": (4, "C3", 501, dict(_XW, TaudiffMax=6.0, WormEta=1e-4, WormMeasG4iw=1), 806, _comp4(4, (0, 0, 3, 3))),
+    "X2_C1": (2, "C1", 501, dict(_XW, WormEta=0.05, WormMeasGiw=1, WormMeasGtau=1), 807, 1),
+})
 _NFLAV = {"C1": 2, "C3": 4, "C4S": 4, "C4N": 6}
 _seed = 700
 for (_sec, _cfg), _eta in _IE_ETA.items():
@@ -406,7 +419,7 @@ for (_sec, _cfg), _eta in _IE_ETA.items():
     _comp = 1 if _sec == 10 else _comp4(_nf, (0, 0, 1, 1))
     WORMEQ["S%d_%s" % (_sec, _cfg)] = (_sec, _cfg, 501, dict(_IE, Nwarmups=2000, Nmeas=300 if _cfg == "C4N" else 1000, WormEta=_eta, **_IEM[_sec]), _seed, _comp)
 
-WORMEQ_KEYS = ("h4iw_worm", "qq_worm", "qqtau_worm", "qqqq_worm", "nqqdag_worm", "qqdd_worm", "ucaca_worm", "ucacatau_worm", "uccaa_worm", "uccaatau_worm", "quddag_worm",
+WORMEQ_KEYS = ("g4iw_worm", "giw_worm", "gtau_worm", "accadd4", "accrem4", "h4iw_worm", "qq_worm", "qqtau_worm", "qqqq_worm", "nqqdag_worm", "qqdd_worm", "ucaca_worm", "ucacatau_worm", "uccaa_worm", "uccaatau_worm", "quddag_worm",
                "gsigmaiw_worm", "p2iw_worm", "p2iwpp_worm", "p2tau_worm", "p2taupp_worm", "p3iw_worm", "p3iwpp_worm", "mean_sign", "accwormadd", "accwormrem",
                "accwormrep", "cntsampling", "accadd", "accrem", "occ", "histo")
 
@@ -416,7 +429,7 @@ def gen_wormeq(only=None):
         if only and name not in only:
             continue
         p, ps = pstring_for(cfg, nftau, over)
-        s = refdrive.RefSolver(p, ps, seed, fourpnt=8 if sector in (5, 11) else 0)
+        s = refdrive.RefSolver(p, ps, seed, fourpnt=8 if sector in (4, 5, 11) else 0)
         s.set_taudiffmax(over["TaudiffMax"])
         s.warmup(over["Nwarmups"])
         steps = s.count_steps(sector, comp, 3000)

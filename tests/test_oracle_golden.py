@@ -370,6 +370,8 @@ WORMEQ = ["P2_C1a", "P2_C1b", "P2_C3a", "P2pp_C1a", "P2pp_C3a", "P3_C1a", "P3_C3
 # sectors 5 and 10 - 16: worms of four to twelve operators in equal-time objects, U-matrix factors in the proposal
 WORMEQ += ["S%d_%s" % (sec, cfg) for cfg in ("C1", "C3", "C4S") for sec in (5, 10, 11, 12, 13, 14, 15, 16)] + ["S%d_C4N" % sec for sec in (5, 10, 14, 15, 16)]
 WORMEQ.remove("S11_C3")        # the twelve-operator worm never gets in at this size
+# worm sampling together with Percentage4OperatorMove / PercentageOuterMove (the extra pair moves inside Z and worm space, CTQMC.F90:8441-8516)
+WORMEQ += ["X4_C4S", "X2_C4S", "X3_C4S", "X6_C4N", "X10_C4S", "X4_C3", "X2_C1"]
 
 
 @pytest.mark.parametrize("name", WORMEQ)
@@ -381,7 +383,7 @@ def test_oracle_equal_time_worm_sampling_retraces_reference(name):
     g = util.load_golden("wormeq_%s.npz" % name)
     over = g["overrides"]; comp = int(g["component"]); sec = int(g["sector"])
     p, ps, pset = util.setup(g["config"], g["nftau"], over)
-    w = pyoracle.OracleWalker(p, pset, ("std", int(g["seed"])), fourpnt=8 if sec in (5, 11) else 0)
+    w = pyoracle.OracleWalker(p, pset, ("std", int(g["seed"])), fourpnt=8 if sec in (4, 5, 11) else 0)
     w.set_taudiffmax(over["TaudiffMax"])
     w.warmup(over["Nwarmups"])
     assert w.count_steps(sec, comp, 3000) == tuple(int(x) for x in g["count_steps"])
@@ -395,7 +397,7 @@ def test_oracle_equal_time_worm_sampling_retraces_reference(name):
     for key, num, den in (("accwormadd", "acc_wadd", "try_wadd"), ("accwormrep", "acc_wrep", "try_wrep"), ("accwormrem", "acc_wrem", "try_wrem")):
         assert wc[num] / max(wc[den], 1.0) == pytest.approx(float(g["res_" + key][sec - 2]), rel=1e-12, abs=1e-300), key
     checked = 0
-    for k in pyoracle.WORM_EQ_NAMES + pyoracle.WORM_MORE_NAMES + ("gsigmaiw_worm",):
+    for k in pyoracle.WORM_EQ_NAMES + pyoracle.WORM_MORE_NAMES + ("gsigmaiw_worm", "g4iw_worm", "giw_worm", "gtau_worm"):
         if "res_" + k in g and g["res_" + k].size > 1:
             assert k in r, k
             assert r[k].shape == g["res_" + k].shape and rel(r[k], g["res_" + k]) < 1e-10, k
