@@ -704,12 +704,9 @@ def test_unsupported_modes_are_refused():
             q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
         assert e.value.code == -2, over
         q.close()
-    # the moves outside the default mix run in Z space only: worm sampling and the window calibration with them are refused
+    # the window calibration with the moves outside the default mix is refused (worm sampling with them runs on the tree-product trace path)
     _, ps, _ = util.setup("C1", 501, dict(Percentage4OperatorMove=0.1, WormMeasGiw=1, PercentageWormInsert=0.2, PercentageWormReplace=0.2))
     q = MCTQMC(nwalkers=4); q.init_rnd(1); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
-    with pytest.raises(W2DynError) as e:
-        q.ctqmc_measure(2, 1)
-    assert e.value.code == -2
     with pytest.raises(W2DynError) as e:
         q.ctqmc_calibrate(True, 10, 10, 10, 100)
     assert e.value.code == -2
@@ -722,6 +719,13 @@ def test_unsupported_modes_are_refused():
         with pytest.raises(W2DynError) as e:
             q.ctqmc_measure(sec, comp)
         assert e.value.code == -1, (sec, comp)
+    q.close()
+    # worm sampling together with the two-pair / outer-block moves: tree-product trace path only (blocks of up to four states)
+    p9, ps9, _ = util.setup("C4N", 501, dict(Percentage4OperatorMove=0.1, WormMeasGiw=1, PercentageWormInsert=0.2, PercentageWormReplace=0.2))
+    q = MCTQMC(nwalkers=4); q.init_rnd(1); q.init_paras(ps9); q.init_solver(p9.umatrix, p9.ftau, p9.muimp, p9.screening, 1)
+    with pytest.raises(W2DynError) as e:
+        q.ctqmc_measure(2, 1)
+    assert e.value.code == -2
     q.close()
     # blocks of more than 8 states are refused: 3-orbital Kanamori with the particle number as the only quantum number
     from w2dynamics_amd import params, synth
@@ -969,6 +973,8 @@ WORMEQ_CASES = ["P2_C1a", "P2_C1b", "P2_C3a", "P2pp_C1a", "P2pp_C3a", "P3_C1a", 
 # sectors 5 and 10 - 16: worms of four, six, eight and twelve operators with U-matrix factors (those with more than four: matrix trace path, also for C1 / C3)
 WORMEQ_CASES += ["S%d_%s" % (sec, cfg) for cfg in ("C1", "C3", "C4S") for sec in (5, 10, 11, 12, 13, 14, 15, 16) if (sec, cfg) != (11, "C3")]
 WORMEQ_CASES += ["S%d_C4N" % sec for sec in (5, 10, 14, 15, 16)]
+# worm sampling together with Percentage4OperatorMove / PercentageOuterMove (matrix trace path, also for C1 / C3; sectors 2, 3, 4, 6)
+WORMEQ_CASES += ["X4_C4S", "X2_C4S", "X3_C4S", "X4_C3", "X2_C1"]        # blocks of more than four states (X6_C4N, oracle only): refused
 
 
 @pytest.mark.parametrize("name", WORMEQ_CASES)
@@ -981,7 +987,7 @@ def test_equal_time_worm_sampling_chains_vs_oracle(name):
     comp = int(g["component"]); sec = int(g["sector"]); nw = 5
     over = g["overrides"]
     p, ps, pset = util.setup(g["config"], g["nftau"], over)
-    fourpnt = 8 if sec in (5, 11) else 0
+    fourpnt = 8 if sec in (4, 5, 11) else 0
     q = MCTQMC(nwalkers=nw, walkers_per_bin=1); q.fourpnt = fourpnt
     q.init_rnd(29); q.init_paras(ps)
     q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
@@ -993,9 +999,9 @@ def test_equal_time_worm_sampling_chains_vs_oracle(name):
     q.ctqmc_worm_warmup(0, sec, comp)
     q.ctqmc_measure(sec, comp)
     wc = q.worm_counters
-    keys = [k for k in pyoracle.WORM_EQ_NAMES + pyoracle.WORM_MORE_NAMES + ("gsigmaiw_worm",) if "res_" + k in g and g["res_" + k].size > 1]
+    keys = [k for k in pyoracle.WORM_EQ_NAMES + pyoracle.WORM_MORE_NAMES + ("gsigmaiw_worm", "g4iw_worm", "giw_worm", "gtau_worm") if "res_" + k in g and g["res_" + k].size > 1]
     assert keys
-    pooled = {k: 0.0 for k in keys}; cw = cz = mw = 0.0; nrep = 0.0
+    pooled = {k: 0.0 for k in keys}; cw = cz = mw = 0.0; nrep = 0.0; n4 = 0.0
     for w in range(nw):
         o = pyoracle.OracleWalker(p, pset, ("philox", 29, w), fourpnt=fourpnt)
         o.set_taudiffmax(over["TaudiffMax"]); o.warmup(over["Nwarmups"])
@@ -1004,7 +1010,7 @@ def test_equal_time_worm_sampling_chains_vs_oracle(name):
         r = o.results(); oc = o.worm_counters(); c = o.get_config()
         got = [r["counters"][11], oc["cnt_sampling_w"], oc["try_wadd"], oc["acc_wadd"], oc["try_wrem"], oc["acc_wrem"], oc["try_wrep"], oc["acc_wrep"]]
         assert np.array_equal(wc[w], got), (w, wc[w], got)
-        nrep += oc["acc_wrep"]
+        nrep += oc["acc_wrep"]; n4 += float(r["counters_more"][[1, 3, 5, 7]].sum())
         n, osst, _ = q.get_mc_config_scalars(w)
         assert n == len(c["taus"]) and osst == c["outer_sst"]
         taus, orbs, spins, cas, hyb, _, _ = q.get_mc_config(n, w)
@@ -1021,6 +1027,8 @@ def test_equal_time_worm_sampling_chains_vs_oracle(name):
     assert mw > 0
     if float(g["res_accwormrep"][sec - 2]) > 0.01:
         assert nrep > 0                                 # the replacement with a moved partner is in play
+    if name.startswith("X"):
+        assert n4 > 0                                   # accepted two-pair / outer-block moves
     for k in keys:
         assert rel(getattr(q, k) * q.mean_sign, pooled[k] * cw / (mw * cz)) < TOL, k
     assert q.cntsampling[0] == cz and q.cntsampling[sec - 1] == cw

@@ -16,6 +16,10 @@
 // (at most three) intervals between consecutive worm operators, the second involves the worm times only.
 #pragma once
 
+// the two-pair moves (cthyb_xmoves.hip.h, included after this file) that the worm kernels with XM make
+template <int MAT> __device__ W2DYN_INLINE void step_add4(Ctx &x);
+template <int MAT> __device__ W2DYN_INLINE void step_rem4(Ctx &x);
+
 // sort of the NW worm operators by time: ord[m] = container index of the m-th operator in time
 template <int NW>
 __device__ __forceinline__ void worm_order(const double (&t)[NWMAX], int (&ord)[4])
@@ -738,7 +742,8 @@ __device__ W2DYN_INLINE void step_worm_rem_mat(Ctx &x)
 
 // sweep kernel with worm sampling: Z space CTQMC.F90:8431-8488, worm space 8489-8528.  MAT = 0: scalar trace path,
 // otherwise the matrix trace path instantiation (2, 3, 4, 9 as in k_sweep)
-template <int NW, int MAT, bool IE = false>
+// XM: with the two-pair moves and the pair moves that change the outer block (matrix trace path only; CTQMC.F90:8441-8449, 8497-8516)
+template <int NW, int MAT, bool IE = false, bool XM = false>
 __global__ __launch_bounds__(256, W2DYN_WPE_WORM) void k_sweep_worm(DevConst C, long long nsteps_launch, int resume)
 {
     extern __shared__ unsigned char smem[];
@@ -750,11 +755,25 @@ __global__ __launch_bounds__(256, W2DYN_WPE_WORM) void k_sweep_worm(DevConst C, 
     const long long nsteps = launch_steps(C, x.w, x.lane, nsteps_launch, resume);
     if (nsteps == 0) continue;
     ctx_load(x);
-    flag_full(x);
+    if constexpr (XM) flag_full(x, 1); else flag_full(x);
     if constexpr (MAT != 0) mat_trace_current<MAT>(x);
     const double pg = C.p_glob, ps = C.p_shift, pw = C.p_wins, pr = C.p_wrep;
     unsigned int phase = (unsigned int)((x.cnt[C_TRYADD] + x.cnt[C_TRYREM] + x.cnt[C_W_TRYADD] + x.cnt[C_W_TRYREM]) % (unsigned long long)C.nslide);
     phase = (unsigned int)uni((int)phase);
+    // XM: pair insertion / removal of a step is one pair (with the outer block left alone or not) or two pairs at once; the kernels without
+    // these moves keep their four call sites as they were
+    constexpr bool XMK = XM && MAT != 0;
+    // (always inlined: left out of line, the four call sites made a second call level above the sequential evaluator's - the constellation
+    // that hung the GPU in round 2 - and this kernel hung the same way on blocks of nine states)
+    auto pair_step = [&](bool add) __attribute__((always_inline)) {
+        if constexpr (XMK) {
+            if (x.draw() >= C.p_4op) {
+                const bool outer = x.draw() < C.p_outer;
+                if (add) step_add<MAT, NW, false, true>(x, outer); else step_rem<MAT, NW, false, true>(x, outer);
+                phase += 1;
+            } else if (add) step_add4<MAT>(x); else step_rem4<MAT>(x);
+        }
+    };
     long long it = 0;
     for (; it < nsteps && !(x.err & ERR_KMAX); ++it) {
 #ifdef W2DYN_STAMPS_WORM      // diagnostic build: shader-clock cycles per move type
@@ -766,16 +785,16 @@ __global__ __launch_bounds__(256, W2DYN_WPE_WORM) void k_sweep_worm(DevConst C, 
         if (x.sector == 1) {
             x.count(C_SAMPLING);
             const double r = x.draw();
-            if (r < (1.0 - ps - pg - pw) / 2.0) { x.skip(2); step_add<MAT, NW>(x); phase += 1; WORM_KIND(C_CYC_ADD); }
-            else if (r <= 1.0 - ps - pg - pw) { x.skip(2); step_rem<MAT, NW>(x); phase += 1; WORM_KIND(C_CYC_REM); }
+            if (r < (1.0 - ps - pg - pw) / 2.0) { if constexpr (XMK) pair_step(true); else { x.skip(2); step_add<MAT, NW>(x); phase += 1; } WORM_KIND(C_CYC_ADD); }
+            else if (r <= 1.0 - ps - pg - pw) { if constexpr (XMK) pair_step(false); else { x.skip(2); step_rem<MAT, NW>(x); phase += 1; } WORM_KIND(C_CYC_REM); }
             else if (r <= 1.0 - ps - pg) { if constexpr (MAT != 0) step_worm_add_mat<NW, MAT, IE>(x); else step_worm_add<NW, IE>(x); WORM_KIND(C_CYC_GLOB); }
             else if (r <= 1.0 - ps) { if constexpr (MAT != 0) step_glob_mat<MAT>(x); else step_glob(x); WORM_KIND(C_CYC_SHIFT); }
             else { step_shift<MAT>(x); WORM_KIND(C_CYC_SHIFT); }
         } else {
             x.count(C_W_SAMPLING);
             const double r = x.draw();
-            if (r < (1.0 - pr - pw) / 2.0) { x.skip(2); step_add<MAT, NW>(x); phase += 1; WORM_KIND(C_DBG5); }
-            else if (r < 1.0 - pr - pw) { x.skip(2); step_rem<MAT, NW>(x); phase += 1; WORM_KIND(C_DBG5); }
+            if (r < (1.0 - pr - pw) / 2.0) { if constexpr (XMK) pair_step(true); else { x.skip(2); step_add<MAT, NW>(x); phase += 1; } WORM_KIND(C_DBG5); }
+            else if (r < 1.0 - pr - pw) { if constexpr (XMK) pair_step(false); else { x.skip(2); step_rem<MAT, NW>(x); phase += 1; } WORM_KIND(C_DBG5); }
             else if (r < 1.0 - pw) { step_worm_replace<NW, MAT, IE>(x); WORM_KIND(C_DBG6); }
             else { if constexpr (MAT != 0) step_worm_rem_mat<NW, MAT, IE>(x); else step_worm_rem<NW, IE>(x); WORM_KIND(C_DBG7); }
         }

@@ -59,7 +59,13 @@ void launch_meas_gw(const DevConst &C, hipStream_t st);
 // estimators of the worm sectors 5, 10 - 16: a complex array of n1 x n2 x n3 frequencies and / or a tau histogram, nbe accumulator bins
 void launch_meas_wie(const DevConst &C, hipStream_t st, int nbe, double *acc_iw, double *acc_tau, int n1, int n2, int n3);
 // mixed Z / worm-space sweep of the sectors 5 and 10 - 16 (those with six, eight and twelve worm operators: matrix trace path only)
-void launch_sweep_worm_big(int nworm, int mat, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume);
+void launch_sweep_worm_big4(int mat, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume);
+void launch_sweep_worm_big6(int mat, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume);
+void launch_sweep_worm_big8(int mat, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume);
+void launch_sweep_worm_big12(int mat, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume);
+// mixed Z / worm-space sweep of the sectors 2, 3, 4, 6 - 9 with the two-pair and outer-block moves (matrix trace path)
+void launch_sweep_worm_x2(int mat, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume);
+void launch_sweep_worm_x4(int mat, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume);
 // moments of B normalised bins of `per` doubles for the cross-rank reduction: out[1 + 3 per] (w2dyn_reduce_pack)
 void launch_pack_moments(hipStream_t st, const double *acc, int B, size_t per, const double *scale, int nleg, double *out);
 

@@ -503,7 +503,15 @@ void launch_sweep_worm(int isector, int mat, const LaunchCfg &l0, const DevConst
 {
     const LaunchCfg l = mat ? queue_launch(l0, C) : l0;
     const int nworm = worm_nops_of(isector);
-    if (isector == 5 || isector >= 10) launch_sweep_worm_big(nworm, mat, l, C, nsteps, resume);      // more than four operators: enter_sector has made sure of the matrix trace path
+    // every tree-product kernel is instantiated for the block size it runs with (mat = 2, 3, 4): a worm kernel with the extra moves built for
+    // blocks of four states faulted on blocks of two (cause not found; the kernels of exact size retrace the oracle)
+    if (C.xmoves) { if (nworm == 2) launch_sweep_worm_x2(mat, l, C, nsteps, resume); else launch_sweep_worm_x4(mat, l, C, nsteps, resume); }   // enter_sector: matrix trace path, sectors 2, 3, 4, 6 - 9
+    else if (isector == 5 || isector >= 10) {                  // more than four operators: enter_sector has made sure of the matrix trace path
+        if (nworm == 4) launch_sweep_worm_big4(mat, l, C, nsteps, resume);
+        else if (nworm == 6) launch_sweep_worm_big6(mat, l, C, nsteps, resume);
+        else if (nworm == 8) launch_sweep_worm_big8(mat, l, C, nsteps, resume);
+        else launch_sweep_worm_big12(mat, l, C, nsteps, resume);
+    }
     else if (mat == 0) launch_sweep_worm_scalar(nworm, l, C, nsteps, resume);
     else if (mat <= 4) launch_sweep_worm_tree(nworm, mat, l, C, nsteps, resume);
     else launch_sweep_worm_seq(nworm, l, C, nsteps, resume);
@@ -738,7 +746,9 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     }
     // the worms with six, eight and twelve operators (sectors 5, 10 - 13) are kept in the operator list only: matrix trace path, whatever the blocks
     const bool big_worms = s->worm_meas_more[0] || s->worm_meas_more[1] || s->worm_meas_more[2] || s->worm_meas_more[3] || s->worm_meas_more[4] || s->worm_meas_more[5];
-    s->mat = !lp.identity_blocks || s->offdiag || big_worms;      // off-diagonal hybridisation: always the matrix trace path (list of operators with their flavours)
+    // worm sampling together with the two-pair / outer-block moves: the worm kernels make those moves on the operator list only
+    const bool worm_xmoves = s->p_wins > 0.0 && (s->p_4op > 0.0 || s->p_outer > 0.0);
+    s->mat = !lp.identity_blocks || s->offdiag || big_worms || worm_xmoves;      // off-diagonal hybridisation: always the matrix trace path (list of operators with their flavours)
     (void)dd;
     if (s->mat && lp.nsmax > 16) return fail(s, W2DYN_EUNSUPPORTED, "largest block of H_loc has %d states with QuantumNumbers '%s': the HIP solver handles up to 16", lp.nsmax, qns.c_str());
     s->eps.assign(nf, 0.0); s->udd.assign((size_t)nf * nf, 0.0);
@@ -1870,8 +1880,10 @@ static int enter_sector(w2dyn_solver *s, int isector, int icomponent)
 {
     if (isector != 1 && s->offdiag)
         return fail(s, W2DYN_EUNSUPPORTED, "worm sampling with offdiag = 1 is not supported");
-    if (isector != 1 && s->C.xmoves)
-        return fail(s, W2DYN_EUNSUPPORTED, "worm sampling with Percentage4OperatorMove or PercentageOuterMove > 0 is not supported (the worm kernels make the default pair moves only)");
+    if (isector != 1 && s->C.xmoves && (!s->mat || mat_variant(s) > 4 || isector == 5 || isector >= 10))
+        return fail(s, W2DYN_EUNSUPPORTED, "worm sampling with Percentage4OperatorMove or PercentageOuterMove > 0 runs on the matrix trace path (which init_solver takes when "
+                    "PercentageWormInsert > 0 as well) with blocks of up to four states, in the sectors 2, 3, 4 and 6 - 9; not supported here (sector %d, largest block %d)",
+                    isector, s->lp.nsmax);
     if (isector < 1 || isector > 16)
         return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d does not exist (1 = Z, 2 - 16: Parameters.F90:28-43)", isector);
     if (worm_nops_of(isector) > 4 && !s->mat)
