@@ -81,8 +81,8 @@ WORKLOADS = {
                 overrides=dict(_BASE, NCorr=200, Niw=2000, PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=1.0, WormMeasGiw=1, WormMeasGtau=1),
                 text="C2S: C2 with worm sampling in sector 2 (giw_worm / gtau_worm of component 1 = flavours 00, Niw=2000, "
                      "PercentageWormInsert=PercentageWormReplace=0.2, eta balanced by count_steps)"),
-    # sector 10: the symmetric improved estimator (QQ: two three-operator equal-time objects with U-matrix factors, six worm operators kept in the
-    # operator list of the matrix trace path; k_sweep_worm<6, 4>, k_meas_wie) at the reference's default Niw
+    # sector 10: the symmetric improved estimator (QQ: two three-operator equal-time objects with U-matrix factors, six worm operators;
+    # k_sweep_worm<6, 0, IE>, k_meas_wie) at the reference's default Niw
     "C2Q": dict(config="C2", nftau=5001, chains=16384, worm=dict(sector=10, component=1, nfix=2000),
                 overrides=dict(_BASE, NCorr=200, Niw=2000, PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=1.0, WormMeasQQ=1, WormMeasQQtau=1),
                 text="C2Q: C2 with worm sampling in sector 10 (qq_worm / qqtau_worm of component 1, the symmetric improved estimator, Niw=2000, "

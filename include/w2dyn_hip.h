@@ -87,9 +87,9 @@ int w2dyn_ctqmc_warmup(w2dyn_solver *s, int64_t nwarmups);
  * isector 5 (H4, six worm operators), 10 (QQ, six), 11 (Q4, twelve), 12 (NQQdag, eight), 13 (QQdd, eight), 14 (Ucaca), 15 (Uccaa), 16 (QUDdag; four
  * each): worms with U-matrix factors in the proposal and random flavours of the operators in the equal-time objects (set_IEOperFlavor
  * Trace.F90:3835-3919, set_OperTime 4022-4158, get_Proposal CTQMC.F90:5698-5796, replacement 5841-5946 and 5997-6162, estimators 1166-1294 and
- * 1708-2128, u_sparsity 9003-9343); icomponent = the component's two (sector 10) or four flavour indices, not 0.  Sectors 14 - 16 run on both
- * trace paths; the sectors with more than four worm operators on the matrix trace path, which init_solver takes when WormMeasH4iw, WormMeasQQ,
- * WormMeasQQtau, WormMeasQQQQ, WormMeasNQQdag or WormMeasQQdd is set (else the call is refused with W2DYN_EINVAL). */
+ * 1708-2128, u_sparsity 9003-9343); icomponent = the component's two (sector 10) or four flavour indices, not 0.  Sectors 5, 10 and 14 - 16 run on
+ * both trace paths; the sectors with eight and twelve worm operators (11 - 13) on the matrix trace path, which init_solver takes when WormMeasQQQQ,
+ * WormMeasNQQdag or WormMeasQQdd is set (else the call is refused with W2DYN_EINVAL). */
 int w2dyn_ctqmc_measure(w2dyn_solver *s, int isector, int icomponent);
 /* module variable `wormeta` (impurity.py:719, 755, 784): the same value for every worm sector, CTQMC.F90:194, 434 */
 int w2dyn_set_wormeta(w2dyn_solver *s, double eta);

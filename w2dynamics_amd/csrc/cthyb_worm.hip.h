@@ -60,9 +60,71 @@ __device__ __forceinline__ bool worm_any_between(Ctx &x, int f, double lo, doubl
 // Quantum-number check and log trace ratio (with worm) / (without worm) for worm operators at times t[] with
 // flavours fl[] on top of the present hybridising operators.  At most two distinct flavours can occur in a valid
 // worm (every flavour needs as many worm creators as annihilators).
+// The same for worms of more than four operators (sectors 5 and 10: six): up to NW / 2 distinct flavours, each with its own running
+// occupation change d; -Delta = sum_f int d_f (eps_f + sum_{g != f} U_fg n_g) + sum_{f < g} U_fg int d_f d_g over the intervals
+// between consecutive worm operators.
+template <int NW>
+__device__ W2DYN_INLINE bool worm_delta_multi(Ctx &x, const double (&t)[NWMAX], const int (&fl)[NWMAX], double &dlog)
+{
+    const DevConst &C = x.C;
+    constexpr int NF = NW / 2;
+    int rk[NW];                                            // rank in time of container operator i
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        int r = 0;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) r += (t[j] < t[i] || (t[j] == t[i] && j < i)) ? 1 : 0;
+        rk[i] = r;
+    }
+    int fs[NF], d[NF];
+#pragma unroll
+    for (int q = 0; q < NF; ++q) { fs[q] = -1; d[q] = 0; }
+    dlog = 0.0;
+    bool valid = true;
+#pragma unroll
+    for (int m = 0; m < NW; ++m) {
+        int i = 0; double tm = 0.0, tn = 0.0; int fm = 0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) { if (rk[q] == m) { i = q; tm = t[q]; fm = fl[q]; } if (rk[q] == m + 1) tn = t[q]; }
+        const bool creator = (i & 1) != 0;                 // container order c, c+, c, c+, ...
+        // the flavour's slot: the first one that holds it or is free (used slots come first)
+        int slot = -1;
+#pragma unroll
+        for (int q = 0; q < NF; ++q) if (slot < 0 && (fs[q] < 0 || fs[q] == fm)) { slot = q; fs[q] = fm; }
+        if (slot < 0) valid = false;                       // more flavours than can be balanced
+        int nc, na;
+        worm_counts(x, fm, tm, nc, na);
+        int dcur = 0;
+#pragma unroll
+        for (int q = 0; q < NF; ++q) if (q == slot) dcur = d[q];
+        const int occ = ((x.outer >> flav_bit(fm, C.nd)) & 1) + nc - na + dcur;
+        if (occ != (creator ? 0 : 1)) valid = false;
+#pragma unroll
+        for (int q = 0; q < NF; ++q) if (q == slot) d[q] += creator ? 1 : -1;
+        if (m < NW - 1) {
+#pragma unroll
+            for (int q = 0; q < NF; ++q) {
+                if (valid && d[q] != 0) {
+                    if (worm_any_between(x, fs[q], tm, tn)) valid = false;
+                    else dlog -= (double)d[q] * level_integral<0>(x, fs[q], tm, tn);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NF; ++q)
+#pragma unroll
+                for (int r = q + 1; r < NF; ++r)
+                    if (valid && d[q] != 0 && d[r] != 0) dlog -= C.udd[fs[q] * C.nflav + fs[r]] * (double)(d[q] * d[r]) * (tn - tm);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NF; ++q) if (d[q] != 0) valid = false;
+    return valid;
+}
+
 template <int NW>
 __device__ W2DYN_INLINE bool worm_delta(Ctx &x, const double (&t)[NWMAX], const int (&fl)[NWMAX], double &dlog)
 {
+    if constexpr (NW > 4) return worm_delta_multi<NW>(x, t, fl, dlog);
     const DevConst &C = x.C;
     int ord[4] = {0, 0, 0, 0};
     worm_order<NW>(t, ord);
@@ -404,6 +466,7 @@ __device__ W2DYN_INLINE void step_worm_rem(Ctx &x)
 // flavours), the new sequence is allowed iff no other operator of g lies where D_g != 0 and the occupation in front of each moved
 // operator's new place is what its type needs; log ratio = - sum_g int D_g (eps_g + sum_g' U_gg' n_g') - U_gg' int D_g D_g' with
 // n from all present operators, worm operators included (level_integral<4>).
+template <int NW = 4>
 __device__ W2DYN_INLINE bool worm_shift_delta(Ctx &x, int p1, int p2, double tn1, double tn2, double &dlog)
 {
     const DevConst &C = x.C;
@@ -413,7 +476,7 @@ __device__ W2DYN_INLINE bool worm_shift_delta(Ctx &x, int p1, int p2, double tn1
         const int p = q == 0 ? p1 : p2; const double tn = q == 0 ? tn1 : tn2;
         double told = 0.0; int fp = 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) if (i == p) { told = x.wtau[i]; fp = x.wfl[i]; }
+        for (int i = 0; i < NW; ++i) if (i == p) { told = x.wtau[i]; fp = x.wfl[i]; }
         const int sgn = (p & 1) ? 1 : -1;
         vt[2 * q] = tn; vf[2 * q] = fp; vs[2 * q] = sgn; vreal[2 * q] = true;
         vt[2 * q + 1] = told; vf[2 * q + 1] = fp; vs[2 * q + 1] = -sgn; vreal[2 * q + 1] = false;
@@ -440,7 +503,7 @@ __device__ W2DYN_INLINE bool worm_shift_delta(Ctx &x, int p1, int p2, double tn1
             int nc, na;
             worm_counts(x, fm, tm, nc, na);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) if (x.wfl[i] == fm && x.wtau[i] < tm) { if (i & 1) nc += 1; else na += 1; }
+            for (int i = 0; i < NW; ++i) if (x.wfl[i] == fm && x.wtau[i] < tm) { if (i & 1) nc += 1; else na += 1; }
             const int occ = ((x.outer >> flav_bit(fm, C.nd)) & 1) + nc - na + (fm == fa ? da : db);
             if (occ != (sm > 0 ? 0 : 1)) valid = false;
         }
@@ -453,14 +516,14 @@ __device__ W2DYN_INLINE bool worm_shift_delta(Ctx &x, int p1, int p2, double tn1
             if (valid && dA != 0) {
                 bool blocked = worm_any_between(x, fa, tm, tn);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) if (i != p1 && i != p2 && x.wfl[i] == fa && x.wtau[i] > tm && x.wtau[i] < tn) blocked = true;
-                if (blocked) valid = false; else dlog -= (double)dA * level_integral<4>(x, fa, tm, tn);
+                for (int i = 0; i < NW; ++i) if (i != p1 && i != p2 && x.wfl[i] == fa && x.wtau[i] > tm && x.wtau[i] < tn) blocked = true;
+                if (blocked) valid = false; else dlog -= (double)dA * level_integral<NW>(x, fa, tm, tn);
             }
             if (valid && dB != 0) {
                 bool blocked = worm_any_between(x, fb, tm, tn);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) if (i != p1 && i != p2 && x.wfl[i] == fb && x.wtau[i] > tm && x.wtau[i] < tn) blocked = true;
-                if (blocked) valid = false; else dlog -= (double)dB * level_integral<4>(x, fb, tm, tn);
+                for (int i = 0; i < NW; ++i) if (i != p1 && i != p2 && x.wfl[i] == fb && x.wtau[i] > tm && x.wtau[i] < tn) blocked = true;
+                if (blocked) valid = false; else dlog -= (double)dB * level_integral<NW>(x, fb, tm, tn);
             }
             if (valid && dA != 0 && dB != 0) dlog -= C.udd[fa * C.nflav + fb] * (double)(dA * dB) * (tn - tm);
         }
@@ -617,7 +680,7 @@ __device__ W2DYN_INLINE void step_worm_replace(Ctx &x)
                     bool ok = !worm_any_between(x, fp, lo, hi);
                     if (fp == f && thn > lo && thn < hi) ok = false;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) if (i != partner && x.wfl[i] == fp && x.wtau[i] > lo && x.wtau[i] < hi) ok = false;
+                    for (int i = 0; i < NW; ++i) if (i != partner && x.wfl[i] == fp && x.wtau[i] > lo && x.wtau[i] < hi) ok = false;
                     if (!ok) return;
                     const double dn = ((pca == 1) == (tpn > tp)) ? -1.0 : 1.0;
                     prob = fabs(detrat * exp(-dn * level_integral<NW>(x, fp, lo, hi)));
@@ -625,7 +688,7 @@ __device__ W2DYN_INLINE void step_worm_replace(Ctx &x)
                     // two partners (three-operator object): with the former hybridising operator at its place in the new object
                     double dl;
                     if (thn != th) { wave_sync(); if (x.lane == 0) { if (creator) tcp[slot] = thn; else tap[slot] = thn; } wave_sync(); slot_moved = true; }
-                    const bool ok = worm_shift_delta(x, partner, partner2, tpn, tpn2, dl);
+                    const bool ok = worm_shift_delta<NW>(x, partner, partner2, tpn, tpn2, dl);
                     if (!ok) { if (slot_moved) { if (x.lane == 0) { if (creator) tcp[slot] = th; else tap[slot] = th; } wave_sync(); } return; }
                     prob = fabs(detrat * exp(dl));
                 }

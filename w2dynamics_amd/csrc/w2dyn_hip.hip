@@ -744,8 +744,8 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
             return fail(s, W2DYN_EUNSUPPORTED, "offdiag = 1 runs the pair, shift and global moves and measures gtau_full / gleg_full, sign, histograms and the density matrix: FourPnt, MeasSusz, AccumGtau = 2, the step series, PercentageOuterMove and Percentage4OperatorMove without flavourchange_moves = 1 are not supported with it");
         s->meas_giw = 0;
     }
-    // the worms with six, eight and twelve operators (sectors 5, 10 - 13) are kept in the operator list only: matrix trace path, whatever the blocks
-    const bool big_worms = s->worm_meas_more[0] || s->worm_meas_more[1] || s->worm_meas_more[2] || s->worm_meas_more[3] || s->worm_meas_more[4] || s->worm_meas_more[5];
+    // the worms with eight and twelve operators (sectors 11 - 13) are kept in the operator list only: matrix trace path, whatever the blocks
+    const bool big_worms = s->worm_meas_more[3] || s->worm_meas_more[4] || s->worm_meas_more[5];       // QQQQ, NQQdag, QQdd; the six-operator worms (H4, QQ) run on both paths
     // worm sampling together with the two-pair / outer-block moves: the worm kernels make those moves on the operator list only
     const bool worm_xmoves = s->p_wins > 0.0 && (s->p_4op > 0.0 || s->p_outer > 0.0);
     s->mat = !lp.identity_blocks || s->offdiag || big_worms || worm_xmoves;      // off-diagonal hybridisation: always the matrix trace path (list of operators with their flavours)
@@ -1886,9 +1886,9 @@ static int enter_sector(w2dyn_solver *s, int isector, int icomponent)
                     isector, s->lp.nsmax);
     if (isector < 1 || isector > 16)
         return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d does not exist (1 = Z, 2 - 16: Parameters.F90:28-43)", isector);
-    if (worm_nops_of(isector) > 4 && !s->mat)
+    if (worm_nops_of(isector) > 6 && !s->mat)
         return fail(s, W2DYN_EINVAL, "worm sector %d has %d worm operators and runs on the matrix trace path, which init_solver chooses when the sector's estimator "
-                    "(WormMeasH4iw, WormMeasQQ, WormMeasQQQQ, WormMeasNQQdag, WormMeasQQdd) is asked for", isector, worm_nops_of(isector));
+                    "(WormMeasQQQQ, WormMeasNQQdag, WormMeasQQdd) is asked for", isector, worm_nops_of(isector));
     if (isector != 1) {
         const int nf = s->nflav, nf4 = nf * nf * nf * nf;
         const bool two = isector == 2 || isector == 3 || isector == 10;          // components of two flavour indices
