@@ -89,7 +89,7 @@ WORKLOADS = {
                      "PercentageWormInsert=PercentageWormReplace=0.2, eta balanced by count_steps)"),
 }
 HEADLINE = "C2"
-SIDE_WORKLOADS = ["C1", "C3", "C4", "C5", "C2G", "C3F"]      # run ahead of the headline by the default invocation
+SIDE_WORKLOADS = ["C1", "C3", "C4", "C5", "C2G", "C3F", "C2Q"]      # run ahead of the headline by the default invocation
 
 
 def _cpu_chain(args):
