@@ -1343,6 +1343,29 @@ def test_solver_qq_worm_symmetric_improved_estimator():
     assert np.abs(gw[:, 0, 0, 0, 1]).max() == 0.0
 
 
+def test_solver_components_of_the_u_matrix_worm_sectors():
+    """HipCtHybSolver.solve_component in the sectors 5, 14 and 16: the eta search balances worm and partition-function space, the result set carries
+    the reference's keys (impurity.py:813-871) with the shapes of the module arrays, divided by nflavours^4, finite, with error bars."""
+    from w2dynamics_amd.solver import HipCtHybSolver
+    from w2dynamics_amd import synth
+    base = dict(BASE, Ntau=40, NLegMax=10, Niw=8, N2iwb=3, N4iwf=2, N4iwb=1, Nwarmups=5000, Nmeas=200, NCorr=20, TaudiffMax=6.0, Nftau=501,
+                PercentageGlobalMove=0.05, PercentageTauShiftMove=0.05, Nwarmups2Plus=2000, PercentageWormInsert=0.2, PercentageWormReplace=0.2,
+                WormEta=1.0, WormSearchEta=1)
+    p = synth.config("C1", nftau=501)
+    comp = 1 + 0 * 8 + 0 * 4 + 1 * 2 + 1
+    for sec, extra, keys, fourpnt in ((14, dict(WormMeasUcaca=1, WormMeasUcacatau=1), {"ucaca-worm": (7,), "ucacatau-worm": (40,)}, 0),
+                                      (16, dict(WormMeasQUDdag=1), {"quddag-worm": (16,)}, 0),
+                                      (5, dict(WormMeasH4iw=1), {"h4iw-worm": (4, 4, 3)}, 8)):
+        s = HipCtHybSolver(dict(base, **extra), seed=21 + sec, nwalkers=256, walkers_per_bin=8)
+        s.set_problem(p, fourpnt)
+        r = s.solve_component(0, sec, comp)
+        st = r["steps-worm-partition/%05d" % comp]
+        assert 0.3 < st[sec - 1] / st[0] < 3.0, (sec, st[0], st[sec - 1])
+        for key, shape in keys.items():
+            m = np.asarray(r["%s/%05d" % (key, comp)].mean()); e = np.asarray(r["%s/%05d" % (key, comp)].stderr())
+            assert m.shape == shape and np.all(np.isfinite(m)) and np.abs(m).max() > 0.0 and np.all(np.isfinite(e)), (sec, key, m.shape)
+
+
 @pytest.mark.parametrize("name", ["C1", "C3", "C4"])
 def test_susceptibility_recorded_configuration_vs_reference_golden(name):
     """f-3, MeasSusz = 1 (matrix solver, meas_ntau_n0, Trace.F90:6472-6835): <n(tau) n(0)> of a recorded configuration ==
