@@ -87,6 +87,11 @@ WORKLOADS = {
                 overrides=dict(_BASE, NCorr=200, Niw=2000, PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=1.0, WormMeasQQ=1, WormMeasQQtau=1),
                 text="C2Q: C2 with worm sampling in sector 10 (qq_worm / qqtau_worm of component 1, the symmetric improved estimator, Niw=2000, "
                      "PercentageWormInsert=PercentageWormReplace=0.2, eta balanced by count_steps)"),
+    # sector 12: eight worm operators (two three-operator objects and an equal-time pair; k_sweep_worm<8, 0, IE>, closed-form local trace)
+    "C2N": dict(config="C2", nftau=5001, chains=16384, worm=dict(sector=12, component=4, nfix=2000),
+                overrides=dict(_BASE, NCorr=200, N3iwf=10, N3iwb=5, PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=1.0, WormMeasNQQdag=1),
+                text="C2N: C2 with worm sampling in sector 12 (nqqdag_worm of component 4 = flavours 0011, eight worm operators, N3iwf=10, N3iwb=5, "
+                     "PercentageWormInsert=PercentageWormReplace=0.2, eta balanced by count_steps)"),
 }
 HEADLINE = "C2"
 SIDE_WORKLOADS = ["C1", "C3", "C4", "C5", "C2G", "C3F", "C2Q"]      # run ahead of the headline by the default invocation
@@ -140,7 +145,7 @@ def _cpu_chain(args):
 
 # measurements per CPU chain: about 10-20 s of CPU work for the headline, a few seconds for the side workloads (the
 # reference's G(iw) / g4iw estimators cost milliseconds to seconds per measurement: far fewer of them)
-_CPU_NMEAS = {"C2Q": 3000, "C4X": 1000, "C4O": 300, "C2": 6000, "C2A": 6000, "C2G": 200, "C3F": 30, "C1": 3000, "C3": 2000, "C4": 1000, "C5Z": 1000, "C5K": 300, "C4W": 1000, "C5": 1000}
+_CPU_NMEAS = {"C2Q": 3000, "C2N": 3000, "C4X": 1000, "C4O": 300, "C2": 6000, "C2A": 6000, "C2G": 200, "C3F": 30, "C1": 3000, "C3": 2000, "C4": 1000, "C5Z": 1000, "C5K": 300, "C4W": 1000, "C5": 1000}
 
 
 def cpu_baseline(cores, wname, nwarm=50000, eta=1.0):
@@ -234,7 +239,7 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
             # eta search of solve_component (impurity.py:717-742): rescale until Z and worm space get equal numbers of
             # steps, to the reference's criterion |sw - sz| / (sw + sz) <= 0.1; starting point: insertion prefactor
             # (beta Nd)^4 eta = 1 (CTQMC.F90:5680-5684).  The reference runs this loop without a bound on its length
-            q.wormeta[:] = 1.0 / (prob.beta * prob.nd) ** (2 if wsec in (2, 10) else 4)
+            q.wormeta[:] = 1.0 / (prob.beta * prob.nd) ** (2 if wsec in (2, 10) else 4)       # sector 12: beta^3 Nd^8 eta; the search rescales from wherever it starts
             for eta_tries in range(1, 101):
                 sw, sz = q.count_steps(wsec, worm["component"], worm["nfix"])
                 if sw != 0 and sz != 0 and abs(sw - sz) / float(sw + sz) <= 0.1:
@@ -252,7 +257,8 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
         q.sweep(ncorr); q.measure_once()
     q.sync()
     tkeys = (sweep_key, "meas_misc", "meas_gleg", "meas_full", "meas_g4w", "meas_gw", "meas_wie", "meas_gtau_ac", "meas_giw", "meas_g2iw", "meas_g4iw")
-    wkey, wres, wkern = {4: ("meas_g4w", "g4iw_worm", "k_meas_g4w"), 10: ("meas_wie", "qq_worm", "k_meas_wie")}.get(wsec, ("meas_gw", "giw_worm", "k_meas_gw"))
+    wkey, wres, wkern = {4: ("meas_g4w", "g4iw_worm", "k_meas_g4w"), 10: ("meas_wie", "qq_worm", "k_meas_wie"),
+                         12: ("meas_wie", "nqqdag_worm", "k_meas_wie")}.get(wsec, ("meas_gw", "giw_worm", "k_meas_gw"))
     for k in tkeys:
         q.kernel_time(k, reset=True)
     if world > 1:
@@ -318,7 +324,8 @@ def run_workload(env, wname, walkers, steps, warmup, thermal, wpb, with_cpu, cpu
         flops_gleg = W * (1 if offd else nflav) * k2 * (5 * over["NLegMax"] + 6)
         if worm:       # 8 (2 N4iwf)^2 (2 N4iwb + 1) flop per worm-space measurement
             nworm_meas = float(q.result("cntmeas_worm")[0]) / max(steps + warmup, 1)
-            flops_gleg = nworm_meas * (8 * (2 * over["N4iwf"]) ** 2 * (2 * over["N4iwb"] + 1) if wsec == 4 else 8 * 2 * over["Niw"])
+            flops_gleg = nworm_meas * (8 * (2 * over["N4iwf"]) ** 2 * (2 * over["N4iwb"] + 1) if wsec == 4 else
+                                       (8 * 2 * over["N3iwf"] * (2 * over["N3iwb"] + 1) if wsec == 12 else 8 * 2 * over["Niw"]))
         ach_tf = flops_gleg / (gleg_ms * 1e-3) / 1e12 if gleg_ms > 0 else 0.0
         value = world * W * ncorr * steps / dt
         kname, mname = ("k_sweep_worm", wkern) if worm else (("k_sweep_od", "k_meas_full") if offd else ("k_sweep", "k_meas_gleg"))

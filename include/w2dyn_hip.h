@@ -87,9 +87,8 @@ int w2dyn_ctqmc_warmup(w2dyn_solver *s, int64_t nwarmups);
  * isector 5 (H4, six worm operators), 10 (QQ, six), 11 (Q4, twelve), 12 (NQQdag, eight), 13 (QQdd, eight), 14 (Ucaca), 15 (Uccaa), 16 (QUDdag; four
  * each): worms with U-matrix factors in the proposal and random flavours of the operators in the equal-time objects (set_IEOperFlavor
  * Trace.F90:3835-3919, set_OperTime 4022-4158, get_Proposal CTQMC.F90:5698-5796, replacement 5841-5946 and 5997-6162, estimators 1166-1294 and
- * 1708-2128, u_sparsity 9003-9343); icomponent = the component's two (sector 10) or four flavour indices, not 0.  Sectors 5, 10 and 14 - 16 run on
- * both trace paths; the sectors with eight and twelve worm operators (11 - 13) on the matrix trace path, which init_solver takes when WormMeasQQQQ,
- * WormMeasNQQdag or WormMeasQQdd is set (else the call is refused with W2DYN_EINVAL). */
+ * 1708-2128, u_sparsity 9003-9343); icomponent = the component's two (sector 10) or four flavour indices, not 0.  All of them run on
+ * both trace paths. */
 int w2dyn_ctqmc_measure(w2dyn_solver *s, int isector, int icomponent);
 /* module variable `wormeta` (impurity.py:719, 755, 784): the same value for every worm sector, CTQMC.F90:194, 434 */
 int w2dyn_set_wormeta(w2dyn_solver *s, double eta);
@@ -184,7 +183,8 @@ int w2dyn_get_walker_state(w2dyn_solver *s, int walker, double *out6);
  * Writes min(bytes, size) bytes; *needed (if not NULL) receives the full size. */
 int w2dyn_get_result(w2dyn_solver *s, const char *name, void *out, size_t bytes, size_t *needed);
 /* scalars: "mean_sign" "aborted" "time_warmup" "time_sim" "time_sim_steps" "accglob" "accshift" "accadd4"
- *          "accrem4" "accflavc" "nwalkers" "nbins" "kmax" "steps_done" "meas_done" */
+ *          "accrem4" "accflavc" "nwalkers" "nbins" "kmax" "steps_done" "meas_done"
+ *          "trace_path" (after init_solver: 0 = closed-form local trace of one-state blocks, 2 | 3 | 4 = tree of block products of that size, 9 = sequential) */
 int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out);
 
 /* timing of the last w2dyn_sweep / w2dyn_measure_once launches, measured with HIP events on the context's own

@@ -711,11 +711,10 @@ def test_unsupported_modes_are_refused():
         q.ctqmc_calibrate(True, 10, 10, 10, 100)
     assert e.value.code == -2
     q.close()
-    # worms with more than six operators live in the operator list of the matrix trace path, which init_solver takes when their estimator is
-    # asked for; without it the call is an error of the caller.  A component whose U-matrix slices vanish would never let the worm in.
+    # a component whose U-matrix slices vanish would never let the worm in
     _, ps, _ = util.setup("C1", 501, dict(PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormMeasUcaca=1))
     q = MCTQMC(nwalkers=4); q.init_rnd(1); q.init_paras(ps); q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
-    for sec, comp in ((11, 4), (12, 4), (15, 2), (14, 0)):      # (15, 2): u1 = u3, the antisymmetrised U(u1, u3, ., .) vanishes; (14, 0): these sectors sample one component
+    for sec, comp in ((15, 2), (14, 0)):      # (15, 2): u1 = u3, the antisymmetrised U(u1, u3, ., .) vanishes; (14, 0): these sectors sample one component
         with pytest.raises(W2DynError) as e:
             q.ctqmc_measure(sec, comp)
         assert e.value.code == -1, (sec, comp)
@@ -991,6 +990,9 @@ def test_equal_time_worm_sampling_chains_vs_oracle(name):
     q = MCTQMC(nwalkers=nw, walkers_per_bin=1); q.fourpnt = fourpnt
     q.init_rnd(29); q.init_paras(ps)
     q.init_solver(p.umatrix, p.ftau, p.muimp, p.screening, 1)
+    # one-state blocks without the extra moves: closed-form local trace, for worms of up to twelve operators; otherwise the operator list
+    closed = str(g["config"]) in ("C1", "C3") and not name.startswith("X")
+    assert (int(q.scalar("trace_path")) == 0) == closed, (name, q.scalar("trace_path"))
     q.set_taudiffmax(over["TaudiffMax"])
     q.ctqmc_warmup(over["Nwarmups"])
     sw, sz = q.count_steps(sec, comp, 3000)
@@ -1145,16 +1147,9 @@ def test_solver_worm_giw_kanamori_agrees_with_z_space_estimate():
 
 
 def test_worm_modes_refused_or_ignored():
-    """A sector with more than six worm operators (Q4 = 11, NQQdag = 12, QQdd = 13) on a context that was not set up for it (its estimator not asked for:
-    closed-form trace path) is an error of the call; eta = 0 samples nothing (CTQMC.F90:8409-8418)."""
+    """eta = 0 samples nothing (CTQMC.F90:8409-8418)."""
     g = util.load_golden("worm_C1a.npz")
     q, p, pset, over = _worm_gpu(g, 4, 2, 3)
-    with pytest.raises(W2DynError) as e:
-        q.ctqmc_measure(11, 1)
-    assert e.value.code == -1
-    with pytest.raises(W2DynError) as e:
-        q.count_steps(12, 1, 100)
-    assert e.value.code == -1
     q.wormeta[:] = 0.0
     q.ctqmc_measure(4, 1)
     assert q.aborted == 0 and np.all(q.g4iw_worm == 0.0) and q.cntsampling[3] == 0

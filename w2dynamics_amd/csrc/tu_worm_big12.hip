@@ -1,10 +1,11 @@
 // translation unit: mixed Z / worm-space sweep of the worm sectors with U-matrix factors beyond sector 3 (the IE = true bodies of cthyb_worm.hip.h)
-// with 12 worm operators (sector 11; matrix trace path).  The context holds twelve worm operators here.
+// with 12 worm operators (sector 11; both trace paths).  The context holds twelve worm operators here.
 #define W2DYN_NWMAX 12
 #include "launch.hpp"
 namespace w2dyn {
 void launch_sweep_worm_big12(int mat, const LaunchCfg &l, const DevConst &C, long long nsteps, int resume)
 {
+    if (mat == 0) { hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_worm<12, 0, true>), l.grid, l.block, l.lds, l.stream, C, nsteps, resume); return; }
     if (mat == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_worm<12, 2, true>), l.grid, l.block, l.lds, l.stream, C, nsteps, resume);
     else if (mat == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_worm<12, 3, true>), l.grid, l.block, l.lds, l.stream, C, nsteps, resume);
     else if (mat == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sweep_worm<12, 4, true>), l.grid, l.block, l.lds, l.stream, C, nsteps, resume);

@@ -506,7 +506,7 @@ void launch_sweep_worm(int isector, int mat, const LaunchCfg &l0, const DevConst
     // every tree-product kernel is instantiated for the block size it runs with (mat = 2, 3, 4): a worm kernel with the extra moves built for
     // blocks of four states faulted on blocks of two (cause not found; the kernels of exact size retrace the oracle)
     if (C.xmoves) { if (nworm == 2) launch_sweep_worm_x2(mat, l, C, nsteps, resume); else launch_sweep_worm_x4(mat, l, C, nsteps, resume); }   // enter_sector: matrix trace path, sectors 2, 3, 4, 6 - 9
-    else if (isector == 5 || isector >= 10) {                  // more than four operators: enter_sector has made sure of the matrix trace path
+    else if (isector == 5 || isector >= 10) {                  // U-matrix factors beyond sector 3, up to twelve operators: kernels whose context holds twelve worm operators, both trace paths
         if (nworm == 4) launch_sweep_worm_big4(mat, l, C, nsteps, resume);
         else if (nworm == 6) launch_sweep_worm_big6(mat, l, C, nsteps, resume);
         else if (nworm == 8) launch_sweep_worm_big8(mat, l, C, nsteps, resume);
@@ -744,11 +744,9 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
             return fail(s, W2DYN_EUNSUPPORTED, "offdiag = 1 runs the pair, shift and global moves and measures gtau_full / gleg_full, sign, histograms and the density matrix: FourPnt, MeasSusz, AccumGtau = 2, the step series, PercentageOuterMove and Percentage4OperatorMove without flavourchange_moves = 1 are not supported with it");
         s->meas_giw = 0;
     }
-    // the worms with eight and twelve operators (sectors 11 - 13) are kept in the operator list only: matrix trace path, whatever the blocks
-    const bool big_worms = s->worm_meas_more[3] || s->worm_meas_more[4] || s->worm_meas_more[5];       // QQQQ, NQQdag, QQdd; the six-operator worms (H4, QQ) run on both paths
     // worm sampling together with the two-pair / outer-block moves: the worm kernels make those moves on the operator list only
     const bool worm_xmoves = s->p_wins > 0.0 && (s->p_4op > 0.0 || s->p_outer > 0.0);
-    s->mat = !lp.identity_blocks || s->offdiag || big_worms || worm_xmoves;      // off-diagonal hybridisation: always the matrix trace path (list of operators with their flavours)
+    s->mat = !lp.identity_blocks || s->offdiag || worm_xmoves;      // off-diagonal hybridisation: always the matrix trace path (list of operators with their flavours)
     (void)dd;
     if (s->mat && lp.nsmax > 16) return fail(s, W2DYN_EUNSUPPORTED, "largest block of H_loc has %d states with QuantumNumbers '%s': the HIP solver handles up to 16", lp.nsmax, qns.c_str());
     s->eps.assign(nf, 0.0); s->udd.assign((size_t)nf * nf, 0.0);
@@ -1886,9 +1884,6 @@ static int enter_sector(w2dyn_solver *s, int isector, int icomponent)
                     isector, s->lp.nsmax);
     if (isector < 1 || isector > 16)
         return fail(s, W2DYN_EUNSUPPORTED, "worm sector %d does not exist (1 = Z, 2 - 16: Parameters.F90:28-43)", isector);
-    if (worm_nops_of(isector) > 6 && !s->mat)
-        return fail(s, W2DYN_EINVAL, "worm sector %d has %d worm operators and runs on the matrix trace path, which init_solver chooses when the sector's estimator "
-                    "(WormMeasQQQQ, WormMeasNQQdag, WormMeasQQdd) is asked for", isector, worm_nops_of(isector));
     if (isector != 1) {
         const int nf = s->nflav, nf4 = nf * nf * nf * nf;
         const bool two = isector == 2 || isector == 3 || isector == 10;          // components of two flavour indices
@@ -2359,6 +2354,7 @@ int w2dyn_get_scalar(w2dyn_solver *s, const char *name, double *out)
     else if (n == "nbw") *out = s->nbw;
     else if (n == "nbe") *out = s->nbe;
     else if (n == "nbie") *out = s->nbie;
+    else if (n == "trace_path") *out = mat_variant(s);
     else if (n == "n3iwb") *out = s->n3iwb;
     else if (n == "nbl") *out = s->nbl;
     else if (n == "nbs") *out = s->nbs;
