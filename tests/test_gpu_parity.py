@@ -1338,6 +1338,43 @@ def test_solver_qq_worm_symmetric_improved_estimator():
     assert np.abs(gw[:, 0, 0, 0, 1]).max() == 0.0
 
 
+def test_solver_ucaca_worm_agrees_with_z_space_density_correlation_and_spin_symmetry():
+    """HipCtHybSolver.solve_component in sector 14 (Ucaca: two equal-time pairs c+ c, each weighted with the doubly antisymmetrised U
+    matrix, CTQMC.F90:5778-5782): on the one-orbital model the component (0 0 1 1) picks (U/2)^2 n_dn(tau) n_up(0), (0 0 0 0) picks
+    (U/2)^2 n_dn(tau) n_dn(0) and (0 1 1 0) picks (-U/2)^2 S-(tau) S+(0).  ucacatau-worm times nflavours^4 / 16 times beta is the correlator
+    (the module array carries the 2^4 of wormNorm and 1 / beta): the first two agree with MeasSusz of a Z-space run, the third with <n_up n_up> - <n_up n_dn>
+    (spin rotation symmetry of the paramagnetic model), within the error bars."""
+    from w2dynamics_amd.solver import HipCtHybSolver
+    from w2dynamics_amd import synth
+    base = dict(BASE, Ntau=20, Nwarmups=20000, Nmeas=1000, NCorr=20, TaudiffMax=6.0, Nftau=501)
+    p = synth.config("C1", nftau=501); nfl = 2 * p.nd
+    uh2 = (0.5 * float(np.asarray(p.umatrix).reshape(nfl, nfl, nfl, nfl)[0, 1, 0, 1])) ** 2
+    s = HipCtHybSolver(dict(base, MeasSusz=1), seed=3, nwalkers=1024, walkers_per_bin=8)
+    s.set_problem(p)
+    chi = np.asarray(s.solve(0)["ntau-n0"].mean())
+    mid = lambda a: 0.5 * (a[:-1] + a[1:])            # the worm estimator averages over a tau bin, the Z-space one sits on the bin edges
+    nn_same, nn_diff = mid(0.5 * (chi[0, 0, 0, 0] + chi[0, 1, 0, 1])), mid(0.5 * (chi[0, 1, 0, 0] + chi[0, 0, 0, 1]))
+    got = {}
+    for c4 in ((0, 0, 1, 1), (0, 0, 0, 0), (0, 1, 1, 0)):
+        comp = 1 + ((c4[0] * nfl + c4[1]) * nfl + c4[2]) * nfl + c4[3]
+        s2 = HipCtHybSolver(dict(base, Nwarmups2Plus=4000, N2iwb=3, PercentageWormInsert=0.2, PercentageWormReplace=0.2, WormEta=1.0,
+                                 WormSearchEta=1, WormMeasUcaca=1, WormMeasUcacatau=1), seed=5, nwalkers=1024, walkers_per_bin=8)
+        s2.set_problem(p)
+        r2 = s2.solve_component(0, 14, comp)
+        st = r2["steps-worm-partition/%05d" % comp]
+        assert 0.5 < st[13] / st[0] < 2.0
+        f = nfl ** 4 / 16.0 * p.beta / uh2             # 16: the 2^4 of wormNorm (CTQMC.F90:8830), as in sector 6
+        got[c4] = (np.asarray(r2["ucacatau-worm/%05d" % comp].mean()) * f, np.asarray(r2["ucacatau-worm/%05d" % comp].stderr()) * f)
+        # the static component of ucaca-worm is the integral of the same correlator over tau
+        uiw = np.asarray(r2["ucaca-worm/%05d" % comp].mean()) * f
+        assert abs(uiw[3].real - got[c4][0].mean() * p.beta) < 0.02 * abs(uiw[3].real) and abs(uiw[3].imag) < 1e-9
+    for c4, ref in (((0, 0, 1, 1), nn_diff), ((0, 0, 0, 0), nn_same), ((0, 1, 1, 0), nn_same - nn_diff)):
+        m, e = got[c4]
+        assert np.all(np.abs(m - ref) < 5.0 * e + 0.02 * np.abs(ref)), (c4, np.abs(m - ref).max(), e.max())
+    m = got[(0, 0, 0, 0)][0] - got[(0, 0, 1, 1)][0]; e = np.sqrt(got[(0, 0, 0, 0)][1] ** 2 + got[(0, 0, 1, 1)][1] ** 2 + got[(0, 1, 1, 0)][1] ** 2)
+    assert np.all(np.abs(got[(0, 1, 1, 0)][0] - m) < 5.0 * e), np.abs(got[(0, 1, 1, 0)][0] - m).max()
+
+
 def test_solver_components_of_the_u_matrix_worm_sectors():
     """HipCtHybSolver.solve_component in the sectors 5, 14 and 16: the eta search balances worm and partition-function space, the result set carries
     the reference's keys (impurity.py:813-871) with the shapes of the module arrays, divided by nflavours^4, finite, with error bars."""
