@@ -185,6 +185,9 @@ struct DevConst {
     double *apt_tau;              // [nwalkers][napt]
     int *apt_cnt;                 // [nwalkers]
     int *calib_pairs;             // [nwalkers][nflav]
+    // [nflav] bit g of entry f: flavours f and g have the same F(tau) table to the last bit, so a relabelling f -> g without the exchange of
+    // creators and annihilators carries the inverse hybridisation matrix along (step_glob)
+    const int *fsame;
 };
 
 // bytes of LDS one wave needs (host and device agree through this one function)
@@ -1562,9 +1565,23 @@ __device__ W2DYN_INLINE void step_glob(Ctx &x)
     double ltr_old, ltr_new;
     glob_logtraces(x, gmap, flip, outer_new, ltr_old, ltr_new);
     GLOB_STAMP(x, C_DBG3);
-    // new inverse matrices into the second buffer, determinant in the reference's time order
+    // new inverse matrices into the second buffer, determinant in the reference's time order.  A relabelling between flavours of identical
+    // F(tau) that leaves creators creators (spin flip of a paramagnetic bath, symmetry moves) maps every hybridisation matrix onto one that
+    // is already inverted - same slots, same determinant, same sign: the matrices move along with their flavours and nothing is inverted
+    // (the reference inverts from scratch and gets the same numbers up to rounding).
     double *MBw = C.MB + (size_t)x.w * nf * kmax * kmax;
     double logdet_new = 0.0, sign_new = 1.0;
+    bool carried = !flip;
+    for (int g = 0; g < nf; ++g) { const int f = fsrc[g]; if (x.order(f) > 0 && !((C.fsame[f] >> g) & 1)) carried = false; }
+    if (carried) {
+        logdet_new = x.det_log; sign_new = x.det_sign;
+        for (int g = 0; g < nf; ++g) {
+            const int f = fsrc[g], k = x.order(f), kk = k * k;
+            const double *Mo = x.mat(f); double *Mn = MBw + (size_t)g * kmax * kmax;
+            const unsigned magic = k > 0 ? (1u << 24) / (unsigned)k + 1u : 0u;
+            for (int e = x.lane; e < kk; e += 64) { const int i = (int)(((unsigned)e * magic) >> 24), o = i * kmax + (e - i * k); Mn[o] = Mo[o]; }
+        }
+    } else
     for (int g = 0; g < nf; ++g) {
         double ld, sg;
         const int f = fsrc[g], k = x.order(f);

@@ -814,6 +814,13 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     C.nslide = std::max(2 * nd, (int)std::floor((double)s->ncorr / (double)C.num_windows));   // CTQMC.F90:8069
     int rc;
     if ((rc = dev_upload(s, C.ftab, s->ftab))) return rc;
+    {   // flavours with the same F(tau) table, to the last bit (step_glob carries the inverse matrices along a relabelling between them)
+        std::vector<int> same(nf, 0);
+        for (int f = 0; f < nf; ++f)
+            for (int g = 0; g < nf; ++g)
+                if (!memcmp(&s->ftab[(size_t)f * s->nftau], &s->ftab[(size_t)g * s->nftau], (size_t)s->nftau * sizeof(double))) same[f] |= 1 << g;
+        const int *ds = nullptr; if ((rc = dev_upload(s, ds, same))) return rc; C.fsame = ds;
+    }
     if ((rc = dev_upload(s, C.energies, s->energies))) return rc;
     if ((rc = dev_upload(s, C.udd, s->udd))) return rc;
     if ((rc = dev_upload(s, C.eps, s->eps))) return rc;
