@@ -255,8 +255,18 @@ def test_matrix_path_lds_layouts_retrace_oracle(monkeypatch, in_lds):
     _retrace(cfg, nftau, over, seed + 1)
 
 
-def _retrace(cfg, nftau, over, seed):
+def test_chains_retrace_oracle_spin_dependent_bath():
+    """Global moves with a bath that depends on the spin: the spin flip maps a flavour onto one with another F(tau), so its inverse matrices are
+    built from scratch, while the relabellings between flavours of identical F(tau) (the other test cases: every spin flip) carry them along
+    (step_glob, DevConst::fsame); M, det_sign and the estimators of every chain agree with the oracle either way."""
+    _retrace("C3", 501, dict(BASE, Nwarmups=3000, Nmeas=30, NCorr=30, TaudiffMax=6.0, PercentageGlobalMove=0.3, PercentageTauShiftMove=0.05), 79,
+             patch=lambda p: p.ftau.__setitem__((slice(None), 1, slice(None), 1), 0.7 * p.ftau[:, 1, :, 1]))
+
+
+def _retrace(cfg, nftau, over, seed, patch=None):
     p, ps, pset = util.setup(cfg, nftau, over)
+    if patch is not None:
+        p.ftau = np.array(p.ftau, copy=True); patch(p)
     nw = 6
     q = make_gpu(p, ps, seed, nw)
     tdm = pset.get_real("TaudiffMax")
