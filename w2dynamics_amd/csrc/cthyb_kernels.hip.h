@@ -188,6 +188,7 @@ struct DevConst {
     // [nflav] bit g of entry f: flavours f and g have the same F(tau) table to the last bit, so a relabelling f -> g without the exchange of
     // creators and annihilators carries the inverse hybridisation matrix along (step_glob)
     const int *fsame;
+    const int *fclass;            // offdiag: [nflav][nflav] class of the two-flavour table F_ac(tau), equal for tables identical to the last bit
 };
 
 // bytes of LDS one wave needs (host and device agree through this one function)

@@ -463,12 +463,27 @@ __device__ W2DYN_INLINE void step_glob_od(Ctx &x)
     }
     double *Mb = C.MB + (size_t)x.w * nf * kmax * kmax;
     double ld, sg;
-    const int err0 = x.err;
-    od_build_and_invert(x, kt, tcn, tan, fcn, fan, Mb, ld, sg);
-    // relabelled flavours that the bath does not couple leave a matrix with a vanishing determinant: the reference takes
-    // det = 0 and rejects the move (MatrixUpdate.F90:74-78); nothing to report
-    const bool singular = (x.err & ERR_SINGULAR) != 0;
-    x.err = err0;
+    // a relabelling that leaves creators creators and maps every two-flavour table onto an identical one leaves the hybridisation matrix - slot
+    // by slot - as it is: the inverse and log|det| stay, the sign changes by the parities of the (flavour, time) orders before and after
+    // (the reference builds and inverts anew and gets the same numbers up to rounding; see step_glob)
+    bool carried = !flip;
+    if (carried) {
+        int bad = 0;
+        for (int e = x.lane; e < nf * nf; e += 64) { const int a = e / nf, c = e - a * nf; bad |= C.fclass[lut[2 * MAXFLAV + a] * nf + lut[2 * MAXFLAV + c]] != C.fclass[e] ? 1 : 0; }
+        carried = __ballot(bad != 0) == 0ull;
+    }
+    bool singular = false;
+    if (carried) {
+        ld = x.det_log;
+        sg = x.det_sign * od_sort_parity(x, x.tc(0), od_fc(x), kt) * od_sort_parity(x, x.ta(0), od_fa(x), kt);
+    } else {
+        const int err0 = x.err;
+        od_build_and_invert(x, kt, tcn, tan, fcn, fan, Mb, ld, sg);
+        // relabelled flavours that the bath does not couple leave a matrix with a vanishing determinant: the reference takes
+        // det = 0 and rejects the move (MatrixUpdate.F90:74-78); nothing to report
+        singular = (x.err & ERR_SINGULAR) != 0;
+        x.err = err0;
+    }
     sg *= od_sort_parity(x, tcn, fcn, kt) * od_sort_parity(x, tan, fan, kt);
     double tl, ts;
     mat_walk_into(x, outer_new, x.tsst);
@@ -483,7 +498,7 @@ __device__ W2DYN_INLINE void step_glob_od(Ctx &x)
     {
         double *tcp = x.tc(0), *tap = x.ta(0), *Mg = x.mat(0); int *fcs = od_fc(x), *fas = od_fa(x);
         for (int e = x.lane; e < kt; e += 64) { tcp[e] = tcn[e]; tap[e] = tan[e]; fcs[e] = fcn[e]; fas[e] = fan[e]; }
-        for (int e = x.lane; e < kt * kt; e += 64) { const int i = e / kt, j = e - i * kt; Mg[(size_t)i * kmax + j] = Mb[(size_t)i * kmax + j]; }
+        if (!carried) for (int e = x.lane; e < kt * kt; e += 64) { const int i = e / kt, j = e - i * kt; Mg[(size_t)i * kmax + j] = Mb[(size_t)i * kmax + j]; }
     }
     wave_sync();
     x.outer = outer_new;

@@ -857,12 +857,20 @@ int w2dyn_init_solver(w2dyn_solver *s, const double *U, const double *ftau_full,
     if (s->offdiag) {      // HybrF_full as handed over (CTQMC.F90:7950-7955), the flavours of the slots, the full-matrix accumulators
         std::vector<double> ff(ftau_full, ftau_full + (size_t)nf * nf * nftau);
         if ((rc = dev_upload(s, C.ffull, ff))) return rc;
+        {   // classes of identical two-flavour tables (step_glob_od: a relabelling that maps every table onto an identical one leaves the matrix as it is)
+            std::vector<int> cls((size_t)nf * nf, 0);
+            for (int e = 0; e < nf * nf; ++e) {
+                cls[e] = e;
+                for (int d = 0; d < e; ++d) if (!memcmp(&ff[(size_t)e * nftau], &ff[(size_t)d * nftau], (size_t)nftau * sizeof(double))) { cls[e] = d; break; }
+            }
+            const int *dc = nullptr; if ((rc = dev_upload(s, dc, cls))) return rc; C.fclass = dc;
+        }
         if ((rc = dev_alloc(s, C.FC, W * kmax))) return rc;
         if ((rc = dev_alloc(s, C.FA, W * kmax))) return rc;
         HIPCHK(hipMemsetAsync(C.FC, 0, sizeof(int) * W * kmax, s->stream)); HIPCHK(hipMemsetAsync(C.FA, 0, sizeof(int) * W * kmax, s->stream));
         if ((rc = dev_alloc(s, s->acc_gleg_full, (size_t)C.nbins * nf * nf * s->nleg))) return rc;
         if ((rc = dev_alloc(s, s->acc_gtau_full, (size_t)C.nbins * nf * nf * s->ntau))) return rc;
-    } else { s->acc_gleg_full = s->acc_gtau_full = nullptr; }
+    } else { s->acc_gleg_full = s->acc_gtau_full = nullptr; C.fclass = nullptr; }
     const size_t B = C.nbins;
     if ((rc = dev_alloc(s, C.acc_gleg, B * nf * s->nleg))) return rc;
     {   // prefix sums, workgroup totals, ticket of k_gleg_segments (layout: tu_meas.hip)
