@@ -83,7 +83,7 @@ __device__ W2DYN_INLINE bool worm_delta_multi(Ctx &x, const double (&t)[NWMAX], 
     bool valid = true;
 #pragma unroll
     for (int m = 0; m < NW; ++m) {
-        if (!valid) continue;                              // wave-uniform: nothing after the first violation is looked at (dlog is not used then)
+        if (NW <= 8 && !valid) continue;                   // wave-uniform: nothing after the first violation is looked at (dlog is not used then); twelve operators: the loop would no longer unroll
         int i = 0; double tm = 0.0, tn = 0.0; int fm = 0;
 #pragma unroll
         for (int q = 0; q < NW; ++q) { if (rk[q] == m) { i = q; tm = t[q]; fm = fl[q]; } if (rk[q] == m + 1) tn = t[q]; }
